@@ -1,0 +1,236 @@
+/*
+ * niqki_hip.h -- C ABI of the MI355X-native NIQKI sketch/query engine
+ * (libniqki_hip.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * has no FFI layer: its boundary is the C++ class Index
+ * (/root/reference/src/niqki_index.h:35-213) whose inner operators
+ *
+ *     void         compute_sketch(const string&, vector<int32_t>&) const;   niqki_index.h:103
+ *     void         insert_sketch(const vector<int32_t>&, uint32_t gid);      niqki_index.h:108
+ *     query_output query_sketch(const vector<int32_t>&) const;               niqki_index.h:142
+ *
+ * are what the file drivers call per record.  Each entry point below names the
+ * reference interface (file:line under /root/reference) it replaces.  All
+ * signatures are plain C: opaque handle, pointers and sizes, int status.
+ * No exceptions cross the boundary.  Calls on one handle must be serialised by
+ * the caller (one handle per GPU; the reference's const query methods map to
+ * batched calls here, not to concurrent ones).
+ *
+ * Memory spaces: every array argument of a call lives in the space named by
+ * the call's `mem` argument -- NIQKI_MEM_HOST (pageable or pinned host memory;
+ * the library stages it) or NIQKI_MEM_DEVICE (device memory of the handle's
+ * GPU; nothing is copied, work is enqueued on the handle's stream and the call
+ * returns without synchronising unless stated otherwise).
+ *
+ * Sketch layout: F = 2^S int32 per sketch, row major, -1 = empty cell, exactly
+ * the reference's vector<int32_t>.
+ */
+#ifndef NIQKI_HIP_H
+#define NIQKI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NIQKI_ABI_VERSION 1
+
+/* Bytes the caller must keep readable after the last sequence byte of a
+ * NIQKI_MEM_DEVICE sequence buffer (the sketch kernel reads whole dwords). */
+#define NIQKI_SEQ_PAD 64
+
+enum niqki_status {
+  NIQKI_OK = 0,
+  NIQKI_E_INVALID = 1,     /* bad argument / unsupported parameter combination */
+  NIQKI_E_NOMEM = 2,       /* host or device allocation failed */
+  NIQKI_E_HIP = 3,         /* a HIP runtime call failed; see niqki_last_error */
+  NIQKI_E_CAPACITY = 4,    /* caller buffer too small; sizes were still reported */
+  NIQKI_E_STATE = 5,       /* call not valid in the handle's current state */
+  NIQKI_E_NODEVICE = 6     /* no usable gfx950 device */
+};
+
+enum niqki_mem { NIQKI_MEM_HOST = 0, NIQKI_MEM_DEVICE = 1 };
+
+typedef struct niqki_index niqki_index; /* opaque */
+
+/* Constructor arguments: Index(lF,K,W,H,filename,min_fract),
+ * src/niqki_index.cpp:13-38 (output-file handling stays in the host program).
+ * Supported: 1<=K<=31 (K=32 is UB in the reference, :28-29), 1<=S<=15,
+ * H<=W<=15, S+W<=30. */
+typedef struct niqki_params {
+  uint32_t K;          /* k-mer length */
+  uint32_t S;          /* lF: log2 of the number of sketch slots */
+  uint32_t W;          /* fingerprint bits */
+  uint32_t H;          /* HyperLogLog bits inside the fingerprint */
+  uint32_t min_score;  /* hits need count >= min_score (niqki_min_score) */
+  uint32_t slot_begin; /* this shard owns sketch slots [slot_begin, slot_end); */
+  uint32_t slot_end;   /*   0,0 means the whole range [0, 2^S)                 */
+  int32_t device;      /* HIP device ordinal; -1 = current device */
+  uint32_t tile_genomes; /* genomes per counter tile (0 = choose); see DESIGN.md */
+  uint32_t reserved[3];
+} niqki_params;
+
+int niqki_abi_version(void);
+const char *niqki_status_string(int status);
+
+/* min_score = (uint32)(min_fract * 2^S): src/niqki_index.cpp:21-22 */
+uint32_t niqki_min_score(double min_fract, uint32_t S);
+
+/* Index::Index / Index::~Index: src/niqki_index.cpp:13-38, :106-109.
+ * Fails with NIQKI_E_NODEVICE when there is no GPU: there is no CPU path. */
+int niqki_create(const niqki_params *params, niqki_index **out);
+void niqki_destroy(niqki_index *ix);
+const char *niqki_last_error(const niqki_index *ix);
+int niqki_get_params(const niqki_index *ix, niqki_params *out);
+
+/* Work is enqueued on this hipStream_t (default: a stream the handle owns). */
+int niqki_set_stream(niqki_index *ix, void *hip_stream);
+void *niqki_get_stream(const niqki_index *ix);
+int niqki_synchronize(niqki_index *ix);
+
+/* Tuning knobs (no reference counterpart): "gather_variant", "query_batch",
+ * "tile_genomes" (multiple of 64, <= 65536; takes effect at the next build),
+ * "min_score". */
+int niqki_set_option(niqki_index *ix, const char *key, int64_t value);
+
+/* Pre-sizes the sketch store for n_genomes (optional; the store grows). */
+int niqki_reserve(niqki_index *ix, uint32_t n_genomes);
+
+/* Index::compute_sketch (src/niqki_index.cpp:335-358) including
+ * sketch_densification (:313-331), batched.
+ *   seqs        concatenated record bytes (ASCII, no newlines)
+ *   rec_off     n_rec+1 byte offsets into seqs
+ *   entry_rec   n_entry+1 record indices: sketch e accumulates records
+ *               [entry_rec[e], entry_rec[e+1]) (whole-file mode,
+ *               src/niqki_index.cpp:442-456); NULL = one record per sketch
+ *               (lines mode, :383-408) and then n_entry must equal n_rec
+ *   sketches    n_entry x F int32 out
+ * Records with length <= K contribute nothing (:395,:450).  Densification
+ * runs once per sketch after all its records (the reference's per-record
+ * densification hangs on multi-record files).  Where
+ * the reference would never terminate (B.2) the remaining cells stay -1. */
+int niqki_sketch(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off,
+                 uint32_t n_rec, const uint32_t *entry_rec, uint32_t n_entry,
+                 int32_t *sketches, int mem);
+
+/* Index::sketch_densification alone (src/niqki_index.cpp:313-331), in place. */
+int niqki_densify(niqki_index *ix, int32_t *sketches, uint32_t n, int mem);
+
+/* Index::insert_sketch (src/niqki_index.cpp:362-370) for n sketches; they get
+ * genome ids genome_count .. genome_count+n-1 in order, like the id counter of
+ * :396-401 / :479-490 does single-threaded. */
+int niqki_insert(niqki_index *ix, const int32_t *sketches, uint32_t n, int mem);
+
+/* Number of inserted genomes: Index::getNbGenomes, src/niqki_index.h:138-140 */
+uint32_t niqki_genome_count(const niqki_index *ix);
+
+/* Builds the device-resident inverted index (CSR per genome tile) from
+ * everything inserted so far.  Replaces the reference's incremental
+ * vector<gid> Buckets[] appends (src/niqki_index.h:55, :365-367).  Idempotent;
+ * the query calls run it when inserts are pending. */
+int niqki_build(niqki_index *ix);
+
+/* Counting half of Index::query_sketch (src/niqki_index.cpp:652-661): for
+ * query q, counts[q*stride + g] = number of this shard's slots whose bucket
+ * holds genome g.  uint16 counters like the reference's lF<=15 branch.
+ * stride >= genome_count (in elements), even.  This is the per-genome hit
+ * vector the multi-GPU path sums across slot shards. */
+int niqki_query_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq,
+                       uint16_t *counts, uint64_t stride, int mem);
+
+/* Threshold + order half of Index::query_sketch (src/niqki_index.cpp:662-666,
+ * :685): from (possibly cross-shard summed) counters of genomes
+ * [gid_begin, gid_begin+n_gids) produce, per query, the (count,gid) pairs with
+ * count >= min_score sorted by descending (count, gid).
+ *   hit_off     nq+1 exclusive prefix offsets (always exact, even on
+ *               NIQKI_E_CAPACITY)
+ *   hit_counts, hit_gids   capacity entries each
+ * Synchronises the stream when mem == NIQKI_MEM_HOST. */
+int niqki_hits_from_counts(niqki_index *ix, const uint16_t *counts, uint32_t nq,
+                           uint64_t stride, uint32_t gid_begin, uint32_t n_gids,
+                           uint64_t *hit_off, uint32_t *hit_counts,
+                           uint32_t *hit_gids, uint64_t capacity, int mem);
+
+/* Index::query_sketch (src/niqki_index.cpp:633-687), batched: both halves. */
+int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq,
+                uint64_t *hit_off, uint32_t *hit_counts, uint32_t *hit_gids,
+                uint64_t capacity, int mem);
+
+/* Index::query_sequence (src/niqki_index.cpp:691-695), batched: sketch +
+ * query.  Arguments as niqki_sketch / niqki_query. */
+int niqki_query_sequences(niqki_index *ix, const uint8_t *seqs,
+                          const uint64_t *rec_off, uint32_t n_rec,
+                          const uint32_t *entry_rec, uint32_t n_entry,
+                          uint64_t *hit_off, uint32_t *hit_counts,
+                          uint32_t *hit_gids, uint64_t capacity, int mem);
+
+/* Counting loop of Index::query_range (src/niqki_index.cpp:570-597): for
+ * target genomes t in [begin,end), counts[(t-begin)*stride + a] = number of
+ * buckets holding both a and t (the reference's counts[a*batch + t-begin];
+ * the matrix is symmetric).  uint16 like :572. */
+int niqki_matrix_range(niqki_index *ix, uint32_t begin, uint32_t end,
+                       uint16_t *counts, uint64_t stride, int mem);
+
+/* dump_index_disk payload (src/niqki_index.cpp:42-55), before gzip and
+ * without the trailing names: 6 x u32 header {lF,K,H,W,min_score,N} then per
+ * bucket u32 size + size x u32 gid, buckets in fp + slot*2^W order, gids
+ * ascending.  Call with buf == NULL to get the size.  Host memory only;
+ * whole-range handles only. */
+int niqki_export_dump(niqki_index *ix, uint8_t *buf, uint64_t capacity,
+                      uint64_t *size);
+
+/* Loading constructor (src/niqki_index.cpp:63-90) from the gunzipped bytes of
+ * a dump (names excluded; *consumed = offset of the first name byte).  The
+ * parameters stored in the dump override those given (like :67-72), except
+ * device / tile_genomes / slot range, which are taken from `params`. */
+int niqki_import_dump(const niqki_params *params, const uint8_t *buf,
+                      uint64_t len, uint64_t *consumed, niqki_index **out);
+
+/* Reads back the stored sketches of genomes [begin, begin+n) as n x F int32
+ * (slots outside the shard's range read -1). */
+int niqki_get_sketches(niqki_index *ix, uint32_t begin, uint32_t n,
+                       int32_t *sketches, int mem);
+
+/* Sum over the shard's slots of the bucket length each query touches (the T
+ * of the roofline formula).  Host out. Synchronises. */
+int niqki_query_gathered(niqki_index *ix, const int32_t *sketches, uint32_t nq,
+                         uint64_t *gathered_per_query, int mem);
+
+/* ---- measurement support -------------------------------------------------- */
+
+enum niqki_kernel_class {
+  NIQKI_KC_SKETCH = 0,   /* rolling hash + per-slot min */
+  NIQKI_KC_DENSIFY = 1,
+  NIQKI_KC_GATHER = 2,   /* gather-histogram over the inverted index */
+  NIQKI_KC_HITS = 3,     /* threshold + compaction + sort */
+  NIQKI_KC_BUILD = 4,    /* insert transpose + CSR build */
+  NIQKI_KC_COUNT = 5
+};
+
+/* When enabled, every launch of the classes above is bracketed by HIP events
+ * on the handle's stream; niqki_profile_read synchronises and returns the
+ * accumulated device time and launch count since the last reset. */
+int niqki_profile_enable(niqki_index *ix, int on);
+int niqki_profile_reset(niqki_index *ix);
+int niqki_profile_read(niqki_index *ix, int kernel_class, double *ms,
+                       uint64_t *launches);
+
+/* Deterministic synthetic genomes (bench / parity inputs):
+ * genome i is the ancestor of family[i] with per-base substitutions drawn for
+ * (family[i], member[i]) at rate rate14[i]/16384.  Output: n records of len
+ * bytes each, record i at out + i*stride.  Upper-case ACGT. The host and
+ * device generators produce identical bytes. */
+int niqki_synth_genomes(niqki_index *ix, uint64_t seed, const uint32_t *family,
+                        const uint32_t *member, const uint32_t *rate14,
+                        uint32_t n, uint64_t len, uint64_t stride, uint8_t *out,
+                        int mem);
+void niqki_synth_genome_host(uint64_t seed, uint32_t family, uint32_t member,
+                             uint32_t rate14, uint64_t len, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIQKI_HIP_H */

@@ -1,0 +1,349 @@
+"""ctypes binding of include/niqki_hip.h (libniqki_hip.so).
+
+Fails loudly when the shared library is missing or cannot be loaded: there is
+no CPU fallback for any entry point.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libniqki_hip.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+SEQ_PAD = 64
+KC_SKETCH, KC_DENSIFY, KC_GATHER, KC_HITS, KC_BUILD = 0, 1, 2, 3, 4
+E_CAPACITY = 4
+
+
+class NiqkiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("niqki status %d: %s" % (code, msg))
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("K", C.c_uint32), ("S", C.c_uint32), ("W", C.c_uint32), ("H", C.c_uint32),
+                ("min_score", C.c_uint32), ("slot_begin", C.c_uint32), ("slot_end", C.c_uint32),
+                ("device", C.c_int32), ("tile_genomes", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+def lib_path():
+    return _LIB
+
+
+def build_native(force=False):
+    """Compile libniqki_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", src, "-j4"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+# every symbol include/niqki_hip.h declares: (name, restype, argtypes)
+_vp, _u32, _u64, _i32, _i64, _int, _dbl = (C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32,
+                                         C.c_int64, C.c_int, C.c_double)
+ABI = [
+    ("niqki_abi_version", _int, []),
+    ("niqki_status_string", C.c_char_p, [_int]),
+    ("niqki_min_score", _u32, [_dbl, _u32]),
+    ("niqki_create", _int, [C.POINTER(Params), C.POINTER(_vp)]),
+    ("niqki_destroy", None, [_vp]),
+    ("niqki_last_error", C.c_char_p, [_vp]),
+    ("niqki_get_params", _int, [_vp, C.POINTER(Params)]),
+    ("niqki_set_stream", _int, [_vp, _vp]),
+    ("niqki_get_stream", _vp, [_vp]),
+    ("niqki_synchronize", _int, [_vp]),
+    ("niqki_set_option", _int, [_vp, C.c_char_p, _i64]),
+    ("niqki_reserve", _int, [_vp, _u32]),
+    ("niqki_sketch", _int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _int]),
+    ("niqki_densify", _int, [_vp, _vp, _u32, _int]),
+    ("niqki_insert", _int, [_vp, _vp, _u32, _int]),
+    ("niqki_genome_count", _u32, [_vp]),
+    ("niqki_build", _int, [_vp]),
+    ("niqki_query_counts", _int, [_vp, _vp, _u32, _vp, _u64, _int]),
+    ("niqki_hits_from_counts", _int, [_vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_query", _int, [_vp, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_query_sequences", _int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_matrix_range", _int, [_vp, _u32, _u32, _vp, _u64, _int]),
+    ("niqki_export_dump", _int, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    ("niqki_import_dump", _int, [C.POINTER(Params), _vp, _u64, C.POINTER(_u64), C.POINTER(_vp)]),
+    ("niqki_get_sketches", _int, [_vp, _u32, _u32, _vp, _int]),
+    ("niqki_query_gathered", _int, [_vp, _vp, _u32, _vp, _int]),
+    ("niqki_profile_enable", _int, [_vp, _int]),
+    ("niqki_profile_reset", _int, [_vp]),
+    ("niqki_profile_read", _int, [_vp, _int, C.POINTER(_dbl), C.POINTER(_u64)]),
+    ("niqki_synth_genomes", _int, [_vp, _u64, _vp, _vp, _vp, _u32, _u64, _u64, _vp, _int]),
+    ("niqki_synth_genome_host", None, [_u64, _u32, _u32, _u32, _u64, _vp]),
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise ImportError("%s is missing: run __graft_entry__.build() (make -C niqki_amd/csrc); "
+                              "there is no fallback path" % _LIB)
+        L = C.CDLL(_LIB)
+        for name, res, args in ABI:
+            f = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def min_score(J, S):
+    return lib().niqki_min_score(J, S)
+
+
+def synth_genome_host(seed, family, member, rate14, length):
+    out = np.empty(length, dtype=np.uint8)
+    lib().niqki_synth_genome_host(seed, family, member, rate14, length, out.ctypes.data)
+    return out
+
+
+def _p(x):
+    """numpy array / torch tensor / int / None -> raw address."""
+    if x is None:
+        return None
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()  # torch tensor
+
+
+class Engine:
+    """One handle = one GPU (or one slot shard of an index)."""
+
+    def __init__(self, K=31, S=15, W=12, H=4, J=0.0, min_score_value=None, device=-1,
+                 slot_begin=0, slot_end=0, tile_genomes=0, _handle=None):
+        self.L = lib()
+        if _handle is not None:
+            self.h = _handle
+        else:
+            ms = self.L.niqki_min_score(J, S) if min_score_value is None else min_score_value
+            p = Params(K, S, W, H, ms, slot_begin, slot_end, device, tile_genomes)
+            h = _vp()
+            rc = self.L.niqki_create(C.byref(p), C.byref(h))
+            if rc:
+                raise NiqkiError(rc, self.L.niqki_status_string(rc).decode())
+            self.h = h
+        q = Params()
+        self.L.niqki_get_params(self.h, C.byref(q))
+        self.K, self.S, self.W, self.H, self.min_score = q.K, q.S, q.W, q.H, q.min_score
+        self.slot_begin, self.slot_end, self.device = q.slot_begin, q.slot_end, q.device
+        self.F = 1 << self.S
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.niqki_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, allow=()):
+        if rc and rc not in allow:
+            raise NiqkiError(rc, "%s (%s)" % (self.L.niqki_status_string(rc).decode(),
+                                              self.L.niqki_last_error(self.h).decode()))
+        return rc
+
+    # -- plumbing
+    def set_stream(self, stream_ptr):
+        self._ck(self.L.niqki_set_stream(self.h, stream_ptr))
+
+    def synchronize(self):
+        self._ck(self.L.niqki_synchronize(self.h))
+
+    def set_option(self, key, value):
+        self._ck(self.L.niqki_set_option(self.h, key.encode(), int(value)))
+
+    def reserve(self, n):
+        self._ck(self.L.niqki_reserve(self.h, n))
+
+    @property
+    def n_genomes(self):
+        return self.L.niqki_genome_count(self.h)
+
+    def tile_genomes(self):
+        q = Params()
+        self.L.niqki_get_params(self.h, C.byref(q))
+        return q.tile_genomes
+
+    # -- host-memory convenience (numpy in / numpy out)
+    @staticmethod
+    def pack_records(records):
+        """list of bytes/str/uint8 arrays -> (seqs uint8, rec_off uint64)."""
+        arrs = []
+        for r in records:
+            if isinstance(r, str):
+                r = r.encode()
+            if isinstance(r, (bytes, bytearray)):
+                r = np.frombuffer(bytes(r), dtype=np.uint8)
+            arrs.append(np.ascontiguousarray(r, dtype=np.uint8))
+        off = np.zeros(len(arrs) + 1, dtype=np.uint64)
+        if arrs:
+            off[1:] = np.cumsum([a.size for a in arrs], dtype=np.uint64)
+        seqs = np.concatenate(arrs) if arrs else np.zeros(0, dtype=np.uint8)
+        return np.ascontiguousarray(seqs), off
+
+    def sketch(self, records, entry_rec=None):
+        seqs, off = self.pack_records(records)
+        n_rec = off.size - 1
+        if entry_rec is None:
+            n_entry, er = n_rec, None
+        else:
+            er = np.ascontiguousarray(entry_rec, dtype=np.uint32)
+            n_entry = er.size - 1
+        out = np.empty((n_entry, self.F), dtype=np.int32)
+        self._ck(self.L.niqki_sketch(self.h, _p(seqs) if seqs.size else _p(np.zeros(1, np.uint8)),
+                                     _p(off), n_rec, _p(er), n_entry, _p(out), MEM_HOST))
+        return out
+
+    def densify(self, sketches):
+        sk = np.ascontiguousarray(sketches, dtype=np.int32).copy()
+        sk2 = sk.reshape(-1, self.F)
+        self._ck(self.L.niqki_densify(self.h, _p(sk2), sk2.shape[0], MEM_HOST))
+        return sk
+
+    def insert(self, sketches):
+        sk = np.ascontiguousarray(sketches, dtype=np.int32).reshape(-1, self.F)
+        self._ck(self.L.niqki_insert(self.h, _p(sk), sk.shape[0], MEM_HOST))
+
+    def build(self):
+        self._ck(self.L.niqki_build(self.h))
+
+    def query_counts(self, sketches):
+        sk = np.ascontiguousarray(sketches, dtype=np.int32).reshape(-1, self.F)
+        n = self.n_genomes
+        stride = (n + 1) & ~1
+        out = np.zeros((sk.shape[0], max(stride, 2)), dtype=np.uint16)
+        self._ck(self.L.niqki_query_counts(self.h, _p(sk), sk.shape[0], _p(out), out.shape[1], MEM_HOST))
+        return out[:, :n]
+
+    def _hits(self, call, nq, capacity):
+        off = np.zeros(nq + 1, dtype=np.uint64)
+        while True:
+            hc = np.empty(max(capacity, 1), dtype=np.uint32)
+            hg = np.empty(max(capacity, 1), dtype=np.uint32)
+            rc = call(off, hc, hg, capacity)
+            self._ck(rc, allow=(E_CAPACITY,))
+            if rc == 0:
+                tot = int(off[nq])
+                return off, hc[:tot], hg[:tot]
+            capacity = int(off[nq])
+
+    def query(self, sketches, capacity=None):
+        sk = np.ascontiguousarray(sketches, dtype=np.int32).reshape(-1, self.F)
+        nq = sk.shape[0]
+        cap = capacity if capacity is not None else max(1024, nq * 64)
+        return self._hits(lambda off, hc, hg, c: self.L.niqki_query(
+            self.h, _p(sk), nq, _p(off), _p(hc), _p(hg), c, MEM_HOST), nq, cap)
+
+    def hits_from_counts(self, counts, gid_begin=0, n_gids=None, capacity=None):
+        ct = np.ascontiguousarray(counts, dtype=np.uint16)
+        nq, stride = ct.shape
+        ng = stride - gid_begin if n_gids is None else n_gids
+        cap = capacity if capacity is not None else max(1024, nq * 64)
+        return self._hits(lambda off, hc, hg, c: self.L.niqki_hits_from_counts(
+            self.h, _p(ct), nq, stride, gid_begin, ng, _p(off), _p(hc), _p(hg), c, MEM_HOST), nq, cap)
+
+    def query_sequences(self, records, capacity=None):
+        seqs, off = self.pack_records(records)
+        nq = off.size - 1
+        cap = capacity if capacity is not None else max(1024, nq * 64)
+        return self._hits(lambda ho, hc, hg, c: self.L.niqki_query_sequences(
+            self.h, _p(seqs), _p(off), nq, None, nq, _p(ho), _p(hc), _p(hg), c, MEM_HOST), nq, cap)
+
+    def matrix_range(self, begin, end):
+        n = self.n_genomes
+        stride = max((n + 1) & ~1, 2)
+        out = np.zeros((end - begin, stride), dtype=np.uint16)
+        self._ck(self.L.niqki_matrix_range(self.h, begin, end, _p(out), stride, MEM_HOST))
+        return out[:, :n]
+
+    def get_sketches(self, begin, n):
+        out = np.empty((n, self.F), dtype=np.int32)
+        self._ck(self.L.niqki_get_sketches(self.h, begin, n, _p(out), MEM_HOST))
+        return out
+
+    def gathered(self, sketches):
+        sk = np.ascontiguousarray(sketches, dtype=np.int32).reshape(-1, self.F)
+        out = np.zeros(sk.shape[0], dtype=np.uint64)
+        self._ck(self.L.niqki_query_gathered(self.h, _p(sk), sk.shape[0], _p(out), MEM_HOST))
+        return out
+
+    def export_dump(self):
+        size = _u64(0)
+        self._ck(self.L.niqki_export_dump(self.h, None, 0, C.byref(size)))
+        buf = np.empty(size.value, dtype=np.uint8)
+        self._ck(self.L.niqki_export_dump(self.h, _p(buf), buf.size, C.byref(size)))
+        return buf.tobytes()
+
+    @classmethod
+    def import_dump(cls, data, device=-1, tile_genomes=0):
+        L = lib()
+        buf = np.frombuffer(data, dtype=np.uint8)
+        p = Params(31, 15, 12, 4, 0, 0, 0, device, tile_genomes)
+        h = _vp()
+        consumed = _u64(0)
+        rc = L.niqki_import_dump(C.byref(p), _p(buf), buf.size, C.byref(consumed), C.byref(h))
+        if rc:
+            raise NiqkiError(rc, L.niqki_status_string(rc).decode())
+        e = cls(_handle=h)
+        e.names_offset = consumed.value
+        return e
+
+    # -- profiling
+    def profile(self, on=True):
+        self._ck(self.L.niqki_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._ck(self.L.niqki_profile_reset(self.h))
+
+    def profile_read(self, kc):
+        ms, n = _dbl(0), _u64(0)
+        self._ck(self.L.niqki_profile_read(self.h, kc, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # -- raw device-pointer calls (torch tensors or addresses)
+    def synth_dev(self, seed, family, member, rate14, n, length, stride, out):
+        self._ck(self.L.niqki_synth_genomes(self.h, seed, _p(family), _p(member), _p(rate14), n,
+                                            length, stride, _p(out), MEM_DEVICE))
+
+    def sketch_dev(self, seqs, rec_off, n_rec, sketches, entry_rec=None, n_entry=None):
+        self._ck(self.L.niqki_sketch(self.h, _p(seqs), _p(rec_off), n_rec, _p(entry_rec),
+                                     n_rec if n_entry is None else n_entry, _p(sketches), MEM_DEVICE))
+
+    def insert_dev(self, sketches, n):
+        self._ck(self.L.niqki_insert(self.h, _p(sketches), n, MEM_DEVICE))
+
+    def query_counts_dev(self, sketches, nq, counts, stride):
+        self._ck(self.L.niqki_query_counts(self.h, _p(sketches), nq, _p(counts), stride, MEM_DEVICE))
+
+    def hits_from_counts_dev(self, counts, nq, stride, gid_begin, n_gids, hit_off, hc, hg, capacity):
+        self._ck(self.L.niqki_hits_from_counts(self.h, _p(counts), nq, stride, gid_begin, n_gids,
+                                               _p(hit_off), _p(hc), _p(hg), capacity, MEM_DEVICE))
+
+    def query_dev(self, sketches, nq, hit_off, hc, hg, capacity):
+        self._ck(self.L.niqki_query(self.h, _p(sketches), nq, _p(hit_off), _p(hc), _p(hg), capacity,
+                                    MEM_DEVICE))
+
+    def query_sequences_dev(self, seqs, rec_off, n, hit_off, hc, hg, capacity):
+        self._ck(self.L.niqki_query_sequences(self.h, _p(seqs), _p(rec_off), n, None, n, _p(hit_off),
+                                              _p(hc), _p(hg), capacity, MEM_DEVICE))
+
+    def gathered_dev(self, sketches, nq):
+        out = np.zeros(nq, dtype=np.uint64)
+        self._ck(self.L.niqki_query_gathered(self.h, _p(sketches), nq, _p(out), MEM_DEVICE))
+        return out

@@ -1,0 +1,870 @@
+// nq_api.hip -- the C ABI of libniqki_hip.so (include/niqki_hip.h): handle,
+// device memory, staging of host buffers, and the launch sequences.  No
+// compute happens on the host here and there is no CPU fallback: without a
+// gfx950 device niqki_create fails.
+#include "../../include/niqki_hip.h"
+#include "nq_kernels.h"
+#include "nq_synth.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Buf {
+  void *p = nullptr;
+  size_t n = 0;
+};
+
+struct ProfSpan {
+  int kc;
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct niqki_index {
+  niqki_params p{};
+  nq::Derived d{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // sketch store, u16 [f_local][cap]
+  uint16_t *store = nullptr;
+  uint64_t cap = 0;
+  uint32_t n_genomes = 0;
+
+  // inverted index
+  uint32_t tile = 0, n_tiles = 0, built_n = 0;
+  uint32_t *offsets = nullptr;
+  uint16_t *gids = nullptr;
+  size_t offsets_bytes = 0, gids_bytes = 0;
+  bool built = false;
+
+  int gather_variant = 0;
+  uint32_t query_batch = 1024;
+
+  Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
+      ws_misc;
+
+  bool prof = false;
+  double prof_ms[NIQKI_KC_COUNT] = {0};
+  uint64_t prof_n[NIQKI_KC_COUNT] = {0};
+  std::vector<ProfSpan> spans;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int fail(niqki_index *ix, int code, const std::string &msg) {
+  if (ix) ix->err = msg;
+  return code;
+}
+
+#define NQ_HIP(ix, call)                                                                    \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(ix, e_ == hipErrorOutOfMemory ? NIQKI_E_NOMEM : NIQKI_E_HIP,              \
+                  std::string(#call) + ": " + hipGetErrorString(e_));                       \
+  } while (0)
+
+int ensure(niqki_index *ix, Buf &b, size_t bytes) {
+  if (bytes <= b.n && b.p) return NIQKI_OK;
+  if (b.p) NQ_HIP(ix, hipFree(b.p));
+  b.p = nullptr;
+  b.n = 0;
+  size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    want = std::max<size_t>(bytes, 256);
+    NQ_HIP(ix, hipMalloc(&b.p, want));
+  }
+  b.n = want;
+  return NIQKI_OK;
+}
+
+hipEvent_t get_event(niqki_index *ix) {
+  if (!ix->ev_pool.empty()) {
+    hipEvent_t e = ix->ev_pool.back();
+    ix->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+struct Span {
+  niqki_index *ix;
+  int kc;
+  hipEvent_t a = nullptr, b = nullptr;
+  Span(niqki_index *ix_, int kc_) : ix(ix_), kc(kc_) {
+    if (ix->prof) {
+      a = get_event(ix);
+      b = get_event(ix);
+      (void)hipEventRecord(a, ix->stream);
+    }
+  }
+  ~Span() {
+    if (ix->prof && a && b) {
+      (void)hipEventRecord(b, ix->stream);
+      ix->spans.push_back({kc, a, b});
+    }
+  }
+};
+
+int collect_spans(niqki_index *ix) {
+  if (ix->spans.empty()) return NIQKI_OK;
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  for (auto &s : ix->spans) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      ix->prof_ms[s.kc] += ms;
+      ix->prof_n[s.kc] += 1;
+    }
+    ix->ev_pool.push_back(s.a);
+    ix->ev_pool.push_back(s.b);
+  }
+  ix->spans.clear();
+  return NIQKI_OK;
+}
+
+int derive(const niqki_params &p, nq::Derived &d, std::string &why) {
+  if (p.K < 1 || p.K > 31) { why = "K must be in 1..31"; return NIQKI_E_INVALID; }
+  if (p.S < 1 || p.S > 15) { why = "S must be in 1..15"; return NIQKI_E_INVALID; }
+  if (p.W < 1 || p.W > 15 || p.H > p.W) { why = "need H <= W <= 15"; return NIQKI_E_INVALID; }
+  if (p.S + p.W > 30) { why = "S+W must be <= 30"; return NIQKI_E_INVALID; }
+  d.K = p.K; d.S = p.S; d.W = p.W; d.H = p.H; d.M = p.W - p.H;
+  d.F = 1u << p.S;
+  d.R = 1u << p.W;
+  d.mask_m = (1u << d.M) - 1u;
+  d.max_rem = (1u << p.H) - 1u;
+  d.min_score = p.min_score;
+  d.slot_begin = p.slot_begin;
+  d.slot_end = p.slot_end;
+  if (d.slot_begin == 0 && d.slot_end == 0) d.slot_end = d.F;
+  if (d.slot_begin >= d.slot_end || d.slot_end > d.F) { why = "bad slot range"; return NIQKI_E_INVALID; }
+  d.kmer_mask = (1ULL << (2 * p.K)) - 1ULL;
+  return NIQKI_OK;
+}
+
+nq::IndexView view(const niqki_index *ix) {
+  nq::IndexView v;
+  v.d = ix->d;
+  v.n_genomes = ix->built_n;
+  v.tile = ix->tile;
+  v.n_tiles = ix->n_tiles;
+  v.f_local = ix->d.slot_end - ix->d.slot_begin;
+  v.cap = ix->cap;
+  v.store = ix->store;
+  v.offsets = ix->offsets;
+  v.gids = ix->gids;
+  return v;
+}
+
+int reserve_store(niqki_index *ix, uint64_t want) {
+  if (want <= ix->cap) return NIQKI_OK;
+  uint64_t cap = std::max<uint64_t>(want, ix->cap * 2);
+  cap = (cap + 63) / 64 * 64;
+  const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
+  uint16_t *ns = nullptr;
+  hipError_t e = hipMalloc((void **)&ns, (size_t)f_local * cap * 2);
+  if (e != hipSuccess && cap > (want + 63) / 64 * 64) {
+    cap = (want + 63) / 64 * 64;
+    e = hipMalloc((void **)&ns, (size_t)f_local * cap * 2);
+  }
+  if (e != hipSuccess) return fail(ix, NIQKI_E_NOMEM, "sketch store allocation failed");
+  if (ix->store && ix->n_genomes) {
+    NQ_HIP(ix, hipMemcpy2DAsync(ns, cap * 2, ix->store, ix->cap * 2, (size_t)ix->n_genomes * 2, f_local,
+                                hipMemcpyDeviceToDevice, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  }
+  if (ix->store) NQ_HIP(ix, hipFree(ix->store));
+  ix->store = ns;
+  ix->cap = cap;
+  return NIQKI_OK;
+}
+
+// Launches the sketch kernel(s) on device-resident inputs.
+int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, uint32_t n_rec,
+               const uint32_t *entry_rec, uint32_t n_entry, int32_t *sketches, uint64_t total_bytes) {
+  if (n_entry == 0) return NIQKI_OK;
+  nq::SketchArgs a;
+  a.d = ix->d;
+  a.seqs = seqs;
+  a.rec_off = rec_off;
+  a.entry_rec = entry_rec;
+  a.sketches = sketches;
+  a.accumulate = 0;
+  a.densify = 1;
+  a.splits = 1;
+  const uint64_t avg = total_bytes / n_entry;
+  const bool short_records = avg < 16384;
+  if (!short_records && !entry_rec && n_entry < 128 && avg >= (1u << 20))
+    a.splits = std::min<uint32_t>(32, 512 / n_entry);
+  if (a.splits > 1) {
+    {
+      Span sp(ix, NIQKI_KC_SKETCH);
+      NQ_HIP(ix, nq::launch_fill_u32((uint32_t *)sketches, (uint64_t)n_entry * ix->d.F, nq::kEmpty32,
+                                     ix->stream));
+      a.densify = 0;
+      NQ_HIP(ix, nq::launch_sketch(a, n_entry, false, ix->stream));
+    }
+    Span sp(ix, NIQKI_KC_DENSIFY);
+    nq::SketchArgs b = a;
+    b.seqs = nullptr;
+    b.splits = 1;
+    b.accumulate = 1;
+    b.densify = 1;
+    NQ_HIP(ix, nq::launch_sketch(b, n_entry, false, ix->stream));
+  } else {
+    Span sp(ix, NIQKI_KC_SKETCH);
+    NQ_HIP(ix, nq::launch_sketch(a, n_entry, short_records, ix->stream));
+  }
+  (void)n_rec;
+  return NIQKI_OK;
+}
+
+int build_if_needed(niqki_index *ix) {
+  if (ix->built && ix->built_n == ix->n_genomes) return NIQKI_OK;
+  return niqki_build(ix);
+}
+
+// counts for nq device-resident sketches into a device buffer
+int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *counts, uint64_t stride) {
+  int rc = build_if_needed(ix);
+  if (rc) return rc;
+  if (nq == 0) return NIQKI_OK;
+  if (stride < ix->built_n || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
+  if (ix->built_n == 0) return NIQKI_OK;
+  Span sp(ix, NIQKI_KC_GATHER);
+  NQ_HIP(ix, nq::launch_gather(view(ix), sketches, nq, counts, stride, ix->gather_variant, ix->stream));
+  return NIQKI_OK;
+}
+
+// hits from device-resident counters into device buffers; hit_off device (nq+1)
+int hits_dev(niqki_index *ix, const uint16_t *counts, uint32_t nq, uint64_t stride, uint32_t gid_begin,
+             uint32_t n_gids, unsigned long long *hit_off, uint32_t *hc, uint32_t *hg, uint64_t capacity,
+             bool check_capacity, uint64_t *total_out) {
+  nq::HitsArgs a;
+  a.counts = counts;
+  a.stride = stride;
+  a.nq = nq;
+  a.gid_begin = gid_begin;
+  a.n_gids = n_gids;
+  a.min_score = ix->d.min_score;
+  a.n_blk = (n_gids + nq::kHitsBlk - 1) / nq::kHitsBlk;
+  a.hit_off = hit_off;
+  a.hit_counts = hc;
+  a.hit_gids = hg;
+  a.capacity = capacity;
+  if (nq == 0 || a.n_blk == 0) {
+    NQ_HIP(ix, hipMemsetAsync(hit_off, 0, (size_t)(nq + 1) * 8, ix->stream));
+    if (total_out) *total_out = 0;
+    return NIQKI_OK;
+  }
+  int rc = ensure(ix, ix->ws_blk, (size_t)nq * a.n_blk * 4);
+  if (rc) return rc;
+  if ((rc = ensure(ix, ix->ws_tc, (size_t)std::max<uint64_t>(capacity, 1) * 4))) return rc;
+  if ((rc = ensure(ix, ix->ws_tg, (size_t)std::max<uint64_t>(capacity, 1) * 4))) return rc;
+  a.blk_counts = (uint32_t *)ix->ws_blk.p;
+  a.tmp_counts = (uint32_t *)ix->ws_tc.p;
+  a.tmp_gids = (uint32_t *)ix->ws_tg.p;
+  Span sp(ix, NIQKI_KC_HITS);
+  NQ_HIP(ix, nq::launch_hits_count(a, ix->stream));
+  if (check_capacity) {
+    unsigned long long total = 0;
+    NQ_HIP(ix, hipMemcpyAsync(&total, hit_off + nq, 8, hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    if (total_out) *total_out = total;
+    if (total > capacity) return NIQKI_E_CAPACITY;
+  }
+  NQ_HIP(ix, nq::launch_hits_emit(a, ix->stream));
+  return NIQKI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int niqki_abi_version(void) { return NIQKI_ABI_VERSION; }
+
+const char *niqki_status_string(int s) {
+  switch (s) {
+    case NIQKI_OK: return "ok";
+    case NIQKI_E_INVALID: return "invalid argument";
+    case NIQKI_E_NOMEM: return "out of memory";
+    case NIQKI_E_HIP: return "HIP runtime error";
+    case NIQKI_E_CAPACITY: return "output capacity too small";
+    case NIQKI_E_STATE: return "invalid state";
+    case NIQKI_E_NODEVICE: return "no gfx950 device";
+    default: return "unknown status";
+  }
+}
+
+uint32_t niqki_min_score(double min_fract, uint32_t S) {
+  double f = (double)(1u << S);
+  return (uint32_t)(min_fract * f);
+}
+
+int niqki_create(const niqki_params *params, niqki_index **out) {
+  if (!params || !out) return NIQKI_E_INVALID;
+  *out = nullptr;
+  niqki_index *ix = new (std::nothrow) niqki_index();
+  if (!ix) return NIQKI_E_NOMEM;
+  ix->p = *params;
+  std::string why;
+  int rc = derive(*params, ix->d, why);
+  if (rc) { delete ix; return rc; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { delete ix; return NIQKI_E_NODEVICE; }
+  int dev = params->device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { delete ix; return NIQKI_E_NODEVICE; }
+  if (dev >= ndev || hipSetDevice(dev) != hipSuccess) { delete ix; return NIQKI_E_NODEVICE; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete ix; return NIQKI_E_NODEVICE; }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete ix; return NIQKI_E_NODEVICE; }
+  ix->device = dev;
+  if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) { delete ix; return NIQKI_E_HIP; }
+  ix->own_stream = true;
+  if (const char *v = std::getenv("NIQKI_GATHER_VARIANT")) ix->gather_variant = std::atoi(v);
+  *out = ix;
+  return NIQKI_OK;
+}
+
+void niqki_destroy(niqki_index *ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  (void)hipStreamSynchronize(ix->stream);
+  for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
+                 &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc})
+    if (b->p) (void)hipFree(b->p);
+  if (ix->store) (void)hipFree(ix->store);
+  if (ix->offsets) (void)hipFree(ix->offsets);
+  if (ix->gids) (void)hipFree(ix->gids);
+  for (auto &s : ix->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+  for (auto e : ix->ev_pool) (void)hipEventDestroy(e);
+  if (ix->own_stream) (void)hipStreamDestroy(ix->stream);
+  delete ix;
+}
+
+const char *niqki_last_error(const niqki_index *ix) { return ix ? ix->err.c_str() : "null handle"; }
+
+int niqki_get_params(const niqki_index *ix, niqki_params *out) {
+  if (!ix || !out) return NIQKI_E_INVALID;
+  *out = ix->p;
+  out->slot_begin = ix->d.slot_begin;
+  out->slot_end = ix->d.slot_end;
+  out->device = ix->device;
+  out->tile_genomes = ix->tile ? ix->tile : ix->p.tile_genomes;
+  return NIQKI_OK;
+}
+
+int niqki_set_stream(niqki_index *ix, void *s) {
+  if (!ix) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  if (ix->own_stream) { (void)hipStreamDestroy(ix->stream); ix->own_stream = false; }
+  ix->stream = (hipStream_t)s;
+  return NIQKI_OK;
+}
+
+void *niqki_get_stream(const niqki_index *ix) { return ix ? (void *)ix->stream : nullptr; }
+
+int niqki_synchronize(niqki_index *ix) {
+  if (!ix) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  return NIQKI_OK;
+}
+
+int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
+  if (!ix || !key) return NIQKI_E_INVALID;
+  if (!std::strcmp(key, "gather_variant")) { ix->gather_variant = (int)value; return NIQKI_OK; }
+  if (!std::strcmp(key, "query_batch")) { if (value < 1) return NIQKI_E_INVALID; ix->query_batch = (uint32_t)value; return NIQKI_OK; }
+  if (!std::strcmp(key, "tile_genomes")) {
+    if (value < 0 || value > 65536 || (value & 63)) return fail(ix, NIQKI_E_INVALID, "tile_genomes must be a multiple of 64, <= 65536");
+    ix->p.tile_genomes = (uint32_t)value;
+    ix->built = false;
+    return NIQKI_OK;
+  }
+  if (!std::strcmp(key, "min_score")) { ix->p.min_score = ix->d.min_score = (uint32_t)value; return NIQKI_OK; }
+  return fail(ix, NIQKI_E_INVALID, std::string("unknown option ") + key);
+}
+
+int niqki_reserve(niqki_index *ix, uint32_t n_genomes) {
+  if (!ix) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  return reserve_store(ix, n_genomes);
+}
+
+int niqki_sketch(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, uint32_t n_rec,
+                 const uint32_t *entry_rec, uint32_t n_entry, int32_t *sketches, int mem) {
+  if (!ix || (!seqs && n_rec) || !rec_off || (!sketches && n_entry)) return NIQKI_E_INVALID;
+  if (!entry_rec && n_entry != n_rec) return fail(ix, NIQKI_E_INVALID, "n_entry must equal n_rec without entry_rec");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  if (n_entry == 0) return NIQKI_OK;
+  const size_t sk_bytes = (size_t)n_entry * ix->d.F * 4;
+  if (mem == NIQKI_MEM_DEVICE) {
+    // total size is only needed to pick the launch shape: read the last offset
+    uint64_t total = 0;
+    NQ_HIP(ix, hipMemcpyAsync(&total, rec_off + n_rec, 8, hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    return sketch_dev(ix, seqs, rec_off, n_rec, entry_rec, n_entry, sketches, total);
+  }
+  const uint64_t total = rec_off[n_rec];
+  int rc;
+  if ((rc = ensure(ix, ix->ws_seq, (size_t)total + NIQKI_SEQ_PAD))) return rc;
+  if ((rc = ensure(ix, ix->ws_recoff, (size_t)(n_rec + 1) * 8))) return rc;
+  if ((rc = ensure(ix, ix->ws_sk, sk_bytes))) return rc;
+  NQ_HIP(ix, hipMemcpyAsync(ix->ws_seq.p, seqs, total, hipMemcpyHostToDevice, ix->stream));
+  NQ_HIP(ix, hipMemsetAsync((uint8_t *)ix->ws_seq.p + total, 0, NIQKI_SEQ_PAD, ix->stream));
+  NQ_HIP(ix, hipMemcpyAsync(ix->ws_recoff.p, rec_off, (size_t)(n_rec + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+  const uint32_t *d_entry = nullptr;
+  if (entry_rec) {
+    if ((rc = ensure(ix, ix->ws_entry, (size_t)(n_entry + 1) * 4))) return rc;
+    NQ_HIP(ix, hipMemcpyAsync(ix->ws_entry.p, entry_rec, (size_t)(n_entry + 1) * 4, hipMemcpyHostToDevice, ix->stream));
+    d_entry = (const uint32_t *)ix->ws_entry.p;
+  }
+  rc = sketch_dev(ix, (const uint8_t *)ix->ws_seq.p, (const uint64_t *)ix->ws_recoff.p, n_rec, d_entry,
+                  n_entry, (int32_t *)ix->ws_sk.p, total);
+  if (rc) return rc;
+  NQ_HIP(ix, hipMemcpyAsync(sketches, ix->ws_sk.p, sk_bytes, hipMemcpyDeviceToHost, ix->stream));
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  return NIQKI_OK;
+}
+
+int niqki_densify(niqki_index *ix, int32_t *sketches, uint32_t n, int mem) {
+  if (!ix || (!sketches && n)) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  if (n == 0) return NIQKI_OK;
+  int32_t *d_sk = sketches;
+  const size_t bytes = (size_t)n * ix->d.F * 4;
+  if (mem == NIQKI_MEM_HOST) {
+    int rc = ensure(ix, ix->ws_sk, bytes);
+    if (rc) return rc;
+    NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, sketches, bytes, hipMemcpyHostToDevice, ix->stream));
+    d_sk = (int32_t *)ix->ws_sk.p;
+  }
+  nq::SketchArgs a;
+  a.d = ix->d;
+  a.seqs = nullptr;
+  a.rec_off = nullptr;
+  a.entry_rec = nullptr;
+  a.sketches = d_sk;
+  a.splits = 1;
+  a.accumulate = 1;
+  a.densify = 1;
+  {
+    Span sp(ix, NIQKI_KC_DENSIFY);
+    NQ_HIP(ix, nq::launch_sketch(a, n, ix->d.F <= 4096, ix->stream));
+  }
+  if (mem == NIQKI_MEM_HOST) {
+    NQ_HIP(ix, hipMemcpyAsync(sketches, d_sk, bytes, hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  }
+  return NIQKI_OK;
+}
+
+int niqki_insert(niqki_index *ix, const int32_t *sketches, uint32_t n, int mem) {
+  if (!ix || (!sketches && n)) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  if (n == 0) return NIQKI_OK;
+  if ((uint64_t)ix->n_genomes + n > 0xFFFFFFFFull) return fail(ix, NIQKI_E_INVALID, "too many genomes");
+  int rc = reserve_store(ix, (uint64_t)ix->n_genomes + n);
+  if (rc) return rc;
+  const int32_t *d_sk = sketches;
+  if (mem == NIQKI_MEM_HOST) {
+    const size_t bytes = (size_t)n * ix->d.F * 4;
+    if ((rc = ensure(ix, ix->ws_sk, bytes))) return rc;
+    NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, sketches, bytes, hipMemcpyHostToDevice, ix->stream));
+    d_sk = (const int32_t *)ix->ws_sk.p;
+  }
+  {
+    Span sp(ix, NIQKI_KC_BUILD);
+    NQ_HIP(ix, nq::launch_store_insert(ix->d, d_sk, n, ix->store, ix->cap, ix->n_genomes, ix->stream));
+  }
+  if (mem == NIQKI_MEM_HOST) NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  ix->n_genomes += n;
+  ix->built = false;
+  return NIQKI_OK;
+}
+
+uint32_t niqki_genome_count(const niqki_index *ix) { return ix ? ix->n_genomes : 0; }
+
+int niqki_build(niqki_index *ix) {
+  if (!ix) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  const uint32_t N = ix->n_genomes;
+  const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
+  uint32_t tile = ix->p.tile_genomes;
+  if (const char *v = std::getenv("NIQKI_TILE_GENOMES")) tile = (uint32_t)std::atoi(v);
+  if (tile == 0 || tile > 65536 || (tile & 63)) {
+    // as few tiles as the 16-bit tile-local ids and the LDS counter array allow
+    uint32_t nt = std::max<uint32_t>(1, (N + 65535) / 65536);
+    tile = ((N + nt - 1) / nt + 63) / 64 * 64;
+    if (tile == 0) tile = 64;
+  }
+  const uint32_t n_tiles = (N + tile - 1) / tile;
+  const size_t ob = (size_t)n_tiles * f_local * (ix->d.R + 1) * 4;
+  const size_t gb = (size_t)n_tiles * f_local * tile * 2;
+  if (ob > ix->offsets_bytes) {
+    if (ix->offsets) NQ_HIP(ix, hipFree(ix->offsets));
+    ix->offsets = nullptr; ix->offsets_bytes = 0;
+    NQ_HIP(ix, hipMalloc((void **)&ix->offsets, std::max<size_t>(ob, 256)));
+    ix->offsets_bytes = std::max<size_t>(ob, 256);
+  }
+  if (gb > ix->gids_bytes) {
+    if (ix->gids) NQ_HIP(ix, hipFree(ix->gids));
+    ix->gids = nullptr; ix->gids_bytes = 0;
+    NQ_HIP(ix, hipMalloc((void **)&ix->gids, std::max<size_t>(gb, 256)));
+    ix->gids_bytes = std::max<size_t>(gb, 256);
+  }
+  ix->tile = tile;
+  ix->n_tiles = n_tiles;
+  ix->built_n = N;
+  {
+    Span sp(ix, NIQKI_KC_BUILD);
+    NQ_HIP(ix, nq::launch_build(view(ix), ix->offsets, ix->gids, ix->stream));
+  }
+  ix->built = true;
+  return NIQKI_OK;
+}
+
+int niqki_query_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *counts,
+                       uint64_t stride, int mem) {
+  if (!ix || (!sketches && nq) || (!counts && nq)) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  if (mem == NIQKI_MEM_DEVICE) return counts_dev(ix, sketches, nq, counts, stride);
+  if (stride < ix->n_genomes || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
+  const uint32_t qb = ix->query_batch;
+  for (uint32_t q0 = 0; q0 < nq; q0 += qb) {
+    const uint32_t n = std::min(qb, nq - q0);
+    int rc;
+    if ((rc = ensure(ix, ix->ws_sk, (size_t)n * ix->d.F * 4))) return rc;
+    if ((rc = ensure(ix, ix->ws_counts, (size_t)n * stride * 2))) return rc;
+    NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, sketches + (size_t)q0 * ix->d.F, (size_t)n * ix->d.F * 4, hipMemcpyHostToDevice, ix->stream));
+    NQ_HIP(ix, hipMemsetAsync(ix->ws_counts.p, 0, (size_t)n * stride * 2, ix->stream));
+    if ((rc = counts_dev(ix, (const int32_t *)ix->ws_sk.p, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+    NQ_HIP(ix, hipMemcpyAsync(counts + (size_t)q0 * stride, ix->ws_counts.p, (size_t)n * stride * 2, hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  }
+  return NIQKI_OK;
+}
+
+int niqki_hits_from_counts(niqki_index *ix, const uint16_t *counts, uint32_t nq, uint64_t stride,
+                           uint32_t gid_begin, uint32_t n_gids, uint64_t *hit_off, uint32_t *hit_counts,
+                           uint32_t *hit_gids, uint64_t capacity, int mem) {
+  if (!ix || !hit_off || (!counts && nq)) return NIQKI_E_INVALID;
+  if ((uint64_t)gid_begin + n_gids > stride) return fail(ix, NIQKI_E_INVALID, "gid range exceeds stride");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  if (mem == NIQKI_MEM_DEVICE)
+    return hits_dev(ix, counts, nq, stride, gid_begin, n_gids, (unsigned long long *)hit_off, hit_counts,
+                    hit_gids, capacity, false, nullptr);
+  int rc;
+  if ((rc = ensure(ix, ix->ws_counts, std::max<size_t>((size_t)nq * stride * 2, 2)))) return rc;
+  if ((rc = ensure(ix, ix->ws_hitoff, (size_t)(nq + 1) * 8))) return rc;
+  if ((rc = ensure(ix, ix->ws_hc, (size_t)std::max<uint64_t>(capacity, 1) * 4))) return rc;
+  if ((rc = ensure(ix, ix->ws_hg, (size_t)std::max<uint64_t>(capacity, 1) * 4))) return rc;
+  if (nq) NQ_HIP(ix, hipMemcpyAsync(ix->ws_counts.p, counts, (size_t)nq * stride * 2, hipMemcpyHostToDevice, ix->stream));
+  uint64_t total = 0;
+  rc = hits_dev(ix, (const uint16_t *)ix->ws_counts.p, nq, stride, gid_begin, n_gids,
+                (unsigned long long *)ix->ws_hitoff.p, (uint32_t *)ix->ws_hc.p, (uint32_t *)ix->ws_hg.p,
+                capacity, true, &total);
+  if (rc && rc != NIQKI_E_CAPACITY) return rc;
+  NQ_HIP(ix, hipMemcpyAsync(hit_off, ix->ws_hitoff.p, (size_t)(nq + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
+  if (rc == NIQKI_OK && total) {
+    NQ_HIP(ix, hipMemcpyAsync(hit_counts, ix->ws_hc.p, (size_t)total * 4, hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipMemcpyAsync(hit_gids, ix->ws_hg.p, (size_t)total * 4, hipMemcpyDeviceToHost, ix->stream));
+  }
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  return rc;
+}
+
+int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint64_t *hit_off,
+                uint32_t *hit_counts, uint32_t *hit_gids, uint64_t capacity, int mem) {
+  if (!ix || !hit_off || (!sketches && nq)) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = build_if_needed(ix);
+  if (rc) return rc;
+  const uint32_t N = ix->built_n;
+  const uint64_t stride = ((uint64_t)N + 1) & ~1ull;
+  if (mem == NIQKI_MEM_DEVICE) {
+    if ((rc = ensure(ix, ix->ws_counts, std::max<size_t>((size_t)nq * stride * 2, 2)))) return rc;
+    if ((rc = counts_dev(ix, sketches, nq, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+    return hits_dev(ix, (const uint16_t *)ix->ws_counts.p, nq, stride, 0, N, (unsigned long long *)hit_off,
+                    hit_counts, hit_gids, capacity, false, nullptr);
+  }
+  // host: batches of query_batch sketches, hits appended in query order
+  uint64_t base = 0;
+  bool overflow = false;
+  hit_off[0] = 0;
+  const uint32_t qb = ix->query_batch;
+  std::vector<unsigned long long> off(qb + 1);
+  for (uint32_t q0 = 0; q0 < nq; q0 += qb) {
+    const uint32_t n = std::min(qb, nq - q0);
+    if ((rc = ensure(ix, ix->ws_sk, (size_t)n * ix->d.F * 4))) return rc;
+    if ((rc = ensure(ix, ix->ws_counts, std::max<size_t>((size_t)n * stride * 2, 2)))) return rc;
+    if ((rc = ensure(ix, ix->ws_hitoff, (size_t)(n + 1) * 8))) return rc;
+    const uint64_t room = overflow || base > capacity ? 0 : capacity - base;
+    if ((rc = ensure(ix, ix->ws_hc, (size_t)std::max<uint64_t>(room, 1) * 4))) return rc;
+    if ((rc = ensure(ix, ix->ws_hg, (size_t)std::max<uint64_t>(room, 1) * 4))) return rc;
+    NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, sketches + (size_t)q0 * ix->d.F, (size_t)n * ix->d.F * 4, hipMemcpyHostToDevice, ix->stream));
+    if ((rc = counts_dev(ix, (const int32_t *)ix->ws_sk.p, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+    uint64_t total = 0;
+    rc = hits_dev(ix, (const uint16_t *)ix->ws_counts.p, n, stride, 0, N, (unsigned long long *)ix->ws_hitoff.p,
+                  (uint32_t *)ix->ws_hc.p, (uint32_t *)ix->ws_hg.p, room, true, &total);
+    if (rc && rc != NIQKI_E_CAPACITY) return rc;
+    NQ_HIP(ix, hipMemcpyAsync(off.data(), ix->ws_hitoff.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
+    if (rc == NIQKI_OK && total) {
+      NQ_HIP(ix, hipMemcpyAsync(hit_counts + base, ix->ws_hc.p, (size_t)total * 4, hipMemcpyDeviceToHost, ix->stream));
+      NQ_HIP(ix, hipMemcpyAsync(hit_gids + base, ix->ws_hg.p, (size_t)total * 4, hipMemcpyDeviceToHost, ix->stream));
+    }
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    if (rc == NIQKI_E_CAPACITY) overflow = true;
+    for (uint32_t i = 0; i < n; ++i) hit_off[q0 + i + 1] = base + off[i + 1];
+    base += off[n];
+  }
+  return overflow ? NIQKI_E_CAPACITY : NIQKI_OK;
+}
+
+int niqki_query_sequences(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, uint32_t n_rec,
+                          const uint32_t *entry_rec, uint32_t n_entry, uint64_t *hit_off,
+                          uint32_t *hit_counts, uint32_t *hit_gids, uint64_t capacity, int mem) {
+  if (!ix) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  if (mem == NIQKI_MEM_DEVICE) {
+    int rc = ensure(ix, ix->ws_sk, std::max<size_t>((size_t)n_entry * ix->d.F * 4, 4));
+    if (rc) return rc;
+    if ((rc = niqki_sketch(ix, seqs, rec_off, n_rec, entry_rec, n_entry, (int32_t *)ix->ws_sk.p, NIQKI_MEM_DEVICE))) return rc;
+    return niqki_query(ix, (const int32_t *)ix->ws_sk.p, n_entry, hit_off, hit_counts, hit_gids, capacity, NIQKI_MEM_DEVICE);
+  }
+  std::vector<int32_t> sk((size_t)n_entry * ix->d.F);
+  int rc = niqki_sketch(ix, seqs, rec_off, n_rec, entry_rec, n_entry, sk.data(), NIQKI_MEM_HOST);
+  if (rc) return rc;
+  return niqki_query(ix, sk.data(), n_entry, hit_off, hit_counts, hit_gids, capacity, NIQKI_MEM_HOST);
+}
+
+int niqki_get_sketches(niqki_index *ix, uint32_t begin, uint32_t n, int32_t *sketches, int mem) {
+  if (!ix || (!sketches && n)) return NIQKI_E_INVALID;
+  if ((uint64_t)begin + n > ix->n_genomes) return fail(ix, NIQKI_E_INVALID, "genome range out of bounds");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  if (n == 0) return NIQKI_OK;
+  int32_t *d_sk = sketches;
+  const size_t bytes = (size_t)n * ix->d.F * 4;
+  if (mem == NIQKI_MEM_HOST) {
+    int rc = ensure(ix, ix->ws_sk, bytes);
+    if (rc) return rc;
+    d_sk = (int32_t *)ix->ws_sk.p;
+  }
+  NQ_HIP(ix, nq::launch_store_read(ix->d, ix->store, ix->cap, begin, n, d_sk, ix->stream));
+  if (mem == NIQKI_MEM_HOST) {
+    NQ_HIP(ix, hipMemcpyAsync(sketches, d_sk, bytes, hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  }
+  return NIQKI_OK;
+}
+
+int niqki_matrix_range(niqki_index *ix, uint32_t begin, uint32_t end, uint16_t *counts, uint64_t stride,
+                       int mem) {
+  if (!ix || begin > end || end > ix->n_genomes || (!counts && end > begin)) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = build_if_needed(ix);
+  if (rc) return rc;
+  if (stride < ix->built_n || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
+  // The bucket co-occurrence count of (a, t) equals the hit count of genome a
+  // for the stored sketch of t: both count the slots where the two sketches
+  // hold the same valid fingerprint.  So the range is answered by the gather
+  // kernel on the stored sketches of [begin, end).
+  const uint32_t qb = std::min<uint32_t>(ix->query_batch, 256);
+  for (uint32_t t0 = begin; t0 < end; t0 += qb) {
+    const uint32_t n = std::min(qb, end - t0);
+    if ((rc = ensure(ix, ix->ws_misc, (size_t)n * ix->d.F * 4))) return rc;
+    NQ_HIP(ix, nq::launch_store_read(ix->d, ix->store, ix->cap, t0, n, (int32_t *)ix->ws_misc.p, ix->stream));
+    uint16_t *dst = counts + (size_t)(t0 - begin) * stride;
+    if (mem == NIQKI_MEM_DEVICE) {
+      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, n, dst, stride))) return rc;
+    } else {
+      if ((rc = ensure(ix, ix->ws_counts, (size_t)n * stride * 2))) return rc;
+      NQ_HIP(ix, hipMemsetAsync(ix->ws_counts.p, 0, (size_t)n * stride * 2, ix->stream));
+      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+      NQ_HIP(ix, hipMemcpyAsync(dst, ix->ws_counts.p, (size_t)n * stride * 2, hipMemcpyDeviceToHost, ix->stream));
+      NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    }
+  }
+  return NIQKI_OK;
+}
+
+int niqki_export_dump(niqki_index *ix, uint8_t *buf, uint64_t capacity, uint64_t *size) {
+  if (!ix || !size) return NIQKI_E_INVALID;
+  if (ix->d.slot_begin != 0 || ix->d.slot_end != ix->d.F) return fail(ix, NIQKI_E_STATE, "export needs a whole-range handle");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = build_if_needed(ix);
+  if (rc) return rc;
+  nq::IndexView v = view(ix);
+  // total entries = sum over tiles of the valid entries
+  if ((rc = ensure(ix, ix->ws_misc, std::max<size_t>((size_t)v.n_tiles * (v.f_local + 1) * 8, 8)))) return rc;
+  uint64_t *slot_base = (uint64_t *)ix->ws_misc.p;
+  uint64_t entries = 0;
+  const uint64_t n_buckets = (uint64_t)v.f_local * v.d.R;
+  if (v.n_tiles) {
+    // first pass only for the size: slot_base_kernel is part of launch_export,
+    // so size the buffer from an upper bound (every genome valid in every slot)
+    entries = (uint64_t)v.n_genomes * v.f_local;
+  }
+  const uint64_t max_words = n_buckets + entries;
+  Buf out;
+  hipError_t e = hipMalloc(&out.p, std::max<uint64_t>(max_words * 4, 4));
+  if (e != hipSuccess) return fail(ix, NIQKI_E_NOMEM, "export buffer allocation failed");
+  auto cleanup = [&]() { (void)hipFree(out.p); };
+  e = nq::launch_export(v, slot_base, (uint32_t *)out.p, ix->stream);
+  if (e != hipSuccess) { cleanup(); return fail(ix, NIQKI_E_HIP, hipGetErrorString(e)); }
+  uint64_t exact_entries = 0;
+  for (uint32_t t = 0; t < v.n_tiles; ++t) {
+    uint64_t x = 0;
+    e = hipMemcpyAsync(&x, slot_base + (uint64_t)t * (v.f_local + 1) + v.f_local, 8, hipMemcpyDeviceToHost, ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) { cleanup(); return fail(ix, NIQKI_E_HIP, hipGetErrorString(e)); }
+    exact_entries += x;
+  }
+  const uint64_t total = 24 + (n_buckets + exact_entries) * 4;
+  *size = total;
+  if (!buf) { cleanup(); return NIQKI_OK; }
+  if (capacity < total) { cleanup(); return NIQKI_E_CAPACITY; }
+  uint32_t hdr[6] = {ix->d.S, ix->d.K, ix->d.H, ix->d.W, ix->d.min_score, v.n_genomes};
+  std::memcpy(buf, hdr, 24);
+  e = hipMemcpyAsync(buf + 24, out.p, total - 24, hipMemcpyDeviceToHost, ix->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+  cleanup();
+  if (e != hipSuccess) return fail(ix, NIQKI_E_HIP, hipGetErrorString(e));
+  return NIQKI_OK;
+}
+
+int niqki_import_dump(const niqki_params *params, const uint8_t *buf, uint64_t len, uint64_t *consumed,
+                      niqki_index **out) {
+  if (!params || !buf || !out || len < 24) return NIQKI_E_INVALID;
+  uint32_t hdr[6];
+  std::memcpy(hdr, buf, 24);
+  niqki_params p = *params;
+  p.S = hdr[0]; p.K = hdr[1]; p.H = hdr[2]; p.W = hdr[3]; p.min_score = hdr[4];
+  p.slot_begin = p.slot_end = 0;
+  const uint32_t N = hdr[5];
+  niqki_index *ix = nullptr;
+  int rc = niqki_create(&p, &ix);
+  if (rc) return rc;
+  const uint64_t F = ix->d.F, R = ix->d.R;
+  // sequential walk of the bucket sizes (they chain), recording where each slot starts
+  std::vector<uint64_t> slot_word(F + 1);
+  uint64_t w = 0;
+  const uint64_t n_words = (len - 24) / 4;
+  const uint8_t *body = buf + 24;
+  for (uint64_t s = 0; s < F; ++s) {
+    slot_word[s] = w;
+    for (uint64_t fp = 0; fp < R; ++fp) {
+      if (w >= n_words) { niqki_destroy(ix); return NIQKI_E_INVALID; }
+      uint32_t sz;
+      std::memcpy(&sz, body + w * 4, 4);
+      w += 1 + (uint64_t)sz;
+    }
+  }
+  if (w > n_words) { niqki_destroy(ix); return NIQKI_E_INVALID; }
+  slot_word[F] = w;
+  if (consumed) *consumed = 24 + w * 4;
+  rc = reserve_store(ix, std::max<uint32_t>(N, 1));
+  if (rc) { niqki_destroy(ix); return rc; }
+  auto bail = [&](int code, const char *msg) { ix->err = msg; niqki_destroy(ix); return code; };
+  void *d_words = nullptr, *d_slot = nullptr, *d_bad = nullptr;
+  if (hipMalloc(&d_words, std::max<uint64_t>(w * 4, 4)) != hipSuccess) return bail(NIQKI_E_NOMEM, "import alloc");
+  if (hipMalloc(&d_slot, (F + 1) * 8) != hipSuccess) { (void)hipFree(d_words); return bail(NIQKI_E_NOMEM, "import alloc"); }
+  if (hipMalloc(&d_bad, 4) != hipSuccess) { (void)hipFree(d_words); (void)hipFree(d_slot); return bail(NIQKI_E_NOMEM, "import alloc"); }
+  hipError_t e = hipMemcpyAsync(d_words, body, w * 4, hipMemcpyHostToDevice, ix->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_slot, slot_word.data(), (F + 1) * 8, hipMemcpyHostToDevice, ix->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 4, ix->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(ix->store, 0xFF, (size_t)F * ix->cap * 2, ix->stream);
+  if (e == hipSuccess) e = nq::launch_import(ix->d, (const uint32_t *)d_words, (const uint64_t *)d_slot, ix->store, ix->cap, N, (uint32_t *)d_bad, ix->stream);
+  uint32_t bad = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ix->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+  (void)hipFree(d_words); (void)hipFree(d_slot); (void)hipFree(d_bad);
+  if (e != hipSuccess) return bail(NIQKI_E_HIP, hipGetErrorString(e));
+  if (bad) return bail(NIQKI_E_INVALID, "dump holds genome ids >= genome count");
+  ix->n_genomes = N;
+  ix->built = false;
+  *out = ix;
+  return NIQKI_OK;
+}
+
+int niqki_query_gathered(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint64_t *gathered, int mem) {
+  if (!ix || (!sketches && nq) || (!gathered && nq)) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = build_if_needed(ix);
+  if (rc) return rc;
+  if (nq == 0) return NIQKI_OK;
+  const int32_t *d_sk = sketches;
+  if (mem == NIQKI_MEM_HOST) {
+    if ((rc = ensure(ix, ix->ws_sk, (size_t)nq * ix->d.F * 4))) return rc;
+    NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, sketches, (size_t)nq * ix->d.F * 4, hipMemcpyHostToDevice, ix->stream));
+    d_sk = (const int32_t *)ix->ws_sk.p;
+  }
+  if ((rc = ensure(ix, ix->ws_misc, (size_t)nq * 8))) return rc;
+  NQ_HIP(ix, hipMemsetAsync(ix->ws_misc.p, 0, (size_t)nq * 8, ix->stream));
+  if (ix->built_n) NQ_HIP(ix, nq::launch_gathered(view(ix), d_sk, nq, (unsigned long long *)ix->ws_misc.p, ix->stream));
+  NQ_HIP(ix, hipMemcpyAsync(gathered, ix->ws_misc.p, (size_t)nq * 8, hipMemcpyDeviceToHost, ix->stream));
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  return NIQKI_OK;
+}
+
+int niqki_profile_enable(niqki_index *ix, int on) {
+  if (!ix) return NIQKI_E_INVALID;
+  int rc = collect_spans(ix);
+  ix->prof = on != 0;
+  return rc;
+}
+
+int niqki_profile_reset(niqki_index *ix) {
+  if (!ix) return NIQKI_E_INVALID;
+  int rc = collect_spans(ix);
+  for (int i = 0; i < NIQKI_KC_COUNT; ++i) { ix->prof_ms[i] = 0; ix->prof_n[i] = 0; }
+  return rc;
+}
+
+int niqki_profile_read(niqki_index *ix, int kc, double *ms, uint64_t *launches) {
+  if (!ix || kc < 0 || kc >= NIQKI_KC_COUNT) return NIQKI_E_INVALID;
+  int rc = collect_spans(ix);
+  if (ms) *ms = ix->prof_ms[kc];
+  if (launches) *launches = ix->prof_n[kc];
+  return rc;
+}
+
+void niqki_synth_genome_host(uint64_t seed, uint32_t family, uint32_t member, uint32_t rate14,
+                             uint64_t len, uint8_t *out) {
+  const uint64_t ka = nq::synth_key_anc(seed, family), km = nq::synth_key_mut(seed, family, member);
+  for (uint64_t blk = 0; blk * 32 < len; ++blk) {
+    uint64_t codes = nq::synth_block(ka, km, rate14, blk);
+    for (uint32_t j = 0; j < 32 && blk * 32 + j < len; ++j)
+      out[blk * 32 + j] = nq::synth_ascii((uint32_t)(codes >> (2 * j)) & 3u);
+  }
+}
+
+int niqki_synth_genomes(niqki_index *ix, uint64_t seed, const uint32_t *family, const uint32_t *member,
+                        const uint32_t *rate14, uint32_t n, uint64_t len, uint64_t stride, uint8_t *out,
+                        int mem) {
+  if (!ix || (n && (!family || !member || !rate14 || !out)) || stride < len) return NIQKI_E_INVALID;
+  if (mem == NIQKI_MEM_HOST) {
+    for (uint32_t i = 0; i < n; ++i)
+      niqki_synth_genome_host(seed, family[i], member[i], rate14[i], len, out + (uint64_t)i * stride);
+    return NIQKI_OK;
+  }
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  NQ_HIP(ix, nq::launch_synth(seed, family, member, rate14, n, len, stride, out, ix->stream));
+  return NIQKI_OK;
+}
+
+}  // extern "C"

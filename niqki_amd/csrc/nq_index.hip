@@ -1,0 +1,258 @@
+// nq_index.hip -- kernel #3: sketch store and inverted-index build for gfx950.
+//
+// Replaces the reference's vector<gid> Buckets[2^W * F] with push_back under
+// striped locks (src/niqki_index.h:55, src/niqki_index.cpp:27,362-370) and the
+// bucket walks of dump_index_disk / the loading constructor (:42-55, :63-90).
+//
+// Layout (DESIGN.md "HBM layout"): inserted sketches are kept slot-major as
+// u16 [F][cap]; the index is rebuilt from that store as one CSR per genome
+// tile, by a stable counting sort of each (tile, slot) row on the fingerprint:
+// every genome has exactly one entry per slot, so slot s of tile t owns the
+// fixed range [s*T, (s+1)*T) of the tile's gid array and no global scan is
+// needed.  Buckets come out ascending in genome id, the order the reference
+// produces single-threaded.
+#include "nq_kernels.h"
+
+namespace nq {
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, uint32_t lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t y = __shfl_up(x, o, 64);
+    if (lane >= (uint32_t)o) x += y;
+  }
+  return x;
+}
+
+// ---- int32 [n][F] sketches -> u16 [F_local][cap] store (64x64 tiles via LDS) ----
+__global__ __launch_bounds__(256) void store_insert_kernel(Derived d, const int32_t *sk, uint32_t n,
+                                                          uint16_t *store, uint64_t cap,
+                                                          uint32_t first_gid) {
+  __shared__ uint16_t tile[64][66];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t f_local = d.slot_end - d.slot_begin;
+  const uint32_t s0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+  for (uint32_t r = wave; r < 64; r += 4) {
+    uint32_t i = i0 + r, s = s0 + lane;
+    uint16_t v = kEmpty16;
+    if (i < n && s < f_local) {
+      int32_t x = sk[(uint64_t)i * d.F + d.slot_begin + s];
+      if (x >= 0 && (uint32_t)x < d.R) v = (uint16_t)x;  // src/niqki_index.cpp:364
+    }
+    tile[r][lane] = v;
+  }
+  __syncthreads();
+  for (uint32_t r = wave; r < 64; r += 4) {
+    uint32_t s = s0 + r, i = i0 + lane;
+    if (s < f_local && i < n) store[(uint64_t)s * cap + first_gid + i] = tile[lane][r];
+  }
+}
+
+hipError_t launch_store_insert(const Derived &d, const int32_t *sketches, uint32_t n,
+                               uint16_t *store, uint64_t cap, uint32_t first_gid,
+                               hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  uint32_t f_local = d.slot_end - d.slot_begin;
+  dim3 grid((f_local + 63) / 64, (n + 63) / 64);
+  hipLaunchKernelGGL(store_insert_kernel, grid, dim3(256), 0, stream, d, sketches, n, store, cap,
+                     first_gid);
+  return hipGetLastError();
+}
+
+// ---- store -> int32 sketches of genomes [begin, begin+n) ----
+__global__ __launch_bounds__(256) void store_read_kernel(Derived d, const uint16_t *store,
+                                                        uint64_t cap, uint32_t begin, uint32_t n,
+                                                        int32_t *sk) {
+  __shared__ uint16_t tile[64][66];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t s0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+  for (uint32_t r = wave; r < 64; r += 4) {
+    uint32_t s = s0 + r, i = i0 + lane;  // s is a global slot number here
+    uint16_t v = kEmpty16;
+    if (s >= d.slot_begin && s < d.slot_end && i < n)
+      v = store[(uint64_t)(s - d.slot_begin) * cap + begin + i];
+    tile[r][lane] = v;
+  }
+  __syncthreads();
+  for (uint32_t r = wave; r < 64; r += 4) {
+    uint32_t i = i0 + r, s = s0 + lane;
+    if (i < n && s < d.F) {
+      uint16_t v = tile[lane][r];
+      sk[(uint64_t)i * d.F + s] = v == kEmpty16 ? -1 : (int32_t)v;
+    }
+  }
+}
+
+hipError_t launch_store_read(const Derived &d, const uint16_t *store, uint64_t cap, uint32_t begin,
+                             uint32_t n, int32_t *sketches, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  dim3 grid((d.F + 63) / 64, (n + 63) / 64);
+  hipLaunchKernelGGL(store_read_kernel, grid, dim3(256), 0, stream, d, store, cap, begin, n,
+                     sketches);
+  return hipGetLastError();
+}
+
+// ---- CSR build: one wave per (tile, slot) row, stable counting sort on fp ----
+__global__ void build_kernel(IndexView v, uint32_t *offsets, uint16_t *gids, uint32_t wpb) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint64_t task = (uint64_t)blockIdx.x * wpb + wave;
+  if (task >= (uint64_t)v.n_tiles * v.f_local) return;  // wave-private work, no block barrier below
+  const uint32_t t = (uint32_t)(task / v.f_local), s = (uint32_t)(task % v.f_local);
+  const uint32_t R = v.d.R, W = v.d.W;
+  uint32_t *cur = smem + (size_t)wave * R;
+  const uint32_t g0 = t * v.tile;
+  const uint32_t n_t = (v.n_genomes - g0) < v.tile ? (v.n_genomes - g0) : v.tile;
+  const uint16_t *row = v.store + (uint64_t)s * v.cap + g0;
+
+  for (uint32_t i = lane; i < R; i += 64) cur[i] = 0;
+  for (uint32_t i = lane; i < n_t; i += 64) {
+    uint32_t fp = row[i];
+    if (fp != kEmpty16) atomicAdd(&cur[fp], 1u);
+  }
+  uint32_t *off = offsets + ((uint64_t)t * v.f_local + s) * (R + 1);
+  uint32_t running = s * v.tile;
+  for (uint32_t c = 0; c < R; c += 64) {
+    uint32_t x = (c + lane < R) ? cur[c + lane] : 0u;
+    uint32_t incl = wave_incl_scan(x, lane);
+    uint32_t excl = running + incl - x;
+    if (c + lane < R) { cur[c + lane] = excl; off[c + lane] = excl; }
+    running += __shfl(incl, 63, 64);
+  }
+  if (lane == 0) off[R] = running;
+
+  uint16_t *gl = gids + (uint64_t)t * v.f_local * v.tile;  // tile's gid array, positions are absolute in it
+  const uint64_t lt_mask = (1ULL << lane) - 1ULL;
+  for (uint32_t base = 0; base < n_t; base += 64) {
+    uint32_t i = base + lane;
+    uint32_t fp = (i < n_t) ? (uint32_t)row[i] : (uint32_t)kEmpty16;
+    bool valid = fp != kEmpty16;
+    uint64_t peers = __ballot(valid);
+    for (uint32_t b = 0; b < W; ++b) {
+      bool bit = (fp >> b) & 1u;
+      uint64_t bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    if (valid) {
+      uint32_t rank = __popcll(peers & lt_mask);
+      uint32_t cnt = __popcll(peers);
+      uint32_t p = cur[fp];
+      gl[p + rank] = (uint16_t)i;
+      if (rank == cnt - 1) cur[fp] = p + cnt;
+    }
+  }
+}
+
+hipError_t launch_build(const IndexView &v, uint32_t *offsets, uint16_t *gids,
+                        hipStream_t stream) {
+  uint64_t tasks = (uint64_t)v.n_tiles * v.f_local;
+  if (tasks == 0) return hipSuccess;
+  size_t per_wave = (size_t)v.d.R * 4;
+  uint32_t wpb = (uint32_t)(65536 / per_wave);
+  if (wpb > 4) wpb = 4;
+  if (wpb < 1) wpb = 1;
+  size_t lds = per_wave * wpb;
+  hipError_t e = hipFuncSetAttribute((const void *)build_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  uint64_t blocks = (tasks + wpb - 1) / wpb;
+  hipLaunchKernelGGL(build_kernel, dim3((uint32_t)blocks), dim3(64 * wpb), lds, stream, v, offsets,
+                     gids, wpb);
+  return hipGetLastError();
+}
+
+// ---- dump stream export (src/niqki_index.cpp:42-55) ----
+// slot_base[t][s] = number of valid entries of tile t in slots < s.
+__global__ __launch_bounds__(1024) void slot_base_kernel(IndexView v, uint64_t *slot_base) {
+  __shared__ uint64_t part[1024];
+  const uint32_t t = blockIdx.x, tid = threadIdx.x;
+  const uint32_t R = v.d.R;
+  const uint32_t per = (v.f_local + 1023) / 1024;
+  const uint32_t lo = tid * per, hi = (lo + per < v.f_local) ? lo + per : v.f_local;
+  const uint32_t *off = v.offsets + (uint64_t)t * v.f_local * (R + 1);
+  uint64_t sum = 0;
+  for (uint32_t s = lo; s < hi; ++s) sum += off[(uint64_t)s * (R + 1) + R] - s * v.tile;
+  part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < 1024; ++i) { uint64_t x = part[i]; part[i] = run; run += x; }
+  }
+  __syncthreads();
+  uint64_t run = part[tid];
+  uint64_t *sb = slot_base + (uint64_t)t * (v.f_local + 1);
+  for (uint32_t s = lo; s < hi; ++s) {
+    sb[s] = run;
+    run += off[(uint64_t)s * (R + 1) + R] - s * v.tile;
+  }
+  if (hi == v.f_local && lo < hi) sb[v.f_local] = run;
+  if (v.f_local == 0 && tid == 0) sb[0] = 0;
+}
+
+__global__ __launch_bounds__(256) void export_kernel(IndexView v, const uint64_t *slot_base,
+                                                    uint32_t *out) {
+  const uint32_t R = v.d.R;
+  const uint64_t n_b = (uint64_t)v.f_local * R;
+  uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; b < n_b; b += stride) {
+    const uint32_t s = (uint32_t)(b / R), fp = (uint32_t)(b % R);
+    uint64_t before = 0;
+    uint32_t size = 0;
+    for (uint32_t t = 0; t < v.n_tiles; ++t) {
+      const uint32_t *off = v.offsets + ((uint64_t)t * v.f_local + s) * (R + 1);
+      before += slot_base[(uint64_t)t * (v.f_local + 1) + s] + (off[fp] - s * v.tile);
+      size += off[fp + 1] - off[fp];
+    }
+    uint64_t pos = b + before;
+    out[pos++] = size;
+    for (uint32_t t = 0; t < v.n_tiles; ++t) {
+      const uint32_t *off = v.offsets + ((uint64_t)t * v.f_local + s) * (R + 1);
+      const uint16_t *gl = v.gids + (uint64_t)t * v.f_local * v.tile;
+      for (uint32_t j = off[fp]; j < off[fp + 1]; ++j) out[pos++] = t * v.tile + gl[j];
+    }
+  }
+}
+
+hipError_t launch_export(const IndexView &v, uint64_t *slot_base, uint32_t *out,
+                         hipStream_t stream) {
+  if (v.n_tiles)
+    hipLaunchKernelGGL(slot_base_kernel, dim3(v.n_tiles), dim3(1024), 0, stream, v, slot_base);
+  uint64_t n_b = (uint64_t)v.f_local * v.d.R;
+  uint64_t blocks = (n_b + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(export_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, v, slot_base, out);
+  return hipGetLastError();
+}
+
+// ---- dump stream import (src/niqki_index.cpp:78-85): one wave per slot ----
+__global__ __launch_bounds__(256) void import_kernel(Derived d, const uint32_t *words,
+                                                    const uint64_t *slot_word, uint16_t *store,
+                                                    uint64_t cap, uint32_t n_genomes, uint32_t *bad) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= d.F) return;
+  uint64_t p = slot_word[s];
+  const uint64_t end = slot_word[s + 1];
+  for (uint32_t fp = 0; fp < d.R; ++fp) {
+    if (p >= end) { if (lane == 0) atomicAdd(bad, 1u); return; }
+    uint32_t size = words[p];
+    for (uint32_t j = lane; j < size; j += 64) {
+      uint32_t g = words[p + 1 + j];
+      if (g < n_genomes) store[(uint64_t)s * cap + g] = (uint16_t)fp;
+      else atomicAdd(bad, 1u);
+    }
+    p += 1 + (uint64_t)size;
+  }
+  if (p != end && lane == 0) atomicAdd(bad, 1u);
+}
+
+hipError_t launch_import(const Derived &d, const uint32_t *words, const uint64_t *slot_word,
+                         uint16_t *store, uint64_t cap, uint32_t n_genomes, uint32_t *bad,
+                         hipStream_t stream) {
+  hipLaunchKernelGGL(import_kernel, dim3((d.F + 3) / 4), dim3(256), 0, stream, d, words, slot_word,
+                     store, cap, n_genomes, bad);
+  return hipGetLastError();
+}
+
+}  // namespace nq

@@ -1,0 +1,91 @@
+// nq_kernels.h -- launch interface between the C ABI (nq_api.hip) and the
+// gfx950 kernels.  All pointers are device pointers unless noted.
+#pragma once
+#include "nq_common.h"
+
+namespace nq {
+
+// ---- sketch (nq_sketch.hip) -------------------------------------------------
+struct SketchArgs {
+  Derived d;
+  const uint8_t *seqs;        // record bytes; nullptr = densify-only launch
+  const uint64_t *rec_off;    // n_rec+1
+  const uint32_t *entry_rec;  // n_entry+1 or nullptr (one record per sketch)
+  int32_t *sketches;          // n_entry x F
+  uint32_t splits;            // workgroups per sketch (>1: partial mins merged in global memory)
+  uint32_t accumulate;        // start from the sketches already in `sketches`
+  uint32_t densify;           // run densification before the store (splits == 1 only)
+};
+hipError_t launch_sketch(const SketchArgs &a, uint32_t n_entry, bool short_records,
+                         hipStream_t stream);
+hipError_t launch_fill_u32(uint32_t *p, uint64_t n, uint32_t v, hipStream_t stream);
+
+// ---- sketch store + inverted index (nq_index.hip) ---------------------------
+// Sketch store: u16 [F_local][cap], slot major; 0xFFFF = empty/invalid cell.
+// Inverted index, per genome tile t (genomes [t*T, min((t+1)*T, N))):
+//   offsets  u32 [F_local][R+1]   offsets[s][fp] .. offsets[s][fp+1] is bucket
+//                                 (s, fp) inside gids; offsets[s][0] = s*T
+//   gids     u16 [F_local][T]     tile-local genome ids, ascending per bucket
+struct IndexView {
+  Derived d;
+  uint32_t n_genomes;
+  uint32_t tile;     // T, genomes per tile (even)
+  uint32_t n_tiles;
+  uint32_t f_local;  // slot_end - slot_begin
+  uint64_t cap;      // row stride of the sketch store (genomes)
+  const uint16_t *store;
+  const uint32_t *offsets;  // n_tiles x f_local x (R+1)
+  const uint16_t *gids;     // n_tiles x f_local x T
+};
+
+hipError_t launch_store_insert(const Derived &d, const int32_t *sketches, uint32_t n,
+                               uint16_t *store, uint64_t cap, uint32_t first_gid,
+                               hipStream_t stream);
+hipError_t launch_store_read(const Derived &d, const uint16_t *store, uint64_t cap,
+                             uint32_t begin, uint32_t n, int32_t *sketches, hipStream_t stream);
+hipError_t launch_build(const IndexView &v, uint32_t *offsets, uint16_t *gids,
+                        hipStream_t stream);
+// dump stream (src/niqki_index.cpp:42-55) of a whole-range index into `out`
+// (u32 words, header excluded); slot_base: n_tiles x (f_local+1) exclusive
+// prefix of valid entries per slot (scratch, filled here).
+hipError_t launch_export(const IndexView &v, uint64_t *slot_base, uint32_t *out,
+                         hipStream_t stream);
+// inverse: walk the dump words of each slot and write the sketch store.
+// slot_word: F+1 word positions of each slot's first bucket inside `words`.
+hipError_t launch_import(const Derived &d, const uint32_t *words, const uint64_t *slot_word,
+                         uint16_t *store, uint64_t cap, uint32_t n_genomes, uint32_t *bad,
+                         hipStream_t stream);
+
+// ---- query (nq_query.hip) ----------------------------------------------------
+// gather-histogram: counts[q*stride + g] for all genomes (u16), one workgroup
+// per (query, tile).
+hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq,
+                         uint16_t *counts, uint64_t stride, int variant, hipStream_t stream);
+hipError_t launch_gathered(const IndexView &v, const int32_t *sketches, uint32_t nq,
+                           unsigned long long *per_query, hipStream_t stream);
+
+// threshold + compaction + order.  blk_counts: nq x n_blk scratch;
+// hit_off nq+1 (u64); tmp_*: capacity-sized scratch for the sort.
+struct HitsArgs {
+  const uint16_t *counts;
+  uint64_t stride;
+  uint32_t nq;
+  uint32_t gid_begin, n_gids;
+  uint32_t min_score;
+  uint32_t *blk_counts;   // nq * n_blk
+  uint32_t n_blk;
+  unsigned long long *hit_off;  // nq+1
+  uint32_t *hit_counts, *hit_gids;
+  uint32_t *tmp_counts, *tmp_gids;
+  uint64_t capacity;
+};
+constexpr uint32_t kHitsBlk = 4096;  // genomes per compaction block
+hipError_t launch_hits_count(const HitsArgs &a, hipStream_t stream);
+hipError_t launch_hits_emit(const HitsArgs &a, hipStream_t stream);
+
+// ---- synthetic genomes (nq_synth.hip) ----------------------------------------
+hipError_t launch_synth(uint64_t seed, const uint32_t *family, const uint32_t *member,
+                        const uint32_t *rate14, uint32_t n, uint64_t len, uint64_t stride,
+                        uint8_t *out, hipStream_t stream);
+
+}  // namespace nq

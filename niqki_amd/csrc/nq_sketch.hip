@@ -1,0 +1,273 @@
+// nq_sketch.hip -- kernel #1/#2: canonical k-mer rolling hash, per-slot
+// HyperMinHash min reduction in LDS, and densification, for gfx950.
+//
+// Replaces Index::compute_sketch (src/niqki_index.cpp:335-358, with
+// update_kmer :225-229, update_kmer_RC :233-236, str2numstrand :255-273,
+// rcb :240-250, revhash64/unrevhash64 :291-305, get_fingerprint :277-287) and
+// Index::sketch_densification (:313-331).
+//
+// Shape: one workgroup per sketch (times `splits` for long single records).
+// The F = 2^S sketch cells live in LDS as u32 with 0xFFFFFFFF (= int32 -1)
+// for "empty", so the per-slot minimum is one unsigned ds_min_u32.  A record
+// is cut into chunks of CHUNK k-mers; each lane rolls one chunk: K-1 cheap
+// warm-up steps rebuild the forward / reverse-complement words (a k-mer only
+// depends on its own K bases, see DESIGN.md "positional codes"), then CHUNK
+// hash steps.  The kernel is integer-ALU bound (4 64-bit multiplies per
+// k-mer), HBM traffic is 1 byte per base.
+#include "nq_kernels.h"
+
+namespace nq {
+
+// Per-byte code table, built in LDS by the first 256 threads.
+//   bits 1:0  forward code of the rolling update   (:114-123  A0 C1 G2 T3, else 0)
+//   bits 3:2  reverse-complement code of the update (:211-221 A3 C2 G1, else 0)
+//   bits 5:4  case-insensitive digit of the K-1 prefix (:255-273)
+//   bit  6    byte is a legal prefix character (ACGTacgt)
+__device__ __forceinline__ uint8_t code_entry(uint32_t c) {
+  uint32_t fwd = c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
+  uint32_t rc = c == 'A' ? 3u : c == 'C' ? 2u : c == 'G' ? 1u : 0u;
+  uint32_t u = c & 0xDFu;  // fold lower case onto upper case
+  uint32_t ok = (u == 'A' || u == 'C' || u == 'G' || u == 'T') ? 1u : 0u;
+  uint32_t pd = u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 0u;
+  return (uint8_t)(fwd | (rc << 2) | ((ok ? pd : 0u) << 4) | (ok << 6));
+}
+
+// 16 bytes of a byte stream that starts at an arbitrary address: the stream is
+// fetched as dword-aligned uint4 loads and re-aligned with v_alignbyte.
+struct ByteStream {
+  const uint32_t *q;  // dword-aligned cursor
+  uint32_t sh;        // byte phase 0..3
+  uint4 cur;
+  __device__ __forceinline__ void open(const uint8_t *p) {
+    uintptr_t a = (uintptr_t)p;
+    sh = (uint32_t)(a & 3u);
+    q = (const uint32_t *)(a & ~(uintptr_t)3);
+    cur = *(const uint4 *)q;  // dword aligned 16-byte load
+    q += 4;
+  }
+  // returns the next 16 stream bytes as 4 dwords (little endian)
+  __device__ __forceinline__ uint4 next16() {
+    uint4 nxt = *(const uint4 *)q;
+    q += 4;
+    uint4 r;
+    r.x = __builtin_amdgcn_alignbyte(cur.y, cur.x, sh);
+    r.y = __builtin_amdgcn_alignbyte(cur.z, cur.y, sh);
+    r.z = __builtin_amdgcn_alignbyte(cur.w, cur.z, sh);
+    r.w = __builtin_amdgcn_alignbyte(nxt.x, cur.w, sh);
+    cur = nxt;
+    return r;
+  }
+};
+
+__device__ __forceinline__ uint32_t dword_of(const uint4 &v, int i) {
+  return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w;
+}
+
+// In-LDS densification, pass-parallel restatement of the serial loop at
+// src/niqki_index.cpp:313-331 (equivalence: DESIGN.md "densification").
+// Within one pass every cell occupied at pass start proposes itself to its
+// target cell with atomicMin of (1<<31 | source index << W | value); real
+// values are < 2^W so occupied targets are never changed, and among several
+// proposals the smallest source index wins, which is the serial loop's
+// first-writer rule.  Returns with cells still empty only where the reference
+// would loop forever (F consecutive passes without a fill prove a fixpoint).
+template <int BLOCK>
+__device__ void densify_lds(uint32_t *sk, const Derived &d, uint32_t *s_flag) {
+  const uint32_t F = d.F;
+  const uint32_t tid = threadIdx.x;
+  // count empties
+  uint32_t local = 0;
+  for (uint32_t i = tid; i < F; i += BLOCK) local += (sk[i] == kEmpty32);
+  if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+  __syncthreads();
+  if (local) atomicAdd(&s_flag[0], local);
+  __syncthreads();
+  uint32_t empty = s_flag[0];
+  if (empty == 0 || empty == F) return;
+  uint32_t step = 0, idle = 0;
+  const uint32_t vmask = d.R - 1u;
+  while (true) {
+    // propose
+    for (uint32_t i = tid; i < F; i += BLOCK) {
+      uint32_t v = sk[i];
+      if (v < 0x80000000u) {
+        // hash_family(v, step) % F, src/niqki_index.cpp:308-310,:319 (low bits only)
+        uint32_t t = ((uint32_t)unrev64(v) + step * (uint32_t)rev64(v)) & (F - 1u);
+        atomicMin(&sk[t], 0x80000000u | (i << d.W) | v);
+      }
+    }
+    __syncthreads();
+    // resolve
+    uint32_t filled = 0;
+    for (uint32_t i = tid; i < F; i += BLOCK) {
+      uint32_t v = sk[i];
+      if (v >= 0x80000000u && v != kEmpty32) { sk[i] = v & vmask; ++filled; }
+    }
+    if (filled) atomicAdd(&s_flag[1], filled);
+    __syncthreads();
+    uint32_t tot = s_flag[1];
+    __syncthreads();
+    if (tid == 0) s_flag[1] = 0;
+    empty -= tot;
+    ++step;
+    idle = tot ? 0u : idle + 1u;
+    if (empty == 0 || idle >= F) break;
+    __syncthreads();
+  }
+}
+
+// One rolling hash step (the body of the loop at src/niqki_index.cpp:342-356).
+__device__ __forceinline__ void hash_step(uint32_t byte, const uint8_t *lut, uint64_t &fw,
+                                          uint64_t &rc, const Derived &d, uint32_t rc_shift,
+                                          uint32_t *sk, bool live) {
+  uint32_t e = lut[byte];
+  fw = ((fw << 2) | (uint64_t)(e & 3u)) & d.kmer_mask;
+  rc = (rc >> 2) | ((uint64_t)((e >> 2) & 3u) << rc_shift);
+  uint64_t canon = fw < rc ? fw : rc;
+  uint32_t slot = slot_of(canon, d.S);
+  uint32_t fp = fingerprint(rev64(canon), d.M, d.mask_m, d.max_rem);
+  if (live) atomicMin(&sk[slot], fp);
+}
+
+// GROUPS 16-byte groups of hash steps per chunk: CHUNK = 16*GROUPS k-mers.
+template <int BLOCK, int GROUPS>
+__global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  const Derived &d = a.d;
+  uint32_t *sk = smem;                              // F cells
+  uint32_t *s_flag = smem + d.F;                    // 4 words
+  uint8_t *lut = (uint8_t *)(smem + d.F + 4);       // 256 bytes
+  const uint32_t tid = threadIdx.x;
+  const uint32_t entry = blockIdx.x / a.splits;
+  const uint32_t part = blockIdx.x % a.splits;
+  constexpr uint32_t CHUNK = 16u * GROUPS;
+
+  if (tid < 256) lut[tid] = code_entry(tid);
+  if (a.accumulate) {
+    const uint32_t *src = (const uint32_t *)a.sketches + (uint64_t)entry * d.F;
+    for (uint32_t i = tid; i < d.F; i += BLOCK) sk[i] = src[i];
+  } else {
+    for (uint32_t i = tid; i < d.F; i += BLOCK) sk[i] = kEmpty32;
+  }
+  __syncthreads();
+
+  const uint32_t Km1 = d.K - 1u;
+  const uint32_t rc_shift = 2u * d.K - 2u;
+  uint32_t r0 = a.entry_rec ? a.entry_rec[entry] : entry;
+  uint32_t r1 = a.entry_rec ? a.entry_rec[entry + 1] : entry + 1;
+  if (a.seqs == nullptr) r1 = r0;  // densify-only launch
+  for (uint32_t rec = r0; rec < r1; ++rec) {
+    const uint64_t b0 = a.rec_off[rec], b1 = a.rec_off[rec + 1];
+    const uint64_t len = b1 - b0;
+    if (len <= d.K) continue;              // src/niqki_index.cpp:395,:450
+    const uint64_t n_kmers = len - d.K;    // last k-mer skipped, :342
+    const uint64_t n_chunks = (n_kmers + CHUNK - 1) / CHUNK;
+    const uint64_t c_lo = n_chunks * part / a.splits;
+    const uint64_t c_hi = n_chunks * (part + 1) / a.splits;
+    const uint8_t *base = a.seqs + b0;
+    for (uint64_t c = c_lo + tid; c < c_hi; c += BLOCK) {
+      const uint64_t i0 = c * CHUNK;
+      const uint64_t left = n_kmers - i0;
+      const uint32_t cnt = left < CHUNK ? (uint32_t)left : CHUNK;
+      // ---- warm-up: K-1 rolling updates from zero rebuild both words ----
+      // Chunk 0 packs the record's first K-1 bases the str2numstrand way
+      // (case-insensitive; any other byte zeroes all K-1 digits, :255-273),
+      // every other chunk uses the rolling tables.
+      uint64_t fw = 0, rc = 0;
+      {
+        ByteStream bs;
+        bs.open(base + i0);
+        uint4 g0 = bs.next16(), g1 = bs.next16();
+        uint32_t shift_f = 0, shift_r = 2, and_f = 3, or_r = 0;
+        if (i0 == 0) {
+          uint32_t ok = 1;
+#pragma unroll
+          for (int j = 0; j < 32; ++j) {
+            uint32_t w = dword_of(j < 16 ? g0 : g1, (j & 15) >> 2);
+            uint32_t e = lut[(w >> (8 * (j & 3))) & 0xFFu];
+            if ((uint32_t)j < Km1) ok &= (e >> 6);
+          }
+          shift_f = 4; shift_r = 4;  // prefix digit; rc digit = 3 - digit below
+          if (!ok) { and_f = 0; }
+          or_r = 0x100;  // marker: complement the prefix digit
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          if ((uint32_t)j < Km1) {
+            uint32_t w = dword_of(j < 16 ? g0 : g1, (j & 15) >> 2);
+            uint32_t e = lut[(w >> (8 * (j & 3))) & 0xFFu];
+            uint32_t cf = (e >> shift_f) & and_f;
+            uint32_t cr = or_r ? (3u - cf) : ((e >> shift_r) & 3u);
+            fw = (fw << 2) | cf;
+            rc = (rc >> 2) | ((uint64_t)cr << rc_shift);
+          }
+        }
+      }
+      // ---- CHUNK hash steps, bases i0+K-1 .. ----
+      ByteStream bs;
+      bs.open(base + i0 + Km1);
+      for (int g = 0; g < GROUPS; ++g) {
+        if ((uint32_t)(g * 16) >= cnt) break;
+        uint4 v = bs.next16();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          uint32_t w = dword_of(v, j >> 2);
+          uint32_t byte = (w >> (8 * (j & 3))) & 0xFFu;
+          hash_step(byte, lut, fw, rc, d, rc_shift, sk, (uint32_t)(g * 16 + j) < cnt);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  uint32_t *out = (uint32_t *)a.sketches + (uint64_t)entry * d.F;
+  if (a.splits > 1) {
+    // partial sketch of a split record: merged in global memory, densified
+    // by a second launch once all parts are in
+    for (uint32_t i = tid; i < d.F; i += BLOCK) {
+      uint32_t v = sk[i];
+      if (v != kEmpty32) atomicMin(&out[i], v);
+    }
+    return;
+  }
+  if (a.densify) densify_lds<BLOCK>(sk, d, s_flag);
+  __syncthreads();
+  for (uint32_t i = tid; i < d.F; i += BLOCK) out[i] = sk[i];
+}
+
+static size_t sketch_lds_bytes(const Derived &d) { return (size_t)d.F * 4 + 16 + 256; }
+
+hipError_t launch_sketch(const SketchArgs &a, uint32_t n_entry, bool short_records,
+                         hipStream_t stream) {
+  if (n_entry == 0) return hipSuccess;
+  size_t lds = sketch_lds_bytes(a.d);
+  dim3 grid(n_entry * a.splits);
+  if (short_records) {
+    auto k = sketch_kernel<256, 1>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, a);
+  } else {
+    auto k = sketch_kernel<1024, 8>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, grid, dim3(1024), lds, stream, a);
+  }
+  return hipGetLastError();
+}
+
+__global__ void fill_u32_kernel(uint32_t *p, uint64_t n, uint32_t v) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+hipError_t launch_fill_u32(uint32_t *p, uint64_t n, uint32_t v, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_u32_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, p, n, v);
+  return hipGetLastError();
+}
+
+}  // namespace nq

@@ -1,0 +1,91 @@
+// ref_harness.cpp -- thin extern "C" access to the REAL reference implementation.
+//
+// TEST INFRASTRUCTURE ONLY.  This file is our own code; it contains no
+// reference source.  oracle/Makefile compiles it together with the reference's
+// own src/niqki_index.cpp and src/genome.cpp, taken where they lie under
+// /root/reference, into oracle/_ref/libniqki_ref.so (git-ignored).  It exists
+// so that oracle/make_goldens.py and tests/test_oracle_vs_ref.py can pin the
+// C restatement (niqki_oracle.c) against the reference's actual outputs.
+// Nothing here is reachable from the product library.
+//
+// Every member of the reference's Index class is public
+// (src/niqki_index.h:35-213), so the harness calls the hot-path methods
+// directly.
+#include "niqki_index.h"
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" {
+
+// Index(lF,K,W,H,out,min_fract): src/niqki_index.cpp:13-38.  The constructor
+// opens its output file, so callers pass a scratch path.
+void *ref_create(uint32_t lF, uint32_t K, uint32_t W, uint32_t H,
+                 const char *out_path, double min_fract) {
+  return new Index(lF, K, W, H, std::string(out_path), min_fract);
+}
+
+void ref_destroy(void *h) { delete static_cast<Index *>(h); }
+
+uint32_t ref_min_score(void *h) { return static_cast<Index *>(h)->min_score; }
+
+uint64_t ref_rev64(void *h, uint64_t x) { return static_cast<Index *>(h)->revhash64(x); }
+uint64_t ref_unrev64(void *h, uint64_t x) { return static_cast<Index *>(h)->unrevhash64(x); }
+int32_t ref_fingerprint(void *h, uint64_t x) { return static_cast<Index *>(h)->get_fingerprint(x); }
+uint64_t ref_hash_family(void *h, uint64_t x, uint32_t step) {
+  return static_cast<Index *>(h)->hash_family(x, step);
+}
+
+// compute_sketch on a fresh vector: src/niqki_index.cpp:335-358
+void ref_compute_sketch(void *h, const char *seq, uint64_t len, int32_t *out) {
+  Index *ix = static_cast<Index *>(h);
+  std::string s(seq, len);
+  std::vector<int32_t> sk;
+  ix->compute_sketch(s, sk);
+  std::memcpy(out, sk.data(), sk.size() * sizeof(int32_t));
+}
+
+// sketch_densification alone: src/niqki_index.cpp:313-331
+void ref_densify(void *h, int32_t *sk, uint32_t empty) {
+  Index *ix = static_cast<Index *>(h);
+  std::vector<int32_t> v(sk, sk + ix->F);
+  ix->sketch_densification(v, empty);
+  std::memcpy(sk, v.data(), v.size() * sizeof(int32_t));
+}
+
+// insert_sketch + the bookkeeping the file drivers do around it
+// (src/niqki_index.cpp:362-370, :396-401)
+void ref_insert_sketch(void *h, const int32_t *sk, const char *name) {
+  Index *ix = static_cast<Index *>(h);
+  std::vector<int32_t> v(sk, sk + ix->F);
+  uint32_t id = ix->genome_numbers++;
+  ix->filenames.push_back(std::string(name));
+  ix->insert_sketch(v, id);
+}
+
+// query_sketch: src/niqki_index.cpp:633-687.  Returns the number of hits and
+// writes up to cap (count,gid) pairs in the reference's output order.
+uint32_t ref_query_sketch(void *h, const int32_t *sk, uint32_t *counts,
+                          uint32_t *gids, uint32_t cap) {
+  Index *ix = static_cast<Index *>(h);
+  std::vector<int32_t> v(sk, sk + ix->F);
+  query_output r = ix->query_sketch(v);
+  for (uint32_t i = 0; i < r.size() && i < cap; ++i) {
+    counts[i] = r[i].first;
+    gids[i] = r[i].second;
+  }
+  return (uint32_t)r.size();
+}
+
+uint64_t ref_bucket_size(void *h, uint64_t bucket) {
+  return static_cast<Index *>(h)->Buckets[bucket].size();
+}
+
+// dump_index_disk: src/niqki_index.cpp:42-59 (gzip file)
+void ref_dump(void *h, const char *path) {
+  static_cast<Index *>(h)->dump_index_disk(std::string(path));
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+"""CPU: the oracle (oracle/niqki_oracle.c) against the golden vectors the REAL
+reference produced (oracle/make_goldens.py -> tests/golden/).  This is what pins
+the oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import synth_case
+
+
+def test_hash_and_fingerprint_kats(po, gold):
+    vec, _ = gold
+    # SURVEY.md 8a rows a5/a6 known answers
+    assert po.rev64(1) == 0x4179B061E0C0E0D0
+    assert po.unrev64(1) == 0xB471E5C8635F305A
+    assert po.rev64(0) == 0 and po.unrev64(0) == 0
+    assert po.fingerprint(1) == 1
+    assert po.fingerprint(1 << 63) == 3840
+    assert po.fingerprint((1 << 63) - 1) == 3839
+    assert po.fingerprint(0x0001000000000ABC) == 188
+    assert po.fingerprint(0) == 0
+    L = po.lib()
+    for i, x in enumerate(vec["kat_x"].tolist()):
+        assert po.rev64(x) == int(vec["kat_rev"][i])
+        assert po.unrev64(x) == int(vec["kat_unrev"][i])
+        assert po.fingerprint(x, 12, 4) == int(vec["kat_fp_w12h4"][i])
+        assert po.fingerprint(x, 8, 3) == int(vec["kat_fp_w8h3"][i])
+        assert L.nqo_hash_family(x & 0xFFF, 5) == int(vec["kat_hashfam_step5"][i])
+        # the pair is mutually inverse
+        assert po.unrev64(po.rev64(x)) == x
+
+
+def test_min_score_truncation(po):
+    assert po.lib().nqo_min_score(0.9, 10) == 921
+    assert po.lib().nqo_min_score(0.1, 15) == 3276
+    assert po.lib().nqo_min_score(0.0, 15) == 0
+
+
+@pytest.mark.parametrize("case", ["A", "D1", "D2", "D3", "D4"])
+def test_sketch_index_query_dump_vs_reference(po, native, gold, case):
+    vec, meta = gold
+    m = meta[case]
+    p = po.make_params(m["K"], m["S"], m["W"], m["H"], m["J"])
+    assert p.min_score == int(vec[case + "_min_score"][0])
+    genomes = synth_case(native, m)
+    sk = np.stack([po.compute_sketch(p, g) for g in genomes])
+    assert np.array_equal(sk, vec[case + "_sketches"])
+    ix = po.Index(p, sk)
+    qsk = vec[case + "_qsketches"]
+    off = vec[case + "_hit_off"]
+    for q in range(qsk.shape[0]):
+        hc, hg = ix.query(qsk[q])
+        lo, hi = int(off[q]), int(off[q + 1])
+        assert np.array_equal(hc, vec[case + "_hit_counts"][lo:hi])
+        assert np.array_equal(hg, vec[case + "_hit_gids"][lo:hi])
+    # dump bytes: payload + the names the harness used ("g0\n"...)
+    raw = ix.dump_bytes() + "".join("g%d\n" % i for i in range(len(genomes))).encode()
+    assert len(raw) == m["dump_len"]
+    assert hashlib.md5(raw).hexdigest() == m["dump_md5"]
+    # load(dump) round trip
+    ix2 = po.Index.load_bytes(raw)
+    assert ix2.n == len(genomes) and np.array_equal(ix2.gids(), ix.gids())
+    if case == "A":
+        qs = synth_case(native, m, "queries")
+        assert np.array_equal(np.stack([po.compute_sketch(p, q) for q in qs]), qsk)
+
+
+def test_north_star_parameters_vs_reference(po, native, gold):
+    vec, meta = gold
+    m = meta["B"]
+    p = po.make_params(31, 15, 12, 4, 0.0)
+    genomes = synth_case(native, m)
+    sk = np.stack([po.compute_sketch(p, g) for g in genomes])
+    assert ["%016x" % po.fnv1a64(s) for s in sk] == m["sketch_fnv"]
+    assert sk[:, :8].tolist() == m["sketch_head"]
+    qs = synth_case(native, m, "queries")
+    qsk = np.stack([po.compute_sketch(p, q) for q in qs])
+    assert ["%016x" % po.fnv1a64(s) for s in qsk] == m["qsketch_fnv"]
+    ix = po.Index(p, sk)
+    off = vec["B_hit_off"]
+    for q in range(len(qs)):
+        hc, hg = ix.query(qsk[q])
+        lo, hi = int(off[q]), int(off[q + 1])
+        assert np.array_equal(hc, vec["B_hit_counts"][lo:hi])
+        assert np.array_equal(hg, vec["B_hit_gids"][lo:hi])
+
+
+def test_short_and_edge_reads_vs_reference(po, gold):
+    vec, meta = gold
+    m = meta["C"]
+    p = po.make_params(m["K"], m["S"], m["W"], m["H"], 0.0)
+    off = vec["C_read_off"]
+    for i in range(m["n"]):
+        rd = vec["C_reads"][int(off[i]):int(off[i + 1])]
+        assert np.array_equal(po.compute_sketch(p, rd), vec["C_sketches"][i]), i
+
+
+def test_densify_guard_on_reference_hangs(po):
+    # poly-A: every canonical k-mer is 0, rev(0) = 0 is even: the reference spins
+    # forever; the oracle reports it instead.
+    p = po.make_params(31, 12, 10, 4, 0.0)
+    sk = po.sketch_accumulate(p, b"A" * 100)
+    assert (sk != -1).sum() == 1
+    out, rc = po.densify(p, sk)
+    assert rc == -1 and np.array_equal(out, sk)
+    # an all-empty sketch likewise
+    out, rc = po.densify(p, np.full(4096, -1, np.int32))
+    assert rc == -1
+
+
+def test_records_not_longer_than_k_contribute_nothing(po):
+    p = po.make_params(31, 10, 12, 4, 0.0)
+    for L in (0, 1, 30, 31):
+        sk = po.sketch_accumulate(p, b"ACGT" * 8)[:0]  # noqa: F841
+        s = po.sketch_accumulate(p, (b"ACGT" * 8)[:L])
+        assert (s == -1).all()
+    s = po.sketch_accumulate(p, (b"ACGTTGCA" * 5)[:32])
+    assert (s != -1).sum() == 1  # exactly one k-mer: the last one is skipped
+
+
+def test_matrix_equals_pairwise_queries(po, native, gold):
+    """query_range counts (bucket co-occurrence) equal the query counts of the
+    stored sketches -- the identity the GPU matrix path relies on."""
+    vec, meta = gold
+    m = meta["A"]
+    p = po.make_params(m["K"], m["S"], m["W"], m["H"], m["J"])
+    sk = vec["A_sketches"]
+    ix = po.Index(p, sk)
+    mat = ix.matrix_range(3, 11)
+    for t in range(3, 11):
+        assert np.array_equal(mat[:, t - 3].astype(np.uint32), ix.counts(sk[t]))
+
+
+def test_cli_golden_first_line_shape(gold):
+    _, meta = gold
+    hits = meta["cli"]["hits"].splitlines()
+    assert len(hits) == 12 and hits[0].startswith("syn00.fa syn00.fa:1 ")
+    assert meta["cli"]["matrix"].startswith("##Names\tsyn00.fa\t")
