@@ -83,6 +83,8 @@ uint32_t niqki_min_score(double min_fract, uint32_t S);
  * Fails with NIQKI_E_NODEVICE when there is no GPU: there is no CPU path. */
 int niqki_create(const niqki_params *params, niqki_index **out);
 void niqki_destroy(niqki_index *ix);
+/* Text of the last error on the handle; with ix == NULL, why the last
+ * niqki_create / niqki_import_dump of the calling thread failed. */
 const char *niqki_last_error(const niqki_index *ix);
 int niqki_get_params(const niqki_index *ix, niqki_params *out);
 
@@ -93,7 +95,9 @@ int niqki_synchronize(niqki_index *ix);
 
 /* Tuning knobs (no reference counterpart): "gather_variant", "query_batch",
  * "tile_genomes" (multiple of 64, <= 65536; takes effect at the next build),
- * "min_score". */
+ * "min_score", "record_len_hint" (average bytes per sketch of NIQKI_MEM_DEVICE
+ * batches, so that niqki_sketch need not read rec_off back to pick a launch
+ * shape; 0 = read it back). */
 int niqki_set_option(niqki_index *ix, const char *key, int64_t value);
 
 /* Pre-sizes the sketch store for n_genomes (optional; the store grows). */

@@ -133,7 +133,8 @@ class Engine:
             h = _vp()
             rc = self.L.niqki_create(C.byref(p), C.byref(h))
             if rc:
-                raise NiqkiError(rc, self.L.niqki_status_string(rc).decode())
+                raise NiqkiError(rc, "%s (%s)" % (self.L.niqki_status_string(rc).decode(),
+                                                  self.L.niqki_last_error(None).decode()))
             self.h = h
         q = Params()
         self.L.niqki_get_params(self.h, C.byref(q))

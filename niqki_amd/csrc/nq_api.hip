@@ -49,6 +49,7 @@ struct niqki_index {
   bool built = false;
 
   int gather_variant = 0;
+  uint64_t record_len_hint = 0;  // avg bytes per sketch for device-side batches (0 = read it back)
   uint32_t query_batch = 1024;
 
   Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
@@ -62,6 +63,8 @@ struct niqki_index {
 };
 
 namespace {
+
+thread_local std::string g_create_err;  // why the last niqki_create / niqki_import_dump on this thread failed
 
 int fail(niqki_index *ix, int code, const std::string &msg) {
   if (ix) ix->err = msg;
@@ -321,19 +324,23 @@ int niqki_create(const niqki_params *params, niqki_index **out) {
   niqki_index *ix = new (std::nothrow) niqki_index();
   if (!ix) return NIQKI_E_NOMEM;
   ix->p = *params;
+  auto bail = [&](int code, const std::string &why) { g_create_err = why; delete ix; return code; };
   std::string why;
   int rc = derive(*params, ix->d, why);
-  if (rc) { delete ix; return rc; }
+  if (rc) return bail(rc, why);
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { delete ix; return NIQKI_E_NODEVICE; }
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return bail(NIQKI_E_NODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e) + ", devices " + std::to_string(ndev));
   int dev = params->device;
-  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) { delete ix; return NIQKI_E_NODEVICE; }
-  if (dev >= ndev || hipSetDevice(dev) != hipSuccess) { delete ix; return NIQKI_E_NODEVICE; }
+  if (dev < 0 && (e = hipGetDevice(&dev)) != hipSuccess) return bail(NIQKI_E_NODEVICE, std::string("hipGetDevice: ") + hipGetErrorString(e));
+  if (dev >= ndev) return bail(NIQKI_E_NODEVICE, "device ordinal " + std::to_string(dev) + " >= device count " + std::to_string(ndev));
+  if ((e = hipSetDevice(dev)) != hipSuccess) return bail(NIQKI_E_NODEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { delete ix; return NIQKI_E_NODEVICE; }
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete ix; return NIQKI_E_NODEVICE; }
+  if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return bail(NIQKI_E_NODEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return bail(NIQKI_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is gfx950 only");
   ix->device = dev;
-  if (hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking) != hipSuccess) { delete ix; return NIQKI_E_HIP; }
+  if ((e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking)) != hipSuccess) return bail(NIQKI_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   ix->own_stream = true;
   if (const char *v = std::getenv("NIQKI_GATHER_VARIANT")) ix->gather_variant = std::atoi(v);
   *out = ix;
@@ -356,7 +363,7 @@ void niqki_destroy(niqki_index *ix) {
   delete ix;
 }
 
-const char *niqki_last_error(const niqki_index *ix) { return ix ? ix->err.c_str() : "null handle"; }
+const char *niqki_last_error(const niqki_index *ix) { return ix ? ix->err.c_str() : g_create_err.c_str(); }
 
 int niqki_get_params(const niqki_index *ix, niqki_params *out) {
   if (!ix || !out) return NIQKI_E_INVALID;
@@ -395,6 +402,7 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
     ix->built = false;
     return NIQKI_OK;
   }
+  if (!std::strcmp(key, "record_len_hint")) { ix->record_len_hint = (uint64_t)value; return NIQKI_OK; }
   if (!std::strcmp(key, "min_score")) { ix->p.min_score = ix->d.min_score = (uint32_t)value; return NIQKI_OK; }
   return fail(ix, NIQKI_E_INVALID, std::string("unknown option ") + key);
 }
@@ -414,9 +422,11 @@ int niqki_sketch(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, 
   const size_t sk_bytes = (size_t)n_entry * ix->d.F * 4;
   if (mem == NIQKI_MEM_DEVICE) {
     // total size is only needed to pick the launch shape: read the last offset
-    uint64_t total = 0;
-    NQ_HIP(ix, hipMemcpyAsync(&total, rec_off + n_rec, 8, hipMemcpyDeviceToHost, ix->stream));
-    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    uint64_t total = ix->record_len_hint * n_entry;
+    if (total == 0) {
+      NQ_HIP(ix, hipMemcpyAsync(&total, rec_off + n_rec, 8, hipMemcpyDeviceToHost, ix->stream));
+      NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    }
     return sketch_dev(ix, seqs, rec_off, n_rec, entry_rec, n_entry, sketches, total);
   }
   const uint64_t total = rec_off[n_rec];

@@ -170,34 +170,36 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
       const uint64_t left = n_kmers - i0;
       const uint32_t cnt = left < CHUNK ? (uint32_t)left : CHUNK;
       // ---- warm-up: K-1 rolling updates from zero rebuild both words ----
-      // Chunk 0 packs the record's first K-1 bases the str2numstrand way
-      // (case-insensitive; any other byte zeroes all K-1 digits, :255-273),
-      // every other chunk uses the rolling tables.
+      // Positions < K-1 of a record carry the str2numstrand digits
+      // (case-insensitive; any other byte among the first K-1 zeroes all of
+      // them, :255-273) and their complements (rcb, :240-250); every later
+      // position carries the codes of the rolling tables.
       uint64_t fw = 0, rc = 0;
       {
+        uint32_t ok = 1;
+        if (i0 < Km1) {
+          ByteStream ps;
+          ps.open(base);
+          uint4 p0 = ps.next16(), p1 = ps.next16();
+#pragma unroll
+          for (int j = 0; j < 32; ++j) {
+            uint32_t w = dword_of(j < 16 ? p0 : p1, (j & 15) >> 2);
+            uint32_t e = lut[(w >> (8 * (j & 3))) & 0xFFu];
+            if ((uint32_t)j < Km1) ok &= (e >> 6) & 1u;
+          }
+        }
         ByteStream bs;
         bs.open(base + i0);
         uint4 g0 = bs.next16(), g1 = bs.next16();
-        uint32_t shift_f = 0, shift_r = 2, and_f = 3, or_r = 0;
-        if (i0 == 0) {
-          uint32_t ok = 1;
-#pragma unroll
-          for (int j = 0; j < 32; ++j) {
-            uint32_t w = dword_of(j < 16 ? g0 : g1, (j & 15) >> 2);
-            uint32_t e = lut[(w >> (8 * (j & 3))) & 0xFFu];
-            if ((uint32_t)j < Km1) ok &= (e >> 6);
-          }
-          shift_f = 4; shift_r = 4;  // prefix digit; rc digit = 3 - digit below
-          if (!ok) { and_f = 0; }
-          or_r = 0x100;  // marker: complement the prefix digit
-        }
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
           if ((uint32_t)j < Km1) {
             uint32_t w = dword_of(j < 16 ? g0 : g1, (j & 15) >> 2);
             uint32_t e = lut[(w >> (8 * (j & 3))) & 0xFFu];
-            uint32_t cf = (e >> shift_f) & and_f;
-            uint32_t cr = or_r ? (3u - cf) : ((e >> shift_r) & 3u);
+            const bool pfx = i0 + (uint32_t)j < Km1;
+            uint32_t dgt = ok ? ((e >> 4) & 3u) : 0u;
+            uint32_t cf = pfx ? dgt : (e & 3u);
+            uint32_t cr = pfx ? (3u - dgt) : ((e >> 2) & 3u);
             fw = (fw << 2) | cf;
             rc = (rc >> 2) | ((uint64_t)cr << rc_shift);
           }

@@ -1,0 +1,81 @@
+"""CPU: the C-ABI library loads and exports every symbol include/niqki_hip.h
+declares; without a GPU the product refuses to run (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "niqki_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(niqki_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported(native):
+    import ctypes
+    L = ctypes.CDLL(native.lib_path())
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(L, s), "libniqki_hip.so lacks %s" % s
+    # the ctypes table covers the whole header too
+    from niqki_amd import capi
+    assert sorted(n for n, _, _ in capi.ABI) == syms
+
+
+def test_header_cites_the_reference_interfaces():
+    text = open(os.path.join(ROOT, "include", "niqki_hip.h")).read()
+    for cite in ("src/niqki_index.cpp:335-358", "src/niqki_index.cpp:362-370",
+                 "src/niqki_index.cpp:633-687", "src/niqki_index.cpp:42-55"):
+        assert cite in text
+
+
+def test_abi_version_and_min_score(native):
+    L = native.lib()
+    assert L.niqki_abi_version() == 1
+    assert native.min_score(0.9, 10) == 921
+    assert native.min_score(0.1, 15) == 3276
+    assert L.niqki_status_string(6) == b"no gfx950 device"
+
+
+def test_no_gpu_means_no_engine(native):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.NiqkiError) as ei:
+        native.Engine()
+    assert ei.value.code == 6  # NIQKI_E_NODEVICE: there is no CPU path to fall back to
+
+
+def test_invalid_parameters_rejected_before_touching_a_device(native):
+    for kw in (dict(K=32), dict(S=16), dict(W=16), dict(H=13, W=12), dict(K=0)):
+        with pytest.raises(native.NiqkiError) as ei:
+            native.Engine(**kw)
+        assert ei.value.code == 1, kw
+
+
+def test_host_synth_is_deterministic_acgt(native):
+    import numpy as np
+    a = native.synth_genome_host(5, 3, 0, 0, 1000)
+    b = native.synth_genome_host(5, 3, 0, 0, 1000)
+    c = native.synth_genome_host(5, 3, 7, 400, 1000)
+    assert np.array_equal(a, b) and set(a.tolist()) <= set(b"ACGT")
+    d = int((a != c).sum())
+    assert 5 <= d <= 60  # ~2.4 % substitutions
+    assert np.array_equal(native.synth_genome_host(5, 3, 0, 0, 333), a[:333])
+
+
+def test_product_never_touches_the_oracle():
+    """No file of the product (package, host program, headers) may reference oracle/."""
+    bad = []
+    for base in ("niqki_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".h", ".hip", ".cpp", ".hpp", "Makefile")):
+                    t = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"oracle|liboracle|nqo_", t):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

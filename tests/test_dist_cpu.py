@@ -1,0 +1,116 @@
+"""CPU, world_size 2 over gloo: the slot-shard exchange of niqki_amd/dist.py
+(all_gather of sketches, reduce of packed u16 hit vectors, per-rank threshold)
+gives exactly the single-index answer.  The local compute is played by an
+oracle-backed stand-in engine with the *_dev method names of niqki_amd.Engine."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from niqki_amd.dist import ShardedQuery, padded_batch, slot_range
+
+S, W, N, NQ = 9, 8, 333, 6
+
+
+class OracleShard:
+    def __init__(self, po, p, sketches, sb, se):
+        sk = sketches.copy()
+        sk[:, :sb] = -1
+        sk[:, se:] = -1          # only this shard's slots are inserted
+        self.ix = po.Index(p, sk)
+        self.sb, self.se, self.po, self.p = sb, se, po, p
+
+    def query_counts_dev(self, sk, nq, counts, stride):
+        a = sk.numpy()
+        out = counts.numpy().view(np.uint16)
+        for q in range(nq):
+            s = a[q].copy()
+            s[:self.sb] = -1
+            s[self.se:] = -1
+            out[q, :self.ix.n] = self.ix.counts(s).astype(np.uint16)
+
+    def hits_from_counts_dev(self, red, per, stride, g0, n, hit_off, hc, hg, cap):
+        c = red.numpy().view(np.uint16)
+        L = self.po.lib()
+        tot = 0
+        hit_off[0] = 0
+        for q in range(per):
+            row = np.ascontiguousarray(c[q, g0:g0 + n].astype(np.uint32))
+            oc = np.empty(n, np.uint32)
+            og = np.empty(n, np.uint32)
+            k = L.nqo_hits_from_counts(row.ctypes.data, n, self.p.min_score, oc.ctypes.data, og.ctypes.data, n)
+            hc[tot:tot + k] = torch.from_numpy(oc[:k].astype(np.int32))
+            hg[tot:tot + k] = torch.from_numpy(og[:k].astype(np.int32))
+            tot += k
+            hit_off[q + 1] = tot
+
+
+def _data():
+    rng = np.random.default_rng(77)
+    sk = rng.integers(0, 1 << W, (N, 1 << S)).astype(np.int32)
+    sk[7, 5:40] = -1
+    sk[100] = sk[8]
+    q = rng.integers(0, 1 << W, (NQ, 1 << S)).astype(np.int32)
+    q[0] = sk[8]
+    q[1] = sk[200]
+    q[1, ::2] = sk[201, ::2]
+    return sk, q
+
+
+def _worker(rank, world, port, exchange, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as po
+    p = po.make_params(31, S, W, 4, 0.0)
+    p.min_score = 5
+    sk, q = _data()
+    F = 1 << S
+    sb, se = slot_range(rank, world, F)
+    eng = OracleShard(po, p, sk, sb, se)
+    sq = ShardedQuery(eng, N, F, torch.device("cpu"), exchange=exchange)
+    per = padded_batch(NQ, world)
+    mine = torch.from_numpy(q[rank * per:(rank + 1) * per].copy())
+    hit_off = torch.zeros(per + 1, dtype=torch.int64)
+    hc = torch.zeros(per * N, dtype=torch.int32)
+    hg = torch.zeros(per * N, dtype=torch.int32)
+    sq.step(mine, hit_off, hc, hg, per * N)
+    whole = po.Index(p, sk)
+    ok = True
+    for i in range(per):
+        ehc, ehg = whole.query(q[rank * per + i], min_score=5)
+        lo, hi = int(hit_off[i]), int(hit_off[i + 1])
+        ok &= np.array_equal(hc[lo:hi].numpy().astype(np.uint32), ehc)
+        ok &= np.array_equal(hg[lo:hi].numpy().astype(np.uint32), ehg)
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize("exchange", ["reduce_scatter", "all_to_all"])
+def test_slot_sharded_query_world2(exchange):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), exchange, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_slot_ranges_partition_the_sketch():
+    for F in (32768, 4096, 64):
+        for world in (1, 2, 3, 4, 8):
+            cuts = [slot_range(r, world, F) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == F
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+    assert padded_batch(10, 4) == 3

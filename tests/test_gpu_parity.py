@@ -1,0 +1,317 @@
+"""GPU parity: the HIP path (through the C ABI of libniqki_hip.so) against the
+oracle and against the reference's golden vectors.  Bit-exact everywhere: the
+whole path is integer arithmetic; the only floating point value (Jaccard =
+count/F) is formed on the host from exact counts (tolerance 1e-6 is met with 0).
+"""
+import numpy as np
+import pytest
+
+from conftest import family_spec, synth_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng_a(native, gold):
+    _, meta = gold
+    m = meta["A"]
+    e = native.Engine(K=m["K"], S=m["S"], W=m["W"], H=m["H"], J=m["J"])
+    yield e
+    e.close()
+
+
+def test_library_is_the_native_one(native):
+    import os
+    assert os.path.exists(native.lib_path())
+    assert native.lib().niqki_abi_version() == 1
+
+
+def test_synth_host_equals_device(native):
+    import torch
+    e = native.Engine(S=10)
+    fam, mem, rate = family_spec(3, 5, fam0=7)
+    n, L, stride = fam.size, 10007, 10048
+    d = lambda a: torch.from_numpy(a.astype(np.int64)).to(torch.int32).cuda()  # noqa: E731
+    out = torch.zeros(n * stride, dtype=torch.uint8, device="cuda")
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    e.synth_dev(99, d(fam), d(mem), d(rate), n, L, stride, out)
+    e.synchronize()
+    got = out.cpu().numpy().reshape(n, stride)[:, :L]
+    for i in range(n):
+        ref = native.synth_genome_host(99, int(fam[i]), int(mem[i]), int(rate[i]), L)
+        assert np.array_equal(got[i], ref), i
+    e.close()
+
+
+@pytest.mark.parametrize("case", ["A", "D1", "D2", "D3", "D4"])
+def test_sketch_insert_query_vs_reference_goldens(native, po, gold, case):
+    vec, meta = gold
+    m = meta[case]
+    e = native.Engine(K=m["K"], S=m["S"], W=m["W"], H=m["H"], J=m["J"])
+    assert e.min_score == int(vec[case + "_min_score"][0])
+    genomes = synth_case(native, m)
+    sk = e.sketch(genomes)
+    assert np.array_equal(sk, vec[case + "_sketches"])
+    e.insert(sk)
+    assert e.n_genomes == len(genomes)
+    qsk = vec[case + "_qsketches"]
+    off, hc, hg = e.query(qsk)
+    assert np.array_equal(off, vec[case + "_hit_off"])
+    assert np.array_equal(hc, vec[case + "_hit_counts"])
+    assert np.array_equal(hg, vec[case + "_hit_gids"])
+    # dense counters against the oracle
+    p = po.make_params(m["K"], m["S"], m["W"], m["H"], m["J"])
+    ix = po.Index(p, sk)
+    cnt = e.query_counts(qsk)
+    for q in range(qsk.shape[0]):
+        assert np.array_equal(cnt[q].astype(np.uint32), ix.counts(qsk[q]))
+    # stored sketches read back
+    assert np.array_equal(e.get_sketches(0, len(genomes)), sk)
+    # dump payload byte-identical to the reference's (names appended by the host program)
+    import hashlib
+    raw = e.export_dump() + "".join("g%d\n" % i for i in range(len(genomes))).encode()
+    assert len(raw) == m["dump_len"] and hashlib.md5(raw).hexdigest() == m["dump_md5"]
+    # load the dump into a fresh handle and query again
+    e2 = native.Engine.import_dump(raw)
+    assert e2.n_genomes == len(genomes) and (e2.K, e2.S, e2.W, e2.H) == (m["K"], m["S"], m["W"], m["H"])
+    assert e2.min_score == e.min_score
+    off2, hc2, hg2 = e2.query(qsk)
+    assert np.array_equal(off2, off) and np.array_equal(hc2, hc) and np.array_equal(hg2, hg)
+    e2.close()
+    e.close()
+
+
+def test_north_star_parameters_vs_reference_goldens(native, po, gold):
+    vec, meta = gold
+    m = meta["B"]
+    e = native.Engine(K=31, S=15, W=12, H=4, J=0.0)
+    genomes = synth_case(native, m)
+    sk = e.sketch(genomes)
+    assert ["%016x" % po.fnv1a64(s) for s in sk] == m["sketch_fnv"]
+    assert sk[:, :8].tolist() == m["sketch_head"]
+    e.insert(sk)
+    off, hc, hg = e.query_sequences(synth_case(native, m, "queries"))
+    assert np.array_equal(off, vec["B_hit_off"])
+    assert np.array_equal(hc, vec["B_hit_counts"])
+    assert np.array_equal(hg, vec["B_hit_gids"])
+    e.close()
+
+
+def test_short_and_edge_reads_vs_reference_goldens(native, gold):
+    vec, meta = gold
+    m = meta["C"]
+    e = native.Engine(K=m["K"], S=m["S"], W=m["W"], H=m["H"])
+    off = vec["C_read_off"]
+    reads = [vec["C_reads"][int(off[i]):int(off[i + 1])] for i in range(m["n"])]
+    sk = e.sketch(reads)
+    for i in range(m["n"]):
+        assert np.array_equal(sk[i], vec["C_sketches"][i]), i
+    e.close()
+
+
+def test_reference_hang_cases_terminate_like_the_oracle(native, po):
+    p = po.make_params(31, 12, 10, 4, 0.0)
+    e = native.Engine(K=31, S=12, W=10, H=4)
+    recs = [b"A" * 100, b"ACGT" * 5, b"", b"ACGTACGTAC" * 3 + b"A"]  # poly-A, too short, empty, exactly K
+    sk = e.sketch(recs)
+    for i, r in enumerate(recs):
+        exp, _ = po.densify(p, po.sketch_accumulate(p, r))
+        assert np.array_equal(sk[i], exp), i
+    assert (sk[1] == -1).all() and (sk[2] == -1).all() and (sk[3] == -1).all()
+    e.close()
+
+
+def test_densify_alone_vs_oracle(native, po):
+    p = po.make_params(31, 10, 12, 4, 0.0)
+    e = native.Engine(K=31, S=10, W=12, H=4)
+    rng = np.random.default_rng(3)
+    sks = []
+    for occ in (1, 2, 5, 40, 300, 1000, 1023, 1024):
+        s = np.full(1024, -1, np.int32)
+        idx = rng.choice(1024, occ, replace=False)
+        s[idx] = rng.integers(0, 4096, occ)
+        sks.append(s)
+    sks = np.stack(sks)
+    got = e.densify(sks)
+    for i in range(sks.shape[0]):
+        exp, rc = po.densify(p, sks[i])
+        assert np.array_equal(got[i], exp), (i, rc)
+    e.close()
+
+
+def test_random_reads_many_lengths_vs_oracle(native, po):
+    p = po.make_params(31, 10, 12, 4, 0.0)
+    e = native.Engine(K=31, S=10, W=12, H=4)
+    rng = np.random.default_rng(5)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    recs = []
+    for t in range(160):
+        L = int(rng.integers(33, 4000))
+        s = alpha[rng.integers(0, 4, L)].copy()
+        if t % 4 == 1:
+            s[rng.integers(0, L, 4)] = ord("N")
+        if t % 4 == 2:
+            s[rng.integers(0, L, 25)] |= 0x20
+        if t % 4 == 3:
+            s[:10] |= 0x20
+        recs.append(s)
+    keep = [r for r in recs if po.densify(p, po.sketch_accumulate(p, r))[1] >= 0]
+    sk = e.sketch(keep)
+    for i, r in enumerate(keep):
+        assert np.array_equal(sk[i], po.compute_sketch(p, r)), (i, len(r))
+    e.close()
+
+
+def test_whole_file_mode_accumulates_records(native, po):
+    """entry_rec: several records min-accumulated into one sketch, densified once."""
+    p = po.make_params(31, 10, 12, 4, 0.0)
+    e = native.Engine(K=31, S=10, W=12, H=4)
+    rng = np.random.default_rng(8)
+    alpha = np.frombuffer(b"ACGT", np.uint8)
+    recs = [alpha[rng.integers(0, 4, L)].copy() for L in (500, 20, 3000, 31, 800, 1200)]
+    entry_rec = np.array([0, 3, 3, 6], np.uint32)  # entry 1 is empty
+    sk = e.sketch(recs, entry_rec=entry_rec)
+    for en in range(3):
+        acc = np.full(1024, -1, np.int32)
+        for r in recs[entry_rec[en]:entry_rec[en + 1]]:
+            po.sketch_accumulate(p, r, acc)
+        exp, _ = po.densify(p, acc)
+        assert np.array_equal(sk[en], exp), en
+    e.close()
+
+
+def test_split_long_record_equals_oracle(native, po):
+    """Few long records: the sketch is split over several workgroups and merged."""
+    p = po.make_params(31, 12, 12, 4, 0.0)
+    e = native.Engine(K=31, S=12, W=12, H=4)
+    g = [native.synth_genome_host(4, 1, k, 100 * k, 1_200_000) for k in range(2)]
+    sk = e.sketch(g)
+    for i in range(2):
+        assert np.array_equal(sk[i], po.compute_sketch(p, g[i]))
+    e.close()
+
+
+def test_multi_tile_index_and_threshold_order(native, po):
+    """N spread over several counter tiles, ragged last tile, ties in count."""
+    S, W = 8, 6
+    p = po.make_params(21, S, W, 3, 0.0)
+    p.min_score = 6
+    rng = np.random.default_rng(21)
+    N = 64 * 3 + 37
+    sk = rng.integers(0, 1 << W, (N, 1 << S)).astype(np.int32)
+    sk[5, :17] = -1                      # empty cells are not inserted
+    sk[9] = sk[3]                        # duplicates: ties broken by descending gid
+    sk[200] = sk[3]
+    e = native.Engine(K=21, S=S, W=W, H=3, min_score_value=6, tile_genomes=64)
+    e.insert(sk[:100])
+    e.insert(sk[100:])                   # second insert grows the store
+    q = np.concatenate([sk[[3, 5, 77]], rng.integers(0, 1 << W, (3, 1 << S)).astype(np.int32)])
+    q[4, ::3] = -1
+    ix = po.Index(p, sk)
+    cnt = e.query_counts(q)
+    off, hc, hg = e.query(q)
+    for i in range(q.shape[0]):
+        assert np.array_equal(cnt[i].astype(np.uint32), ix.counts(q[i]))
+        ehc, ehg = ix.query(q[i], min_score=6)
+        lo, hi = int(off[i]), int(off[i + 1])
+        assert np.array_equal(hc[lo:hi], ehc) and np.array_equal(hg[lo:hi], ehg), i
+    assert np.array_equal(e.gathered(q), np.array([ix.gathered(x) for x in q], np.uint64))
+    # matrix rows equal the reference's bucket co-occurrence counts
+    mat = e.matrix_range(60, 140)
+    exp = ix.matrix_range(60, 140)      # [a][t-begin]
+    assert np.array_equal(mat, exp.T)
+    # same index under a different tiling gives the same answers
+    e.set_option("tile_genomes", 128)
+    e.build()
+    assert np.array_equal(e.query_counts(q), cnt)
+    # dump bytes equal the oracle's
+    assert e.export_dump() == ix.dump_bytes()
+    e.close()
+
+
+def test_min_score_zero_reports_every_genome(native, po):
+    S, W = 7, 8
+    rng = np.random.default_rng(2)
+    N = 300
+    sk = rng.integers(0, 1 << W, (N, 1 << S)).astype(np.int32)
+    e = native.Engine(K=31, S=S, W=W, H=4, J=0.0)
+    e.insert(sk)
+    off, hc, hg = e.query(sk[:4], capacity=10)   # forces the capacity retry path
+    p = po.make_params(31, S, W, 4, 0.0)
+    ix = po.Index(p, sk)
+    for i in range(4):
+        ehc, ehg = ix.query(sk[i])
+        assert len(ehc) == N
+        assert np.array_equal(hc[int(off[i]):int(off[i + 1])], ehc)
+        assert np.array_equal(hg[int(off[i]):int(off[i + 1])], ehg)
+    e.close()
+
+
+def test_empty_index_and_empty_batches(native):
+    e = native.Engine(K=31, S=8, W=8, H=4)
+    off, hc, hg = e.query(np.zeros((2, 256), np.int32))
+    assert off.tolist() == [0, 0, 0] and hc.size == 0
+    assert e.sketch([]).shape == (0, 256)
+    e.insert(np.zeros((0, 256), np.int32))
+    assert e.n_genomes == 0
+    e.close()
+
+
+def test_slot_shards_sum_to_whole(native, po):
+    """Slot-range shards (the multi-GPU partition): partial counters add up."""
+    S, W = 9, 8
+    rng = np.random.default_rng(13)
+    N = 150
+    sk = rng.integers(0, 1 << W, (N, 1 << S)).astype(np.int32)
+    q = rng.integers(0, 1 << W, (5, 1 << S)).astype(np.int32)
+    q[0] = sk[17]
+    whole = native.Engine(K=31, S=S, W=W, H=4, min_score_value=3)
+    whole.insert(sk)
+    ref = whole.query_counts(q).astype(np.uint32)
+    tot = np.zeros_like(ref)
+    for r in range(4):
+        sh = native.Engine(K=31, S=S, W=W, H=4, min_score_value=3,
+                           slot_begin=r * 128, slot_end=(r + 1) * 128)
+        sh.insert(sk)
+        tot += sh.query_counts(q).astype(np.uint32)
+        sh.close()
+    assert np.array_equal(tot, ref)
+    off, hc, hg = whole.query(q)
+    off2, hc2, hg2 = whole.hits_from_counts(np.pad(tot, ((0, 0), (0, tot.shape[1] & 1))).astype(np.uint16),
+                                            0, N)
+    assert np.array_equal(off, off2) and np.array_equal(hc, hc2) and np.array_equal(hg, hg2)
+    whole.close()
+
+
+def test_full_size_properties_north_star(native):
+    """At BASELINE sizes the oracle is too slow: size-independent properties.
+    5 Mbp genomes, S=15: self query gives F; a mutant's count is below F and
+    above an unrelated genome's; insert order does not change counts."""
+    import torch
+    L = 5_000_000
+    e = native.Engine(K=31, S=15, W=12, H=4, J=0.1)
+    fam = np.array([0, 0, 0, 1, 2], np.uint32)
+    mem = np.array([0, 1, 2, 0, 0], np.uint32)
+    rate = np.array([0, 16, 400, 0, 0], np.uint32)
+    n = 5
+    t = lambda a: torch.from_numpy(a.astype(np.int64)).to(torch.int32).cuda()  # noqa: E731
+    seqs = torch.zeros(n * L + native.SEQ_PAD, dtype=torch.uint8, device="cuda")
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    e.synth_dev(1, t(fam), t(mem), t(rate), n, L, L, seqs)
+    rec_off = torch.from_numpy(np.arange(n + 1, dtype=np.int64) * L).cuda()
+    sk = torch.empty((n, 1 << 15), dtype=torch.int32, device="cuda")
+    e.sketch_dev(seqs, rec_off, n, sk)
+    e.synchronize()
+    assert int((sk == -1).sum()) == 0
+    skh = sk.cpu().numpy()
+    e.insert(skh)
+    cnt = e.query_counts(skh).astype(np.int64)
+    F = 1 << 15
+    assert all(cnt[i, i] == F for i in range(n))
+    assert F > cnt[0, 1] > cnt[0, 2] > cnt[0, 3]
+    assert np.array_equal(cnt, cnt.T)
+    e2 = native.Engine(K=31, S=15, W=12, H=4, J=0.1)
+    e2.insert(skh[::-1].copy())
+    assert np.array_equal(e2.query_counts(skh).astype(np.int64), cnt[:, ::-1])
+    e2.close()
+    e.close()
