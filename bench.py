@@ -285,16 +285,25 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
         n_sub = min(n_sub, N)
         sub = eng.get_sketches(0, n_sub)
         ix = po.Index(p, sub)
-        t0 = time.perf_counter()
-        off, c, g = ix.query_batch(sk_cpu, threads=cores)
-        pts.append((n_sub, time.perf_counter() - t0))
+        best = None
+        for _ in range(3):  # first pass warms the pages, keep the fastest
+            t0 = time.perf_counter()
+            off, c, g = ix.query_batch(sk_cpu, threads=cores)
+            t = time.perf_counter() - t0
+            best = t if best is None else min(best, t)
+        pts.append((n_sub, best))
         if n_sub == min(16384, N):
             cnt = eng.query_counts(sk_gpu)[:, :n_sub]
             for i in range(min(n_s, 4)):
                 parity_counts &= bool(np.array_equal(cnt[i].astype(np.uint32), ix.counts(sk_cpu[i])))
         del ix
     (n1, t1), (n2, t2) = pts
-    t_q = t2 if n2 == n1 else t1 + (t2 - t1) * (N - n1) / (n2 - n1)
+    if n2 == n1:
+        t_q = t2
+    elif t2 > t1:
+        t_q = t1 + (t2 - t1) * (N - n1) / (n2 - n1)   # linear in N through both points
+    else:
+        t_q = t2                                      # no measurable growth: take the larger index as is
     val = n_s / (t_sk + t_q)
     return {
         "value": val, "unit": "genomes/s", "cores": cores, "kind": "port",

@@ -89,6 +89,15 @@ def lib():
         if not os.path.exists(_LIB):
             raise ImportError("%s is missing: run __graft_entry__.build() (make -C niqki_amd/csrc); "
                               "there is no fallback path" % _LIB)
+        # libniqki_hip.so binds to the HIP runtime by soname (libamdhip64.so.7).
+        # PyTorch wheels ship their own copy under the same soname; when both are
+        # used in one process PyTorch's must be loaded first, otherwise the process
+        # ends up with two runtimes and the second one to initialise finds no
+        # device.  (The C++ host program never loads PyTorch.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_LIB)
         for name, res, args in ABI:
             f = getattr(L, name)  # AttributeError if the library lacks a declared symbol

@@ -524,7 +524,7 @@ int niqki_build(niqki_index *ix) {
   }
   const uint32_t n_tiles = (N + tile - 1) / tile;
   const size_t ob = (size_t)n_tiles * f_local * (ix->d.R + 1) * 4;
-  const size_t gb = (size_t)n_tiles * f_local * tile * 2;
+  const size_t gb = (size_t)n_tiles * f_local * tile * 2 + 256;  // + pad: the gather kernel may read one id past an empty last bucket
   if (ob > ix->offsets_bytes) {
     if (ix->offsets) NQ_HIP(ix, hipFree(ix->offsets));
     ix->offsets = nullptr; ix->offsets_bytes = 0;

@@ -21,7 +21,15 @@ __device__ __forceinline__ void bump(uint32_t *cnt, uint32_t g) {
   atomicAdd(&cnt[g >> 1], 1u << ((g & 1u) * 16u));  // ds_add_u32, result unused
 }
 
-template <int BLOCK, int UNROLL>
+struct __attribute__((packed, aligned(4))) OffPair { uint32_t lo, hi; };
+
+// UNROLL buckets are fetched per round trip; two rounds are kept in flight
+// (the gid loads of round r+1 are issued before the LDS atomics of round r), and
+// the CSR lookups run two 64-slot iterations ahead of the bucket walk, so the
+// wave never waits on a load it has just issued.
+// MODE is a measurement aid (bench ablations only, results are wrong for MODE != 0):
+//   1 = no LDS atomics, 2 = no gid loads (synthetic ids), 3 = lookups only.
+template <int BLOCK, int UNROLL, int MODE = 0, int ROT = 0>
 __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_t *sketches,
                                                        uint16_t *counts, uint64_t stride) {
   extern __shared__ __align__(16) uint32_t cnt[];
@@ -39,34 +47,88 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
   const int32_t *sk = sketches + (uint64_t)q * v.d.F + v.d.slot_begin;
   const uint32_t *off = v.offsets + (uint64_t)t * v.f_local * (R + 1);
   const uint16_t *gl = v.gids + (uint64_t)t * v.f_local * v.tile;
+  const uint32_t n_it = (v.f_local + 63) / 64;
 
-  for (uint32_t s0 = wave * 64; s0 < v.f_local; s0 += NW * 64) {
-    const uint32_t s = s0 + lane;
-    uint32_t o0 = 0, len = 0;
-    if (s < v.f_local) {
-      int32_t fp = sk[s];
-      if (fp >= 0 && (uint32_t)fp < R) {  // src/niqki_index.cpp:654
-        const uint32_t *p = off + (uint64_t)s * (R + 1) + (uint32_t)fp;
-        o0 = p[0];
-        len = p[1] - o0;
-      }
-    }
-    for (uint32_t j0 = 0; j0 < 64; j0 += UNROLL) {
-      uint32_t g[UNROLL], l[UNROLL], b[UNROLL];
+  // Both lookups are unconditional loads from clamped addresses (validity is
+  // applied when the values are used), so that they stay in flight across the
+  // bucket walk instead of being waited for where they are issued.
+  // ROT: every workgroup starts its walk over the slots at a different place, so
+  // that the workgroups in flight do not all hit the same window of the table.
+  const uint32_t rot = (ROT && n_it % NW == 0) ? (uint32_t)(((uint64_t)blockIdx.x * 2654435761u) >> 12) % n_it : 0u;
+  auto phys = [&](uint32_t it) -> uint32_t { uint32_t e = it + rot; return e >= n_it && it < n_it ? e - n_it : e; };
+  auto load_fp = [&](uint32_t it) -> int32_t {
+    const uint32_t s = phys(it) * 64 + lane;
+    return sk[s < v.f_local ? s : v.f_local - 1];
+  };
+  auto slot_ok = [&](uint32_t it) -> bool { return it < n_it && phys(it) * 64 + lane < v.f_local; };
+  auto load_off = [&](uint32_t it, int32_t fp, bool ok) -> OffPair {
+    ok = ok && fp >= 0 && (uint32_t)fp < R;  // src/niqki_index.cpp:654
+    const uint64_t key = ok ? (uint64_t)(phys(it) * 64 + lane) * (R + 1) + (uint32_t)fp : 0;
+    return *(const OffPair *)(off + key);
+  };
+  auto valid_of = [&](uint32_t it, int32_t fp) -> bool {
+    return slot_ok(it) && fp >= 0 && (uint32_t)fp < R;
+  };
+
+  uint32_t sink = 0;  // keeps the loads alive in the ablation modes
+  // pipeline prologue
+  uint32_t it = wave;
+  int32_t fp0 = load_fp(it);
+  int32_t fp1 = load_fp(it + NW);                         // fingerprints one iteration ahead
+  OffPair cur = load_off(it, fp0, slot_ok(it));           // bucket extents of the current iteration
+  bool cur_ok = valid_of(it, fp0);
+
+  for (; it < n_it; it += NW) {
+    // lookups for the next iteration, fingerprints for the one after
+    const OffPair nxt = load_off(it + NW, fp1, slot_ok(it + NW));
+    const bool nxt_ok = valid_of(it + NW, fp1);
+    fp1 = load_fp(it + 2 * NW);
+    const uint32_t o0 = cur.lo, len = cur_ok ? cur.hi - cur.lo : 0u;
+
+    uint32_t ga[UNROLL], gb[UNROLL];
+    // Unconditional loads (lanes past the end re-read the bucket's last id, an
+    // empty bucket reads one id at its offset -- the gid array is padded), so
+    // that the compiler can count them in vmcnt and keep both rounds in flight.
+    auto fetch = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
 #pragma unroll
       for (int u = 0; u < UNROLL; ++u) {
-        b[u] = __builtin_amdgcn_readlane(o0, j0 + u);
-        l[u] = __builtin_amdgcn_readlane(len, j0 + u);
-        g[u] = (lane < l[u]) ? (uint32_t)gl[b[u] + lane] : 0u;
+        const uint32_t b = __builtin_amdgcn_readlane(o0, j0 + u);
+        const uint32_t l = __builtin_amdgcn_readlane(len, j0 + u);
+        const uint32_t last = l ? l - 1 : 0;
+        if (MODE >= 2) g[u] = ((b * 2654435761u + lane * 40503u) >> 17) & 0x7FFFu;
+        else g[u] = gl[b + (lane < last ? lane : last)];
       }
+    };
+    auto apply = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
-        if (lane < l[u]) bump(cnt, g[u]);
+      for (int u = 0; u < UNROLL; ++u) {
+        const uint32_t l = __builtin_amdgcn_readlane(len, j0 + u);
+        if (MODE == 1 || MODE == 3) { if (lane < l) sink ^= g[u]; }
+        else if (lane < l) bump(cnt, g[u]);
+      }
+    };
+    fetch(0, ga);
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u)
-        for (uint32_t e = 64 + lane; e < l[u]; e += 64) bump(cnt, gl[b[u] + e]);
+    for (uint32_t j0 = 0; j0 < 64; j0 += 2 * UNROLL) {
+      fetch(j0 + UNROLL, gb);
+      apply(j0, ga);
+      if (j0 + 2 * UNROLL < 64) fetch(j0 + 2 * UNROLL, ga);
+      apply(j0 + UNROLL, gb);
     }
+    // buckets longer than one wave: the rest, 64 ids at a time
+    if (__any(len > 64)) {
+      for (uint32_t j = 0; j < 64; ++j) {
+        const uint32_t l = __builtin_amdgcn_readlane(len, j);
+        if (l > 64) {
+          const uint32_t b = __builtin_amdgcn_readlane(o0, j);
+          for (uint32_t e = 64 + lane; e < l; e += 64) bump(cnt, gl[b + e]);
+        }
+      }
+    }
+    cur = nxt;
+    cur_ok = nxt_ok;
   }
+  if (MODE != 0) cnt[tid % n_words] ^= sink;
   __syncthreads();
 
   // dense counter row of this tile: u16 counts[q*stride + g0 + i], written as the packed words
@@ -82,18 +144,25 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
   size_t lds = (size_t)((v.tile + 1) / 2) * 4;
   dim3 grid(nq * v.n_tiles);
   hipError_t e;
-#define NQ_LAUNCH_GATHER(B, U)                                                                   \
+#define NQ_LAUNCH_GATHER(B, U, ...)                                                              \
   do {                                                                                           \
-    auto k = gather_kernel<B, U>;                                                                \
+    auto k = gather_kernel<B, U, ##__VA_ARGS__>;                                                                \
     e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                               \
     hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, v, sketches, counts, stride);              \
   } while (0)
   switch (variant) {
-    case 1: NQ_LAUNCH_GATHER(1024, 4); break;
-    case 2: NQ_LAUNCH_GATHER(1024, 16); break;
-    case 3: NQ_LAUNCH_GATHER(512, 8); break;
-    default: NQ_LAUNCH_GATHER(1024, 8); break;
+    case 1: NQ_LAUNCH_GATHER(1024, 8); break;
+    case 2: NQ_LAUNCH_GATHER(1024, 32); break;
+    case 3: NQ_LAUNCH_GATHER(512, 16); break;
+    case 4: NQ_LAUNCH_GATHER(512, 32); break;
+    case 5: NQ_LAUNCH_GATHER(1024, 16, 0, 1); break;  // rotated slot walk
+    case 6: NQ_LAUNCH_GATHER(1024, 8, 0, 1); break;
+    case 15: NQ_LAUNCH_GATHER(1024, 16, 3, 1); break;
+    case 11: NQ_LAUNCH_GATHER(1024, 16, 1); break;  // ablations, see MODE
+    case 12: NQ_LAUNCH_GATHER(1024, 16, 2); break;
+    case 13: NQ_LAUNCH_GATHER(1024, 16, 3); break;
+    default: NQ_LAUNCH_GATHER(1024, 16); break;
   }
 #undef NQ_LAUNCH_GATHER
   return hipGetLastError();
