@@ -1,0 +1,315 @@
+// index_host.cpp -- file-level drivers of the `niqki` host program.  Reads
+// FASTA/FASTQ exactly like the reference (seqio.h), batches records, and calls
+// the gfx950 engine through the C ABI (include/niqki_hip.h).  No sketching,
+// counting or sorting happens on the host.
+#include "index_host.h"
+
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+
+#include "seqio.h"
+
+namespace nqhost {
+
+namespace {
+bool exists_test(const std::string &name) {  // src/niqki_index.h:150-153
+  struct stat st;
+  return stat(name.c_str(), &st) == 0;
+}
+// default ostream << double: 6 significant digits, %g style (src/niqki_index.cpp:550,:758)
+std::string fmt_double(double v) {
+  char buf[64];
+  snprintf(buf, sizeof buf, "%g", v);
+  return buf;
+}
+constexpr size_t kBatchBytes = size_t(1) << 30;   // sequence bytes per GPU call
+constexpr size_t kBatchEntries = 4096;            // sketches per GPU call
+}  // namespace
+
+// A batch of records on their way to the GPU: entry e = records
+// [entry_rec[e], entry_rec[e+1]) of seqs, name[e] its label.
+struct Index::Batch {
+  std::vector<uint8_t> seqs;
+  std::vector<uint64_t> rec_off{0};
+  std::vector<uint32_t> entry_rec{0};
+  std::vector<std::string> names;
+  void add_record(const std::string &s) {
+    seqs.insert(seqs.end(), s.begin(), s.end());
+    rec_off.push_back(seqs.size());
+  }
+  void end_entry(const std::string &name) {
+    entry_rec.push_back((uint32_t)(rec_off.size() - 1));
+    names.push_back(name);
+  }
+  size_t n_entries() const { return names.size(); }
+  bool full() const { return seqs.size() >= kBatchBytes || names.size() >= kBatchEntries; }
+  void clear() {
+    seqs.clear();
+    rec_off.assign(1, 0);
+    entry_rec.assign(1, 0);
+    names.clear();
+  }
+};
+
+void Index::check(int rc, const char *what) const {
+  if (rc == NIQKI_OK) return;
+  throw std::runtime_error(std::string(what) + ": " + niqki_status_string(rc) + " (" + niqki_last_error(h_) + ")");
+}
+
+Index::Index(uint32_t ilF, uint32_t iK, uint32_t iW, uint32_t iH, const std::string &out_filename,
+             double min_fract, int device) {
+  niqki_params p{};
+  p.K = iK; p.S = ilF; p.W = iW; p.H = iH;
+  p.min_score = niqki_min_score(min_fract, ilF);
+  p.device = device;
+  int rc = niqki_create(&p, &h_);
+  if (rc) throw std::runtime_error(std::string("niqki_create: ") + niqki_status_string(rc) + " (" + niqki_last_error(nullptr) + ")");
+  K = iK; W = iW; H = iH; lF = ilF; F = 1u << ilF; min_score = p.min_score;
+  outfile.reset(new GzWriter(out_filename));
+}
+
+Index::Index(const std::string &dump_file, bool pretty, const std::string &out_filename, int device) {
+  pretty_printing = pretty;
+  std::vector<uint8_t> raw;
+  {
+    GzReader in(dump_file);
+    in.read_all(raw);
+  }
+  niqki_params p{};
+  p.device = device;
+  uint64_t consumed = 0;
+  int rc = niqki_import_dump(&p, raw.data(), raw.size(), &consumed, &h_);
+  if (rc) throw std::runtime_error(std::string("niqki_import_dump: ") + niqki_status_string(rc) + " (" + niqki_last_error(nullptr) + ")");
+  niqki_params q{};
+  niqki_get_params(h_, &q);
+  K = q.K; W = q.W; H = q.H; lF = q.S; F = 1u << q.S; min_score = q.min_score;
+  // genome names, one per line after the buckets (src/niqki_index.cpp:91-95)
+  const uint32_t n = niqki_genome_count(h_);
+  size_t pos = consumed;
+  for (uint32_t i = 0; i < n; ++i) {
+    size_t e = pos;
+    while (e < raw.size() && raw[e] != '\n') ++e;
+    filenames.emplace_back((const char *)raw.data() + pos, e - pos);
+    pos = e < raw.size() ? e + 1 : e;
+  }
+  outfile.reset(new GzWriter(out_filename));
+}
+
+Index::~Index() {
+  if (outfile) outfile->close();
+  if (h_) niqki_destroy(h_);
+}
+
+void Index::compute_sketch(const std::string &reference, std::vector<int32_t> &sketch) const {
+  sketch.assign(F, -1);
+  uint64_t off[2] = {0, reference.size()};
+  check(niqki_sketch(h_, (const uint8_t *)reference.data(), off, 1, nullptr, 1, sketch.data(), NIQKI_MEM_HOST), "niqki_sketch");
+}
+
+void Index::insert_sketch(const std::vector<int32_t> &sketch, uint32_t genome_id) {
+  if (genome_id != niqki_genome_count(h_)) throw std::runtime_error("insert_sketch: ids must be consecutive");
+  check(niqki_insert(h_, sketch.data(), 1, NIQKI_MEM_HOST), "niqki_insert");
+}
+
+query_output Index::query_sketch(const std::vector<int32_t> &sketch) const {
+  const uint32_t n = niqki_genome_count(h_);
+  std::vector<uint32_t> hc(n ? n : 1), hg(n ? n : 1);
+  uint64_t off[2] = {0, 0};
+  check(niqki_query(h_, sketch.data(), 1, off, hc.data(), hg.data(), n, NIQKI_MEM_HOST), "niqki_query");
+  query_output r;
+  for (uint64_t i = 0; i < off[1]; ++i) r.push_back({hc[i], hg[i]});
+  return r;
+}
+
+// ---- insertion ---------------------------------------------------------------
+
+void Index::flush_insert(Batch &b) {
+  const size_t n = b.n_entries();
+  if (!n) return;
+  std::vector<int32_t> sk(n * (size_t)F);
+  check(niqki_sketch(h_, b.seqs.data(), b.rec_off.data(), (uint32_t)(b.rec_off.size() - 1), b.entry_rec.data(),
+                     (uint32_t)n, sk.data(), NIQKI_MEM_HOST), "niqki_sketch");
+  check(niqki_insert(h_, sk.data(), (uint32_t)n, NIQKI_MEM_HOST), "niqki_insert");
+  for (auto &nm : b.names) filenames.push_back(nm);
+  b.clear();
+}
+
+void Index::insert_file_of_file_whole(const std::string &filestr) {
+  std::ifstream in(filestr);
+  if (!in) {
+    std::cout << "Unable to open the file '" << filestr << "'" << std::endl;
+    exit(0);  // src/niqki_index.cpp:464-467
+  }
+  Batch b;
+  std::string ref, rec, header;
+  while (!in.eof()) {
+    std::getline(in, ref);
+    if (ref.size() > 2 && exists_test(ref)) {  // :479-490; ids follow the list order
+      // insert_file_whole (:442-456): every record longer than K goes into ONE sketch
+      const char type = data_type(ref);
+      GzReader fin(ref);
+      while (!fin.eof()) {
+        bio_getline(fin, rec, type, header, K);
+        if (rec.size() > K) b.add_record(rec);
+      }
+      b.end_entry(ref);
+      if (b.full()) flush_insert(b);
+    }
+    ref.clear();
+  }
+  flush_insert(b);
+}
+
+void Index::insert_file_lines(const std::string &filestr) {
+  const char type = data_type(filestr);
+  GzReader in(filestr);
+  Batch b;
+  std::string ref, header;
+  while (!in.eof()) {
+    bio_getline(in, ref, type, header, K);
+    if (ref.size() > K) {  // :395: one entry per record, named by its header line
+      b.add_record(ref);
+      b.end_entry(header);
+      if (b.full()) flush_insert(b);
+    }
+  }
+  flush_insert(b);
+}
+
+// ---- query ---------------------------------------------------------------------
+
+void Index::flush_query(Batch &b) {
+  const size_t n = b.n_entries();
+  if (!n) return;
+  const uint64_t N = niqki_genome_count(h_);
+  uint64_t cap = std::max<uint64_t>(uint64_t(1) << 20, n * 64);
+  std::vector<uint64_t> off(n + 1);
+  std::vector<uint32_t> hc, hg;
+  for (;;) {
+    hc.resize(cap);
+    hg.resize(cap);
+    int rc = niqki_query_sequences(h_, b.seqs.data(), b.rec_off.data(), (uint32_t)(b.rec_off.size() - 1),
+                                   b.entry_rec.data(), (uint32_t)n, off.data(), hc.data(), hg.data(), cap,
+                                   NIQKI_MEM_HOST);
+    if (rc == NIQKI_E_CAPACITY && cap < n * N) { cap = std::max(off[n], cap * 2); continue; }
+    check(rc, "niqki_query_sequences");
+    break;
+  }
+  query_output one;
+  for (size_t i = 0; i < n; ++i) {
+    one.clear();
+    for (uint64_t j = off[i]; j < off[i + 1]; ++j) one.push_back({hc[j], hg[j]});
+    output_query(one, b.names[i]);
+  }
+  b.clear();
+}
+
+void Index::query_file_of_file_whole(const std::string &filestr) {
+  GzReader in(filestr);
+  Batch b;
+  std::string ref, rec, header;
+  while (!in.eof()) {
+    in.getline(ref);
+    if (exists_test(ref)) {  // :534
+      const char type = data_type(ref);
+      GzReader fin(ref);
+      while (!fin.eof()) {  // query_file_whole :505-519
+        bio_getline(fin, rec, type, header, K);
+        if (rec.size() > K) b.add_record(rec);
+      }
+      b.end_entry(ref);
+      if (b.full()) flush_query(b);
+    }
+    ref.clear();
+  }
+  flush_query(b);
+}
+
+void Index::query_file_lines(const std::string &filestr) {
+  const char type = data_type(filestr);
+  GzReader in(filestr);
+  Batch b;
+  std::string ref, head;
+  while (!in.eof()) {
+    bio_getline(in, ref, type, head, K);
+    if (ref.size() > K) {
+      b.add_record(ref);
+      b.end_entry(head);
+      if (b.full()) flush_query(b);
+    }
+  }
+  flush_query(b);
+}
+
+void Index::output_query(const query_output &toprint, const std::string &queryname) {
+  if (pretty_printing) {  // :546-553
+    std::string line = queryname + " ";
+    for (const auto &h : toprint) {
+      line += filenames[h.second];
+      line += ':';
+      line += fmt_double((double)h.first / F);
+      line += ' ';
+    }
+    line += '\n';
+    outfile->write(line);
+  } else {  // :555-564 (unreachable from the reference CLI, kept for API parity)
+    outfile->write(queryname + "\n");
+    uint32_t size = (uint32_t)toprint.size();
+    outfile->write(&size, 4);
+    for (const auto &h : toprint) {
+      outfile->write(&h.second, 4);
+      outfile->write(&h.first, 4);
+    }
+  }
+}
+
+// ---- matrix ----------------------------------------------------------------------
+
+void Index::output_matrix_row(const uint16_t *counts, const std::string &queryname) {
+  // query_range threshold (:600-606) + output_matrix (:747-763)
+  std::string line = queryname + "\t";
+  const size_t n = filenames.size();
+  for (size_t j = 0; j < n; ++j) {
+    double v = counts[j] >= min_score ? (double)counts[j] / F : 0.0;
+    line += fmt_double(v);
+    line += '\t';
+  }
+  line += '\n';
+  outfile->write(line);
+}
+
+void Index::query_matrix() {
+  std::string head = "##Names\t";  // :615-619
+  for (const auto &nm : filenames) { head += nm; head += '\t'; }
+  head += '\n';
+  outfile->write(head);
+  const uint32_t n = (uint32_t)filenames.size();
+  const uint64_t stride = ((uint64_t)n + 1) & ~1ull;
+  const uint32_t rows = 256;
+  std::vector<uint16_t> counts((size_t)rows * std::max<uint64_t>(stride, 2));
+  for (uint32_t t0 = 0; t0 < n; t0 += rows) {
+    const uint32_t t1 = std::min(n, t0 + rows);
+    check(niqki_matrix_range(h_, t0, t1, counts.data(), stride, NIQKI_MEM_HOST), "niqki_matrix_range");
+    for (uint32_t t = t0; t < t1; ++t) output_matrix_row(counts.data() + (size_t)(t - t0) * stride, filenames[t]);
+  }
+}
+
+// ---- dump ------------------------------------------------------------------------
+
+void Index::dump_index_disk(const std::string &filestr) {
+  uint64_t size = 0;
+  check(niqki_export_dump(h_, nullptr, 0, &size), "niqki_export_dump");
+  std::vector<uint8_t> buf(size);
+  check(niqki_export_dump(h_, buf.data(), buf.size(), &size), "niqki_export_dump");
+  GzWriter out(filestr);
+  out.write(buf.data(), size);
+  for (const auto &nm : filenames) out.write(nm + "\n");  // :56-58
+  out.close();
+}
+
+}  // namespace nqhost

@@ -1,0 +1,61 @@
+// index_host.h -- host-side mirror of the reference's Index class
+// (src/niqki_index.h:35-213) for the file-level drivers: same method names and
+// argument meaning, the per-record work (compute_sketch / insert_sketch /
+// query_sketch) batched through the C ABI of libniqki_hip.so.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/niqki_hip.h"
+#include "gzio.h"
+
+namespace nqhost {
+
+using query_output = std::vector<std::pair<uint32_t, uint32_t>>;  // (count, gid), src/niqki_index.h:31
+
+class Index {
+ public:
+  // Index(lF,K,W,H,filename,min_fract): src/niqki_index.cpp:13-38
+  Index(uint32_t lF, uint32_t K, uint32_t W, uint32_t H, const std::string &out_filename, double min_fract,
+        int device = -1);
+  // Index(dump file, pretty, filename): src/niqki_index.cpp:63-102
+  Index(const std::string &dump_file, bool pretty_printing, const std::string &out_filename, int device = -1);
+  ~Index();
+  Index(const Index &) = delete;
+  Index &operator=(const Index &) = delete;
+
+  uint32_t K = 0, W = 0, H = 0, lF = 0, F = 0, min_score = 0;
+  bool pretty_printing = true;
+  std::vector<std::string> filenames;
+  std::unique_ptr<GzWriter> outfile;
+
+  size_t getNbGenomes() const { return filenames.size(); }  // src/niqki_index.h:138-140
+
+  // per-record operators, kept for API parity (src/niqki_index.h:103,108,142)
+  void compute_sketch(const std::string &reference, std::vector<int32_t> &sketch) const;
+  void insert_sketch(const std::vector<int32_t> &sketch, uint32_t genome_id);
+  query_output query_sketch(const std::vector<int32_t> &sketch) const;
+
+  // file drivers
+  void insert_file_of_file_whole(const std::string &filestr);  // :461-500
+  void insert_file_lines(const std::string &filestr);          // :383-408
+  void query_file_of_file_whole(const std::string &filestr);   // :523-540
+  void query_file_lines(const std::string &filestr);           // :412-430
+  void query_matrix();                                          // :614-628
+  void dump_index_disk(const std::string &filestr);            // :42-59
+
+  void output_query(const query_output &toprint, const std::string &queryname);   // :544-566
+  void output_matrix_row(const uint16_t *counts, const std::string &queryname);   // :747-763
+
+ private:
+  struct Batch;
+  void flush_insert(Batch &b);
+  void flush_query(Batch &b);
+  void check(int rc, const char *what) const;
+  niqki_index *h_ = nullptr;
+};
+
+}  // namespace nqhost

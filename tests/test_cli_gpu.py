@@ -1,0 +1,102 @@
+"""GPU: the `niqki` host program (niqki_amd/bin/niqki, C++17 on the C ABI)
+against the text / dump outputs the reference's own CLI produced for the same
+files (tests/golden/reference_meta.json "cli", made by oracle/make_goldens.py)."""
+import gzip
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, family_spec
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "niqki_amd", "bin", "niqki")
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory, native, gold):
+    _, meta = gold
+    td = tmp_path_factory.mktemp("cli")
+    fam, mem, rate = family_spec(4, 8)
+    genomes = [native.synth_genome_host(meta["seed"], int(f), int(m), int(r), 40000)
+               for f, m, r in zip(fam, mem, rate)]
+    names = []
+    for i, g in enumerate(genomes[:12]):
+        fn = "syn%02d.fa" % i
+        with open(td / fn, "wb") as f:
+            f.write(b">syn%02d\n" % i)
+            for a in range(0, len(g), 70):
+                f.write(bytes(g[a:a + 70]) + b"\n")
+        names.append(fn)
+    (td / "fof.txt").write_text("\n".join(names) + "\n")
+    with open(td / "reads.fa", "wb") as f:
+        for i in range(30):
+            f.write(b">read%d some text\n" % i + bytes(genomes[i % 12][200 * i:200 * i + 150]) + b"\n")
+    return td
+
+
+def run(td, args):
+    assert os.path.exists(BIN), "niqki_amd/bin/niqki missing: run __graft_entry__.build()"
+    r = subprocess.run([BIN] + args, cwd=td, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def gunzip(path):
+    return gzip.open(path, "rb").read()
+
+
+def assert_same_text(got, exp):
+    """Identical tokens; Jaccard values within 1e-6 (they are equal: same %g of exact counts)."""
+    gl, el = got.splitlines(), exp.splitlines()
+    assert len(gl) == len(el)
+    for a, b in zip(gl, el):
+        if a == b:
+            continue
+        ta, tb = a.replace("\t", " ").split(" "), b.replace("\t", " ").split(" ")
+        assert len(ta) == len(tb), (a, b)
+        for x, y in zip(ta, tb):
+            if x == y:
+                continue
+            nx, vx = x.rsplit(":", 1) if ":" in x else ("", x)
+            ny, vy = y.rsplit(":", 1) if ":" in y else ("", y)
+            assert nx == ny and abs(float(vx) - float(vy)) <= 1e-6, (x, y)
+
+
+def test_index_query_dump(workdir, gold):
+    _, meta = gold
+    out = run(workdir, ["-I", "fof.txt", "-Q", "fof.txt", "-S", "10", "-J", "0.1", "-O", "hits.gz", "-D", "idx.dump"])
+    assert "Number of indexed genomes" in out and "12 |" in out
+    assert_same_text(gunzip(workdir / "hits.gz").decode(), meta["cli"]["hits"])
+    raw = gunzip(workdir / "idx.dump")
+    assert len(raw) == meta["cli"]["dump_len"]
+    assert hashlib.md5(raw).hexdigest() == meta["cli"]["dump_md5"]
+
+
+def test_matrix(workdir, gold):
+    _, meta = gold
+    run(workdir, ["-M", "fof.txt", "-S", "10", "-O", "matrix.gz"])
+    assert_same_text(gunzip(workdir / "matrix.gz").decode(), meta["cli"]["matrix"])
+
+
+def test_lines_mode(workdir, gold):
+    _, meta = gold
+    run(workdir, ["-i", "reads.fa", "-l", "reads.fa", "-S", "10", "-W", "10", "-J", "0.2", "-O", "lines.gz"])
+    assert_same_text(gunzip(workdir / "lines.gz").decode(), meta["cli"]["lines"])
+
+
+def test_load_then_query(workdir, gold):
+    _, meta = gold
+    if not (workdir / "idx.dump").exists():
+        run(workdir, ["-I", "fof.txt", "-S", "10", "-J", "0.1", "-O", "tmp.gz", "-D", "idx.dump"])
+    run(workdir, ["-L", "idx.dump", "-Q", "fof.txt", "-O", "hits_loaded.gz"])
+    assert_same_text(gunzip(workdir / "hits_loaded.gz").decode(), meta["cli"]["hits_loaded"])
+
+
+def test_bad_usage(workdir):
+    r = subprocess.run([BIN, "stray"], cwd=workdir, capture_output=True, text=True)
+    assert r.returncode == 1 and "Bad usage!!!" in r.stdout
+    r = subprocess.run([BIN, "-K", "x"], cwd=workdir, capture_output=True, text=True)
+    assert r.returncode == 1 and "requires a numeric argument" in r.stderr
