@@ -137,3 +137,31 @@ def test_cli_golden_first_line_shape(gold):
     hits = meta["cli"]["hits"].splitlines()
     assert len(hits) == 12 and hits[0].startswith("syn00.fa syn00.fa:1 ")
     assert meta["cli"]["matrix"].startswith("##Names\tsyn00.fa\t")
+
+
+def test_ecoli_pins_when_reference_present(po, gold):
+    """the 9 shipped E. coli genomes (only in the build
+    container, where /root/reference exists)."""
+    import gzip
+    import os
+    d = "/root/reference/resources"
+    if not os.path.isdir(d):
+        pytest.skip("reference resources not present")
+    _, meta = gold
+    m = meta["ecoli"]
+    p = po.make_params(31, 15, 12, 4, 0.0)
+    sks = []
+    for fn in m["files"]:
+        lines = gzip.open(os.path.join(d, fn), "rb").read().split(b"\n")
+        seq = np.frombuffer(b"".join(l for l in lines if not l.startswith(b">")), np.uint8)
+        sks.append(po.compute_sketch(p, seq))
+    assert ["%016x" % po.fnv1a64(s) for s in sks] == m["sketch_fnv"]
+    # values SURVEY.md 8c recorded from its own probe of the reference (its checksum
+    # variant differs from nqo_fnv1a64, so only the raw values are compared)
+    assert sks[0][:8].tolist() == [1895, 2012, 2088, 1521, 2142, 1625, 2631, 2590] == m["g1_head"]
+    ix = po.Index(p, np.stack(sks))
+    hc, hg = ix.query(sks[0])
+    assert hc.tolist() == m["q1_counts"] == [32768, 31712, 30737, 29845, 28993, 28220, 27415, 26677, 25930]
+    assert hg.tolist() == m["q1_gids"]
+    # README matrix value (README.md:118-128): ecoli01p vs 02p = 31712/32768
+    assert "%g" % (31712 / 32768) == "0.967773"
