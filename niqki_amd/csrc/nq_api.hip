@@ -42,10 +42,13 @@ struct niqki_index {
   uint32_t n_genomes = 0;
 
   // inverted index
-  uint32_t tile = 0, n_tiles = 0, built_n = 0;
-  uint32_t *offsets = nullptr;
+  uint32_t tile = 0, n_tiles = 0, built_n = 0, align_log2 = 0;
+  nq::Entry *entries = nullptr;
   uint16_t *gids = nullptr;
-  size_t offsets_bytes = 0, gids_bytes = 0;
+  uint64_t *tile_base = nullptr;   // n_tiles+1, device
+  uint32_t *slot_units = nullptr;  // n_tiles x (f_local+1), device
+  size_t entries_bytes = 0, gids_bytes = 0, tile_base_bytes = 0, slot_units_bytes = 0;
+  int bucket_align = -1;           // option: log2 ids per bucket alignment unit, -1 = choose
   bool built = false;
 
   int gather_variant = 0;
@@ -53,7 +56,7 @@ struct niqki_index {
   uint32_t query_batch = 1024;
 
   Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
-      ws_misc;
+      ws_misc, ws_stash;
 
   bool prof = false;
   double prof_ms[NIQKI_KC_COUNT] = {0};
@@ -166,10 +169,13 @@ nq::IndexView view(const niqki_index *ix) {
   v.tile = ix->tile;
   v.n_tiles = ix->n_tiles;
   v.f_local = ix->d.slot_end - ix->d.slot_begin;
+  v.align_log2 = ix->align_log2;
   v.cap = ix->cap;
   v.store = ix->store;
-  v.offsets = ix->offsets;
+  v.entries = ix->entries;
   v.gids = ix->gids;
+  v.tile_base = ix->tile_base;
+  v.slot_units = ix->slot_units;
   return v;
 }
 
@@ -248,8 +254,13 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *
   if (nq == 0) return NIQKI_OK;
   if (stride < ix->built_n || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
   if (ix->built_n == 0) return NIQKI_OK;
+  if (ix->n_tiles > 1) {
+    rc = ensure(ix, ix->ws_stash, (size_t)nq * (ix->n_tiles - 1) * (ix->d.slot_end - ix->d.slot_begin) * sizeof(nq::Entry));
+    if (rc) return rc;
+  }
   Span sp(ix, NIQKI_KC_GATHER);
-  NQ_HIP(ix, nq::launch_gather(view(ix), sketches, nq, counts, stride, ix->gather_variant, ix->stream));
+  NQ_HIP(ix, nq::launch_gather(view(ix), sketches, nq, counts, stride, (nq::Entry *)ix->ws_stash.p,
+                               ix->gather_variant, ix->stream));
   return NIQKI_OK;
 }
 
@@ -352,11 +363,13 @@ void niqki_destroy(niqki_index *ix) {
   (void)hipSetDevice(ix->device);
   (void)hipStreamSynchronize(ix->stream);
   for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
-                 &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc})
+                 &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash})
     if (b->p) (void)hipFree(b->p);
   if (ix->store) (void)hipFree(ix->store);
-  if (ix->offsets) (void)hipFree(ix->offsets);
+  if (ix->entries) (void)hipFree(ix->entries);
   if (ix->gids) (void)hipFree(ix->gids);
+  if (ix->tile_base) (void)hipFree(ix->tile_base);
+  if (ix->slot_units) (void)hipFree(ix->slot_units);
   for (auto &s : ix->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : ix->ev_pool) (void)hipEventDestroy(e);
   if (ix->own_stream) (void)hipStreamDestroy(ix->stream);
@@ -399,6 +412,12 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
   if (!std::strcmp(key, "tile_genomes")) {
     if (value < 0 || value > 65536 || (value & 63)) return fail(ix, NIQKI_E_INVALID, "tile_genomes must be a multiple of 64, <= 65536");
     ix->p.tile_genomes = (uint32_t)value;
+    ix->built = false;
+    return NIQKI_OK;
+  }
+  if (!std::strcmp(key, "bucket_align_log2")) {
+    if (value < -1 || value > 6) return fail(ix, NIQKI_E_INVALID, "bucket_align_log2 must be -1 (choose) .. 6");
+    ix->bucket_align = (int)value;
     ix->built = false;
     return NIQKI_OK;
   }
@@ -523,26 +542,45 @@ int niqki_build(niqki_index *ix) {
     if (tile == 0) tile = 64;
   }
   const uint32_t n_tiles = (N + tile - 1) / tile;
-  const size_t ob = (size_t)n_tiles * f_local * (ix->d.R + 1) * 4;
-  const size_t gb = (size_t)n_tiles * f_local * tile * 2 + 256;  // + pad: the gather kernel may read one id past an empty last bucket
-  if (ob > ix->offsets_bytes) {
-    if (ix->offsets) NQ_HIP(ix, hipFree(ix->offsets));
-    ix->offsets = nullptr; ix->offsets_bytes = 0;
-    NQ_HIP(ix, hipMalloc((void **)&ix->offsets, std::max<size_t>(ob, 256)));
-    ix->offsets_bytes = std::max<size_t>(ob, 256);
-  }
-  if (gb > ix->gids_bytes) {
-    if (ix->gids) NQ_HIP(ix, hipFree(ix->gids));
-    ix->gids = nullptr; ix->gids_bytes = 0;
-    NQ_HIP(ix, hipMalloc((void **)&ix->gids, std::max<size_t>(gb, 256)));
-    ix->gids_bytes = std::max<size_t>(gb, 256);
-  }
+  // 128-byte aligned buckets pay off once buckets are long (big tiles); for small
+  // tiles the padding would dominate the id array.
+  int al = ix->bucket_align;
+  if (const char *v = std::getenv("NIQKI_BUCKET_ALIGN_LOG2")) al = std::atoi(v);
+  if (al < 0 || al > 6) al = tile >= 16384 ? 6 : (tile >= 2048 ? 3 : 0);
+  auto grow = [&](void **p, size_t &have, size_t want) -> int {
+    want = std::max<size_t>(want, 256);
+    if (want <= have) return NIQKI_OK;
+    if (*p) NQ_HIP(ix, hipFree(*p));
+    *p = nullptr; have = 0;
+    NQ_HIP(ix, hipMalloc(p, want));
+    have = want;
+    return NIQKI_OK;
+  };
+  int rc;
+  if ((rc = grow((void **)&ix->entries, ix->entries_bytes, (size_t)f_local * ix->d.R * n_tiles * sizeof(nq::Entry)))) return rc;
+  if ((rc = grow((void **)&ix->slot_units, ix->slot_units_bytes, (size_t)n_tiles * (f_local + 1) * 4))) return rc;
+  if ((rc = grow((void **)&ix->tile_base, ix->tile_base_bytes, (size_t)(n_tiles + 1) * 8))) return rc;
   ix->tile = tile;
   ix->n_tiles = n_tiles;
   ix->built_n = N;
+  ix->align_log2 = (uint32_t)al;
+  if (n_tiles == 0) { ix->built = true; return NIQKI_OK; }
   {
     Span sp(ix, NIQKI_KC_BUILD);
-    NQ_HIP(ix, nq::launch_build(view(ix), ix->offsets, ix->gids, ix->stream));
+    NQ_HIP(ix, nq::launch_build_sizes(view(ix), ix->slot_units, ix->tile_base, ix->stream));
+  }
+  std::vector<uint64_t> tb(n_tiles + 1);
+  NQ_HIP(ix, hipMemcpyAsync(tb.data(), ix->tile_base, (size_t)(n_tiles + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  for (uint32_t t = 0; t < n_tiles; ++t)
+    if (((tb[t + 1] - tb[t]) >> al) >= (1ull << 32))  // bucket starts are 32-bit unit counts
+      return fail(ix, NIQKI_E_INVALID, "tile id array too large for 32-bit bucket starts");
+  const uint64_t total_ids = tb[n_tiles];
+  // + pad: the gather kernel reads up to 64 ids from a bucket's start whatever its length
+  if ((rc = grow((void **)&ix->gids, ix->gids_bytes, (size_t)total_ids * 2 + 512))) return rc;
+  {
+    Span sp(ix, NIQKI_KC_BUILD);
+    NQ_HIP(ix, nq::launch_build_fill(view(ix), ix->entries, ix->gids, ix->stream));
   }
   ix->built = true;
   return NIQKI_OK;
@@ -719,38 +757,30 @@ int niqki_export_dump(niqki_index *ix, uint8_t *buf, uint64_t capacity, uint64_t
   int rc = build_if_needed(ix);
   if (rc) return rc;
   nq::IndexView v = view(ix);
-  // total entries = sum over tiles of the valid entries
-  if ((rc = ensure(ix, ix->ws_misc, std::max<size_t>((size_t)v.n_tiles * (v.f_local + 1) * 8, 8)))) return rc;
-  uint64_t *slot_base = (uint64_t *)ix->ws_misc.p;
-  uint64_t entries = 0;
   const uint64_t n_buckets = (uint64_t)v.f_local * v.d.R;
-  if (v.n_tiles) {
-    // first pass only for the size: slot_base_kernel is part of launch_export,
-    // so size the buffer from an upper bound (every genome valid in every slot)
-    entries = (uint64_t)v.n_genomes * v.f_local;
-  }
-  const uint64_t max_words = n_buckets + entries;
+  if ((rc = ensure(ix, ix->ws_misc, (size_t)(v.f_local + 1) * 8))) return rc;
+  unsigned long long *slot_word = (unsigned long long *)ix->ws_misc.p;
+  uint64_t total_words = n_buckets;  // empty index: one size word per bucket
   Buf out;
-  hipError_t e = hipMalloc(&out.p, std::max<uint64_t>(max_words * 4, 4));
-  if (e != hipSuccess) return fail(ix, NIQKI_E_NOMEM, "export buffer allocation failed");
-  auto cleanup = [&]() { (void)hipFree(out.p); };
-  e = nq::launch_export(v, slot_base, (uint32_t *)out.p, ix->stream);
-  if (e != hipSuccess) { cleanup(); return fail(ix, NIQKI_E_HIP, hipGetErrorString(e)); }
-  uint64_t exact_entries = 0;
-  for (uint32_t t = 0; t < v.n_tiles; ++t) {
-    uint64_t x = 0;
-    e = hipMemcpyAsync(&x, slot_base + (uint64_t)t * (v.f_local + 1) + v.f_local, 8, hipMemcpyDeviceToHost, ix->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
-    if (e != hipSuccess) { cleanup(); return fail(ix, NIQKI_E_HIP, hipGetErrorString(e)); }
-    exact_entries += x;
+  auto cleanup = [&]() { if (out.p) (void)hipFree(out.p); };
+  hipError_t e = hipSuccess;
+  if (v.n_tiles) {
+    NQ_HIP(ix, nq::launch_export(v, slot_word, nullptr, ix->stream));
+    NQ_HIP(ix, hipMemcpyAsync(&total_words, slot_word + v.f_local, 8, hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
   }
+  const uint64_t exact_entries = total_words - n_buckets;
   const uint64_t total = 24 + (n_buckets + exact_entries) * 4;
   *size = total;
-  if (!buf) { cleanup(); return NIQKI_OK; }
-  if (capacity < total) { cleanup(); return NIQKI_E_CAPACITY; }
+  if (!buf) return NIQKI_OK;
+  if (capacity < total) return NIQKI_E_CAPACITY;
   uint32_t hdr[6] = {ix->d.S, ix->d.K, ix->d.H, ix->d.W, ix->d.min_score, v.n_genomes};
   std::memcpy(buf, hdr, 24);
-  e = hipMemcpyAsync(buf + 24, out.p, total - 24, hipMemcpyDeviceToHost, ix->stream);
+  if (hipMalloc(&out.p, std::max<uint64_t>(total_words * 4, 4)) != hipSuccess)
+    return fail(ix, NIQKI_E_NOMEM, "export buffer allocation failed");
+  if (v.n_tiles) e = nq::launch_export(v, slot_word, (uint32_t *)out.p, ix->stream);
+  else e = hipMemsetAsync(out.p, 0, total_words * 4, ix->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(buf + 24, out.p, total - 24, hipMemcpyDeviceToHost, ix->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
   cleanup();
   if (e != hipSuccess) return fail(ix, NIQKI_E_HIP, hipGetErrorString(e));

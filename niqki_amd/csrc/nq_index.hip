@@ -92,14 +92,18 @@ hipError_t launch_store_read(const Derived &d, const uint16_t *store, uint64_t c
   return hipGetLastError();
 }
 
-// ---- CSR build: one wave per (tile, slot) row, stable counting sort on fp ----
-__global__ void build_kernel(IndexView v, uint32_t *offsets, uint16_t *gids, uint32_t wpb) {
+// ---- index build: one wave per (tile, slot) row, stable counting sort on fp ----
+// FILL = false: units (1 << align_log2 ids) the row needs -> slot_units[t][s]
+// FILL = true : entries {start, len} of every fingerprint and the ascending id lists
+template <bool FILL>
+__global__ void build_kernel(IndexView v, uint32_t *slot_units, Entry *entries, uint16_t *gids, uint32_t wpb) {
   extern __shared__ __align__(16) uint32_t smem[];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint64_t task = (uint64_t)blockIdx.x * wpb + wave;
   if (task >= (uint64_t)v.n_tiles * v.f_local) return;  // wave-private work, no block barrier below
   const uint32_t t = (uint32_t)(task / v.f_local), s = (uint32_t)(task % v.f_local);
-  const uint32_t R = v.d.R, W = v.d.W;
+  const uint32_t R = v.d.R, W = v.d.W, a = v.align_log2;
+  const uint32_t round = (1u << a) - 1u;
   uint32_t *cur = smem + (size_t)wave * R;
   const uint32_t g0 = t * v.tile;
   const uint32_t n_t = (v.n_genomes - g0) < v.tile ? (v.n_genomes - g0) : v.tile;
@@ -110,18 +114,28 @@ __global__ void build_kernel(IndexView v, uint32_t *offsets, uint16_t *gids, uin
     uint32_t fp = row[i];
     if (fp != kEmpty16) atomicAdd(&cur[fp], 1u);
   }
-  uint32_t *off = offsets + ((uint64_t)t * v.f_local + s) * (R + 1);
-  uint32_t running = s * v.tile;
+  if (!FILL) {
+    uint32_t units = 0;
+    for (uint32_t c = lane; c < R; c += 64) units += (cur[c] + round) >> a;
+    for (int o = 32; o > 0; o >>= 1) units += __shfl_down(units, o, 64);
+    if (lane == 0) slot_units[(uint64_t)t * (v.f_local + 1) + s] = units;
+    return;
+  }
+  const uint32_t base_units = slot_units[(uint64_t)t * (v.f_local + 1) + s];
+  uint32_t running = 0;  // units used so far inside this row
   for (uint32_t c = 0; c < R; c += 64) {
-    uint32_t x = (c + lane < R) ? cur[c + lane] : 0u;
+    const uint32_t fp = c + lane;
+    uint32_t h = fp < R ? cur[fp] : 0u;
+    uint32_t x = (h + round) >> a;
     uint32_t incl = wave_incl_scan(x, lane);
     uint32_t excl = running + incl - x;
-    if (c + lane < R) { cur[c + lane] = excl; off[c + lane] = excl; }
+    if (fp < R) {
+      cur[fp] = excl << a;  // cursor, in ids, relative to the row's first unit
+      entries[((uint64_t)s * R + fp) * v.n_tiles + t] = Entry{base_units + excl, h};
+    }
     running += __shfl(incl, 63, 64);
   }
-  if (lane == 0) off[R] = running;
-
-  uint16_t *gl = gids + (uint64_t)t * v.f_local * v.tile;  // tile's gid array, positions are absolute in it
+  uint16_t *gl = gids + v.tile_base[t] + ((uint64_t)base_units << a);
   const uint64_t lt_mask = (1ULL << lane) - 1ULL;
   for (uint32_t base = 0; base < n_t; base += 64) {
     uint32_t i = base + lane;
@@ -143,85 +157,133 @@ __global__ void build_kernel(IndexView v, uint32_t *offsets, uint16_t *gids, uin
   }
 }
 
-hipError_t launch_build(const IndexView &v, uint32_t *offsets, uint16_t *gids,
-                        hipStream_t stream) {
-  uint64_t tasks = (uint64_t)v.n_tiles * v.f_local;
-  if (tasks == 0) return hipSuccess;
-  size_t per_wave = (size_t)v.d.R * 4;
-  uint32_t wpb = (uint32_t)(65536 / per_wave);
-  if (wpb > 4) wpb = 4;
-  if (wpb < 1) wpb = 1;
-  size_t lds = per_wave * wpb;
-  hipError_t e = hipFuncSetAttribute((const void *)build_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  uint64_t blocks = (tasks + wpb - 1) / wpb;
-  hipLaunchKernelGGL(build_kernel, dim3((uint32_t)blocks), dim3(64 * wpb), lds, stream, v, offsets,
-                     gids, wpb);
-  return hipGetLastError();
-}
-
-// ---- dump stream export (src/niqki_index.cpp:42-55) ----
-// slot_base[t][s] = number of valid entries of tile t in slots < s.
-__global__ __launch_bounds__(1024) void slot_base_kernel(IndexView v, uint64_t *slot_base) {
+// per tile: exclusive prefix of slot_units over the slots; total -> totals[t] (in ids)
+__global__ __launch_bounds__(1024) void slot_scan_kernel(IndexView v, uint32_t *slot_units, uint64_t *totals) {
   __shared__ uint64_t part[1024];
   const uint32_t t = blockIdx.x, tid = threadIdx.x;
-  const uint32_t R = v.d.R;
   const uint32_t per = (v.f_local + 1023) / 1024;
   const uint32_t lo = tid * per, hi = (lo + per < v.f_local) ? lo + per : v.f_local;
-  const uint32_t *off = v.offsets + (uint64_t)t * v.f_local * (R + 1);
+  uint32_t *u = slot_units + (uint64_t)t * (v.f_local + 1);
   uint64_t sum = 0;
-  for (uint32_t s = lo; s < hi; ++s) sum += off[(uint64_t)s * (R + 1) + R] - s * v.tile;
+  for (uint32_t s = lo; s < hi; ++s) sum += u[s];
   part[tid] = sum;
   __syncthreads();
   if (tid == 0) {
     uint64_t run = 0;
     for (uint32_t i = 0; i < 1024; ++i) { uint64_t x = part[i]; part[i] = run; run += x; }
+    u[v.f_local] = (uint32_t)run;
+    totals[t + 1] = run << v.align_log2;
   }
   __syncthreads();
   uint64_t run = part[tid];
-  uint64_t *sb = slot_base + (uint64_t)t * (v.f_local + 1);
-  for (uint32_t s = lo; s < hi; ++s) {
-    sb[s] = run;
-    run += off[(uint64_t)s * (R + 1) + R] - s * v.tile;
-  }
-  if (hi == v.f_local && lo < hi) sb[v.f_local] = run;
-  if (v.f_local == 0 && tid == 0) sb[0] = 0;
+  for (uint32_t s = lo; s < hi; ++s) { uint32_t x = u[s]; u[s] = (uint32_t)run; run += x; }
 }
 
-__global__ __launch_bounds__(256) void export_kernel(IndexView v, const uint64_t *slot_base,
-                                                    uint32_t *out) {
-  const uint32_t R = v.d.R;
-  const uint64_t n_b = (uint64_t)v.f_local * R;
-  uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (; b < n_b; b += stride) {
-    const uint32_t s = (uint32_t)(b / R), fp = (uint32_t)(b % R);
-    uint64_t before = 0;
+__global__ void tile_base_kernel(uint64_t *tile_base, uint32_t n_tiles) {
+  if (threadIdx.x || blockIdx.x) return;
+  uint64_t run = 0;
+  tile_base[0] = 0;
+  for (uint32_t t = 0; t < n_tiles; ++t) { run += tile_base[t + 1]; tile_base[t + 1] = run; }
+}
+
+static void build_shape(const IndexView &v, uint32_t &wpb, size_t &lds, uint64_t &blocks) {
+  size_t per_wave = (size_t)v.d.R * 4;
+  wpb = (uint32_t)(65536 / per_wave);
+  if (wpb > 4) wpb = 4;
+  if (wpb < 1) wpb = 1;
+  lds = per_wave * wpb;
+  uint64_t tasks = (uint64_t)v.n_tiles * v.f_local;
+  blocks = (tasks + wpb - 1) / wpb;
+}
+
+hipError_t launch_build_sizes(const IndexView &v, uint32_t *slot_units, uint64_t *tile_base,
+                              hipStream_t stream) {
+  if ((uint64_t)v.n_tiles * v.f_local == 0) return hipSuccess;
+  uint32_t wpb; size_t lds; uint64_t blocks;
+  build_shape(v, wpb, lds, blocks);
+  hipError_t e = hipFuncSetAttribute((const void *)build_kernel<false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(build_kernel<false>, dim3((uint32_t)blocks), dim3(64 * wpb), lds, stream, v, slot_units,
+                     (Entry *)nullptr, (uint16_t *)nullptr, wpb);
+  hipLaunchKernelGGL(slot_scan_kernel, dim3(v.n_tiles), dim3(1024), 0, stream, v, slot_units, tile_base);
+  hipLaunchKernelGGL(tile_base_kernel, dim3(1), dim3(64), 0, stream, tile_base, v.n_tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids, hipStream_t stream) {
+  if ((uint64_t)v.n_tiles * v.f_local == 0) return hipSuccess;
+  uint32_t wpb; size_t lds; uint64_t blocks;
+  build_shape(v, wpb, lds, blocks);
+  hipError_t e = hipFuncSetAttribute((const void *)build_kernel<true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(build_kernel<true>, dim3((uint32_t)blocks), dim3(64 * wpb), lds, stream, v,
+                     (uint32_t *)v.slot_units, entries, gids, wpb);
+  return hipGetLastError();
+}
+
+// ---- dump stream export (src/niqki_index.cpp:42-55) ----
+// slot_word[s] = word position of bucket (s, 0): s*R buckets' size words + the ids before it.
+__global__ __launch_bounds__(256) void export_slot_ids_kernel(IndexView v, unsigned long long *slot_word) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= v.f_local) return;
+  const uint64_t n = (uint64_t)v.d.R * v.n_tiles;
+  const Entry *e = v.entries + (uint64_t)s * n;
+  unsigned long long sum = 0;
+  for (uint64_t i = lane; i < n; i += 64) sum += e[i].len;
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+  if (lane == 0) slot_word[s + 1] = sum;  // raw; prefixed below
+}
+
+__global__ void export_slot_scan_kernel(unsigned long long *slot_word, uint32_t f_local, uint32_t R) {
+  if (threadIdx.x || blockIdx.x) return;
+  unsigned long long run = 0;
+  slot_word[0] = 0;
+  for (uint32_t s = 0; s < f_local; ++s) { run += slot_word[s + 1] + R; slot_word[s + 1] = run; }
+}
+
+__global__ __launch_bounds__(256) void export_kernel(IndexView v, const unsigned long long *slot_word, uint32_t *out) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= v.f_local) return;
+  const uint32_t R = v.d.R, a = v.align_log2;
+  unsigned long long running = slot_word[s];
+  for (uint32_t c = 0; c < R; c += 64) {
+    const uint32_t fp = c + lane;
     uint32_t size = 0;
-    for (uint32_t t = 0; t < v.n_tiles; ++t) {
-      const uint32_t *off = v.offsets + ((uint64_t)t * v.f_local + s) * (R + 1);
-      before += slot_base[(uint64_t)t * (v.f_local + 1) + s] + (off[fp] - s * v.tile);
-      size += off[fp + 1] - off[fp];
+    if (fp < R)
+      for (uint32_t t = 0; t < v.n_tiles; ++t) size += v.entries[((uint64_t)s * R + fp) * v.n_tiles + t].len;
+    // inclusive scan of (1 + size) words
+    unsigned long long x = fp < R ? 1ull + size : 0ull, incl = x;
+    for (int o = 1; o < 64; o <<= 1) {
+      unsigned long long y = __shfl_up(incl, o, 64);
+      if (lane >= (uint32_t)o) incl += y;
     }
-    uint64_t pos = b + before;
-    out[pos++] = size;
-    for (uint32_t t = 0; t < v.n_tiles; ++t) {
-      const uint32_t *off = v.offsets + ((uint64_t)t * v.f_local + s) * (R + 1);
-      const uint16_t *gl = v.gids + (uint64_t)t * v.f_local * v.tile;
-      for (uint32_t j = off[fp]; j < off[fp + 1]; ++j) out[pos++] = t * v.tile + gl[j];
+    unsigned long long pos = running + incl - x;
+    if (fp < R) {
+      out[pos++] = size;
+      for (uint32_t t = 0; t < v.n_tiles; ++t) {
+        const Entry e = v.entries[((uint64_t)s * R + fp) * v.n_tiles + t];
+        const uint16_t *gl = v.gids + v.tile_base[t] + ((uint64_t)e.start << a);
+        for (uint32_t j = 0; j < e.len; ++j) out[pos++] = t * v.tile + gl[j];
+      }
     }
+    running += __shfl(incl, 63, 64);
   }
 }
 
-hipError_t launch_export(const IndexView &v, uint64_t *slot_base, uint32_t *out,
+hipError_t launch_export(const IndexView &v, unsigned long long *slot_word, uint32_t *out,
                          hipStream_t stream) {
-  if (v.n_tiles)
-    hipLaunchKernelGGL(slot_base_kernel, dim3(v.n_tiles), dim3(1024), 0, stream, v, slot_base);
-  uint64_t n_b = (uint64_t)v.f_local * v.d.R;
-  uint64_t blocks = (n_b + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(export_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, v, slot_base, out);
+  if (v.f_local == 0) return hipSuccess;
+  dim3 grid((v.f_local + 3) / 4);
+  if (out == nullptr) {
+    hipLaunchKernelGGL(export_slot_ids_kernel, grid, dim3(256), 0, stream, v, slot_word);
+    hipLaunchKernelGGL(export_slot_scan_kernel, dim3(1), dim3(64), 0, stream, slot_word, v.f_local, v.d.R);
+  } else {
+    hipLaunchKernelGGL(export_kernel, grid, dim3(256), 0, stream, v, slot_word, out);
+  }
   return hipGetLastError();
 }
 

@@ -22,20 +22,30 @@ hipError_t launch_fill_u32(uint32_t *p, uint64_t n, uint32_t v, hipStream_t stre
 
 // ---- sketch store + inverted index (nq_index.hip) ---------------------------
 // Sketch store: u16 [F_local][cap], slot major; 0xFFFF = empty/invalid cell.
-// Inverted index, per genome tile t (genomes [t*T, min((t+1)*T, N))):
-//   offsets  u32 [F_local][R+1]   offsets[s][fp] .. offsets[s][fp+1] is bucket
-//                                 (s, fp) inside gids; offsets[s][0] = s*T
-//   gids     u16 [F_local][T]     tile-local genome ids, ascending per bucket
+// Inverted index over genome tiles (tile t = genomes [t*T, min((t+1)*T, N))):
+//   entries  Entry [F_local][R][n_tiles]   bucket (slot, fp) of every tile side by
+//                                          side, so ONE lookup serves all tiles
+//   gids     u16, tile t at gids + tile_base[t]; a bucket starts at
+//            (entry.start << align_log2) inside its tile and holds entry.len
+//            tile-local genome ids, ascending.  With align_log2 = 6 every bucket
+//            starts on a 128-byte line.
+struct Entry {
+  uint32_t start;  // in units of (1 << align_log2) ids
+  uint32_t len;
+};
 struct IndexView {
   Derived d;
   uint32_t n_genomes;
-  uint32_t tile;     // T, genomes per tile (even)
+  uint32_t tile;     // T, genomes per tile (multiple of 64, <= 65536)
   uint32_t n_tiles;
   uint32_t f_local;  // slot_end - slot_begin
+  uint32_t align_log2;
   uint64_t cap;      // row stride of the sketch store (genomes)
   const uint16_t *store;
-  const uint32_t *offsets;  // n_tiles x f_local x (R+1)
-  const uint16_t *gids;     // n_tiles x f_local x T
+  const Entry *entries;
+  const uint16_t *gids;
+  const uint64_t *tile_base;   // n_tiles+1 (in ids), device
+  const uint32_t *slot_units;  // n_tiles x (f_local+1): units before slot s of tile t
 };
 
 hipError_t launch_store_insert(const Derived &d, const int32_t *sketches, uint32_t n,
@@ -43,12 +53,16 @@ hipError_t launch_store_insert(const Derived &d, const int32_t *sketches, uint32
                                hipStream_t stream);
 hipError_t launch_store_read(const Derived &d, const uint16_t *store, uint64_t cap,
                              uint32_t begin, uint32_t n, int32_t *sketches, hipStream_t stream);
-hipError_t launch_build(const IndexView &v, uint32_t *offsets, uint16_t *gids,
-                        hipStream_t stream);
+// Build, phase 1: units per (tile, slot) -> exclusive prefix per tile in
+// slot_units, tile totals as a prefix (in ids) in tile_base.
+hipError_t launch_build_sizes(const IndexView &v, uint32_t *slot_units, uint64_t *tile_base,
+                              hipStream_t stream);
+// Build, phase 2: entries + gids (gids sized from tile_base[n_tiles]).
+hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids, hipStream_t stream);
 // dump stream (src/niqki_index.cpp:42-55) of a whole-range index into `out`
-// (u32 words, header excluded); slot_base: n_tiles x (f_local+1) exclusive
-// prefix of valid entries per slot (scratch, filled here).
-hipError_t launch_export(const IndexView &v, uint64_t *slot_base, uint32_t *out,
+// (u32 words, header excluded); bucket_word: F*R+1 scratch (word position of
+// every bucket, filled here).
+hipError_t launch_export(const IndexView &v, unsigned long long *bucket_word, uint32_t *out,
                          hipStream_t stream);
 // inverse: walk the dump words of each slot and write the sketch store.
 // slot_word: F+1 word positions of each slot's first bucket inside `words`.
@@ -59,8 +73,10 @@ hipError_t launch_import(const Derived &d, const uint32_t *words, const uint64_t
 // ---- query (nq_query.hip) ----------------------------------------------------
 // gather-histogram: counts[q*stride + g] for all genomes (u16), one workgroup
 // per (query, tile).
+// stash: nq x (n_tiles-1) x f_local Entry scratch (unused for n_tiles == 1)
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq,
-                         uint16_t *counts, uint64_t stride, int variant, hipStream_t stream);
+                         uint16_t *counts, uint64_t stride, Entry *stash, int variant,
+                         hipStream_t stream);
 hipError_t launch_gathered(const IndexView &v, const int32_t *sketches, uint32_t nq,
                            unsigned long long *per_query, hipStream_t stream);
 

@@ -5,13 +5,14 @@
 // loop (:652-661) is gather_kernel, the threshold (:662-666) and the
 // descending (count, gid) order (:685) are the hits_* kernels.
 //
-// gather_kernel: one workgroup per (query, genome tile).  The tile's per-genome
-// hit counters live in LDS as packed u16 pairs (a count never exceeds F <= 2^15,
-// so the two halves of a word cannot carry into each other) and are bumped with
-// ds_add_u32.  Each wave takes 64 sketch slots at a time: every lane looks up
-// the bucket of its slot (fp -> two adjacent CSR offsets), then the wave walks
-// the 64 buckets one after another, all lanes reading consecutive u16 genome
-// ids of one bucket (coalesced, <=128 B per bucket chunk).  HBM-bound by design:
+// gather_kernel: one workgroup per query, the genome tiles walked one after
+// another.  The tile's per-genome hit counters live in LDS as packed u16 pairs (a
+// count never exceeds F <= 2^15, so the two halves of a word cannot carry into
+// each other) and are bumped with ds_add_u32.  Each wave takes 64 sketch slots at
+// a time: every lane looks up the bucket of its slot for ALL tiles with one random
+// table access (the other tiles' entries are parked in a coalesced stash), then
+// the wave walks the 64 buckets one after another, all lanes reading consecutive
+// u16 genome ids of one 128-byte aligned bucket.  HBM-bound by design:
 // algorithmic bytes per query = 4T + 20F.
 #include "nq_kernels.h"
 
@@ -21,149 +22,226 @@ __device__ __forceinline__ void bump(uint32_t *cnt, uint32_t g) {
   atomicAdd(&cnt[g >> 1], 1u << ((g & 1u) * 16u));  // ds_add_u32, result unused
 }
 
-struct __attribute__((packed, aligned(4))) OffPair { uint32_t lo, hi; };
+// A bucket chunk: up to 64 consecutive ids at unit `pos` (1 << align_log2 ids per
+// unit, counted from the tile's base).
+struct Item {
+  uint32_t pos, len;
+};
+constexpr uint32_t kQueue = 256;  // items per wave-private LDS work queue
 
-// UNROLL buckets are fetched per round trip; two rounds are kept in flight
-// (the gid loads of round r+1 are issued before the LDS atomics of round r), and
-// the CSR lookups run two 64-slot iterations ahead of the bucket walk, so the
-// wave never waits on a load it has just issued.
-// MODE is a measurement aid (bench ablations only, results are wrong for MODE != 0):
-//   1 = no LDS atomics, 2 = no gid loads (synthetic ids), 3 = lookups only.
-template <int BLOCK, int UNROLL, int MODE = 0, int ROT = 0>
-__global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_t *sketches,
-                                                       uint16_t *counts, uint64_t stride) {
-  extern __shared__ __align__(16) uint32_t cnt[];
-  const uint32_t q = blockIdx.x / v.n_tiles, t = blockIdx.x % v.n_tiles;
+// Walks 64 chunks held one per lane (pos, len <= 64): all lanes read consecutive
+// u16 ids of one chunk, UNROLL chunks per round trip, two rounds in flight (the
+// loads of round r+1 are issued before the LDS atomics of round r; unconditional
+// loads, lanes past a chunk's end read what follows it and are masked).
+template <int UNROLL, int MODE>
+__device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t pos, uint32_t len,
+                                       uint32_t lane, uint32_t *cnt, uint32_t &sink) {
+  uint32_t ga[UNROLL], gb[UNROLL];
+  auto fetch = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t b = __builtin_amdgcn_readlane(pos, j0 + u);
+      g[u] = (gl + ((uint64_t)b << a))[lane];
+    }
+  };
+  auto apply = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t l = __builtin_amdgcn_readlane(len, j0 + u);
+      if (MODE == 1) { if (lane < l) sink ^= g[u]; }
+      else if (lane < l) bump(cnt, g[u]);
+    }
+  };
+  fetch(0, ga);
+#pragma unroll
+  for (uint32_t j0 = 0; j0 < 64; j0 += 2 * UNROLL) {
+    fetch(j0 + UNROLL, gb);
+    apply(j0, ga);
+    if (j0 + 2 * UNROLL < 64) fetch(j0 + 2 * UNROLL, ga);
+    apply(j0 + UNROLL, gb);
+  }
+}
+
+// One pass of a workgroup over all slots of one tile.
+//   STASH_OUT: the lookup fetched the entries of NT tiles at once; tile 0 is
+//              walked now, the others are parked in `stash` (coalesced) for the
+//              later passes, so every slot costs ONE random table line per query.
+//   STASH_IN : entries come from the stash (coalesced 8-byte loads).
+// Each wave takes 64 slots per iteration; lookups run one iteration ahead,
+// fingerprints two.  Buckets are cut into chunks of <= 64 ids that go through a
+// wave-private LDS queue, so the walk always runs on full batches of 64 chunks
+// whatever the bucket lengths are.
+// MODE is a measurement aid (results are wrong for MODE != 0): 1 = no LDS
+// atomics, 6 = lookups only.
+template <int BLOCK, int UNROLL, int NT, bool STASH_OUT, bool STASH_IN, int MODE>
+__device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk, uint32_t q, uint32_t t,
+                                          uint32_t *cnt, Item *queue, Entry *stash, uint32_t &sink) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   constexpr uint32_t NW = BLOCK / 64;
-  const uint32_t R = v.d.R;
-  const uint32_t g0 = t * v.tile;
-  const uint32_t n_t = (v.n_genomes - g0) < v.tile ? (v.n_genomes - g0) : v.tile;
-  const uint32_t n_words = (n_t + 1) / 2;
-
-  for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
-  __syncthreads();
-
-  const int32_t *sk = sketches + (uint64_t)q * v.d.F + v.d.slot_begin;
-  const uint32_t *off = v.offsets + (uint64_t)t * v.f_local * (R + 1);
-  const uint16_t *gl = v.gids + (uint64_t)t * v.f_local * v.tile;
+  constexpr int NE = STASH_OUT ? NT : 1;  // entries fetched per lookup
+  const uint32_t R = v.d.R, a = v.align_log2;
   const uint32_t n_it = (v.f_local + 63) / 64;
+  const uint16_t *gl = v.gids + v.tile_base[t];
+  Entry *my_stash = stash + (uint64_t)q * (v.n_tiles - 1) * v.f_local;
+  Item *wq = queue + wave * kQueue;
+  uint32_t q_head = 0, q_count = 0;  // wave-uniform
 
-  // Both lookups are unconditional loads from clamped addresses (validity is
-  // applied when the values are used), so that they stay in flight across the
-  // bucket walk instead of being waited for where they are issued.
-  // ROT: every workgroup starts its walk over the slots at a different place, so
-  // that the workgroups in flight do not all hit the same window of the table.
-  const uint32_t rot = (ROT && n_it % NW == 0) ? (uint32_t)(((uint64_t)blockIdx.x * 2654435761u) >> 12) % n_it : 0u;
-  auto phys = [&](uint32_t it) -> uint32_t { uint32_t e = it + rot; return e >= n_it && it < n_it ? e - n_it : e; };
+  struct Look { Entry e[NE]; };
+  auto slot_ok = [&](uint32_t it) -> bool { return it < n_it && it * 64 + lane < v.f_local; };
   auto load_fp = [&](uint32_t it) -> int32_t {
-    const uint32_t s = phys(it) * 64 + lane;
+    if (STASH_IN) return 0;
+    const uint32_t s = it * 64 + lane;
     return sk[s < v.f_local ? s : v.f_local - 1];
   };
-  auto slot_ok = [&](uint32_t it) -> bool { return it < n_it && phys(it) * 64 + lane < v.f_local; };
-  auto load_off = [&](uint32_t it, int32_t fp, bool ok) -> OffPair {
-    ok = ok && fp >= 0 && (uint32_t)fp < R;  // src/niqki_index.cpp:654
-    const uint64_t key = ok ? (uint64_t)(phys(it) * 64 + lane) * (R + 1) + (uint32_t)fp : 0;
-    return *(const OffPair *)(off + key);
-  };
   auto valid_of = [&](uint32_t it, int32_t fp) -> bool {
-    return slot_ok(it) && fp >= 0 && (uint32_t)fp < R;
+    if (STASH_IN) return slot_ok(it);
+    return slot_ok(it) && fp >= 0 && (uint32_t)fp < R;  // src/niqki_index.cpp:654
+  };
+  // unconditional loads from clamped addresses: they stay in flight across the walk
+  auto lookup = [&](uint32_t it, int32_t fp) -> Look {
+    Look L;
+    uint32_t s = it * 64 + lane;
+    if (s >= v.f_local) s = v.f_local - 1;
+    if (STASH_IN) {
+      L.e[0] = my_stash[(uint64_t)(t - 1) * v.f_local + s];
+    } else {
+      const bool ok = fp >= 0 && (uint32_t)fp < R;
+      const Entry *p = v.entries + ((uint64_t)s * R + (ok ? (uint32_t)fp : 0u)) * v.n_tiles + (STASH_OUT ? 0u : t);
+#pragma unroll
+      for (int k = 0; k < NE; ++k) L.e[k] = p[k];
+    }
+    return L;
+  };
+  auto drain = [&]() {
+    while (q_count >= 64) {
+      const Item x = wq[(q_head + lane) & (kQueue - 1)];
+      q_head = (q_head + 64) & (kQueue - 1);
+      q_count -= 64;
+      walk64<UNROLL, MODE>(gl, a, x.pos, x.len, lane, cnt, sink);
+    }
   };
 
-  uint32_t sink = 0;  // keeps the loads alive in the ablation modes
-  // pipeline prologue
   uint32_t it = wave;
   int32_t fp0 = load_fp(it);
-  int32_t fp1 = load_fp(it + NW);                         // fingerprints one iteration ahead
-  OffPair cur = load_off(it, fp0, slot_ok(it));           // bucket extents of the current iteration
+  int32_t fp1 = load_fp(it + NW);
+  Look cur = lookup(it, fp0);
   bool cur_ok = valid_of(it, fp0);
 
   for (; it < n_it; it += NW) {
-    // lookups for the next iteration, fingerprints for the one after
-    const OffPair nxt = load_off(it + NW, fp1, slot_ok(it + NW));
+    const Look nxt = lookup(it + NW, fp1);
     const bool nxt_ok = valid_of(it + NW, fp1);
     fp1 = load_fp(it + 2 * NW);
-    const uint32_t o0 = cur.lo, len = cur_ok ? cur.hi - cur.lo : 0u;
-
-    uint32_t ga[UNROLL], gb[UNROLL];
-    // Unconditional loads (lanes past the end re-read the bucket's last id, an
-    // empty bucket reads one id at its offset -- the gid array is padded), so
-    // that the compiler can count them in vmcnt and keep both rounds in flight.
-    auto fetch = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
+    uint32_t pos = cur.e[0].start, rem = cur_ok ? cur.e[0].len : 0u;
+    const uint32_t step = 64u >> a;  // units per 64 ids (align_log2 <= 6)
+    if (STASH_OUT) {
+      const uint32_t s = it * 64 + lane;
+      if (s < v.f_local) {
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const uint32_t b = __builtin_amdgcn_readlane(o0, j0 + u);
-        const uint32_t l = __builtin_amdgcn_readlane(len, j0 + u);
-        const uint32_t last = l ? l - 1 : 0;
-        if (MODE >= 2) g[u] = ((b * 2654435761u + lane * 40503u) >> 17) & 0x7FFFu;
-        else g[u] = gl[b + (lane < last ? lane : last)];
+        for (int k = 1; k < NE; ++k)
+          my_stash[(uint64_t)(k - 1) * v.f_local + s] = Entry{cur.e[k].start, cur_ok ? cur.e[k].len : 0u};
       }
-    };
-    auto apply = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const uint32_t l = __builtin_amdgcn_readlane(len, j0 + u);
-        if (MODE == 1 || MODE == 3) { if (lane < l) sink ^= g[u]; }
-        else if (lane < l) bump(cnt, g[u]);
-      }
-    };
-    fetch(0, ga);
-#pragma unroll
-    for (uint32_t j0 = 0; j0 < 64; j0 += 2 * UNROLL) {
-      fetch(j0 + UNROLL, gb);
-      apply(j0, ga);
-      if (j0 + 2 * UNROLL < 64) fetch(j0 + 2 * UNROLL, ga);
-      apply(j0 + UNROLL, gb);
     }
-    // buckets longer than one wave: the rest, 64 ids at a time
-    if (__any(len > 64)) {
-      for (uint32_t j = 0; j < 64; ++j) {
-        const uint32_t l = __builtin_amdgcn_readlane(len, j);
-        if (l > 64) {
-          const uint32_t b = __builtin_amdgcn_readlane(o0, j);
-          for (uint32_t e = 64 + lane; e < l; e += 64) bump(cnt, gl[b + e]);
+    if (MODE == 6) { sink += pos ^ rem; cur = nxt; cur_ok = nxt_ok; continue; }
+    // cut the 64 buckets into chunks of <= 64 ids, at most 3 per lane and round
+    // (q_count < 64 here, so at most 63 + 192 items are ever queued)
+    do {
+      uint32_t nch = (rem + 63) >> 6;
+      if (nch > 3) nch = 3;
+      uint32_t incl = nch;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += y;
+      }
+      const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+      uint32_t slot = q_head + q_count + incl - nch;
+#pragma unroll
+      for (uint32_t k = 0; k < 3; ++k)
+        if (k < nch) {
+          const uint32_t left = rem - 64 * k;
+          wq[(slot + k) & (kQueue - 1)] = Item{pos + step * k, left < 64 ? left : 64u};
         }
-      }
-    }
+      q_count += total;
+      pos += step * nch;
+      rem -= rem < 192 ? rem : 192u;
+      drain();
+    } while (__any(rem != 0));
     cur = nxt;
     cur_ok = nxt_ok;
   }
-  if (MODE != 0) cnt[tid % n_words] ^= sink;
-  __syncthreads();
+  if (q_count) {  // the last partial batch
+    Item x = wq[(q_head + lane) & (kQueue - 1)];
+    if (lane >= q_count) x = Item{0u, 0u};
+    walk64<UNROLL, MODE>(gl, a, x.pos, x.len, lane, cnt, sink);
+  }
+}
 
-  // dense counter row of this tile: u16 counts[q*stride + g0 + i], written as the packed words
-  uint32_t *out = (uint32_t *)(counts + (uint64_t)q * stride + g0);
-  const uint32_t full = n_t / 2;
-  for (uint32_t i = tid; i < full; i += BLOCK) out[i] = cnt[i];
-  if ((n_t & 1u) && tid == 0) counts[(uint64_t)q * stride + g0 + n_t - 1] = (uint16_t)(cnt[full] & 0xFFFFu);
+// One workgroup per query; the genome tiles are walked one after another with
+// the tile's hit counters (packed u16 pairs) in LDS.
+template <int BLOCK, int UNROLL, int NT, int MODE = 0>
+__global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_t *sketches,
+                                                       uint16_t *counts, uint64_t stride, Entry *stash) {
+  extern __shared__ __align__(16) uint32_t cnt[];
+  const uint32_t q = blockIdx.x;
+  const uint32_t tid = threadIdx.x;
+  const int32_t *sk = sketches + (uint64_t)q * v.d.F + v.d.slot_begin;
+  Item *queue = (Item *)(cnt + (v.tile + 1) / 2);  // behind the counters: kQueue items per wave
+  uint32_t sink = 0;
+  for (uint32_t t = 0; t < v.n_tiles; ++t) {
+    const uint32_t g0 = t * v.tile;
+    const uint32_t n_t = (v.n_genomes - g0) < v.tile ? (v.n_genomes - g0) : v.tile;
+    const uint32_t n_words = (n_t + 1) / 2;
+    for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
+    __syncthreads();
+    if (NT >= 2) {
+      if (t == 0) walk_tile<BLOCK, UNROLL, NT, true, false, MODE>(v, sk, q, t, cnt, queue, stash, sink);
+      else walk_tile<BLOCK, UNROLL, NT, false, true, MODE>(v, sk, q, t, cnt, queue, stash, sink);
+    } else {
+      walk_tile<BLOCK, UNROLL, 1, false, false, MODE>(v, sk, q, t, cnt, queue, stash, sink);
+    }
+    if (MODE != 0) cnt[tid % n_words] ^= sink;
+    __syncthreads();
+    // dense counter row of this tile: u16 counts[q*stride + g0 + i], written as the packed words
+    uint32_t *out = (uint32_t *)(counts + (uint64_t)q * stride + g0);
+    const uint32_t full = n_t / 2;
+    for (uint32_t i = tid; i < full; i += BLOCK) out[i] = cnt[i];
+    if ((n_t & 1u) && tid == 0) counts[(uint64_t)q * stride + g0 + n_t - 1] = (uint16_t)(cnt[full] & 0xFFFFu);
+    __syncthreads();
+  }
 }
 
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq, uint16_t *counts,
-                         uint64_t stride, int variant, hipStream_t stream) {
+                         uint64_t stride, Entry *stash, int variant, hipStream_t stream) {
   if (nq == 0 || v.n_tiles == 0) return hipSuccess;
-  size_t lds = (size_t)((v.tile + 1) / 2) * 4;
-  dim3 grid(nq * v.n_tiles);
+#define NQ_GATHER_LDS(B) ((size_t)((v.tile + 1) / 2) * 4 + (size_t)(B / 64) * kQueue * sizeof(Item))
+  dim3 grid(nq);
   hipError_t e;
-#define NQ_LAUNCH_GATHER(B, U, ...)                                                              \
+#define NQ_LAUNCH_GATHER(B, U, NT, ...)                                                          \
   do {                                                                                           \
-    auto k = gather_kernel<B, U, ##__VA_ARGS__>;                                                                \
+    auto k = gather_kernel<B, U, NT, ##__VA_ARGS__>;                                             \
+    const size_t lds = NQ_GATHER_LDS(B);                                                         \
     e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                               \
-    hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, v, sketches, counts, stride);              \
+    hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, v, sketches, counts, stride, stash);       \
+  } while (0)
+#define NQ_BY_TILES(B, U, ...)                                                                   \
+  do {                                                                                           \
+    if (v.n_tiles == 2) NQ_LAUNCH_GATHER(B, U, 2, ##__VA_ARGS__);                                \
+    else if (v.n_tiles == 3) NQ_LAUNCH_GATHER(B, U, 3, ##__VA_ARGS__);                           \
+    else if (v.n_tiles == 4) NQ_LAUNCH_GATHER(B, U, 4, ##__VA_ARGS__);                           \
+    else NQ_LAUNCH_GATHER(B, U, 1, ##__VA_ARGS__);                                               \
   } while (0)
   switch (variant) {
-    case 1: NQ_LAUNCH_GATHER(1024, 8); break;
-    case 2: NQ_LAUNCH_GATHER(1024, 32); break;
-    case 3: NQ_LAUNCH_GATHER(512, 16); break;
-    case 4: NQ_LAUNCH_GATHER(512, 32); break;
-    case 5: NQ_LAUNCH_GATHER(1024, 16, 0, 1); break;  // rotated slot walk
-    case 6: NQ_LAUNCH_GATHER(1024, 8, 0, 1); break;
-    case 15: NQ_LAUNCH_GATHER(1024, 16, 3, 1); break;
-    case 11: NQ_LAUNCH_GATHER(1024, 16, 1); break;  // ablations, see MODE
-    case 12: NQ_LAUNCH_GATHER(1024, 16, 2); break;
-    case 13: NQ_LAUNCH_GATHER(1024, 16, 3); break;
-    default: NQ_LAUNCH_GATHER(1024, 16); break;
+    case 1: NQ_BY_TILES(1024, 8); break;
+    case 2: NQ_BY_TILES(1024, 32); break;
+    case 3: NQ_BY_TILES(512, 16); break;
+    case 7: NQ_LAUNCH_GATHER(1024, 16, 1); break;  // one lookup per (slot, tile), no stash
+    case 11: NQ_BY_TILES(1024, 16, 1); break;      // ablations, see MODE
+    case 16: NQ_BY_TILES(1024, 16, 6); break;
+    default: NQ_BY_TILES(1024, 16); break;
   }
+#undef NQ_BY_TILES
+#undef NQ_GATHER_LDS
 #undef NQ_LAUNCH_GATHER
   return hipGetLastError();
 }
@@ -177,11 +255,10 @@ __global__ __launch_bounds__(256) void gathered_kernel(IndexView v, const int32_
   unsigned long long sum = 0;
   for (uint32_t s = threadIdx.x; s < v.f_local; s += blockDim.x) {
     int32_t fp = sk[s];
-    if (fp >= 0 && (uint32_t)fp < R)
-      for (uint32_t t = 0; t < v.n_tiles; ++t) {
-        const uint32_t *p = v.offsets + ((uint64_t)t * v.f_local + s) * (R + 1) + (uint32_t)fp;
-        sum += p[1] - p[0];
-      }
+    if (fp >= 0 && (uint32_t)fp < R) {
+      const Entry *p = v.entries + ((uint64_t)s * R + (uint32_t)fp) * v.n_tiles;
+      for (uint32_t t = 0; t < v.n_tiles; ++t) sum += p[t].len;
+    }
   }
   atomicAdd(&per_query[q], sum);
 }
