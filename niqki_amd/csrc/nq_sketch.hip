@@ -117,20 +117,28 @@ __device__ void densify_lds(uint32_t *sk, const Derived &d, uint32_t *s_flag) {
 }
 
 // One rolling hash step (the body of the loop at src/niqki_index.cpp:342-356).
-__device__ __forceinline__ void hash_step(uint32_t byte, const uint8_t *lut, uint64_t &fw,
-                                          uint64_t &rc, const Derived &d, uint32_t rc_shift,
-                                          uint32_t *sk, bool live) {
-  uint32_t e = lut[byte];
-  fw = ((fw << 2) | (uint64_t)(e & 3u)) & d.kmer_mask;
-  rc = (rc >> 2) | ((uint64_t)((e >> 2) & 3u) << rc_shift);
+// `e` is the code-table entry of the incoming base; KFIX != 0 fixes K at compile
+// time (K = 31: the 62-bit words need no low-word mask and constant shifts).
+template <int KFIX, bool TAIL>
+__device__ __forceinline__ void hash_step(uint32_t e, uint64_t &fw, uint64_t &rc, const Derived &d,
+                                          uint32_t rc_shift, uint32_t *sk, bool live) {
+  if (KFIX) {
+    constexpr uint64_t mask = (1ULL << (2 * KFIX)) - 1ULL;
+    fw = ((fw << 2) | (uint64_t)(e & 3u)) & mask;
+    rc = (rc >> 2) | ((uint64_t)((e >> 2) & 3u) << (2 * KFIX - 2));
+  } else {
+    fw = ((fw << 2) | (uint64_t)(e & 3u)) & d.kmer_mask;
+    rc = (rc >> 2) | ((uint64_t)((e >> 2) & 3u) << rc_shift);
+  }
   uint64_t canon = fw < rc ? fw : rc;
   uint32_t slot = slot_of(canon, d.S);
   uint32_t fp = fingerprint(rev64(canon), d.M, d.mask_m, d.max_rem);
-  if (live) atomicMin(&sk[slot], fp);
+  if (TAIL) fp = live ? fp : kEmpty32;  // a min with "empty" changes nothing
+  atomicMin(&sk[slot], fp);
 }
 
 // GROUPS 16-byte groups of hash steps per chunk: CHUNK = 16*GROUPS k-mers.
-template <int BLOCK, int GROUPS>
+template <int BLOCK, int GROUPS, int KFIX>
 __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
   extern __shared__ __align__(16) uint32_t smem[];
   const Derived &d = a.d;
@@ -191,11 +199,16 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
         ByteStream bs;
         bs.open(base + i0);
         uint4 g0 = bs.next16(), g1 = bs.next16();
+        uint32_t ew[32];  // all table look-ups first, then the dependent updates
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          uint32_t w = dword_of(j < 16 ? g0 : g1, (j & 15) >> 2);
+          ew[j] = lut[(w >> (8 * (j & 3))) & 0xFFu];
+        }
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
           if ((uint32_t)j < Km1) {
-            uint32_t w = dword_of(j < 16 ? g0 : g1, (j & 15) >> 2);
-            uint32_t e = lut[(w >> (8 * (j & 3))) & 0xFFu];
+            const uint32_t e = ew[j];
             const bool pfx = i0 + (uint32_t)j < Km1;
             uint32_t dgt = ok ? ((e >> 4) & 3u) : 0u;
             uint32_t cf = pfx ? dgt : (e & 3u);
@@ -206,16 +219,35 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
         }
       }
       // ---- CHUNK hash steps, bases i0+K-1 .. ----
+      // Per 16-byte group the 16 table look-ups are issued together, so the
+      // rolling chain never waits on LDS latency.
+      // The look-ups of group g+1 are issued before the 16 steps of group g: they
+      // return ahead of that group's ds_min traffic (LDS answers in order).
       ByteStream bs;
       bs.open(base + i0 + Km1);
+      uint32_t en[16];
+      {
+        const uint4 v = bs.next16();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) en[j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
+      }
       for (int g = 0; g < GROUPS; ++g) {
         if ((uint32_t)(g * 16) >= cnt) break;
-        uint4 v = bs.next16();
+        uint32_t e[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          uint32_t w = dword_of(v, j >> 2);
-          uint32_t byte = (w >> (8 * (j & 3))) & 0xFFu;
-          hash_step(byte, lut, fw, rc, d, rc_shift, sk, (uint32_t)(g * 16 + j) < cnt);
+        for (int j = 0; j < 16; ++j) e[j] = en[j];
+        if (g + 1 < GROUPS) {
+          const uint4 v = bs.next16();
+#pragma unroll
+          for (int j = 0; j < 16; ++j) en[j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
+        }
+        if (cnt - (uint32_t)(g * 16) >= 16u) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) hash_step<KFIX, false>(e[j], fw, rc, d, rc_shift, sk, true);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            hash_step<KFIX, true>(e[j], fw, rc, d, rc_shift, sk, (uint32_t)(g * 16 + j) < cnt);
         }
       }
     }
@@ -244,17 +276,19 @@ hipError_t launch_sketch(const SketchArgs &a, uint32_t n_entry, bool short_recor
   if (n_entry == 0) return hipSuccess;
   size_t lds = sketch_lds_bytes(a.d);
   dim3 grid(n_entry * a.splits);
+#define NQ_LAUNCH_SKETCH(B, G, KF)                                                               \
+  do {                                                                                           \
+    auto k = sketch_kernel<B, G, KF>;                                                            \
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                               \
+    hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, a);                                        \
+  } while (0)
   if (short_records) {
-    auto k = sketch_kernel<256, 1>;
-    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, a);
+    if (a.d.K == 31) NQ_LAUNCH_SKETCH(256, 1, 31); else NQ_LAUNCH_SKETCH(256, 1, 0);
   } else {
-    auto k = sketch_kernel<1024, 8>;
-    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, grid, dim3(1024), lds, stream, a);
+    if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 8, 31); else NQ_LAUNCH_SKETCH(1024, 8, 0);
   }
+#undef NQ_LAUNCH_SKETCH
   return hipGetLastError();
 }
 
