@@ -116,6 +116,69 @@ __device__ void densify_lds(uint32_t *sk, const Derived &d, uint32_t *s_flag) {
   }
 }
 
+// Densification over DISTINCT VALUES (short-read path).  A fill copies a value,
+// so every copy of a value proposes the same target in a pass and only the copy
+// with the smallest index can win: it is enough to track, per fingerprint value v,
+// mi[v] = smallest cell index holding v (at pass start), and the two hash words of
+// v, which never change.  A pass is then one proposal per distinct value (~120 for a
+// 150-base read) instead of one per occupied cell (up to F), with the same result
+// as densify_lds.  aux: 3*R words of LDS (mi, A = low word of unrev(v), B = low word
+// of rev(v)).
+template <int BLOCK>
+__device__ void densify_lds_distinct(uint32_t *sk, const Derived &d, uint32_t *s_flag, uint32_t *aux) {
+  const uint32_t F = d.F, R = d.R, W = d.W;
+  const uint32_t tid = threadIdx.x;
+  uint32_t *mi = aux, *ha = aux + R, *hb = aux + 2 * R;
+  uint32_t local = 0;
+  for (uint32_t i = tid; i < F; i += BLOCK) local += (sk[i] == kEmpty32);
+  for (uint32_t v = tid; v < R; v += BLOCK) mi[v] = kEmpty32;
+  if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+  __syncthreads();
+  if (local) atomicAdd(&s_flag[0], local);
+  for (uint32_t i = tid; i < F; i += BLOCK) {
+    uint32_t v = sk[i];
+    if (v != kEmpty32) atomicMin(&mi[v], i);
+  }
+  __syncthreads();
+  uint32_t empty = s_flag[0];
+  if (empty == 0 || empty == F) return;
+  for (uint32_t v = tid; v < R; v += BLOCK)
+    if (mi[v] != kEmpty32) { ha[v] = (uint32_t)unrev64(v); hb[v] = (uint32_t)rev64(v); }
+  uint32_t step = 0, idle = 0;
+  while (true) {
+    for (uint32_t v = tid; v < R; v += BLOCK) {
+      const uint32_t m = mi[v];
+      if (m != kEmpty32) {
+        const uint32_t t = (ha[v] + step * hb[v]) & (F - 1u);  // hash_family(v, step) % F, :308-310,:319
+        if (sk[t] >= 0x80000000u) atomicMin(&sk[t], 0x80000000u | (m << W) | v);
+      }
+    }
+    __syncthreads();
+    uint32_t filled = 0;
+    for (uint32_t v = tid; v < R; v += BLOCK) {
+      const uint32_t m = mi[v];
+      if (m != kEmpty32) {
+        const uint32_t t = (ha[v] + step * hb[v]) & (F - 1u);
+        if (sk[t] == (0x80000000u | (m << W) | v)) {
+          sk[t] = v;
+          if (t < m) mi[v] = t;
+          ++filled;
+        }
+      }
+    }
+    if (filled) atomicAdd(&s_flag[1], filled);
+    __syncthreads();
+    const uint32_t tot = s_flag[1];  // every proposed-to cell now holds its winner's value
+    __syncthreads();
+    if (tid == 0) s_flag[1] = 0;
+    empty -= tot;
+    ++step;
+    idle = tot ? 0u : idle + 1u;
+    if (empty == 0 || idle >= F) break;
+    __syncthreads();
+  }
+}
+
 // One rolling hash step (the body of the loop at src/niqki_index.cpp:342-356).
 // `e` is the code-table entry of the incoming base; KFIX != 0 fixes K at compile
 // time (K = 31: the 62-bit words need no low-word mask and constant shifts).
@@ -264,17 +327,25 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
     }
     return;
   }
-  if (a.densify) densify_lds<BLOCK>(sk, d, s_flag);
+  if (a.densify) {
+    if (a.distinct) densify_lds_distinct<BLOCK>(sk, d, s_flag, smem + d.F + 4 + 64);
+    else densify_lds<BLOCK>(sk, d, s_flag);
+  }
   __syncthreads();
   for (uint32_t i = tid; i < d.F; i += BLOCK) out[i] = sk[i];
 }
 
-static size_t sketch_lds_bytes(const Derived &d) { return (size_t)d.F * 4 + 16 + 256; }
+static size_t sketch_lds_bytes(const Derived &d, bool distinct) {
+  return (size_t)d.F * 4 + 16 + 256 + (distinct ? (size_t)d.R * 12 : 0);
+}
 
-hipError_t launch_sketch(const SketchArgs &a, uint32_t n_entry, bool short_records,
+hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, bool short_records,
                          hipStream_t stream) {
   if (n_entry == 0) return hipSuccess;
-  size_t lds = sketch_lds_bytes(a.d);
+  SketchArgs a = a_in;
+  // distinct-value densification where its tables leave room for >= 2 workgroups per CU
+  a.distinct = (short_records && sketch_lds_bytes(a.d, true) <= 64 * 1024) ? 1u : 0u;
+  size_t lds = sketch_lds_bytes(a.d, a.distinct != 0);
   dim3 grid(n_entry * a.splits);
 #define NQ_LAUNCH_SKETCH(B, G, KF)                                                               \
   do {                                                                                           \
