@@ -226,6 +226,16 @@ def main():
     total_hits = int(hit_off[args.warmup:, per].sum().item())
     overflow = bool((hit_off[:, per] > cap).any().item())
 
+    # HBM bytes of the gather kernel from the committed PMC passes (separate rocprofv3
+    # --pmc runs of this same command; bench.py cannot collect counters itself)
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "gather_traffic.json")))
+        if (tj["index_genomes"], tj["query_batch"], tj["tile_genomes"]) == (N, per * world, eng.tile_genomes()) and world == 1:
+            traffic = tj["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, (K, S, W, H, J))
@@ -258,7 +268,7 @@ def main():
                 "kernel": "nq::gather_kernel (gather-histogram, rank 0's slot shard)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes / max(1, gather_launches),
                 "launches": gather_launches, "avg_launch_ms": gather_ms / max(1, gather_launches),
                 "gathered_ids_per_query": T / max(1, n_q_local),
