@@ -4,13 +4,12 @@
 // striped locks (src/niqki_index.h:55, src/niqki_index.cpp:27,362-370) and the
 // bucket walks of dump_index_disk / the loading constructor (:42-55, :63-90).
 //
-// Layout (DESIGN.md "HBM layout"): inserted sketches are kept slot-major as
-// u16 [F][cap]; the index is rebuilt from that store as one CSR per genome
-// tile, by a stable counting sort of each (tile, slot) row on the fingerprint:
-// every genome has exactly one entry per slot, so slot s of tile t owns the
-// fixed range [s*T, (s+1)*T) of the tile's gid array and no global scan is
-// needed.  Buckets come out ascending in genome id, the order the reference
-// produces single-threaded.
+// Layout: inserted sketches are kept slot-major as u16
+// [F][cap]; the index is rebuilt from that store by a stable counting sort of each
+// (tile, slot) row on the fingerprint: entries {start,len} for every (slot, fp,
+// tile) and the tile-local u16 id lists, optionally padded so that every bucket
+// starts on a 128-byte line.  Buckets come out ascending in genome id, the order
+// the reference produces single-threaded.
 #include "nq_kernels.h"
 
 namespace nq {
