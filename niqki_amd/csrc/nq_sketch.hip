@@ -16,6 +16,8 @@
 // k-mer), HBM traffic is 1 byte per base.
 #include "nq_kernels.h"
 
+#include <cstdlib>
+
 namespace nq {
 
 // Per-byte code table, built in LDS by the first 256 threads.
@@ -201,7 +203,7 @@ __device__ __forceinline__ void hash_step(uint32_t e, uint64_t &fw, uint64_t &rc
 }
 
 // GROUPS 16-byte groups of hash steps per chunk: CHUNK = 16*GROUPS k-mers.
-template <int BLOCK, int GROUPS, int KFIX>
+template <int BLOCK, int GROUPS, int KFIX, int NS>
 __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
   extern __shared__ __align__(16) uint32_t smem[];
   const Derived &d = a.d;
@@ -236,17 +238,28 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
     const uint64_t c_lo = n_chunks * part / a.splits;
     const uint64_t c_hi = n_chunks * (part + 1) / a.splits;
     const uint8_t *base = a.seqs + b0;
-    for (uint64_t c = c_lo + tid; c < c_hi; c += BLOCK) {
-      const uint64_t i0 = c * CHUNK;
-      const uint64_t left = n_kmers - i0;
-      const uint32_t cnt = left < CHUNK ? (uint32_t)left : CHUNK;
-      // ---- warm-up: K-1 rolling updates from zero rebuild both words ----
-      // Positions < K-1 of a record carry the str2numstrand digits
-      // (case-insensitive; any other byte among the first K-1 zeroes all of
-      // them, :255-273) and their complements (rcb, :240-250); every later
-      // position carries the codes of the rolling tables.
-      uint64_t fw = 0, rc = 0;
-      {
+    // NS chunks are rolled side by side by every lane: their hash chains are
+    // independent, which gives the scheduler work to put between dependent multiplies.
+    for (uint64_t c = c_lo + tid; c < c_hi; c += (uint64_t)BLOCK * NS) {
+      uint64_t fw[NS], rc[NS];
+      uint32_t cnt[NS];
+      ByteStream bs[NS];
+      uint32_t en[NS][16];
+      uint32_t cnt_max = 0;
+#pragma unroll
+      for (int n = 0; n < NS; ++n) {
+        const uint64_t cc = c + (uint64_t)n * BLOCK;
+        const bool alive = cc < c_hi;
+        const uint64_t i0 = alive ? cc * CHUNK : c * CHUNK;  // a dead stream re-reads chunk c, all its steps are masked
+        const uint64_t left = n_kmers - i0;
+        cnt[n] = alive ? (left < CHUNK ? (uint32_t)left : CHUNK) : 0u;
+        cnt_max = cnt[n] > cnt_max ? cnt[n] : cnt_max;
+        // ---- warm-up: K-1 rolling updates from zero rebuild both words ----
+        // Positions < K-1 of a record carry the str2numstrand digits
+        // (case-insensitive; any other byte among the first K-1 zeroes all of
+        // them, :255-273) and their complements (rcb, :240-250); every later
+        // position carries the codes of the rolling tables.
+        uint64_t f = 0, r = 0;
         uint32_t ok = 1;
         if (i0 < Km1) {
           ByteStream ps;
@@ -259,9 +272,9 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
             if ((uint32_t)j < Km1) ok &= (e >> 6) & 1u;
           }
         }
-        ByteStream bs;
-        bs.open(base + i0);
-        uint4 g0 = bs.next16(), g1 = bs.next16();
+        ByteStream ws;
+        ws.open(base + i0);
+        uint4 g0 = ws.next16(), g1 = ws.next16();
         uint32_t ew[32];  // all table look-ups first, then the dependent updates
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
@@ -276,41 +289,47 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
             uint32_t dgt = ok ? ((e >> 4) & 3u) : 0u;
             uint32_t cf = pfx ? dgt : (e & 3u);
             uint32_t cr = pfx ? (3u - dgt) : ((e >> 2) & 3u);
-            fw = (fw << 2) | cf;
-            rc = (rc >> 2) | ((uint64_t)cr << rc_shift);
+            f = (f << 2) | cf;
+            r = (r >> 2) | ((uint64_t)cr << rc_shift);
           }
         }
-      }
-      // ---- CHUNK hash steps, bases i0+K-1 .. ----
-      // Per 16-byte group the 16 table look-ups are issued together, so the
-      // rolling chain never waits on LDS latency.
-      // The look-ups of group g+1 are issued before the 16 steps of group g: they
-      // return ahead of that group's ds_min traffic (LDS answers in order).
-      ByteStream bs;
-      bs.open(base + i0 + Km1);
-      uint32_t en[16];
-      {
-        const uint4 v = bs.next16();
+        fw[n] = f;
+        rc[n] = r;
+        // ---- stream of the CHUNK hash steps, bases i0+K-1 .. ----
+        bs[n].open(base + i0 + Km1);
+        const uint4 v = bs[n].next16();
 #pragma unroll
-        for (int j = 0; j < 16; ++j) en[j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
+        for (int j = 0; j < 16; ++j) en[n][j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
       }
+      // Per 16-byte group the 16 table look-ups of a stream are issued together and
+      // one group ahead of their use (LDS answers in order, so they return before
+      // the ds_min traffic of the group in between).
       for (int g = 0; g < GROUPS; ++g) {
-        if ((uint32_t)(g * 16) >= cnt) break;
-        uint32_t e[16];
+        if ((uint32_t)(g * 16) >= cnt_max) break;
+        uint32_t e[NS][16];
+        bool full = true;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) e[j] = en[j];
-        if (g + 1 < GROUPS) {
-          const uint4 v = bs.next16();
+        for (int n = 0; n < NS; ++n) {
 #pragma unroll
-          for (int j = 0; j < 16; ++j) en[j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
+          for (int j = 0; j < 16; ++j) e[n][j] = en[n][j];
+          if (g + 1 < GROUPS) {
+            const uint4 v = bs[n].next16();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) en[n][j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
+          }
+          full = full && cnt[n] >= (uint32_t)(g * 16 + 16);
         }
-        if (cnt - (uint32_t)(g * 16) >= 16u) {
+        if (full) {
 #pragma unroll
-          for (int j = 0; j < 16; ++j) hash_step<KFIX, false>(e[j], fw, rc, d, rc_shift, sk, true);
+          for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int n = 0; n < NS; ++n) hash_step<KFIX, false>(e[n][j], fw[n], rc[n], d, rc_shift, sk, true);
         } else {
 #pragma unroll
           for (int j = 0; j < 16; ++j)
-            hash_step<KFIX, true>(e[j], fw, rc, d, rc_shift, sk, (uint32_t)(g * 16 + j) < cnt);
+#pragma unroll
+            for (int n = 0; n < NS; ++n)
+              hash_step<KFIX, true>(e[n][j], fw[n], rc[n], d, rc_shift, sk, (uint32_t)(g * 16 + j) < cnt[n]);
         }
       }
     }
@@ -347,17 +366,20 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, bool short_re
   a.distinct = (short_records && sketch_lds_bytes(a.d, true) <= 64 * 1024) ? 1u : 0u;
   size_t lds = sketch_lds_bytes(a.d, a.distinct != 0);
   dim3 grid(n_entry * a.splits);
-#define NQ_LAUNCH_SKETCH(B, G, KF)                                                               \
+#define NQ_LAUNCH_SKETCH(B, G, KF, NS)                                                           \
   do {                                                                                           \
-    auto k = sketch_kernel<B, G, KF>;                                                            \
+    auto k = sketch_kernel<B, G, KF, NS>;                                                            \
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                               \
     hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, a);                                        \
   } while (0)
+  static const int streams = [] { const char *v = std::getenv("NIQKI_SKETCH_STREAMS"); return v ? std::atoi(v) : 1; }();
   if (short_records) {
-    if (a.d.K == 31) NQ_LAUNCH_SKETCH(256, 1, 31); else NQ_LAUNCH_SKETCH(256, 1, 0);
+    if (a.d.K == 31) NQ_LAUNCH_SKETCH(256, 1, 31, 1); else NQ_LAUNCH_SKETCH(256, 1, 0, 1);
+  } else if (streams == 2) {
+    if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 8, 31, 2); else NQ_LAUNCH_SKETCH(1024, 8, 0, 2);
   } else {
-    if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 8, 31); else NQ_LAUNCH_SKETCH(1024, 8, 0);
+    if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 8, 31, 1); else NQ_LAUNCH_SKETCH(1024, 8, 0, 1);
   }
 #undef NQ_LAUNCH_SKETCH
   return hipGetLastError();
