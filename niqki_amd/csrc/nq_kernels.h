@@ -16,6 +16,7 @@ struct SketchArgs {
   uint32_t accumulate;        // start from the sketches already in `sketches`
   uint32_t densify;           // run densification before the store (splits == 1 only)
   uint32_t distinct;          // set by launch_sketch: densify over distinct values (short-read path)
+  uint32_t filter;            // set by launch_sketch: candidate filter for long inputs
 };
 hipError_t launch_sketch(const SketchArgs &a, uint32_t n_entry, bool short_records,
                          hipStream_t stream);

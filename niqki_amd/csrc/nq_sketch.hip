@@ -181,12 +181,12 @@ __device__ void densify_lds_distinct(uint32_t *sk, const Derived &d, uint32_t *s
   }
 }
 
-// One rolling hash step (the body of the loop at src/niqki_index.cpp:342-356).
-// `e` is the code-table entry of the incoming base; KFIX != 0 fixes K at compile
-// time (K = 31: the 62-bit words need no low-word mask and constant shifts).
-template <int KFIX, bool TAIL>
-__device__ __forceinline__ void hash_step(uint32_t e, uint64_t &fw, uint64_t &rc, const Derived &d,
-                                          uint32_t rc_shift, uint32_t *sk, bool live) {
+// Rolling update of the forward / reverse-complement words with the code-table
+// entry `e` of the incoming base (src/niqki_index.cpp:225-236) and the canonical
+// k-mer (:345).  KFIX != 0 fixes K at compile time (K = 31: constant shifts).
+template <int KFIX>
+__device__ __forceinline__ uint64_t roll_step(uint32_t e, uint64_t &fw, uint64_t &rc, const Derived &d,
+                                              uint32_t rc_shift) {
   if (KFIX) {
     constexpr uint64_t mask = (1ULL << (2 * KFIX)) - 1ULL;
     fw = ((fw << 2) | (uint64_t)(e & 3u)) & mask;
@@ -195,40 +195,53 @@ __device__ __forceinline__ void hash_step(uint32_t e, uint64_t &fw, uint64_t &rc
     fw = ((fw << 2) | (uint64_t)(e & 3u)) & d.kmer_mask;
     rc = (rc >> 2) | ((uint64_t)((e >> 2) & 3u) << rc_shift);
   }
-  uint64_t canon = fw < rc ? fw : rc;
+  return fw < rc ? fw : rc;
+}
+
+// slot + fingerprint of a canonical k-mer and the per-slot min (:346-355)
+__device__ __forceinline__ void sketch_update(uint64_t canon, const Derived &d, uint32_t *sk, bool live) {
   uint32_t slot = slot_of(canon, d.S);
   uint32_t fp = fingerprint(rev64(canon), d.M, d.mask_m, d.max_rem);
-  if (TAIL) fp = live ? fp : kEmpty32;  // a min with "empty" changes nothing
+  fp = live ? fp : kEmpty32;  // a min with "empty" changes nothing
   atomicMin(&sk[slot], fp);
 }
 
-// GROUPS 16-byte groups of hash steps per chunk: CHUNK = 16*GROUPS k-mers.
-template <int BLOCK, int GROUPS, int KFIX, int NS>
-__global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
-  extern __shared__ __align__(16) uint32_t smem[];
+// High word of rev64(canon): enough to bound the fingerprint from below.
+__device__ __forceinline__ uint32_t rev64_hi(uint64_t canon) {
+  uint64_t x = ((canon >> 32) ^ canon) * kRevMul;
+  x = ((x >> 32) ^ x) * kRevMul;
+  return (uint32_t)(x >> 32);
+}
+
+constexpr uint32_t kRing = 128;  // candidate k-mers per wave-private ring (filtered path)
+
+// All records of one sketch, this workgroup's share of the chunks.
+// FILTER (long inputs only): a k-mer whose hash has fewer than T leading zeros
+// (hi word >= thr) has a larger fingerprint than any k-mer with at least T, so it
+// can only matter for a slot that no such k-mer reaches.  Those k-mers (7 of 8 at
+// T = 3) skip the slot hash and the LDS min; the others are compacted into a
+// wave-private ring and finished 64 at a time.  The caller re-runs the records
+// unfiltered if any slot is still empty afterwards, so the result is exact.
+template <int BLOCK, int GROUPS, int KFIX, bool FILTER>
+__device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part, uint32_t *sk, const uint8_t *lut,
+                             uint64_t *ring_base, uint32_t thr) {
   const Derived &d = a.d;
-  uint32_t *sk = smem;                              // F cells
-  uint32_t *s_flag = smem + d.F;                    // 4 words
-  uint8_t *lut = (uint8_t *)(smem + d.F + 4);       // 256 bytes
-  const uint32_t tid = threadIdx.x;
-  const uint32_t entry = blockIdx.x / a.splits;
-  const uint32_t part = blockIdx.x % a.splits;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
   constexpr uint32_t CHUNK = 16u * GROUPS;
-
-  if (tid < 256) lut[tid] = code_entry(tid);
-  if (a.accumulate) {
-    const uint32_t *src = (const uint32_t *)a.sketches + (uint64_t)entry * d.F;
-    for (uint32_t i = tid; i < d.F; i += BLOCK) sk[i] = src[i];
-  } else {
-    for (uint32_t i = tid; i < d.F; i += BLOCK) sk[i] = kEmpty32;
-  }
-  __syncthreads();
-
   const uint32_t Km1 = d.K - 1u;
   const uint32_t rc_shift = 2u * d.K - 2u;
+  uint64_t *ring = ring_base + (tid >> 6) * kRing;
+  uint32_t q_head = 0, q_tail = 0, q_count = 0;  // wave-uniform (scalar registers)
+  auto drain64 = [&](bool partial) {
+    uint64_t c = ring[(q_head + lane) & (kRing - 1)];
+    const bool live = !partial || lane < q_count;
+    sketch_update(live ? c : 0ull, d, sk, live);
+    q_head = (q_head + 64) & (kRing - 1);
+    q_count = partial ? 0u : q_count - 64;
+  };
+
   uint32_t r0 = a.entry_rec ? a.entry_rec[entry] : entry;
   uint32_t r1 = a.entry_rec ? a.entry_rec[entry + 1] : entry + 1;
-  if (a.seqs == nullptr) r1 = r0;  // densify-only launch
   for (uint32_t rec = r0; rec < r1; ++rec) {
     const uint64_t b0 = a.rec_off[rec], b1 = a.rec_off[rec + 1];
     const uint64_t len = b1 - b0;
@@ -238,28 +251,22 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
     const uint64_t c_lo = n_chunks * part / a.splits;
     const uint64_t c_hi = n_chunks * (part + 1) / a.splits;
     const uint8_t *base = a.seqs + b0;
-    // NS chunks are rolled side by side by every lane: their hash chains are
-    // independent, which gives the scheduler work to put between dependent multiplies.
-    for (uint64_t c = c_lo + tid; c < c_hi; c += (uint64_t)BLOCK * NS) {
-      uint64_t fw[NS], rc[NS];
-      uint32_t cnt[NS];
-      ByteStream bs[NS];
-      uint32_t en[NS][16];
-      uint32_t cnt_max = 0;
-#pragma unroll
-      for (int n = 0; n < NS; ++n) {
-        const uint64_t cc = c + (uint64_t)n * BLOCK;
-        const bool alive = cc < c_hi;
-        const uint64_t i0 = alive ? cc * CHUNK : c * CHUNK;  // a dead stream re-reads chunk c, all its steps are masked
-        const uint64_t left = n_kmers - i0;
-        cnt[n] = alive ? (left < CHUNK ? (uint32_t)left : CHUNK) : 0u;
-        cnt_max = cnt[n] > cnt_max ? cnt[n] : cnt_max;
-        // ---- warm-up: K-1 rolling updates from zero rebuild both words ----
-        // Positions < K-1 of a record carry the str2numstrand digits
-        // (case-insensitive; any other byte among the first K-1 zeroes all of
-        // them, :255-273) and their complements (rcb, :240-250); every later
-        // position carries the codes of the rolling tables.
-        uint64_t f = 0, r = 0;
+    // Whole waves step together (uniform loop control: the filtered path's ring
+    // is wave-collective and its counters live in scalar registers).
+    const uint32_t wave0 = __builtin_amdgcn_readfirstlane(tid & ~63u);
+    for (uint64_t cb = c_lo + wave0; cb < c_hi; cb += BLOCK) {
+      const uint64_t c = cb + lane;
+      const bool alive = c < c_hi;
+      const uint64_t i0 = (alive ? c : c_lo) * CHUNK;
+      const uint64_t left = n_kmers - i0;
+      const uint32_t cnt = alive ? (left < CHUNK ? (uint32_t)left : CHUNK) : 0u;
+      // ---- warm-up: K-1 rolling updates from zero rebuild both words ----
+      // Positions < K-1 of a record carry the str2numstrand digits
+      // (case-insensitive; any other byte among the first K-1 zeroes all of
+      // them, :255-273) and their complements (rcb, :240-250); every later
+      // position carries the codes of the rolling tables.
+      uint64_t fw = 0, rc = 0;
+      {
         uint32_t ok = 1;
         if (i0 < Km1) {
           ByteStream ps;
@@ -289,49 +296,125 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
             uint32_t dgt = ok ? ((e >> 4) & 3u) : 0u;
             uint32_t cf = pfx ? dgt : (e & 3u);
             uint32_t cr = pfx ? (3u - dgt) : ((e >> 2) & 3u);
-            f = (f << 2) | cf;
-            r = (r >> 2) | ((uint64_t)cr << rc_shift);
+            fw = (fw << 2) | cf;
+            rc = (rc >> 2) | ((uint64_t)cr << rc_shift);
           }
         }
-        fw[n] = f;
-        rc[n] = r;
-        // ---- stream of the CHUNK hash steps, bases i0+K-1 .. ----
-        bs[n].open(base + i0 + Km1);
-        const uint4 v = bs[n].next16();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) en[n][j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
       }
-      // Per 16-byte group the 16 table look-ups of a stream are issued together and
-      // one group ahead of their use (LDS answers in order, so they return before
-      // the ds_min traffic of the group in between).
+      // ---- CHUNK hash steps, bases i0+K-1 .. ----
+      // Per 16-byte group the 16 table look-ups are issued together and one group
+      // ahead of their use (LDS answers in order, so they return before the LDS
+      // traffic of the group in between).
+      ByteStream bs;
+      bs.open(base + i0 + Km1);
+      uint32_t en[16];
+      {
+        const uint4 v = bs.next16();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) en[j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
+      }
+      const uint32_t cnt_wave = FILTER ? CHUNK : cnt;  // filtered: all lanes run all groups
       for (int g = 0; g < GROUPS; ++g) {
-        if ((uint32_t)(g * 16) >= cnt_max) break;
-        uint32_t e[NS][16];
-        bool full = true;
+        if ((uint32_t)(g * 16) >= cnt_wave) break;
+        uint32_t e[16];
 #pragma unroll
-        for (int n = 0; n < NS; ++n) {
+        for (int j = 0; j < 16; ++j) e[j] = en[j];
+        if (g + 1 < GROUPS) {
+          const uint4 v = bs.next16();
 #pragma unroll
-          for (int j = 0; j < 16; ++j) e[n][j] = en[n][j];
-          if (g + 1 < GROUPS) {
-            const uint4 v = bs[n].next16();
-#pragma unroll
-            for (int j = 0; j < 16; ++j) en[n][j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
-          }
-          full = full && cnt[n] >= (uint32_t)(g * 16 + 16);
+          for (int j = 0; j < 16; ++j) en[j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
         }
-        if (full) {
+        auto filtered = [&](uint64_t canon, uint32_t hh) {
+          const uint64_t bal = __ballot(hh < thr);
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          if (hh < thr) ring[(q_tail + rank) & (kRing - 1)] = canon;
+          const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)__popcll(bal));
+          q_tail = (q_tail + n) & (kRing - 1);
+          q_count += n;
+          if (q_count >= 64) drain64(false);
+        };
+        if (FILTER && __all(cnt == CHUNK)) {
+          // every lane of the wave has a full chunk: no per-step liveness at all
 #pragma unroll
-          for (int j = 0; j < 16; ++j)
-#pragma unroll
-            for (int n = 0; n < NS; ++n) hash_step<KFIX, false>(e[n][j], fw[n], rc[n], d, rc_shift, sk, true);
+          for (int j = 0; j < 16; ++j) {
+            const uint64_t canon = roll_step<KFIX>(e[j], fw, rc, d, rc_shift);
+            filtered(canon, rev64_hi(canon));
+          }
         } else {
 #pragma unroll
-          for (int j = 0; j < 16; ++j)
-#pragma unroll
-            for (int n = 0; n < NS; ++n)
-              hash_step<KFIX, true>(e[n][j], fw[n], rc[n], d, rc_shift, sk, (uint32_t)(g * 16 + j) < cnt[n]);
+          for (int j = 0; j < 16; ++j) {
+            const uint64_t canon = roll_step<KFIX>(e[j], fw, rc, d, rc_shift);
+            const bool live = (uint32_t)(g * 16 + j) < cnt;
+            if (!FILTER) {
+              sketch_update(canon, d, sk, live);
+            } else {
+              // dead steps get an all-ones hash word and never pass
+              filtered(canon, live ? rev64_hi(canon) : 0xFFFFFFFFu);
+            }
+          }
         }
       }
+    }
+  }
+  if (FILTER && q_count) drain64(true);
+}
+
+// GROUPS 16-byte groups of hash steps per chunk: CHUNK = 16*GROUPS k-mers.
+template <int BLOCK, int GROUPS, int KFIX>
+__global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  const Derived &d = a.d;
+  uint32_t *sk = smem;                              // F cells
+  uint32_t *s_flag = smem + d.F;                    // 4 words
+  uint8_t *lut = (uint8_t *)(smem + d.F + 4);       // 256 bytes
+  uint32_t *aux = smem + d.F + 4 + 64;              // distinct-value tables or the filter rings
+  const uint32_t tid = threadIdx.x;
+  const uint32_t entry = blockIdx.x / a.splits;
+  const uint32_t part = blockIdx.x % a.splits;
+
+  if (tid < 256) lut[tid] = code_entry(tid);
+  if (a.accumulate) {
+    const uint32_t *src = (const uint32_t *)a.sketches + (uint64_t)entry * d.F;
+    for (uint32_t i = tid; i < d.F; i += BLOCK) sk[i] = src[i];
+  } else {
+    for (uint32_t i = tid; i < d.F; i += BLOCK) sk[i] = kEmpty32;
+  }
+  __syncthreads();
+
+  if (a.seqs != nullptr) {  // nullptr = densify-only launch
+    // Filter strength from the k-mers per slot: expected undecided slots
+    // F*(1-2^-T)^(n/F) must be negligible (a miss only costs the exact re-run below).
+    uint32_t thr = 0;
+    if (a.filter) {
+      uint64_t n = 0;
+      const uint32_t r0 = a.entry_rec ? a.entry_rec[entry] : entry;
+      const uint32_t r1 = a.entry_rec ? a.entry_rec[entry + 1] : entry + 1;
+      for (uint32_t rec = r0; rec < r1; ++rec) {
+        const uint64_t len = a.rec_off[rec + 1] - a.rec_off[rec];
+        if (len > d.K) n += len - d.K;
+      }
+      // every part of a split record must be exact on its own share
+      const uint64_t per_slot = (n / a.splits) >> d.S;
+      uint32_t T = per_slot >= 240 ? 4u : per_slot >= 115 ? 3u : per_slot >= 55 ? 2u : 0u;
+      if (a.filter >= 2) T = a.filter - 1;  // forced strength (tests)
+      // the ordering argument needs a non-saturated HyperLogLog part: 2^H - 1 >= T
+      if (T > d.max_rem || T > 16) T = 0;
+      thr = T ? (1u << (32 - T)) : 0u;
+    }
+    if (thr) {
+      roll_records<BLOCK, GROUPS, KFIX, true>(a, entry, part, sk, lut, (uint64_t *)aux, thr);
+      __syncthreads();
+      uint32_t local = 0;
+      for (uint32_t i = tid; i < d.F; i += BLOCK) local += (sk[i] == kEmpty32);
+      if (tid == 0) s_flag[2] = 0;
+      __syncthreads();
+      if (local) atomicAdd(&s_flag[2], local);
+      __syncthreads();
+      // a slot without a candidate may still have skipped k-mers: exact re-run.
+      // (With splits > 1 another part may hold the candidates, so every part re-runs.)
+      if (s_flag[2] != 0) roll_records<BLOCK, GROUPS, KFIX, false>(a, entry, part, sk, lut, nullptr, 0);
+    } else {
+      roll_records<BLOCK, GROUPS, KFIX, false>(a, entry, part, sk, lut, nullptr, 0);
     }
   }
   __syncthreads();
@@ -347,15 +430,15 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
     return;
   }
   if (a.densify) {
-    if (a.distinct) densify_lds_distinct<BLOCK>(sk, d, s_flag, smem + d.F + 4 + 64);
+    if (a.distinct) densify_lds_distinct<BLOCK>(sk, d, s_flag, aux);
     else densify_lds<BLOCK>(sk, d, s_flag);
   }
   __syncthreads();
   for (uint32_t i = tid; i < d.F; i += BLOCK) out[i] = sk[i];
 }
 
-static size_t sketch_lds_bytes(const Derived &d, bool distinct) {
-  return (size_t)d.F * 4 + 16 + 256 + (distinct ? (size_t)d.R * 12 : 0);
+static size_t sketch_lds_bytes(const Derived &d, bool distinct, uint32_t ring_waves) {
+  return (size_t)d.F * 4 + 16 + 256 + (distinct ? (size_t)d.R * 12 : 0) + (size_t)ring_waves * kRing * 8;
 }
 
 hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, bool short_records,
@@ -363,23 +446,26 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, bool short_re
   if (n_entry == 0) return hipSuccess;
   SketchArgs a = a_in;
   // distinct-value densification where its tables leave room for >= 2 workgroups per CU
-  a.distinct = (short_records && sketch_lds_bytes(a.d, true) <= 64 * 1024) ? 1u : 0u;
-  size_t lds = sketch_lds_bytes(a.d, a.distinct != 0);
+  a.distinct = (short_records && sketch_lds_bytes(a.d, true, 0) <= 64 * 1024) ? 1u : 0u;
+  // candidate filter: long records only (the kernel picks its strength per sketch);
+  // NIQKI_SKETCH_FILTER=0 switches it off
+  // NIQKI_SKETCH_FILTER: 0 = off, unset/1 = automatic, n >= 2 = force n-1 leading zeros (tests)
+  const char *fv = std::getenv("NIQKI_SKETCH_FILTER");
+  const uint32_t fmode = fv ? (uint32_t)std::atoi(fv) : 1u;
+  a.filter = (!short_records && a.seqs != nullptr) ? fmode : 0u;
+  const size_t lds = sketch_lds_bytes(a.d, a.distinct != 0, a.filter ? (short_records ? 4 : 16) : 0);
   dim3 grid(n_entry * a.splits);
-#define NQ_LAUNCH_SKETCH(B, G, KF, NS)                                                           \
+#define NQ_LAUNCH_SKETCH(B, G, KF)                                                               \
   do {                                                                                           \
-    auto k = sketch_kernel<B, G, KF, NS>;                                                            \
+    auto k = sketch_kernel<B, G, KF>;                                                            \
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                               \
     hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, a);                                        \
   } while (0)
-  static const int streams = [] { const char *v = std::getenv("NIQKI_SKETCH_STREAMS"); return v ? std::atoi(v) : 1; }();
   if (short_records) {
-    if (a.d.K == 31) NQ_LAUNCH_SKETCH(256, 1, 31, 1); else NQ_LAUNCH_SKETCH(256, 1, 0, 1);
-  } else if (streams == 2) {
-    if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 8, 31, 2); else NQ_LAUNCH_SKETCH(1024, 8, 0, 2);
+    if (a.d.K == 31) NQ_LAUNCH_SKETCH(256, 1, 31); else NQ_LAUNCH_SKETCH(256, 1, 0);
   } else {
-    if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 8, 31, 1); else NQ_LAUNCH_SKETCH(1024, 8, 0, 1);
+    if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 8, 31); else NQ_LAUNCH_SKETCH(1024, 8, 0);
   }
 #undef NQ_LAUNCH_SKETCH
   return hipGetLastError();

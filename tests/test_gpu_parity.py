@@ -315,3 +315,28 @@ def test_full_size_properties_north_star(native):
     assert np.array_equal(e2.query_counts(skh).astype(np.int64), cnt[:, ::-1])
     e2.close()
     e.close()
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "3", "7"])
+def test_candidate_filter_is_exact(native, po, mode, monkeypatch):
+    """Long-input sketch path: candidate filter off / automatic / forced to 2 and 6
+    leading zeros.  A strong filter leaves slots without candidates and must fall
+    back to the exact pass; the result never changes."""
+    monkeypatch.setenv("NIQKI_SKETCH_FILTER", mode)
+    p = po.make_params(31, 10, 12, 4, 0.0)
+    e = native.Engine(K=31, S=10, W=12, H=4)
+    g = [native.synth_genome_host(11, 3, k, 150 * k, L) for k, L in ((0, 400_000), (1, 70_000), (2, 20_000))]
+    g[1] = g[1].copy()
+    g[1][5000:5100] = ord("N")
+    sk = e.sketch(g)
+    for i in range(3):
+        assert np.array_equal(sk[i], po.compute_sketch(p, g[i])), (mode, i)
+    # whole-file mode (several records per sketch) and a split long record
+    sk2 = e.sketch([g[0][:200_000], g[0][200_000:], g[2]], entry_rec=np.array([0, 2, 3], np.uint32))
+    acc = np.full(1024, -1, np.int32)
+    po.sketch_accumulate(p, g[0][:200_000], acc)
+    po.sketch_accumulate(p, g[0][200_000:], acc)
+    assert np.array_equal(sk2[0], po.densify(p, acc)[0])
+    big = native.synth_genome_host(11, 9, 0, 0, 2_500_000)
+    assert np.array_equal(e.sketch([big])[0], po.compute_sketch(p, big))
+    e.close()
