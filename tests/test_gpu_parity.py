@@ -340,3 +340,52 @@ def test_candidate_filter_is_exact(native, po, mode, monkeypatch):
     big = native.synth_genome_host(11, 9, 0, 0, 2_500_000)
     assert np.array_equal(e.sketch([big])[0], po.compute_sketch(p, big))
     e.close()
+
+
+def test_config2_index_and_self_query_1k_genomes(native):
+    """BASELINE configs[1]: 1k synthetic 5 Mbp genomes, index + self query,
+    K=31 S=15 W=12 -- too big for the oracle, checked through properties:
+    every genome finds itself with count F on top, hits are ordered by
+    (count, gid) descending, members of other families never reach J=0.1, and
+    the dense counters are symmetric."""
+    import torch
+    N, L, F = 1000, 5_000_000, 1 << 15
+    e = native.Engine(K=31, S=15, W=12, H=4, J=0.1)
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    e.set_option("record_len_hint", L)
+    dev = torch.device("cuda")
+    t = lambda a: torch.from_numpy(a.astype(np.int64)).to(torch.int32).to(dev)  # noqa: E731
+    g = np.arange(N)
+    fam, mem = g // 10, g % 10
+    rate = np.where(mem == 0, 0, 30 * mem)
+    GB = 250
+    seq = torch.zeros(GB * L + native.SEQ_PAD, dtype=torch.uint8, device=dev)
+    sk = torch.empty((N, F), dtype=torch.int32, device=dev)
+    ro = torch.from_numpy(np.arange(GB + 1, dtype=np.int64) * L).to(dev)
+    for b in range(0, N, GB):
+        e.synth_dev(5, t(fam[b:b + GB]), t(mem[b:b + GB]), t(rate[b:b + GB]), GB, L, L, seq)
+        e.sketch_dev(seq, ro, GB, sk[b:b + GB])
+    e.insert_dev(sk, N)
+    cap = N * 64
+    hit_off = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+    hc = torch.zeros(cap, dtype=torch.int32, device=dev)
+    hg = torch.zeros(cap, dtype=torch.int32, device=dev)
+    e.query_dev(sk, N, hit_off, hc, hg, cap)
+    e.synchronize()
+    off = hit_off.cpu().numpy()
+    c, gd = hc.cpu().numpy(), hg.cpu().numpy()
+    assert int(off[N]) <= cap
+    assert int((sk == -1).sum().item()) == 0
+    for q in range(N):
+        lo, hi = int(off[q]), int(off[q + 1])
+        assert hi > lo and c[lo] == F and gd[lo] == q, q
+        keys = c[lo:hi].astype(np.int64) * (1 << 32) + gd[lo:hi]
+        assert (np.diff(keys) < 0).all(), q
+        assert (c[lo:hi] >= 3276).all() and (gd[lo:hi] // 10 == q // 10).all(), q
+    stride = N
+    cnt = torch.zeros((64, stride), dtype=torch.int16, device=dev)
+    e.query_counts_dev(sk[:64], 64, cnt, stride)
+    e.synchronize()
+    m = cnt.cpu().numpy().view(np.uint16)[:, :64]
+    assert np.array_equal(m, m.T) and (np.diag(m) == F).all()
+    e.close()
