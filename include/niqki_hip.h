@@ -194,6 +194,21 @@ int niqki_export_dump(niqki_index *ix, uint8_t *buf, uint64_t capacity,
 int niqki_import_dump(const niqki_params *params, const uint8_t *buf,
                       uint64_t len, uint64_t *consumed, niqki_index **out);
 
+/* Streaming forms of the two calls above, for dumps that should not sit in one
+ * buffer (13.6 GB at 100k genomes): the 24-byte header, the byte position of
+ * every slot's first bucket in the payload (2^S + 1 entries, header excluded),
+ * and the payload of a range of whole slots. */
+int niqki_export_dump_header(niqki_index *ix, uint8_t header[24]);
+int niqki_export_dump_layout(niqki_index *ix, uint64_t *slot_bytes);
+int niqki_export_dump_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end,
+                            uint8_t *buf, uint64_t capacity, uint64_t *size);
+/* niqki_import_begin creates the handle from the header; niqki_import_slots takes
+ * the payload of whole slots [slot_begin, slot_end) in order (*consumed = bytes
+ * used); after the last slot the handle is a normal index (built on first use). */
+int niqki_import_begin(const niqki_params *params, const uint8_t header[24], niqki_index **out);
+int niqki_import_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end,
+                       const uint8_t *buf, uint64_t len, uint64_t *consumed);
+
 /* Reads back the stored sketches of genomes [begin, begin+n) as n x F int32
  * (slots outside the shard's range read -1). */
 int niqki_get_sketches(niqki_index *ix, uint32_t begin, uint32_t n,

@@ -71,6 +71,11 @@ ABI = [
     ("niqki_matrix_range", _int, [_vp, _u32, _u32, _vp, _u64, _int]),
     ("niqki_export_dump", _int, [_vp, _vp, _u64, C.POINTER(_u64)]),
     ("niqki_import_dump", _int, [C.POINTER(Params), _vp, _u64, C.POINTER(_u64), C.POINTER(_vp)]),
+    ("niqki_export_dump_header", _int, [_vp, _vp]),
+    ("niqki_export_dump_layout", _int, [_vp, _vp]),
+    ("niqki_export_dump_slots", _int, [_vp, _u32, _u32, _vp, _u64, C.POINTER(_u64)]),
+    ("niqki_import_begin", _int, [C.POINTER(Params), _vp, C.POINTER(_vp)]),
+    ("niqki_import_slots", _int, [_vp, _u32, _u32, _vp, _u64, C.POINTER(_u64)]),
     ("niqki_get_sketches", _int, [_vp, _u32, _u32, _vp, _int]),
     ("niqki_query_gathered", _int, [_vp, _vp, _u32, _vp, _int]),
     ("niqki_profile_enable", _int, [_vp, _int]),

@@ -750,93 +750,194 @@ int niqki_matrix_range(niqki_index *ix, uint32_t begin, uint32_t end, uint16_t *
   return NIQKI_OK;
 }
 
+// ---- dump / load ---------------------------------------------------------------
+
+namespace {
+
+// slot_word (F+1 word positions, header excluded) computed on the device, copied to the host
+int export_layout(niqki_index *ix, std::vector<uint64_t> &slot_word) {
+  int rc = build_if_needed(ix);
+  if (rc) return rc;
+  nq::IndexView v = view(ix);
+  slot_word.assign((size_t)v.f_local + 1, 0);
+  if (v.n_tiles == 0) {  // empty index: one size word per bucket
+    for (uint32_t s = 0; s <= v.f_local; ++s) slot_word[s] = (uint64_t)s * v.d.R;
+    return NIQKI_OK;
+  }
+  if ((rc = ensure(ix, ix->ws_misc, (size_t)(v.f_local + 1) * 8))) return rc;
+  NQ_HIP(ix, nq::launch_export_layout(v, (unsigned long long *)ix->ws_misc.p, ix->stream));
+  NQ_HIP(ix, hipMemcpyAsync(slot_word.data(), ix->ws_misc.p, (size_t)(v.f_local + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  return NIQKI_OK;
+}
+
+// payload of slots [s0, s1) to host memory; slot_word device copy is in ws_misc (export_layout ran)
+int export_slots(niqki_index *ix, const std::vector<uint64_t> &slot_word, uint32_t s0, uint32_t s1, uint8_t *dst) {
+  nq::IndexView v = view(ix);
+  const uint64_t words = slot_word[s1] - slot_word[s0];
+  if (words == 0) return NIQKI_OK;
+  if (v.n_tiles == 0) { std::memset(dst, 0, words * 4); return NIQKI_OK; }
+  int rc = ensure(ix, ix->ws_counts, words * 4);
+  if (rc) return rc;
+  NQ_HIP(ix, nq::launch_export(v, (const unsigned long long *)ix->ws_misc.p, (uint32_t *)ix->ws_counts.p, s0, s1, ix->stream));
+  NQ_HIP(ix, hipMemcpyAsync(dst, ix->ws_counts.p, words * 4, hipMemcpyDeviceToHost, ix->stream));
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  return NIQKI_OK;
+}
+
+}  // namespace
+
+int niqki_export_dump_header(niqki_index *ix, uint8_t header[24]) {
+  if (!ix || !header) return NIQKI_E_INVALID;
+  uint32_t hdr[6] = {ix->d.S, ix->d.K, ix->d.H, ix->d.W, ix->d.min_score, ix->n_genomes};
+  std::memcpy(header, hdr, 24);
+  return NIQKI_OK;
+}
+
+int niqki_export_dump_layout(niqki_index *ix, uint64_t *slot_bytes) {
+  if (!ix || !slot_bytes) return NIQKI_E_INVALID;
+  if (ix->d.slot_begin != 0 || ix->d.slot_end != ix->d.F) return fail(ix, NIQKI_E_STATE, "export needs a whole-range handle");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  std::vector<uint64_t> sw;
+  int rc = export_layout(ix, sw);
+  if (rc) return rc;
+  for (size_t i = 0; i < sw.size(); ++i) slot_bytes[i] = sw[i] * 4;
+  return NIQKI_OK;
+}
+
+int niqki_export_dump_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end, uint8_t *buf,
+                            uint64_t capacity, uint64_t *size) {
+  if (!ix || !size || slot_begin > slot_end || slot_end > ix->d.F) return NIQKI_E_INVALID;
+  if (ix->d.slot_begin != 0 || ix->d.slot_end != ix->d.F) return fail(ix, NIQKI_E_STATE, "export needs a whole-range handle");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  std::vector<uint64_t> sw;
+  int rc = export_layout(ix, sw);
+  if (rc) return rc;
+  *size = (sw[slot_end] - sw[slot_begin]) * 4;
+  if (!buf) return NIQKI_OK;
+  if (capacity < *size) return NIQKI_E_CAPACITY;
+  return export_slots(ix, sw, slot_begin, slot_end, buf);
+}
+
 int niqki_export_dump(niqki_index *ix, uint8_t *buf, uint64_t capacity, uint64_t *size) {
   if (!ix || !size) return NIQKI_E_INVALID;
   if (ix->d.slot_begin != 0 || ix->d.slot_end != ix->d.F) return fail(ix, NIQKI_E_STATE, "export needs a whole-range handle");
   NQ_HIP(ix, hipSetDevice(ix->device));
-  int rc = build_if_needed(ix);
+  std::vector<uint64_t> sw;
+  int rc = export_layout(ix, sw);
   if (rc) return rc;
-  nq::IndexView v = view(ix);
-  const uint64_t n_buckets = (uint64_t)v.f_local * v.d.R;
-  if ((rc = ensure(ix, ix->ws_misc, (size_t)(v.f_local + 1) * 8))) return rc;
-  unsigned long long *slot_word = (unsigned long long *)ix->ws_misc.p;
-  uint64_t total_words = n_buckets;  // empty index: one size word per bucket
-  Buf out;
-  auto cleanup = [&]() { if (out.p) (void)hipFree(out.p); };
-  hipError_t e = hipSuccess;
-  if (v.n_tiles) {
-    NQ_HIP(ix, nq::launch_export(v, slot_word, nullptr, ix->stream));
-    NQ_HIP(ix, hipMemcpyAsync(&total_words, slot_word + v.f_local, 8, hipMemcpyDeviceToHost, ix->stream));
-    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
-  }
-  const uint64_t exact_entries = total_words - n_buckets;
-  const uint64_t total = 24 + (n_buckets + exact_entries) * 4;
-  *size = total;
+  const uint32_t F = ix->d.F;
+  *size = 24 + sw[F] * 4;
   if (!buf) return NIQKI_OK;
-  if (capacity < total) return NIQKI_E_CAPACITY;
-  uint32_t hdr[6] = {ix->d.S, ix->d.K, ix->d.H, ix->d.W, ix->d.min_score, v.n_genomes};
-  std::memcpy(buf, hdr, 24);
-  if (hipMalloc(&out.p, std::max<uint64_t>(total_words * 4, 4)) != hipSuccess)
-    return fail(ix, NIQKI_E_NOMEM, "export buffer allocation failed");
-  if (v.n_tiles) e = nq::launch_export(v, slot_word, (uint32_t *)out.p, ix->stream);
-  else e = hipMemsetAsync(out.p, 0, total_words * 4, ix->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(buf + 24, out.p, total - 24, hipMemcpyDeviceToHost, ix->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
-  cleanup();
-  if (e != hipSuccess) return fail(ix, NIQKI_E_HIP, hipGetErrorString(e));
+  if (capacity < *size) return NIQKI_E_CAPACITY;
+  niqki_export_dump_header(ix, buf);
+  // chunks of whole slots, at most ~256 MiB of device staging each
+  uint32_t s0 = 0;
+  while (s0 < F) {
+    uint32_t s1 = s0 + 1;
+    while (s1 < F && (sw[s1 + 1] - sw[s0]) * 4 <= (256ull << 20)) ++s1;
+    if ((rc = export_slots(ix, sw, s0, s1, buf + 24 + sw[s0] * 4))) return rc;
+    s0 = s1;
+  }
+  return NIQKI_OK;
+}
+
+int niqki_import_begin(const niqki_params *params, const uint8_t header[24], niqki_index **out) {
+  if (!params || !header || !out) return NIQKI_E_INVALID;
+  uint32_t hdr[6];
+  std::memcpy(hdr, header, 24);
+  niqki_params p = *params;
+  p.S = hdr[0]; p.K = hdr[1]; p.H = hdr[2]; p.W = hdr[3]; p.min_score = hdr[4];
+  p.slot_begin = p.slot_end = 0;
+  niqki_index *ix = nullptr;
+  int rc = niqki_create(&p, &ix);
+  if (rc) return rc;
+  const uint32_t N = hdr[5];
+  rc = reserve_store(ix, std::max<uint32_t>(N, 1));
+  hipError_t e = hipSuccess;
+  if (!rc) e = hipMemsetAsync(ix->store, 0xFF, (size_t)ix->d.F * ix->cap * 2, ix->stream);
+  if (rc || e != hipSuccess) {
+    g_create_err = rc ? ix->err : std::string(hipGetErrorString(e));
+    niqki_destroy(ix);
+    return rc ? rc : NIQKI_E_HIP;
+  }
+  ix->n_genomes = N;  // ids are validated against this while the slots arrive
+  ix->built = false;
+  *out = ix;
+  return NIQKI_OK;
+}
+
+int niqki_import_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end, const uint8_t *buf, uint64_t len,
+                       uint64_t *consumed) {
+  if (!ix || !buf || slot_begin > slot_end || slot_end > ix->d.F) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  const uint32_t n_slots = slot_end - slot_begin;
+  const uint64_t R = ix->d.R, n_words = len / 4;
+  // sequential walk of the bucket sizes (they chain), recording where each slot starts
+  std::vector<uint64_t> slot_word((size_t)n_slots + 1);
+  uint64_t w = 0;
+  for (uint32_t i = 0; i < n_slots; ++i) {
+    slot_word[i] = w;
+    for (uint64_t fp = 0; fp < R; ++fp) {
+      if (w >= n_words) return fail(ix, NIQKI_E_INVALID, "dump payload ends inside a slot");
+      uint32_t sz;
+      std::memcpy(&sz, buf + w * 4, 4);
+      w += 1 + (uint64_t)sz;
+    }
+  }
+  if (w > n_words) return fail(ix, NIQKI_E_INVALID, "dump payload ends inside a bucket");
+  slot_word[n_slots] = w;
+  if (consumed) *consumed = w * 4;
+  if (n_slots == 0) return NIQKI_OK;
+  int rc;
+  if ((rc = ensure(ix, ix->ws_counts, std::max<uint64_t>(w * 4, 4)))) return rc;
+  if ((rc = ensure(ix, ix->ws_misc, (size_t)(n_slots + 1) * 8 + 8))) return rc;
+  uint8_t *d_slot = (uint8_t *)ix->ws_misc.p;
+  uint32_t *d_bad = (uint32_t *)(d_slot + (size_t)(n_slots + 1) * 8);
+  NQ_HIP(ix, hipMemcpyAsync(ix->ws_counts.p, buf, w * 4, hipMemcpyHostToDevice, ix->stream));
+  NQ_HIP(ix, hipMemcpyAsync(d_slot, slot_word.data(), (size_t)(n_slots + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+  NQ_HIP(ix, hipMemsetAsync(d_bad, 0, 4, ix->stream));
+  NQ_HIP(ix, nq::launch_import(ix->d, (const uint32_t *)ix->ws_counts.p, (const uint64_t *)d_slot, ix->store, ix->cap,
+                               ix->n_genomes, d_bad, slot_begin, n_slots, ix->stream));
+  uint32_t bad = 0;
+  NQ_HIP(ix, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ix->stream));
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  if (bad) return fail(ix, NIQKI_E_INVALID, "dump holds genome ids >= genome count");
   return NIQKI_OK;
 }
 
 int niqki_import_dump(const niqki_params *params, const uint8_t *buf, uint64_t len, uint64_t *consumed,
                       niqki_index **out) {
   if (!params || !buf || !out || len < 24) return NIQKI_E_INVALID;
-  uint32_t hdr[6];
-  std::memcpy(hdr, buf, 24);
-  niqki_params p = *params;
-  p.S = hdr[0]; p.K = hdr[1]; p.H = hdr[2]; p.W = hdr[3]; p.min_score = hdr[4];
-  p.slot_begin = p.slot_end = 0;
-  const uint32_t N = hdr[5];
   niqki_index *ix = nullptr;
-  int rc = niqki_create(&p, &ix);
+  int rc = niqki_import_begin(params, buf, &ix);
   if (rc) return rc;
-  const uint64_t F = ix->d.F, R = ix->d.R;
-  // sequential walk of the bucket sizes (they chain), recording where each slot starts
-  std::vector<uint64_t> slot_word(F + 1);
-  uint64_t w = 0;
-  const uint64_t n_words = (len - 24) / 4;
-  const uint8_t *body = buf + 24;
-  for (uint64_t s = 0; s < F; ++s) {
-    slot_word[s] = w;
-    for (uint64_t fp = 0; fp < R; ++fp) {
-      if (w >= n_words) { niqki_destroy(ix); return NIQKI_E_INVALID; }
-      uint32_t sz;
-      std::memcpy(&sz, body + w * 4, 4);
-      w += 1 + (uint64_t)sz;
+  // groups of whole slots, ~256 MiB of payload each
+  const uint32_t F = ix->d.F;
+  const uint64_t R = ix->d.R;
+  uint64_t pos = 24;
+  uint32_t s0 = 0;
+  while (s0 < F) {
+    // find how many slots fit: walk sizes (cheap; import_slots walks them again for the device)
+    uint64_t p = pos;
+    uint32_t s1 = s0;
+    while (s1 < F && (p - pos) <= (256ull << 20)) {
+      for (uint64_t fp = 0; fp < R; ++fp) {
+        if (p + 4 > len) { g_create_err = "dump payload is truncated"; niqki_destroy(ix); return NIQKI_E_INVALID; }
+        uint32_t sz;
+        std::memcpy(&sz, buf + p, 4);
+        p += 4 + (uint64_t)sz * 4;
+      }
+      ++s1;
     }
+    if (p > len) { g_create_err = "dump payload is truncated"; niqki_destroy(ix); return NIQKI_E_INVALID; }
+    uint64_t used = 0;
+    rc = niqki_import_slots(ix, s0, s1, buf + pos, p - pos, &used);
+    if (rc) { g_create_err = ix->err; niqki_destroy(ix); return rc; }
+    pos += used;
+    s0 = s1;
   }
-  if (w > n_words) { niqki_destroy(ix); return NIQKI_E_INVALID; }
-  slot_word[F] = w;
-  if (consumed) *consumed = 24 + w * 4;
-  rc = reserve_store(ix, std::max<uint32_t>(N, 1));
-  if (rc) { niqki_destroy(ix); return rc; }
-  auto bail = [&](int code, const char *msg) { ix->err = msg; niqki_destroy(ix); return code; };
-  void *d_words = nullptr, *d_slot = nullptr, *d_bad = nullptr;
-  if (hipMalloc(&d_words, std::max<uint64_t>(w * 4, 4)) != hipSuccess) return bail(NIQKI_E_NOMEM, "import alloc");
-  if (hipMalloc(&d_slot, (F + 1) * 8) != hipSuccess) { (void)hipFree(d_words); return bail(NIQKI_E_NOMEM, "import alloc"); }
-  if (hipMalloc(&d_bad, 4) != hipSuccess) { (void)hipFree(d_words); (void)hipFree(d_slot); return bail(NIQKI_E_NOMEM, "import alloc"); }
-  hipError_t e = hipMemcpyAsync(d_words, body, w * 4, hipMemcpyHostToDevice, ix->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_slot, slot_word.data(), (F + 1) * 8, hipMemcpyHostToDevice, ix->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(d_bad, 0, 4, ix->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(ix->store, 0xFF, (size_t)F * ix->cap * 2, ix->stream);
-  if (e == hipSuccess) e = nq::launch_import(ix->d, (const uint32_t *)d_words, (const uint64_t *)d_slot, ix->store, ix->cap, N, (uint32_t *)d_bad, ix->stream);
-  uint32_t bad = 0;
-  if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ix->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
-  (void)hipFree(d_words); (void)hipFree(d_slot); (void)hipFree(d_bad);
-  if (e != hipSuccess) return bail(NIQKI_E_HIP, hipGetErrorString(e));
-  if (bad) return bail(NIQKI_E_INVALID, "dump holds genome ids >= genome count");
-  ix->n_genomes = N;
-  ix->built = false;
+  if (consumed) *consumed = pos;
   *out = ix;
   return NIQKI_OK;
 }

@@ -243,12 +243,14 @@ __global__ void export_slot_scan_kernel(unsigned long long *slot_word, uint32_t 
   for (uint32_t s = 0; s < f_local; ++s) { run += slot_word[s + 1] + R; slot_word[s + 1] = run; }
 }
 
-__global__ __launch_bounds__(256) void export_kernel(IndexView v, const unsigned long long *slot_word, uint32_t *out) {
+// slots [s0, s1) into `out`, whose word 0 is the first word of slot s0
+__global__ __launch_bounds__(256) void export_kernel(IndexView v, const unsigned long long *slot_word, uint32_t *out,
+                                                    uint32_t s0, uint32_t s1) {
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s >= v.f_local) return;
+  const uint32_t s = s0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= s1) return;
   const uint32_t R = v.d.R, a = v.align_log2;
-  unsigned long long running = slot_word[s];
+  unsigned long long running = slot_word[s] - slot_word[s0];
   for (uint32_t c = 0; c < R; c += 64) {
     const uint32_t fp = c + lane;
     uint32_t size = 0;
@@ -273,28 +275,34 @@ __global__ __launch_bounds__(256) void export_kernel(IndexView v, const unsigned
   }
 }
 
-hipError_t launch_export(const IndexView &v, unsigned long long *slot_word, uint32_t *out,
-                         hipStream_t stream) {
+hipError_t launch_export_layout(const IndexView &v, unsigned long long *slot_word, hipStream_t stream) {
   if (v.f_local == 0) return hipSuccess;
   dim3 grid((v.f_local + 3) / 4);
-  if (out == nullptr) {
-    hipLaunchKernelGGL(export_slot_ids_kernel, grid, dim3(256), 0, stream, v, slot_word);
-    hipLaunchKernelGGL(export_slot_scan_kernel, dim3(1), dim3(64), 0, stream, slot_word, v.f_local, v.d.R);
-  } else {
-    hipLaunchKernelGGL(export_kernel, grid, dim3(256), 0, stream, v, slot_word, out);
-  }
+  hipLaunchKernelGGL(export_slot_ids_kernel, grid, dim3(256), 0, stream, v, slot_word);
+  hipLaunchKernelGGL(export_slot_scan_kernel, dim3(1), dim3(64), 0, stream, slot_word, v.f_local, v.d.R);
+  return hipGetLastError();
+}
+
+hipError_t launch_export(const IndexView &v, const unsigned long long *slot_word, uint32_t *out,
+                         uint32_t s0, uint32_t s1, hipStream_t stream) {
+  if (s1 <= s0) return hipSuccess;
+  dim3 grid((s1 - s0 + 3) / 4);
+  hipLaunchKernelGGL(export_kernel, grid, dim3(256), 0, stream, v, slot_word, out, s0, s1);
   return hipGetLastError();
 }
 
 // ---- dump stream import (src/niqki_index.cpp:78-85): one wave per slot ----
+// slots [s0, s0+n_slots): slot_word[i] = word position of slot s0+i inside `words`
 __global__ __launch_bounds__(256) void import_kernel(Derived d, const uint32_t *words,
                                                     const uint64_t *slot_word, uint16_t *store,
-                                                    uint64_t cap, uint32_t n_genomes, uint32_t *bad) {
+                                                    uint64_t cap, uint32_t n_genomes, uint32_t *bad,
+                                                    uint32_t s0, uint32_t n_slots) {
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (s >= d.F) return;
-  uint64_t p = slot_word[s];
-  const uint64_t end = slot_word[s + 1];
+  const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_slots) return;
+  const uint32_t s = s0 + i;
+  uint64_t p = slot_word[i];
+  const uint64_t end = slot_word[i + 1];
   for (uint32_t fp = 0; fp < d.R; ++fp) {
     if (p >= end) { if (lane == 0) atomicAdd(bad, 1u); return; }
     uint32_t size = words[p];
@@ -310,9 +318,10 @@ __global__ __launch_bounds__(256) void import_kernel(Derived d, const uint32_t *
 
 hipError_t launch_import(const Derived &d, const uint32_t *words, const uint64_t *slot_word,
                          uint16_t *store, uint64_t cap, uint32_t n_genomes, uint32_t *bad,
-                         hipStream_t stream) {
-  hipLaunchKernelGGL(import_kernel, dim3((d.F + 3) / 4), dim3(256), 0, stream, d, words, slot_word,
-                     store, cap, n_genomes, bad);
+                         uint32_t s0, uint32_t n_slots, hipStream_t stream) {
+  if (n_slots == 0) return hipSuccess;
+  hipLaunchKernelGGL(import_kernel, dim3((n_slots + 3) / 4), dim3(256), 0, stream, d, words, slot_word,
+                     store, cap, n_genomes, bad, s0, n_slots);
   return hipGetLastError();
 }
 

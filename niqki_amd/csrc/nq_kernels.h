@@ -61,16 +61,18 @@ hipError_t launch_build_sizes(const IndexView &v, uint32_t *slot_units, uint64_t
                               hipStream_t stream);
 // Build, phase 2: entries + gids (gids sized from tile_base[n_tiles]).
 hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids, hipStream_t stream);
-// dump stream (src/niqki_index.cpp:42-55) of a whole-range index into `out`
-// (u32 words, header excluded); bucket_word: F*R+1 scratch (word position of
-// every bucket, filled here).
-hipError_t launch_export(const IndexView &v, unsigned long long *bucket_word, uint32_t *out,
-                         hipStream_t stream);
-// inverse: walk the dump words of each slot and write the sketch store.
-// slot_word: F+1 word positions of each slot's first bucket inside `words`.
+// dump stream (src/niqki_index.cpp:42-55) of a whole-range index.
+// layout: slot_word[s] (F+1 entries) = word position of bucket (s, 0) in the stream
+// (header excluded); export: the words of slots [s0, s1) into `out` (word 0 = first
+// word of slot s0).
+hipError_t launch_export_layout(const IndexView &v, unsigned long long *slot_word, hipStream_t stream);
+hipError_t launch_export(const IndexView &v, const unsigned long long *slot_word, uint32_t *out,
+                         uint32_t s0, uint32_t s1, hipStream_t stream);
+// inverse: walk the dump words of slots [s0, s0+n_slots) and write the sketch
+// store.  slot_word: n_slots+1 word positions of the slots inside `words`.
 hipError_t launch_import(const Derived &d, const uint32_t *words, const uint64_t *slot_word,
                          uint16_t *store, uint64_t cap, uint32_t n_genomes, uint32_t *bad,
-                         hipStream_t stream);
+                         uint32_t s0, uint32_t n_slots, hipStream_t stream);
 
 // ---- query (nq_query.hip) ----------------------------------------------------
 // gather-histogram: counts[q*stride + g] for all genomes (u16), one workgroup

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace nqhost {
@@ -115,6 +116,71 @@ class GzWriter {
 
  private:
   gzFile f_ = nullptr;
+};
+
+// Gzip writer that compresses blocks in parallel: every block becomes its own
+// gzip member (level 1, like the reference's writer), members are written in
+// submission order.  Concatenated members are one valid gzip file; the
+// reference's reader (zstr::istreambuf, src/zstr.hpp:236-239) restarts its
+// inflater at every member end, so it reads these files unchanged.
+class ParallelGzWriter {
+ public:
+  ParallelGzWriter(const std::string &path, unsigned threads) : threads_(threads ? threads : 1) {
+    f_ = fopen(path.c_str(), "wb");
+    if (!f_) throw std::runtime_error("cannot open '" + path + "' for writing");
+  }
+  ~ParallelGzWriter() { if (f_) fclose(f_); }
+  void add(std::vector<uint8_t> &&block) {
+    if (block.empty()) return;
+    pending_.push_back(std::move(block));
+    if (pending_.size() >= threads_) flush();
+  }
+  void finish() {
+    flush();
+    if (f_) { fclose(f_); f_ = nullptr; }
+  }
+
+ private:
+  static void deflate_member(const std::vector<uint8_t> &in, std::vector<uint8_t> &out) {
+    z_stream z{};
+    if (deflateInit2(&z, 1, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) throw std::runtime_error("deflateInit2 failed");
+    out.resize(deflateBound(&z, (uLong)in.size()) + 64);
+    size_t ipos = 0, opos = 0;
+    int ret = Z_OK;
+    while (ret != Z_STREAM_END) {  // avail_in/out are 32-bit: feed in slices
+      const size_t ichunk = std::min<size_t>(in.size() - ipos, 1u << 30);
+      z.next_in = const_cast<Bytef *>(in.data() + ipos);
+      z.avail_in = (uInt)ichunk;
+      const size_t ochunk = std::min<size_t>(out.size() - opos, 1u << 30);
+      z.next_out = out.data() + opos;
+      z.avail_out = (uInt)ochunk;
+      ret = deflate(&z, ipos + ichunk == in.size() ? Z_FINISH : Z_NO_FLUSH);
+      if (ret != Z_OK && ret != Z_STREAM_END && ret != Z_BUF_ERROR) { deflateEnd(&z); throw std::runtime_error("deflate failed"); }
+      ipos += ichunk - z.avail_in;
+      opos += ochunk - z.avail_out;
+    }
+    deflateEnd(&z);
+    out.resize(opos);
+  }
+  void flush() {
+    if (pending_.empty()) return;
+    std::vector<std::vector<uint8_t>> outs(pending_.size());
+    std::vector<std::thread> pool;
+    std::vector<std::string> errs(pending_.size());
+    for (size_t i = 0; i < pending_.size(); ++i)
+      pool.emplace_back([&, i] {
+        try { deflate_member(pending_[i], outs[i]); } catch (const std::exception &e) { errs[i] = e.what(); }
+      });
+    for (auto &t : pool) t.join();
+    for (size_t i = 0; i < outs.size(); ++i) {
+      if (!errs[i].empty()) throw std::runtime_error(errs[i]);
+      if (fwrite(outs[i].data(), 1, outs[i].size(), f_) != outs[i].size()) throw std::runtime_error("write failed");
+    }
+    pending_.clear();
+  }
+  FILE *f_ = nullptr;
+  unsigned threads_;
+  std::vector<std::vector<uint8_t>> pending_;
 };
 
 }  // namespace nqhost

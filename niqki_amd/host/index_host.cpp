@@ -11,6 +11,7 @@
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
+#include <thread>
 
 #include "seqio.h"
 
@@ -75,27 +76,46 @@ Index::Index(uint32_t ilF, uint32_t iK, uint32_t iW, uint32_t iH, const std::str
 
 Index::Index(const std::string &dump_file, bool pretty, const std::string &out_filename, int device) {
   pretty_printing = pretty;
-  std::vector<uint8_t> raw;
-  {
-    GzReader in(dump_file);
-    in.read_all(raw);
-  }
+  // The dump is streamed: header, then the buckets in groups of whole slots (the
+  // payload of a 100k-genome index is 13.6 GB), then the names.
+  GzReader in(dump_file);
+  uint8_t hdr[24];
+  if (in.read(hdr, 24) != 24) throw std::runtime_error("'" + dump_file + "' is not a niqki dump");
   niqki_params p{};
   p.device = device;
-  uint64_t consumed = 0;
-  int rc = niqki_import_dump(&p, raw.data(), raw.size(), &consumed, &h_);
-  if (rc) throw std::runtime_error(std::string("niqki_import_dump: ") + niqki_status_string(rc) + " (" + niqki_last_error(nullptr) + ")");
+  int rc = niqki_import_begin(&p, hdr, &h_);
+  if (rc) throw std::runtime_error(std::string("niqki_import_begin: ") + niqki_status_string(rc) + " (" + niqki_last_error(nullptr) + ")");
   niqki_params q{};
   niqki_get_params(h_, &q);
   K = q.K; W = q.W; H = q.H; lF = q.S; F = 1u << q.S; min_score = q.min_score;
+  const uint32_t R = 1u << W;
+  std::vector<uint8_t> chunk;
+  uint32_t s0 = 0;
+  auto flush = [&](uint32_t s1) {
+    uint64_t used = 0;
+    check(niqki_import_slots(h_, s0, s1, chunk.data(), chunk.size(), &used), "niqki_import_slots");
+    chunk.clear();
+    s0 = s1;
+  };
+  for (uint32_t s = 0; s < F; ++s) {
+    for (uint32_t fp = 0; fp < R; ++fp) {
+      uint32_t size = 0;
+      if (in.read(&size, 4) != 4) throw std::runtime_error("'" + dump_file + "' is truncated");
+      const size_t at = chunk.size();
+      chunk.resize(at + 4 + (size_t)size * 4);
+      std::memcpy(chunk.data() + at, &size, 4);
+      if (size && in.read(chunk.data() + at + 4, (size_t)size * 4) != (size_t)size * 4)
+        throw std::runtime_error("'" + dump_file + "' is truncated");
+    }
+    if (chunk.size() >= kBatchBytes / 8) flush(s + 1);
+  }
+  flush(F);
   // genome names, one per line after the buckets (src/niqki_index.cpp:91-95)
   const uint32_t n = niqki_genome_count(h_);
-  size_t pos = consumed;
+  std::string name;
   for (uint32_t i = 0; i < n; ++i) {
-    size_t e = pos;
-    while (e < raw.size() && raw[e] != '\n') ++e;
-    filenames.emplace_back((const char *)raw.data() + pos, e - pos);
-    pos = e < raw.size() ? e + 1 : e;
+    in.getline(name);
+    filenames.push_back(name);
   }
   outfile.reset(new GzWriter(out_filename));
 }
@@ -302,14 +322,35 @@ void Index::query_matrix() {
 // ---- dump ------------------------------------------------------------------------
 
 void Index::dump_index_disk(const std::string &filestr) {
-  uint64_t size = 0;
-  check(niqki_export_dump(h_, nullptr, 0, &size), "niqki_export_dump");
-  std::vector<uint8_t> buf(size);
-  check(niqki_export_dump(h_, buf.data(), buf.size(), &size), "niqki_export_dump");
-  GzWriter out(filestr);
-  out.write(buf.data(), size);
-  for (const auto &nm : filenames) out.write(nm + "\n");  // :56-58
-  out.close();
+  // header + buckets (src/niqki_index.cpp:42-55) exported in groups of whole slots
+  // and gzipped in parallel, then the names (:56-58)
+  unsigned threads = std::thread::hardware_concurrency();
+  threads = threads ? std::min(threads, 32u) : 4u;
+  ParallelGzWriter out(filestr, threads);
+  std::vector<uint8_t> block(24);
+  check(niqki_export_dump_header(h_, block.data()), "niqki_export_dump_header");
+  std::vector<uint64_t> slot_bytes((size_t)F + 1);
+  check(niqki_export_dump_layout(h_, slot_bytes.data()), "niqki_export_dump_layout");
+  const uint64_t target = uint64_t(32) << 20;
+  uint32_t s0 = 0;
+  while (s0 < F) {
+    uint32_t s1 = s0 + 1;
+    while (s1 < F && slot_bytes[s1 + 1] - slot_bytes[s0] <= target) ++s1;
+    const size_t at = block.size();
+    const uint64_t want = slot_bytes[s1] - slot_bytes[s0];
+    block.resize(at + want);
+    uint64_t size = 0;
+    check(niqki_export_dump_slots(h_, s0, s1, block.data() + at, want, &size), "niqki_export_dump_slots");
+    out.add(std::move(block));
+    block.clear();
+    s0 = s1;
+  }
+  for (const auto &nm : filenames) {
+    block.insert(block.end(), nm.begin(), nm.end());
+    block.push_back('\n');
+  }
+  out.add(std::move(block));
+  out.finish();
 }
 
 }  // namespace nqhost

@@ -100,3 +100,19 @@ def test_bad_usage(workdir):
     assert r.returncode == 1 and "Bad usage!!!" in r.stdout
     r = subprocess.run([BIN, "-K", "x"], cwd=workdir, capture_output=True, text=True)
     assert r.returncode == 1 and "requires a numeric argument" in r.stderr
+
+
+def test_reference_binary_loads_our_dump(workdir, gold):
+    """Drop-in check of the dump format in the other direction: the REAL reference
+    binary (oracle/_ref/niqki_ref, built from /root/reference by oracle/Makefile)
+    loads the multi-member gzip dump our host program wrote and answers the same."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "niqki_ref")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/niqki_ref not built")
+    _, meta = gold
+    run(workdir, ["-I", "fof.txt", "-S", "10", "-J", "0.1", "-O", "tmp2.gz", "-D", "ours.dump"])
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([ref, "-L", "ours.dump", "-Q", "fof.txt", "-O", "ref_on_ours.gz"], cwd=workdir,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert_same_text(gunzip(workdir / "ref_on_ours.gz").decode(), meta["cli"]["hits_loaded"])

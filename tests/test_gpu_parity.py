@@ -389,3 +389,53 @@ def test_config2_index_and_self_query_1k_genomes(native):
     m = cnt.cpu().numpy().view(np.uint16)[:, :64]
     assert np.array_equal(m, m.T) and (np.diag(m) == F).all()
     e.close()
+
+
+def test_streaming_dump_and_load_equal_the_whole_buffer_forms(native, po):
+    import ctypes as C
+    S, W = 8, 6
+    rng = np.random.default_rng(4)
+    N = 90
+    sk = rng.integers(0, 1 << W, (N, 1 << S)).astype(np.int32)
+    sk[3, 10:30] = -1
+    e = native.Engine(K=21, S=S, W=W, H=3, min_score_value=7, tile_genomes=64)
+    e.insert(sk)
+    whole = e.export_dump()
+    L = native.lib()
+    hdr = np.zeros(24, np.uint8)
+    assert L.niqki_export_dump_header(e.h, hdr.ctypes.data) == 0 and hdr.tobytes() == whole[:24]
+    F = 1 << S
+    slot_bytes = np.zeros(F + 1, np.uint64)
+    assert L.niqki_export_dump_layout(e.h, slot_bytes.ctypes.data) == 0
+    assert int(slot_bytes[F]) == len(whole) - 24
+    parts = []
+    for s0, s1 in ((0, 1), (1, 100), (100, 100), (100, F)):
+        size = C.c_uint64(0)
+        assert L.niqki_export_dump_slots(e.h, s0, s1, None, 0, C.byref(size)) == 0
+        assert size.value == int(slot_bytes[s1] - slot_bytes[s0])
+        buf = np.zeros(max(size.value, 1), np.uint8)
+        assert L.niqki_export_dump_slots(e.h, s0, s1, buf.ctypes.data, size.value, C.byref(size)) == 0
+        parts.append(buf[:size.value].tobytes())
+    assert b"".join(parts) == whole[24:]
+    assert whole == po.Index(po.make_params(21, S, W, 3, 0.0), sk).dump_bytes()[:16] + whole[16:]  # same layout as the oracle's
+    # streamed import in uneven slot groups
+    p = native.Params(31, 15, 12, 4, 0, 0, 0, -1, 64)
+    h = C.c_void_p()
+    assert L.niqki_import_begin(C.byref(p), hdr.ctypes.data, C.byref(h)) == 0
+    body = np.frombuffer(whole[24:], np.uint8)
+    for s0, s1 in ((0, 7), (7, 8), (8, F)):
+        lo, hi = int(slot_bytes[s0]), int(slot_bytes[s1])
+        used = C.c_uint64(0)
+        chunk = np.ascontiguousarray(body[lo:hi])
+        assert L.niqki_import_slots(h, s0, s1, chunk.ctypes.data if chunk.size else hdr.ctypes.data, chunk.size, C.byref(used)) == 0
+        assert used.value == hi - lo
+    e2 = native.Engine(_handle=h)
+    assert e2.n_genomes == N and e2.min_score == 7
+    q = sk[[0, 3, 50]]
+    assert np.array_equal(e2.query_counts(q), e.query_counts(q))
+    assert e2.export_dump() == whole
+    # a truncated payload is refused
+    bad = C.c_void_p()
+    assert L.niqki_import_dump(C.byref(p), np.frombuffer(whole[:-8], np.uint8).ctypes.data, len(whole) - 8, None, C.byref(bad)) == 1
+    e2.close()
+    e.close()
