@@ -254,13 +254,20 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *
   if (nq == 0) return NIQKI_OK;
   if (stride < ix->built_n || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
   if (ix->built_n == 0) return NIQKI_OK;
+  // launches of at most `chunk` queries bound the per-query stash (one Entry per
+  // slot and extra tile) whatever the caller's batch size is
+  const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
+  const uint32_t chunk = ix->n_tiles > 1 ? 4096u : nq;
   if (ix->n_tiles > 1) {
-    rc = ensure(ix, ix->ws_stash, (size_t)nq * (ix->n_tiles - 1) * (ix->d.slot_end - ix->d.slot_begin) * sizeof(nq::Entry));
+    rc = ensure(ix, ix->ws_stash, (size_t)std::min(nq, chunk) * (ix->n_tiles - 1) * f_local * sizeof(nq::Entry));
     if (rc) return rc;
   }
-  Span sp(ix, NIQKI_KC_GATHER);
-  NQ_HIP(ix, nq::launch_gather(view(ix), sketches, nq, counts, stride, (nq::Entry *)ix->ws_stash.p,
-                               ix->gather_variant, ix->stream));
+  for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
+    const uint32_t n = std::min(chunk, nq - q0);
+    Span sp(ix, NIQKI_KC_GATHER);
+    NQ_HIP(ix, nq::launch_gather(view(ix), sketches + (size_t)q0 * ix->d.F, n, counts + (size_t)q0 * stride, stride,
+                                 (nq::Entry *)ix->ws_stash.p, ix->gather_variant, ix->stream));
+  }
   return NIQKI_OK;
 }
 

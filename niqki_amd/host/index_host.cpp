@@ -10,6 +10,8 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <future>
+#include <memory>
 #include <stdexcept>
 #include <thread>
 
@@ -29,7 +31,49 @@ std::string fmt_double(double v) {
   return buf;
 }
 constexpr size_t kBatchBytes = size_t(1) << 30;   // sequence bytes per GPU call
-constexpr size_t kBatchEntries = 4096;            // sketches per GPU call
+constexpr size_t kBatchEntries = 16384;           // sketches per GPU call
+
+// All records longer than K of one sequence file (insert_file_whole /
+// query_file_whole read loop, src/niqki_index.cpp:446-453, :510-515).
+std::vector<std::string> read_whole_file(const std::string &path, size_t K) {
+  std::vector<std::string> recs;
+  const char type = data_type(path);
+  GzReader fin(path);
+  std::string rec, header;
+  while (!fin.eof()) {
+    bio_getline(fin, rec, type, header, K);
+    if (rec.size() > K) recs.push_back(rec);
+  }
+  return recs;
+}
+
+// Reads (and gunzips) the files of a list on several threads -- the reference
+// does this part in its OpenMP region, one file per thread -- and hands them to
+// `consume` strictly in list order, so genome ids and output order are those of
+// a single-threaded run.
+template <typename Consume>
+void for_each_file_in_order(const std::vector<std::string> &paths, size_t K, Consume consume) {
+  unsigned threads = std::thread::hardware_concurrency();
+  threads = threads ? std::min(threads, 32u) : 4u;
+  const size_t window = (size_t)threads * 2;
+  for (size_t w0 = 0; w0 < paths.size(); w0 += window) {
+    const size_t w1 = std::min(paths.size(), w0 + window);
+    std::vector<std::vector<std::string>> recs(w1 - w0);
+    std::vector<std::string> errs(w1 - w0);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+      pool.emplace_back([&, t] {
+        for (size_t i = w0 + t; i < w1; i += threads) {
+          try { recs[i - w0] = read_whole_file(paths[i], K); } catch (const std::exception &e) { errs[i - w0] = e.what(); }
+        }
+      });
+    for (auto &th : pool) th.join();
+    for (size_t i = w0; i < w1; ++i) {
+      if (!errs[i - w0].empty()) throw std::runtime_error(errs[i - w0]);
+      consume(paths[i], recs[i - w0]);
+    }
+  }
+}
 }  // namespace
 
 // A batch of records on their way to the GPU: entry e = records
@@ -55,6 +99,30 @@ struct Index::Batch {
     entry_rec.assign(1, 0);
     names.clear();
   }
+};
+
+// Runs the GPU call of a full batch on a helper thread while the caller parses
+// the next one; batches are flushed strictly one after another (the handle is
+// used by one thread at a time and output order is input order).
+class Index::Pipeline {
+ public:
+  using Fn = void (Index::*)(Batch &);
+  Pipeline(Index *ix, Fn fn) : ix_(ix), fn_(fn) {}
+  ~Pipeline() { try { wait(); } catch (...) {} }
+  void submit(Batch &b) {
+    wait();
+    auto job = std::make_shared<Batch>(std::move(b));
+    b.clear();
+    pending_ = std::async(std::launch::async, [this, job] { (ix_->*fn_)(*job); });
+  }
+  void wait() {
+    if (pending_.valid()) pending_.get();  // rethrows a failure of the helper thread
+  }
+
+ private:
+  Index *ix_;
+  Fn fn_;
+  std::future<void> pending_;
 };
 
 void Index::check(int rc, const char *what) const {
@@ -165,40 +233,43 @@ void Index::insert_file_of_file_whole(const std::string &filestr) {
     std::cout << "Unable to open the file '" << filestr << "'" << std::endl;
     exit(0);  // src/niqki_index.cpp:464-467
   }
-  Batch b;
-  std::string ref, rec, header;
+  // the list first (:479-490: lines longer than 2 characters naming an existing
+  // file; ids follow the list order), then the files, read in parallel
+  std::vector<std::string> paths;
+  std::string ref;
   while (!in.eof()) {
     std::getline(in, ref);
-    if (ref.size() > 2 && exists_test(ref)) {  // :479-490; ids follow the list order
-      // insert_file_whole (:442-456): every record longer than K goes into ONE sketch
-      const char type = data_type(ref);
-      GzReader fin(ref);
-      while (!fin.eof()) {
-        bio_getline(fin, rec, type, header, K);
-        if (rec.size() > K) b.add_record(rec);
-      }
-      b.end_entry(ref);
-      if (b.full()) flush_insert(b);
-    }
+    if (ref.size() > 2 && exists_test(ref)) paths.push_back(ref);
     ref.clear();
   }
-  flush_insert(b);
+  Batch b;
+  Pipeline pipe(this, &Index::flush_insert);
+  for_each_file_in_order(paths, K, [&](const std::string &path, const std::vector<std::string> &recs) {
+    // insert_file_whole (:442-456): every record longer than K goes into ONE sketch
+    for (const auto &r : recs) b.add_record(r);
+    b.end_entry(path);
+    if (b.full()) pipe.submit(b);
+  });
+  pipe.submit(b);
+  pipe.wait();
 }
 
 void Index::insert_file_lines(const std::string &filestr) {
   const char type = data_type(filestr);
   GzReader in(filestr);
   Batch b;
+  Pipeline pipe(this, &Index::flush_insert);
   std::string ref, header;
   while (!in.eof()) {
     bio_getline(in, ref, type, header, K);
     if (ref.size() > K) {  // :395: one entry per record, named by its header line
       b.add_record(ref);
       b.end_entry(header);
-      if (b.full()) flush_insert(b);
+      if (b.full()) pipe.submit(b);
     }
   }
-  flush_insert(b);
+  pipe.submit(b);
+  pipe.wait();
 }
 
 // ---- query ---------------------------------------------------------------------
@@ -231,39 +302,40 @@ void Index::flush_query(Batch &b) {
 
 void Index::query_file_of_file_whole(const std::string &filestr) {
   GzReader in(filestr);
-  Batch b;
-  std::string ref, rec, header;
+  std::vector<std::string> paths;
+  std::string ref;
   while (!in.eof()) {
     in.getline(ref);
-    if (exists_test(ref)) {  // :534
-      const char type = data_type(ref);
-      GzReader fin(ref);
-      while (!fin.eof()) {  // query_file_whole :505-519
-        bio_getline(fin, rec, type, header, K);
-        if (rec.size() > K) b.add_record(rec);
-      }
-      b.end_entry(ref);
-      if (b.full()) flush_query(b);
-    }
+    if (exists_test(ref)) paths.push_back(ref);  // :534
     ref.clear();
   }
-  flush_query(b);
+  Batch b;
+  Pipeline pipe(this, &Index::flush_query);
+  for_each_file_in_order(paths, K, [&](const std::string &path, const std::vector<std::string> &recs) {
+    for (const auto &r : recs) b.add_record(r);  // query_file_whole :505-519
+    b.end_entry(path);
+    if (b.full()) pipe.submit(b);
+  });
+  pipe.submit(b);
+  pipe.wait();
 }
 
 void Index::query_file_lines(const std::string &filestr) {
   const char type = data_type(filestr);
   GzReader in(filestr);
   Batch b;
+  Pipeline pipe(this, &Index::flush_query);
   std::string ref, head;
   while (!in.eof()) {
     bio_getline(in, ref, type, head, K);
     if (ref.size() > K) {
       b.add_record(ref);
       b.end_entry(head);
-      if (b.full()) flush_query(b);
+      if (b.full()) pipe.submit(b);
     }
   }
-  flush_query(b);
+  pipe.submit(b);
+  pipe.wait();
 }
 
 void Index::output_query(const query_output &toprint, const std::string &queryname) {

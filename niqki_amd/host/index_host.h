@@ -52,6 +52,7 @@ class Index {
 
  private:
   struct Batch;
+  class Pipeline;
   void flush_insert(Batch &b);
   void flush_query(Batch &b);
   void check(int rc, const char *what) const;
