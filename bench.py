@@ -69,7 +69,8 @@ def main():
     ap.add_argument("--family", type=int, default=100)
     ap.add_argument("--seed", type=int, default=20261003)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--exchange", default=os.environ.get("NIQKI_EXCHANGE", "reduce_scatter"))
+    ap.add_argument("--exchange", default=os.environ.get("NIQKI_EXCHANGE", "auto"),
+                    help="cross-shard sum: auto | sparse | reduce_scatter | all_to_all (niqki_amd/dist.py)")
     args = ap.parse_args()
 
     # Only the JSON line may reach stdout: libraries (RCCL prints a version banner)
@@ -190,6 +191,11 @@ def main():
         step(bi)
     eng.synchronize()
     torch.cuda.synchronize()
+    if use_dist and sq.exchange == "sparse" and int(sq.overflow.item()):
+        # a candidate list did not fit: this workload needs the dense exchange
+        log("[rank %d] sparse exchange overflowed its candidate capacity, using reduce_scatter" % rank)
+        sq.exchange = "reduce_scatter"
+        sq.overflow.zero_()
     eng.profile(True)
     eng.profile_reset()
     barrier()
@@ -260,7 +266,8 @@ def main():
                             "%d query genomes per step resident in HBM, K=31 S=15 W=12 H=4 J=0.1"
                             % (N, L, args.family, per * world),
                 "index_genomes": N, "query_batch": per * world, "genome_len": L,
-                "parallelism": "slot-shard x%d (%s)" % (world, args.exchange) if world > 1 else "1 GPU",
+                "parallelism": "slot-shard x%d (%s exchange)" % (world, sq.exchange) if use_dist else "1 GPU",
+                "exchange_overflow": bool(int(sq.overflow.item())) if use_dist else False,
                 "tile_genomes": eng.tile_genomes(), "index_build_s": round(t_index, 2),
                 "hits_per_query": total_hits / max(1, args.steps * per), "hit_overflow": overflow,
             },

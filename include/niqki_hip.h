@@ -159,6 +159,16 @@ int niqki_hits_from_counts(niqki_index *ix, const uint16_t *counts, uint32_t nq,
                            uint64_t *hit_off, uint32_t *hit_counts,
                            uint32_t *hit_gids, uint64_t capacity, int mem);
 
+/* Multi-GPU helper (no reference counterpart; NIQKI_MEM_DEVICE only): for every
+ * query the genomes whose counter in this shard's hit vector is >= threshold, at
+ * most cap per query, unordered: cand[q*cap + i] (padded with -1), n_cand[q] =
+ * how many qualified (may exceed cap).  A genome whose cross-shard sum reaches
+ * min_score has a partial count >= ceil(min_score / shards) in some shard, so the
+ * shards only need to exchange and sum these candidates. */
+int niqki_candidates_from_counts(niqki_index *ix, const uint16_t *counts, uint32_t nq,
+                                 uint64_t stride, uint32_t n_gids, uint32_t threshold,
+                                 uint32_t cap, int32_t *cand, int32_t *n_cand, int mem);
+
 /* Index::query_sketch (src/niqki_index.cpp:633-687), batched: both halves. */
 int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq,
                 uint64_t *hit_off, uint32_t *hit_counts, uint32_t *hit_gids,

@@ -66,6 +66,7 @@ ABI = [
     ("niqki_build", _int, [_vp]),
     ("niqki_query_counts", _int, [_vp, _vp, _u32, _vp, _u64, _int]),
     ("niqki_hits_from_counts", _int, [_vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_candidates_from_counts", _int, [_vp, _vp, _u32, _u64, _u32, _u32, _u32, _vp, _vp, _int]),
     ("niqki_query", _int, [_vp, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_query_sequences", _int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_matrix_range", _int, [_vp, _u32, _u32, _vp, _u64, _int]),
@@ -349,6 +350,10 @@ class Engine:
     def hits_from_counts_dev(self, counts, nq, stride, gid_begin, n_gids, hit_off, hc, hg, capacity):
         self._ck(self.L.niqki_hits_from_counts(self.h, _p(counts), nq, stride, gid_begin, n_gids,
                                                _p(hit_off), _p(hc), _p(hg), capacity, MEM_DEVICE))
+
+    def candidates_dev(self, counts, nq, stride, n_gids, threshold, cap, cand, n_cand):
+        self._ck(self.L.niqki_candidates_from_counts(self.h, _p(counts), nq, stride, n_gids, threshold, cap,
+                                                     _p(cand), _p(n_cand), MEM_DEVICE))
 
     def query_dev(self, sketches, nq, hit_off, hc, hg, capacity):
         self._ck(self.L.niqki_query(self.h, _p(sketches), nq, _p(hit_off), _p(hc), _p(hg), capacity,

@@ -643,6 +643,17 @@ int niqki_hits_from_counts(niqki_index *ix, const uint16_t *counts, uint32_t nq,
   return rc;
 }
 
+int niqki_candidates_from_counts(niqki_index *ix, const uint16_t *counts, uint32_t nq, uint64_t stride,
+                                 uint32_t n_gids, uint32_t threshold, uint32_t cap, int32_t *cand, int32_t *n_cand,
+                                 int mem) {
+  if (!ix || (nq && (!counts || !cand || !n_cand)) || n_gids > stride || cap == 0) return NIQKI_E_INVALID;
+  if (mem != NIQKI_MEM_DEVICE) return fail(ix, NIQKI_E_INVALID, "niqki_candidates_from_counts is device-memory only");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  Span sp(ix, NIQKI_KC_HITS);
+  NQ_HIP(ix, nq::launch_candidates(counts, stride, nq, n_gids, threshold, cap, cand, n_cand, ix->stream));
+  return NIQKI_OK;
+}
+
 int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint64_t *hit_off,
                 uint32_t *hit_counts, uint32_t *hit_gids, uint64_t capacity, int mem) {
   if (!ix || !hit_off || (!sketches && nq)) return NIQKI_E_INVALID;

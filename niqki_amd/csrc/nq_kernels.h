@@ -100,6 +100,8 @@ struct HitsArgs {
   uint64_t capacity;
 };
 constexpr uint32_t kHitsBlk = 4096;  // genomes per compaction block
+hipError_t launch_candidates(const uint16_t *counts, uint64_t stride, uint32_t nq, uint32_t n_gids, uint32_t thr,
+                             uint32_t cap, int32_t *cand, int32_t *n, hipStream_t stream);
 hipError_t launch_hits_count(const HitsArgs &a, hipStream_t stream);
 hipError_t launch_hits_emit(const HitsArgs &a, hipStream_t stream);
 

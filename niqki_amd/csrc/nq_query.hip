@@ -417,6 +417,37 @@ __global__ __launch_bounds__(256) void hits_sort_kernel(HitsArgs a) {
   radix_pass_desc(tc, tg, hc, hg, n, 8, curs[wave], lane);
 }
 
+// Candidate genomes of every query: ids with counts[q][g] >= thr, at most `cap`
+// per query (unordered), cand[q*cap + i], n[q] = how many there are (may exceed
+// cap: the caller must then fall back to the dense exchange).  Used by the
+// multi-GPU path: a genome whose summed count reaches min_score has a partial
+// count >= ceil(min_score / shards) on at least one shard.
+__global__ __launch_bounds__(256) void candidates_kernel(const uint16_t *counts, uint64_t stride, uint32_t n_gids,
+                                                        uint32_t thr, uint32_t cap, int32_t *cand, int32_t *n) {
+  __shared__ uint32_t s_n;
+  const uint32_t q = blockIdx.x;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint16_t *row = counts + (uint64_t)q * stride;
+  for (uint32_t g = threadIdx.x; g < n_gids; g += 256) {
+    if (row[g] >= thr) {
+      const uint32_t i = atomicAdd(&s_n, 1u);
+      if (i < cap) cand[(uint64_t)q * cap + i] = (int32_t)g;
+    }
+  }
+  __syncthreads();
+  const uint32_t tot = s_n;
+  for (uint32_t i = tot + threadIdx.x; i < cap; i += 256) cand[(uint64_t)q * cap + i] = -1;
+  if (threadIdx.x == 0) n[q] = (int32_t)tot;
+}
+
+hipError_t launch_candidates(const uint16_t *counts, uint64_t stride, uint32_t nq, uint32_t n_gids, uint32_t thr,
+                             uint32_t cap, int32_t *cand, int32_t *n, hipStream_t stream) {
+  if (nq == 0) return hipSuccess;
+  hipLaunchKernelGGL(candidates_kernel, dim3(nq), dim3(256), 0, stream, counts, stride, n_gids, thr, cap, cand, n);
+  return hipGetLastError();
+}
+
 hipError_t launch_hits_count(const HitsArgs &a, hipStream_t stream) {
   if (a.nq == 0 || a.n_blk == 0) return hipSuccess;
   hipLaunchKernelGGL(hits_count_kernel, dim3(a.nq * a.n_blk), dim3(256), 0, stream, a);

@@ -5,13 +5,24 @@ Rank r of G owns sketch slots [r*F/G, (r+1)*F/G) of EVERY indexed genome
 (SURVEY.md 8e).  The hit count of a genome is a sum over slots, so a query step
 has exactly one exchange of partial results:
 
-  1. every rank sketches its share of the query batch        (no comm)
-  2. all_gather of the int32 query sketches                   (F*4 B per query)
-  3. gather-histogram on the local slot range for ALL queries (no comm)
-  4. sum of the per-genome u16 hit vectors across ranks, scattered by query:
-     reduce_scatter on the counters viewed as int32 pairs -- a count never
-     exceeds F <= 2^15, so the two u16 halves of a word cannot carry
-     (RCCL has no 16-bit integer type)
+  1. every rank sketches its share of the query batch                 (no comm)
+  2. sketch exchange: each rank needs only ITS slot range of every query, so the
+     int32 sketches go through one all_to_all of F/G-slot slices (4F/G bytes per
+     query and peer) instead of an all_gather of whole sketches
+  3. gather-histogram on the local slot range for ALL queries          (no comm)
+  4. cross-shard sum of the per-genome hit vectors, scattered by query:
+       "dense"   reduce_scatter of the u16 counters viewed as int32 pairs -- a
+                 count never exceeds F <= 2^15, so the two halves of a word
+                 cannot carry (RCCL has no 16-bit integer type); 2N bytes per
+                 query per rank
+       "sparse"  only candidates travel: a genome whose summed count reaches
+                 min_score has a partial count >= ceil(min_score/G) on some
+                 rank, so ranks all_gather those (few) candidate ids, look their
+                 own partial counts up for the union, and reduce_scatter just
+                 these values; exact, a few KB per query.  Needs
+                 min_score >= 4*G; a candidate list overflowing its capacity is
+                 reported (`overflow`) and that step must be redone densely.
+       "all_to_all" / "reduce_scatter" are the two transports of the dense form.
   5. every rank thresholds + orders the hits of its share of the queries
 
 The engine argument is anything with the *_dev methods of niqki_amd.Engine (the
@@ -32,7 +43,8 @@ def padded_batch(nq, world):
 
 
 class ShardedQuery:
-    def __init__(self, engine, n_genomes, F, device, group=None, exchange="reduce_scatter"):
+    def __init__(self, engine, n_genomes, F, device, group=None, exchange="auto", min_score=None,
+                 cand_cap=1024):
         self.e = engine
         self.group = group
         self.rank = dist.get_rank(group)
@@ -41,7 +53,14 @@ class ShardedQuery:
         self.F = F
         self.stride = (n_genomes + 1) & ~1
         self.device = device
+        self.min_score = engine.min_score if min_score is None else min_score
+        self.cand_cap = cand_cap
+        if exchange == "auto":
+            exchange = "sparse" if self.min_score >= 4 * self.world else "reduce_scatter"
+        if exchange == "sparse" and self.min_score < self.world:
+            raise ValueError("the sparse exchange needs min_score >= number of shards")
         self.exchange = exchange
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=device)  # sticky: a sparse step overflowed
         self._bufs = {}
 
     def _buf(self, name, shape, dtype):
@@ -51,13 +70,25 @@ class ShardedQuery:
             self._bufs[name] = b
         return b
 
+    # -- step 2
     def exchange_sketches(self, local_sketches):
-        """[per, F] int32 on every rank -> [world*per, F] (query order: rank major)."""
+        """[per, F] int32 on every rank -> [world*per, F] int32 (query order: rank
+        major) whose columns of THIS rank's slot range are filled."""
         per = local_sketches.shape[0]
-        allsk = self._buf("allsk", (self.world * per, self.F), torch.int32)
-        dist.all_gather_into_tensor(allsk, local_sketches.contiguous(), group=self.group)
+        G = self.world
+        allsk = self._buf("allsk", (G * per, self.F), torch.int32)
+        if self.F % G != 0:
+            dist.all_gather_into_tensor(allsk, local_sketches.contiguous(), group=self.group)
+            return allsk
+        w = self.F // G
+        send = local_sketches.view(per, G, w).permute(1, 0, 2).contiguous()      # [dest][q][slot in dest's range]
+        recv = self._buf("skrecv", (G, per, w), torch.int32)                        # [source][q][my slots]
+        dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+        sb = self.rank * w
+        allsk.view(G, per, self.F)[:, :, sb:sb + w] = recv
         return allsk
 
+    # -- step 4, dense
     def reduce_counts(self, counts):
         """[world*per, stride] int16 partial counters -> [per, stride] int16 summed,
         rank r keeping queries [r*per, (r+1)*per)."""
@@ -74,6 +105,44 @@ class ShardedQuery:
             dist.reduce_scatter_tensor(out.view(-1), words.reshape(-1), group=self.group)
         return out.view(torch.int16)
 
+    # -- step 4, sparse
+    def reduce_candidates(self, counts):
+        """Same result rows as reduce_counts for every genome that can reach
+        min_score (all other entries of the returned rows are 0)."""
+        G, C = self.world, self.cand_cap
+        nq = counts.shape[0]
+        per = nq // G
+        thr = -(-self.min_score // G)  # ceil
+        cand = self._buf("cand", (nq, C), torch.int32)
+        ncand = self._buf("ncand", (nq,), torch.int32)
+        self.e.candidates_dev(counts, nq, self.stride, self.N, thr, C, cand, ncand)
+        cand_all = self._buf("cand_all", (G, nq, C), torch.int32)
+        ncand_all = self._buf("ncand_all", (G, nq), torch.int32)
+        dist.all_gather_into_tensor(cand_all.view(-1), cand.view(-1), group=self.group)
+        dist.all_gather_into_tensor(ncand_all.view(-1), ncand, group=self.group)
+        self.overflow |= (ncand_all > C).any().to(torch.int32)
+        # union per query: the G lists side by side (duplicates are harmless)
+        union = cand_all.permute(1, 0, 2).reshape(nq, G * C)                    # [q][G*C], -1 = no candidate
+        valid = union >= 0
+        idx = union.clamp(min=0).to(torch.int64)
+        mine = torch.gather(counts.view(nq, self.stride), 1, idx).to(torch.int32) & 0xFFFF
+        mine = torch.where(valid, mine, torch.zeros_like(mine))                  # this shard's partial counts
+        total = self._buf("cand_tot", (per, G * C), torch.int32)
+        dist.reduce_scatter_tensor(total.view(-1), mine.contiguous().view(-1), group=self.group)
+        # dense rows of this rank's queries holding the candidates' summed counts
+        red = self._buf("red16", (per, self.stride), torch.int16)
+        red.zero_()
+        own = slice(self.rank * per, (self.rank + 1) * per)
+        vals = torch.where(valid[own], total, torch.zeros_like(total))
+        # u16 bit pattern into int16 storage
+        vals16 = torch.where(vals >= 32768, vals - 65536, vals).to(torch.int16)
+        red.scatter_(1, idx[own], vals16)  # duplicates write the same value; invalid entries write 0 at id 0...
+        # ...which must not clobber a real candidate at id 0: rewrite id 0 from the valid entries only
+        is0 = valid[own] & (idx[own] == 0)
+        v0 = torch.where(is0, vals, torch.zeros_like(vals)).amax(dim=1)
+        red[:, 0] = torch.where(v0 >= 32768, v0 - 65536, v0).to(torch.int16)
+        return red
+
     def step(self, local_sketches, hit_off, hit_counts, hit_gids, capacity):
         """One query batch.  local_sketches: [per, F] int32 of this rank's share.
         Fills hit_off[per+1] (int64), hit_counts / hit_gids (int32, capacity)."""
@@ -82,7 +151,7 @@ class ShardedQuery:
         allsk = self.exchange_sketches(local_sketches)
         counts = self._buf("counts", (nq, self.stride), torch.int16)
         self.e.query_counts_dev(allsk, nq, counts, self.stride)
-        red = self.reduce_counts(counts)
+        red = self.reduce_candidates(counts) if self.exchange == "sparse" else self.reduce_counts(counts)
         self.e.hits_from_counts_dev(red, per, self.stride, 0, self.N, hit_off, hit_counts, hit_gids,
                                     capacity)
         return red

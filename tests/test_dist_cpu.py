@@ -33,6 +33,17 @@ class OracleShard:
             s[self.se:] = -1
             out[q, :self.ix.n] = self.ix.counts(s).astype(np.uint16)
 
+    def candidates_dev(self, counts, nq, stride, n_gids, thr, cap, cand, ncand):
+        c = counts.numpy().view(np.uint16)
+        cand.fill_(-1)
+        for q in range(nq):
+            ids = np.nonzero(c[q, :n_gids] >= thr)[0][::-1]  # any order is allowed
+            ncand[q] = len(ids)
+            k = min(len(ids), cap)
+            cand[q, :k] = torch.from_numpy(ids[:k].astype(np.int32).copy())
+
+    min_score = 5
+
     def hits_from_counts_dev(self, red, per, stride, g0, n, hit_off, hc, hg, cap):
         c = red.numpy().view(np.uint16)
         L = self.po.lib()
@@ -72,7 +83,7 @@ def _worker(rank, world, port, exchange, ret):
     F = 1 << S
     sb, se = slot_range(rank, world, F)
     eng = OracleShard(po, p, sk, sb, se)
-    sq = ShardedQuery(eng, N, F, torch.device("cpu"), exchange=exchange)
+    sq = ShardedQuery(eng, N, F, torch.device("cpu"), exchange=exchange, cand_cap=64 if exchange == "sparse" else 8)
     per = padded_batch(NQ, world)
     mine = torch.from_numpy(q[rank * per:(rank + 1) * per].copy())
     hit_off = torch.zeros(per + 1, dtype=torch.int64)
@@ -86,6 +97,12 @@ def _worker(rank, world, port, exchange, ret):
         lo, hi = int(hit_off[i]), int(hit_off[i + 1])
         ok &= np.array_equal(hc[lo:hi].numpy().astype(np.uint32), ehc)
         ok &= np.array_equal(hg[lo:hi].numpy().astype(np.uint32), ehg)
+    if exchange == "sparse":
+        ok &= int(sq.overflow.item()) == 0
+        # a capacity that is too small must be reported, never silently wrong
+        sq2 = ShardedQuery(eng, N, F, torch.device("cpu"), exchange="sparse", cand_cap=1)
+        sq2.step(mine, hit_off, hc, hg, per * N)
+        ok &= int(sq2.overflow.item()) == 1
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 
@@ -98,7 +115,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("exchange", ["reduce_scatter", "all_to_all"])
+@pytest.mark.parametrize("exchange", ["reduce_scatter", "all_to_all", "sparse"])
 def test_slot_sharded_query_world2(exchange):
     world = 2
     mgr = mp.Manager()
