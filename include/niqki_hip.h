@@ -95,6 +95,7 @@ int niqki_synchronize(niqki_index *ix);
 
 /* Tuning knobs (no reference counterpart): "gather_variant", "query_batch",
  * "tile_genomes" (multiple of 64, <= 65536; takes effect at the next build),
+ * "index_layout" (0 = choose, 1 = CSR entries + id lists, 2 = bucket lines),
  * "bucket_align_log2" (-1 = choose, 0..6: buckets start on multiples of 2^a ids),
  * "min_score", "record_len_hint" (average bytes per sketch of NIQKI_MEM_DEVICE
  * batches, so that niqki_sketch need not read rec_off back to pick a launch

@@ -48,6 +48,10 @@ struct niqki_index {
   uint64_t *tile_base = nullptr;   // n_tiles+1, device
   uint32_t *slot_units = nullptr;  // n_tiles x (f_local+1), device
   size_t entries_bytes = 0, gids_bytes = 0, tile_base_bytes = 0, slot_units_bytes = 0;
+  uint16_t *lines = nullptr;       // bucket-line table (direct layout)
+  size_t lines_bytes = 0;
+  uint32_t direct = 0;             // layout of the built index
+  int layout_opt = 0;              // option: 0 = choose, 1 = CSR entries + id lists, 2 = bucket lines
   int bucket_align = -1;           // option: log2 ids per bucket alignment unit, -1 = choose
   bool built = false;
 
@@ -170,6 +174,8 @@ nq::IndexView view(const niqki_index *ix) {
   v.n_tiles = ix->n_tiles;
   v.f_local = ix->d.slot_end - ix->d.slot_begin;
   v.align_log2 = ix->align_log2;
+  v.direct = ix->direct;
+  v.lines = ix->lines;
   v.cap = ix->cap;
   v.store = ix->store;
   v.entries = ix->entries;
@@ -258,7 +264,7 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *
   // slot and extra tile) whatever the caller's batch size is
   const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
   const uint32_t chunk = ix->n_tiles > 1 ? 4096u : nq;
-  if (ix->n_tiles > 1) {
+  if (ix->n_tiles > 1 && !ix->direct) {
     rc = ensure(ix, ix->ws_stash, (size_t)std::min(nq, chunk) * (ix->n_tiles - 1) * f_local * sizeof(nq::Entry));
     if (rc) return rc;
   }
@@ -374,6 +380,7 @@ void niqki_destroy(niqki_index *ix) {
     if (b->p) (void)hipFree(b->p);
   if (ix->store) (void)hipFree(ix->store);
   if (ix->entries) (void)hipFree(ix->entries);
+  if (ix->lines) (void)hipFree(ix->lines);
   if (ix->gids) (void)hipFree(ix->gids);
   if (ix->tile_base) (void)hipFree(ix->tile_base);
   if (ix->slot_units) (void)hipFree(ix->slot_units);
@@ -419,6 +426,12 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
   if (!std::strcmp(key, "tile_genomes")) {
     if (value < 0 || value > 65536 || (value & 63)) return fail(ix, NIQKI_E_INVALID, "tile_genomes must be a multiple of 64, <= 65536");
     ix->p.tile_genomes = (uint32_t)value;
+    ix->built = false;
+    return NIQKI_OK;
+  }
+  if (!std::strcmp(key, "index_layout")) {
+    if (value < 0 || value > 2) return fail(ix, NIQKI_E_INVALID, "index_layout: 0 = choose, 1 = CSR, 2 = bucket lines");
+    ix->layout_opt = (int)value;
     ix->built = false;
     return NIQKI_OK;
   }
@@ -544,16 +557,29 @@ int niqki_build(niqki_index *ix) {
   if (const char *v = std::getenv("NIQKI_TILE_GENOMES")) tile = (uint32_t)std::atoi(v);
   if (tile == 0 || tile > 65536 || (tile & 63)) {
     // as few tiles as the 16-bit tile-local ids and the LDS counter array allow
-    uint32_t nt = std::max<uint32_t>(1, (N + 65535) / 65536);
+    // (65472: a bucket length must fit the u16 length field of a bucket line)
+    uint32_t nt = std::max<uint32_t>(1, (N + 65471) / 65472);
     tile = ((N + nt - 1) / nt + 63) / 64 * 64;
     if (tile == 0) tile = 64;
   }
   const uint32_t n_tiles = (N + tile - 1) / tile;
-  // 128-byte aligned buckets pay off once buckets are long (big tiles); for small
-  // tiles the padding would dominate the id array.
+  // Layout.  CSR (entries + id lists) by default.  Bucket lines (one 128-byte line per
+  // (tile, slot, fingerprint), found from the fingerprint alone) fetch ~35 % fewer lines
+  // per query but measured no faster on MI355X (the walk is instruction-issue bound,
+  // DESIGN.md 4.4) at twice the memory, so they are opt-in: index_layout = 2.
+  int layout = ix->layout_opt;
+  if (const char *v = std::getenv("NIQKI_INDEX_LAYOUT")) layout = std::atoi(v);
+  const size_t lines_bytes = ((size_t)f_local * ix->d.R + 1) * 128 * n_tiles;
+  if (layout != 2) layout = 1;
+  if (layout == 2 && tile > 65472) return fail(ix, NIQKI_E_INVALID, "bucket lines need tile_genomes <= 65472");
+  const bool direct = layout == 2;
+  // CSR: 128-byte aligned buckets pay off once buckets are long (big tiles); for small
+  // tiles the padding would dominate the id array.  Bucket lines: the overflow parts are
+  // always 128-byte aligned.
   int al = ix->bucket_align;
   if (const char *v = std::getenv("NIQKI_BUCKET_ALIGN_LOG2")) al = std::atoi(v);
   if (al < 0 || al > 6) al = tile >= 16384 ? 6 : (tile >= 2048 ? 3 : 0);
+  if (direct) al = 6;
   auto grow = [&](void **p, size_t &have, size_t want) -> int {
     want = std::max<size_t>(want, 256);
     if (want <= have) return NIQKI_OK;
@@ -563,14 +589,27 @@ int niqki_build(niqki_index *ix) {
     have = want;
     return NIQKI_OK;
   };
+  auto drop = [&](void **p, size_t &have) -> int {
+    if (*p) NQ_HIP(ix, hipFree(*p));
+    *p = nullptr; have = 0;
+    return NIQKI_OK;
+  };
   int rc;
-  if ((rc = grow((void **)&ix->entries, ix->entries_bytes, (size_t)f_local * ix->d.R * n_tiles * sizeof(nq::Entry)))) return rc;
+  if (direct) {
+    if ((rc = drop((void **)&ix->entries, ix->entries_bytes))) return rc;
+    if ((rc = grow((void **)&ix->lines, ix->lines_bytes, lines_bytes))) return rc;
+    NQ_HIP(ix, hipMemsetAsync(ix->lines, 0, lines_bytes, ix->stream));
+  } else {
+    if ((rc = drop((void **)&ix->lines, ix->lines_bytes))) return rc;
+    if ((rc = grow((void **)&ix->entries, ix->entries_bytes, (size_t)f_local * ix->d.R * n_tiles * sizeof(nq::Entry)))) return rc;
+  }
   if ((rc = grow((void **)&ix->slot_units, ix->slot_units_bytes, (size_t)n_tiles * (f_local + 1) * 4))) return rc;
   if ((rc = grow((void **)&ix->tile_base, ix->tile_base_bytes, (size_t)(n_tiles + 1) * 8))) return rc;
   ix->tile = tile;
   ix->n_tiles = n_tiles;
   ix->built_n = N;
   ix->align_log2 = (uint32_t)al;
+  ix->direct = direct ? 1u : 0u;
   if (n_tiles == 0) { ix->built = true; return NIQKI_OK; }
   {
     Span sp(ix, NIQKI_KC_BUILD);
@@ -587,7 +626,7 @@ int niqki_build(niqki_index *ix) {
   if ((rc = grow((void **)&ix->gids, ix->gids_bytes, (size_t)total_ids * 2 + 512))) return rc;
   {
     Span sp(ix, NIQKI_KC_BUILD);
-    NQ_HIP(ix, nq::launch_build_fill(view(ix), ix->entries, ix->gids, ix->stream));
+    NQ_HIP(ix, nq::launch_build_fill(view(ix), ix->entries, ix->gids, ix->lines, ix->stream));
   }
   ix->built = true;
   return NIQKI_OK;

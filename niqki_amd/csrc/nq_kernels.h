@@ -35,13 +35,24 @@ struct Entry {
   uint32_t start;  // in units of (1 << align_log2) ids
   uint32_t len;
 };
+// "Bucket line" layout (direct != 0), used when its table fits the memory budget:
+//   lines  u16 [n_tiles][F_local*R + 1][64]   one 128-byte line per (tile, slot, fp),
+//          found from the fingerprint alone (no lookup table): ids[0..59] = the first
+//          60 tile-local ids of the bucket, [60] = bucket length, [62..63] = u32 start
+//          (in 64-id units) of the rest of the bucket inside the tile's overflow array
+//          (gids / tile_base as above, align_log2 = 6).  Line F_local*R is all zero.
+constexpr uint32_t kLineIds = 60;   // ids stored inline
+constexpr uint32_t kLineLen = 60;   // u16 index of the length field
+constexpr uint32_t kLineOvf = 62;   // u16 index of the low half of the overflow start
 struct IndexView {
   Derived d;
   uint32_t n_genomes;
-  uint32_t tile;     // T, genomes per tile (multiple of 64, <= 65536)
+  uint32_t tile;     // T, genomes per tile (multiple of 64, <= 65536; <= 65472 with bucket lines)
   uint32_t n_tiles;
   uint32_t f_local;  // slot_end - slot_begin
   uint32_t align_log2;
+  uint32_t direct;   // bucket-line layout
+  const uint16_t *lines;
   uint64_t cap;      // row stride of the sketch store (genomes)
   const uint16_t *store;
   const Entry *entries;
@@ -60,7 +71,8 @@ hipError_t launch_store_read(const Derived &d, const uint16_t *store, uint64_t c
 hipError_t launch_build_sizes(const IndexView &v, uint32_t *slot_units, uint64_t *tile_base,
                               hipStream_t stream);
 // Build, phase 2: entries + gids (gids sized from tile_base[n_tiles]).
-hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids, hipStream_t stream);
+hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids, uint16_t *lines,
+                             hipStream_t stream);
 // dump stream (src/niqki_index.cpp:42-55) of a whole-range index.
 // layout: slot_word[s] (F+1 entries) = word position of bucket (s, 0) in the stream
 // (header excluded); export: the words of slots [s0, s1) into `out` (word 0 = first

@@ -21,6 +21,13 @@ namespace nq {
 __device__ __forceinline__ void bump(uint32_t *cnt, uint32_t g) {
   atomicAdd(&cnt[g >> 1], 1u << ((g & 1u) * 16u));  // ds_add_u32, result unused
 }
+// Branch-free form for the bucket walks: lanes past the end of the bucket add 0 to a
+// word of their own (no exec-mask juggling, no same-address serialisation).
+__device__ __forceinline__ void bump_if(uint32_t *cnt, uint32_t g, bool on, uint32_t lane) {
+  const uint32_t gg = on ? g : 2u * lane;
+  const uint32_t inc = on ? (1u << ((g & 1u) * 16u)) : 0u;
+  atomicAdd(&cnt[gg >> 1], inc);
+}
 
 // A bucket chunk: up to 64 consecutive ids at unit `pos` (1 << align_log2 ids per
 // unit, counted from the tile's base).
@@ -49,7 +56,7 @@ __device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t 
     for (int u = 0; u < UNROLL; ++u) {
       const uint32_t l = __builtin_amdgcn_readlane(len, j0 + u);
       if (MODE == 1) { if (lane < l) sink ^= g[u]; }
-      else if (lane < l) bump(cnt, g[u]);
+      else bump_if(cnt, g[u], lane < l, lane);
     }
   };
   fetch(0, ga);
@@ -176,6 +183,116 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
   }
 }
 
+// Bucket-line layout: one pass of a workgroup over all slots of one tile.  The
+// line of bucket (slot, fp) is addressed from the fingerprint alone, so there is no
+// lookup and one dependent memory level: every lane loads its slot's fingerprint
+// (two iterations ahead), then the wave reads the 64 lines one after another, lane l
+// taking the u16 at index l -- ids 0..59, the bucket length at 60, the overflow start
+// at 62..63 -- UNROLL lines per round trip, two rounds in flight.  Ids beyond the
+// first 60 of a bucket live in the tile's overflow array and go through the same
+// wave-private chunk queue as in the CSR walk.
+template <int BLOCK, int UNROLL, int MODE>
+__device__ __forceinline__ void walk_tile_direct(const IndexView &v, const int32_t *sk, uint32_t t, uint32_t *cnt,
+                                                 Item *queue, uint32_t &sink) {
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  constexpr uint32_t NW = BLOCK / 64;
+  const uint32_t R = v.d.R;
+  const uint32_t n_it = (v.f_local + 63) / 64;
+  const uint32_t zero_line = v.f_local * R;  // all-zero line: length 0
+  const uint16_t *lines = v.lines + (uint64_t)t * ((uint64_t)zero_line + 1) * 64;
+  const uint16_t *gl = v.gids + v.tile_base[t];
+  Item *wq = queue + wave * kQueue;
+  uint32_t q_head = 0, q_count = 0;  // wave-uniform
+
+  auto load_fp = [&](uint32_t it) -> int32_t {
+    const uint32_t s = it * 64 + lane;
+    return sk[s < v.f_local ? s : v.f_local - 1];
+  };
+  auto line_of = [&](uint32_t it, int32_t fp) -> uint32_t {
+    const uint32_t s = it * 64 + lane;
+    const bool ok = it < n_it && s < v.f_local && fp >= 0 && (uint32_t)fp < R;  // src/niqki_index.cpp:654
+    return ok ? s * R + (uint32_t)fp : zero_line;
+  };
+  auto drain = [&]() {
+    while (q_count >= 64) {
+      const Item x = wq[(q_head + lane) & (kQueue - 1)];
+      q_head = (q_head + 64) & (kQueue - 1);
+      q_count -= 64;
+      walk64<UNROLL, MODE>(gl, 6, x.pos, x.len, lane, cnt, sink);
+    }
+  };
+
+  uint32_t it = wave;
+  int32_t fp1 = load_fp(it + NW);
+  uint32_t li = line_of(it, load_fp(it));
+  for (; it < n_it; it += NW) {
+    const uint32_t li_next = line_of(it + NW, fp1);
+    fp1 = load_fp(it + 2 * NW);
+    uint32_t pos = 0, rem = 0;  // this lane's slot: overflow start (64-id units) / ids left there
+    if (MODE == 6) { sink += li; li = li_next; continue; }
+
+    uint32_t ga[UNROLL], gb[UNROLL];
+    auto fetch = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const uint32_t b = __builtin_amdgcn_readlane(li, j0 + u);
+        g[u] = (lines + (uint64_t)b * 64)[lane];
+      }
+    };
+    auto apply = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const uint32_t len = __builtin_amdgcn_readlane(g[u], kLineLen);
+        const uint32_t nin = len < kLineIds ? len : kLineIds;
+        if (MODE == 1) { if (lane < nin) sink ^= g[u]; }
+        else bump_if(cnt, g[u] & 0xFFFFu, lane < nin, lane);
+        if (len > kLineIds) {  // wave-uniform: hand the rest of the bucket to lane j0+u
+          const uint32_t ovf = __builtin_amdgcn_readlane(g[u], kLineOvf) |
+                               (__builtin_amdgcn_readlane(g[u], kLineOvf + 1) << 16);
+          if (lane == j0 + u) { pos = ovf; rem = len - kLineIds; }
+        }
+      }
+    };
+    fetch(0, ga);
+#pragma unroll
+    for (uint32_t j0 = 0; j0 < 64; j0 += 2 * UNROLL) {
+      fetch(j0 + UNROLL, gb);
+      apply(j0, ga);
+      if (j0 + 2 * UNROLL < 64) fetch(j0 + 2 * UNROLL, ga);
+      apply(j0 + UNROLL, gb);
+    }
+    // overflow parts: chunks of <= 64 ids through the queue (q_count < 64 here)
+    while (__any(rem != 0)) {
+      uint32_t nch = (rem + 63) >> 6;
+      if (nch > 3) nch = 3;
+      uint32_t incl = nch;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += y;
+      }
+      const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+      uint32_t slot = q_head + q_count + incl - nch;
+#pragma unroll
+      for (uint32_t k = 0; k < 3; ++k)
+        if (k < nch) {
+          const uint32_t left = rem - 64 * k;
+          wq[(slot + k) & (kQueue - 1)] = Item{pos + k, left < 64 ? left : 64u};
+        }
+      q_count += total;
+      pos += nch;
+      rem -= rem < 192 ? rem : 192u;
+      drain();
+    }
+    li = li_next;
+  }
+  if (q_count) {  // the last partial batch
+    Item x = wq[(q_head + lane) & (kQueue - 1)];
+    if (lane >= q_count) x = Item{0u, 0u};
+    walk64<UNROLL, MODE>(gl, 6, x.pos, x.len, lane, cnt, sink);
+  }
+}
+
 // One workgroup per query; the genome tiles are walked one after another with
 // the tile's hit counters (packed u16 pairs) in LDS.
 template <int BLOCK, int UNROLL, int NT, int MODE = 0>
@@ -193,7 +310,9 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     const uint32_t n_words = (n_t + 1) / 2;
     for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
     __syncthreads();
-    if (NT >= 2) {
+    if (NT == 0) {
+      walk_tile_direct<BLOCK, UNROLL, MODE>(v, sk, t, cnt, queue, sink);
+    } else if (NT >= 2) {
       if (t == 0) walk_tile<BLOCK, UNROLL, NT, true, false, MODE>(v, sk, q, t, cnt, queue, stash, sink);
       else walk_tile<BLOCK, UNROLL, NT, false, true, MODE>(v, sk, q, t, cnt, queue, stash, sink);
     } else {
@@ -226,7 +345,8 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
   } while (0)
 #define NQ_BY_TILES(B, U, ...)                                                                   \
   do {                                                                                           \
-    if (v.n_tiles == 2) NQ_LAUNCH_GATHER(B, U, 2, ##__VA_ARGS__);                                \
+    if (v.direct) NQ_LAUNCH_GATHER(B, U, 0, ##__VA_ARGS__);                                      \
+    else if (v.n_tiles == 2) NQ_LAUNCH_GATHER(B, U, 2, ##__VA_ARGS__);                                \
     else if (v.n_tiles == 3) NQ_LAUNCH_GATHER(B, U, 3, ##__VA_ARGS__);                           \
     else if (v.n_tiles == 4) NQ_LAUNCH_GATHER(B, U, 4, ##__VA_ARGS__);                           \
     else NQ_LAUNCH_GATHER(B, U, 1, ##__VA_ARGS__);                                               \
@@ -235,7 +355,6 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     case 1: NQ_BY_TILES(1024, 8); break;
     case 2: NQ_BY_TILES(1024, 32); break;
     case 3: NQ_BY_TILES(512, 16); break;
-    case 7: NQ_LAUNCH_GATHER(1024, 16, 1); break;  // one lookup per (slot, tile), no stash
     case 11: NQ_BY_TILES(1024, 16, 1); break;      // ablations, see MODE
     case 16: NQ_BY_TILES(1024, 16, 6); break;
     default: NQ_BY_TILES(1024, 16); break;
@@ -256,8 +375,13 @@ __global__ __launch_bounds__(256) void gathered_kernel(IndexView v, const int32_
   for (uint32_t s = threadIdx.x; s < v.f_local; s += blockDim.x) {
     int32_t fp = sk[s];
     if (fp >= 0 && (uint32_t)fp < R) {
-      const Entry *p = v.entries + ((uint64_t)s * R + (uint32_t)fp) * v.n_tiles;
-      for (uint32_t t = 0; t < v.n_tiles; ++t) sum += p[t].len;
+      if (v.direct) {
+        for (uint32_t t = 0; t < v.n_tiles; ++t)
+          sum += v.lines[((uint64_t)t * ((uint64_t)v.f_local * R + 1) + (uint64_t)s * R + (uint32_t)fp) * 64 + kLineLen];
+      } else {
+        const Entry *p = v.entries + ((uint64_t)s * R + (uint32_t)fp) * v.n_tiles;
+        for (uint32_t t = 0; t < v.n_tiles; ++t) sum += p[t].len;
+      }
     }
   }
   atomicAdd(&per_query[q], sum);

@@ -11,6 +11,14 @@ from conftest import family_spec, synth_case
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["csr", "lines"])
+def index_layout(request, monkeypatch):
+    """Every test runs under both index layouts: CSR entries +
+    id lists, and bucket lines."""
+    monkeypatch.setenv("NIQKI_INDEX_LAYOUT", "1" if request.param == "csr" else "2")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def eng_a(native, gold):
     _, meta = gold
