@@ -214,6 +214,7 @@ __device__ __forceinline__ uint32_t rev64_hi(uint64_t canon) {
 }
 
 constexpr uint32_t kRing = 128;  // candidate k-mers per wave-private ring (filtered path)
+constexpr uint32_t kRingAlloc = kRing + 64;  // + one scratch slot per lane
 
 // All records of one sketch, this workgroup's share of the chunks.
 // FILTER (long inputs only): a k-mer whose hash has fewer than T leading zeros
@@ -230,7 +231,7 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
   constexpr uint32_t CHUNK = 16u * GROUPS;
   const uint32_t Km1 = d.K - 1u;
   const uint32_t rc_shift = 2u * d.K - 2u;
-  uint64_t *ring = ring_base + (tid >> 6) * kRing;
+  uint64_t *ring = ring_base + (tid >> 6) * kRingAlloc;
   uint32_t q_head = 0, q_tail = 0, q_count = 0;  // wave-uniform (scalar registers)
   auto drain64 = [&](bool partial) {
     uint64_t c = ring[(q_head + lane) & (kRing - 1)];
@@ -327,7 +328,9 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
         auto filtered = [&](uint64_t canon, uint32_t hh) {
           const uint64_t bal = __ballot(hh < thr);
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-          if (hh < thr) ring[(q_tail + rank) & (kRing - 1)] = canon;
+          // every lane stores: candidates into the ring, the others into a scratch
+          // slot of their own behind it (cheaper than masking the store)
+          ring[hh < thr ? ((q_tail + rank) & (kRing - 1)) : kRing + lane] = canon;
           const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)__popcll(bal));
           q_tail = (q_tail + n) & (kRing - 1);
           q_count += n;
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
 }
 
 static size_t sketch_lds_bytes(const Derived &d, bool distinct, uint32_t ring_waves) {
-  return (size_t)d.F * 4 + 16 + 256 + (distinct ? (size_t)d.R * 12 : 0) + (size_t)ring_waves * kRing * 8;
+  return (size_t)d.F * 4 + 16 + 256 + (distinct ? (size_t)d.R * 12 : 0) + (size_t)ring_waves * kRingAlloc * 8;
 }
 
 hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, bool short_records,

@@ -447,3 +447,46 @@ def test_streaming_dump_and_load_equal_the_whole_buffer_forms(native, po):
     assert L.niqki_import_dump(C.byref(p), np.frombuffer(whole[:-8], np.uint8).ctypes.data, len(whole) - 8, None, C.byref(bad)) == 1
     e2.close()
     e.close()
+
+
+def test_maximum_fingerprint_width_and_full_tile(native, po, index_layout):
+    """Corners of the supported range: W = 15 (2^15 fingerprints per slot, one build wave
+    needs 128 KB of LDS) and a counter tile of 65536 genomes (160 KB of LDS)."""
+    # W = 15, H = 7: sketches from sequences, then index + query against the oracle
+    p = po.make_params(31, 8, 15, 7, 0.0)
+    p.min_score = 3
+    e = native.Engine(K=31, S=8, W=15, H=7, min_score_value=3)
+    fam, mem, rate = family_spec(2, 5, fam0=40)
+    g = [native.synth_genome_host(6, int(f), int(m), int(r), 30_000) for f, m, r in zip(fam, mem, rate)]
+    sk = e.sketch(g)
+    assert np.array_equal(sk, np.stack([po.compute_sketch(p, x) for x in g]))
+    e.insert(sk)
+    ix = po.Index(p, sk)
+    off, hc, hg = e.query(sk[:3])
+    for i in range(3):
+        ehc, ehg = ix.query(sk[i])
+        assert np.array_equal(hc[int(off[i]):int(off[i + 1])], ehc) and np.array_equal(hg[int(off[i]):int(off[i + 1])], ehg)
+    e.close()
+    # one tile of 65536 genomes (CSR layout only: a bucket line's length field is 16 bits)
+    S, W, N = 4, 6, 65536
+    rng = np.random.default_rng(9)
+    sk = rng.integers(0, 1 << W, (N, 1 << S)).astype(np.int32)
+    e = native.Engine(K=31, S=S, W=W, H=3, min_score_value=14, tile_genomes=65536)
+    e.insert(sk)
+    q = sk[[0, 65535, 31000]]
+    if index_layout == "lines":
+        with pytest.raises(native.NiqkiError):
+            e.build()
+        e.close()
+        return
+    p2 = po.make_params(31, S, W, 3, 0.0)
+    p2.min_score = 14
+    ix = po.Index(p2, sk)
+    cnt = e.query_counts(q)
+    off, hc, hg = e.query(q)
+    for i in range(3):
+        assert np.array_equal(cnt[i].astype(np.uint32), ix.counts(q[i]))
+        ehc, ehg = ix.query(q[i])
+        assert np.array_equal(hc[int(off[i]):int(off[i + 1])], ehc) and np.array_equal(hg[int(off[i]):int(off[i + 1])], ehg)
+    assert e.tile_genomes() == 65536
+    e.close()
