@@ -572,6 +572,8 @@ int niqki_build(niqki_index *ix) {
   const size_t lines_bytes = ((size_t)f_local * ix->d.R + 1) * 128 * n_tiles;
   if (layout != 2) layout = 1;
   if (layout == 2 && tile > 65472) return fail(ix, NIQKI_E_INVALID, "bucket lines need tile_genomes <= 65472");
+  if (layout == 2 && (size_t)ix->d.R * 8 > 160 * 1024)  // the build keeps two words per fingerprint in LDS
+    return fail(ix, NIQKI_E_INVALID, "bucket lines need W <= 14");
   const bool direct = layout == 2;
   // CSR: 128-byte aligned buckets pay off once buckets are long (big tiles); for small
   // tiles the padding would dominate the id array.  Bucket lines: the overflow parts are
