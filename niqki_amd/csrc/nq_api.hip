@@ -222,8 +222,7 @@ int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, ui
   a.densify = 1;
   a.splits = 1;
   const uint64_t avg = total_bytes / n_entry;
-  const bool short_records = avg < 16384;
-  if (!short_records && !entry_rec && n_entry < 128 && avg >= (1u << 20))
+  if (avg >= 16384 && !entry_rec && n_entry < 128 && avg >= (1u << 20))
     a.splits = std::min<uint32_t>(32, 512 / n_entry);
   if (a.splits > 1) {
     {
@@ -231,7 +230,7 @@ int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, ui
       NQ_HIP(ix, nq::launch_fill_u32((uint32_t *)sketches, (uint64_t)n_entry * ix->d.F, nq::kEmpty32,
                                      ix->stream));
       a.densify = 0;
-      NQ_HIP(ix, nq::launch_sketch(a, n_entry, false, ix->stream));
+      NQ_HIP(ix, nq::launch_sketch(a, n_entry, avg / a.splits, ix->stream));
     }
     Span sp(ix, NIQKI_KC_DENSIFY);
     nq::SketchArgs b = a;
@@ -239,10 +238,10 @@ int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, ui
     b.splits = 1;
     b.accumulate = 1;
     b.densify = 1;
-    NQ_HIP(ix, nq::launch_sketch(b, n_entry, false, ix->stream));
+    NQ_HIP(ix, nq::launch_sketch(b, n_entry, (uint64_t)1 << 22, ix->stream));
   } else {
     Span sp(ix, NIQKI_KC_SKETCH);
-    NQ_HIP(ix, nq::launch_sketch(a, n_entry, short_records, ix->stream));
+    NQ_HIP(ix, nq::launch_sketch(a, n_entry, avg, ix->stream));
   }
   (void)n_rec;
   return NIQKI_OK;
@@ -513,7 +512,7 @@ int niqki_densify(niqki_index *ix, int32_t *sketches, uint32_t n, int mem) {
   a.densify = 1;
   {
     Span sp(ix, NIQKI_KC_DENSIFY);
-    NQ_HIP(ix, nq::launch_sketch(a, n, ix->d.F <= 4096, ix->stream));
+    NQ_HIP(ix, nq::launch_sketch(a, n, ix->d.F <= 4096 ? 150 : ((uint64_t)1 << 22), ix->stream));
   }
   if (mem == NIQKI_MEM_HOST) {
     NQ_HIP(ix, hipMemcpyAsync(sketches, d_sk, bytes, hipMemcpyDeviceToHost, ix->stream));

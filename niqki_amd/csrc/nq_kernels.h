@@ -18,7 +18,8 @@ struct SketchArgs {
   uint32_t distinct;          // set by launch_sketch: densify over distinct values (short-read path)
   uint32_t filter;            // set by launch_sketch: candidate filter for long inputs
 };
-hipError_t launch_sketch(const SketchArgs &a, uint32_t n_entry, bool short_records,
+// avg_len: average input bytes per sketch (picks the launch shape)
+hipError_t launch_sketch(const SketchArgs &a, uint32_t n_entry, uint64_t avg_len,
                          hipStream_t stream);
 hipError_t launch_fill_u32(uint32_t *p, uint64_t n, uint32_t v, hipStream_t stream);
 

@@ -444,10 +444,14 @@ static size_t sketch_lds_bytes(const Derived &d, bool distinct, uint32_t ring_wa
   return (size_t)d.F * 4 + 16 + 256 + (distinct ? (size_t)d.R * 12 : 0) + (size_t)ring_waves * kRingAlloc * 8;
 }
 
-hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, bool short_records,
+hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_len,
                          hipStream_t stream) {
   if (n_entry == 0) return hipSuccess;
   SketchArgs a = a_in;
+  // Launch shape by the average input length of a sketch: a 256-thread workgroup for
+  // reads, else 1024 threads with chunks of 32 / 128 / 512 k-mers per lane (long chunks
+  // amortise the K-1 warm-up steps, short ones keep all lanes busy on short records).
+  const bool short_records = avg_len < 16384;
   // distinct-value densification where its tables leave room for >= 2 workgroups per CU
   a.distinct = (short_records && sketch_lds_bytes(a.d, true, 0) <= 64 * 1024) ? 1u : 0u;
   // candidate filter: long records only (the kernel picks its strength per sketch);
@@ -467,8 +471,12 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, bool short_re
   } while (0)
   if (short_records) {
     if (a.d.K == 31) NQ_LAUNCH_SKETCH(256, 1, 31); else NQ_LAUNCH_SKETCH(256, 1, 0);
-  } else {
+  } else if (avg_len < (1u << 18)) {
+    if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 2, 31); else NQ_LAUNCH_SKETCH(1024, 2, 0);
+  } else if (avg_len < (1u << 21)) {
     if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 8, 31); else NQ_LAUNCH_SKETCH(1024, 8, 0);
+  } else {
+    if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 32, 31); else NQ_LAUNCH_SKETCH(1024, 32, 0);
   }
 #undef NQ_LAUNCH_SKETCH
   return hipGetLastError();
