@@ -281,6 +281,13 @@ def main():
                 "gathered_ids_per_query": T / max(1, n_q_local),
             },
             "kernels": {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items()},
+            # the sketch kernel is integer-ALU bound (4 64-bit multiplies per k-mer):
+            # its rate in k-mers and the HBM bytes it needs (1 byte per base + the sketch)
+            "sketch_kernel": {
+                "gkmers_per_s": (args.steps * per * max(L - K, 0)) / (prof["sketch"][0] * 1e-3) / 1e9 if prof["sketch"][0] else 0.0,
+                "hbm_gbs": (args.steps * per * (L + 4 * F)) / (prof["sketch"][0] * 1e-3) / 1e9 if prof["sketch"][0] else 0.0,
+                "bound": "valu",
+            },
             "cpu_baseline": cpu,
         }
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
