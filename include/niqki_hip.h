@@ -83,6 +83,17 @@ uint32_t niqki_min_score(double min_fract, uint32_t S);
  * Fails with NIQKI_E_NODEVICE when there is no GPU: there is no CPU path. */
 int niqki_create(const niqki_params *params, niqki_index **out);
 void niqki_destroy(niqki_index *ix);
+/* Index::select_best_H(genome_size) (the CLI's -G): src/niqki_index.cpp:126-164.
+ * Picks H in 2..6 from the expected genome size and replaces H and M = W-H on
+ * the handle.  As in the reference, the fingerprint's low-part mask and
+ * saturation constant keep the values the constructor derived from the
+ * ORIGINAL H (:24-25 are not recomputed), so the parts of a fingerprint may
+ * overlap or exceed W bits; cells outside [0, 2^W) are sketched but never
+ * indexed or queried (:364, :654).  May be called at any time, like the
+ * reference's member; *H_out (may be NULL) receives the chosen H.
+ * NIQKI_E_INVALID when the chosen H exceeds W (the reference's unsigned M
+ * wraps there). */
+int niqki_select_best_H(niqki_index *ix, double genome_size, uint32_t *H_out);
 /* Text of the last error on the handle; with ix == NULL, why the last
  * niqki_create / niqki_import_dump of the calling thread failed. */
 const char *niqki_last_error(const niqki_index *ix);

@@ -54,6 +54,7 @@ ABI = [
     ("niqki_destroy", None, [_vp]),
     ("niqki_last_error", C.c_char_p, [_vp]),
     ("niqki_get_params", _int, [_vp, C.POINTER(Params)]),
+    ("niqki_select_best_H", _int, [_vp, _dbl, C.POINTER(C.c_uint32)]),
     ("niqki_set_stream", _int, [_vp, _vp]),
     ("niqki_get_stream", _vp, [_vp]),
     ("niqki_synchronize", _int, [_vp]),
@@ -186,6 +187,13 @@ class Engine:
 
     def reserve(self, n):
         self._ck(self.L.niqki_reserve(self.h, n))
+
+    def select_best_H(self, genome_size):
+        """Index::select_best_H (-G): src/niqki_index.cpp:126-138."""
+        H = C.c_uint32(0)
+        self._ck(self.L.niqki_select_best_H(self.h, float(genome_size), C.byref(H)))
+        self.H = H.value
+        return self.H
 
     @property
     def n_genomes(self):

@@ -7,6 +7,7 @@
 #include "nq_synth.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -339,6 +340,46 @@ const char *niqki_status_string(int s) {
 uint32_t niqki_min_score(double min_fract, uint32_t S) {
   double f = (double)(1u << S);
   return (uint32_t)(min_fract * f);
+}
+
+namespace {
+// Width of the fingerprint interval a candidate H spans between the 2 % and 98 %
+// quantiles of a slot's minimum hash when x k-mers fall into the slot
+// (score_H, src/niqki_index.cpp:142-164).  q -> position of hash quantile u = q * 2^64
+// on the fingerprint axis: below the HyperLogLog range the fingerprint is the hash
+// scaled down, inside it a saturating exponent plus the mantissa share.
+double fingerprint_axis(double u, double h_range, double m_bits) {
+  if (u < std::pow(2, 64 - h_range + 1)) return u * std::pow(2, h_range - 64 - m_bits - 1);
+  const double i = std::log2(u) + h_range - 64;
+  const double j = u * std::pow(2, m_bits - 64 - i + h_range);
+  return i * std::pow(2, m_bits) + j;
+}
+double interval_width(double x, int try_h, uint32_t W) {
+  const double eps = 0.02;
+  // W - try_h is unsigned in the reference (wraps when try_h > W)
+  const double h_range = std::pow(2, try_h), m_bits = (double)(uint32_t)(W - (uint32_t)try_h);
+  const double lo = ((double)1 - std::pow(1 - eps, 1 / x)) * std::pow(2, 64);
+  const double hi = ((double)1 - std::pow(eps, 1 / x)) * std::pow(2, 64);
+  return fingerprint_axis(hi, h_range, m_bits) - fingerprint_axis(lo, h_range, m_bits);
+}
+}  // namespace
+
+int niqki_select_best_H(niqki_index *ix, double genome_size, uint32_t *H_out) {
+  if (!ix) return NIQKI_E_INVALID;
+  const double x = genome_size / (double)ix->d.F;
+  uint32_t H = ix->d.H;
+  double best = 0;
+  for (int try_h = 2; try_h < 7; ++try_h) {  // src/niqki_index.cpp:129-135
+    const double w = interval_width(x, try_h, ix->d.W);
+    if (w > best) { best = w; H = (uint32_t)try_h; }
+  }
+  if (H > ix->d.W) return fail(ix, NIQKI_E_INVALID, "select_best_H chose H > W");
+  // :136 -- H and M only; mask_m / max_rem stay as the constructor left them
+  ix->d.H = H;
+  ix->d.M = ix->d.W - H;
+  ix->p.H = H;
+  if (H_out) *H_out = H;
+  return NIQKI_OK;
 }
 
 int niqki_create(const niqki_params *params, niqki_index **out) {

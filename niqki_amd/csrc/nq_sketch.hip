@@ -453,13 +453,16 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   // amortise the K-1 warm-up steps, short ones keep all lanes busy on short records).
   const bool short_records = avg_len < 16384;
   // distinct-value densification where its tables leave room for >= 2 workgroups per CU
-  a.distinct = (short_records && sketch_lds_bytes(a.d, true, 0) <= 64 * 1024) ? 1u : 0u;
+  // after niqki_select_best_H the fingerprint parts may overlap and leave [0, 2^W): the
+  // value-indexed tables and the filter's ordering argument need the regular form
+  const bool regular = a.d.mask_m == (1u << a.d.M) - 1u && a.d.max_rem == (1u << a.d.H) - 1u;
+  a.distinct = (regular && short_records && sketch_lds_bytes(a.d, true, 0) <= 64 * 1024) ? 1u : 0u;
   // candidate filter: long records only (the kernel picks its strength per sketch);
   // NIQKI_SKETCH_FILTER=0 switches it off
   // NIQKI_SKETCH_FILTER: 0 = off, unset/1 = automatic, n >= 2 = force n-1 leading zeros (tests)
   const char *fv = std::getenv("NIQKI_SKETCH_FILTER");
   const uint32_t fmode = fv ? (uint32_t)std::atoi(fv) : 1u;
-  a.filter = (!short_records && a.seqs != nullptr) ? fmode : 0u;
+  a.filter = (regular && !short_records && a.seqs != nullptr) ? fmode : 0u;
   const size_t lds = sketch_lds_bytes(a.d, a.distinct != 0, a.filter ? (short_records ? 4 : 16) : 0);
   dim3 grid(n_entry * a.splits);
 #define NQ_LAUNCH_SKETCH(B, G, KF)                                                               \

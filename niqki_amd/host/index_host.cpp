@@ -193,6 +193,14 @@ Index::~Index() {
   if (h_) niqki_destroy(h_);
 }
 
+// src/niqki_index.cpp:126-138, including its message
+void Index::select_best_H(double genome_size) {
+  uint32_t chosen = H;
+  check(niqki_select_best_H(h_, genome_size, &chosen), "select_best_H");
+  H = chosen;
+  std::cout << "I chosed H=" << H << std::endl;
+}
+
 void Index::compute_sketch(const std::string &reference, std::vector<int32_t> &sketch) const {
   sketch.assign(F, -1);
   uint64_t off[2] = {0, reference.size()};

@@ -34,6 +34,8 @@ class Index {
 
   size_t getNbGenomes() const { return filenames.size(); }  // src/niqki_index.h:138-140
 
+  void select_best_H(double genome_size);  // src/niqki_index.cpp:126-138 (-G)
+
   // per-record operators, kept for API parity (src/niqki_index.h:103,108,142)
   void compute_sketch(const std::string &reference, std::vector<int32_t> &sketch) const;
   void insert_sketch(const std::vector<int32_t> &sketch, uint32_t genome_id);

@@ -194,8 +194,14 @@ int main(int argc, char *argv[]) {
     cerr << "niqki: " << e.what() << endl;
     return EXIT_FAILURE;
   }
-  if (genomes_sizes != 0)
-    cout << "-G is not supported by this build (select_best_H is outside the GPU hot path); H stays " << H << endl;
+  if (genomes_sizes != 0) {
+    try {
+      monindex->select_best_H(genomes_sizes);  // src/niqki.cpp:303-305
+    } catch (const std::exception &e) {
+      cerr << "niqki: " << e.what() << endl;
+      return EXIT_FAILURE;
+    }
+  }
 
   time_point<system_clock> start, endindex, end;
   start = system_clock::now();

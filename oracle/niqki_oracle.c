@@ -10,6 +10,7 @@
  */
 #include "niqki_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -47,6 +48,53 @@ int32_t nqo_fingerprint(uint64_t h, uint32_t W, uint32_t H) {
   int32_t rem = (int32_t)(((uint32_t)1 << H) - 1u) - lz;
   if (rem < 0) rem = 0;
   return (int32_t)((uint32_t)(h & mask_m) + ((uint32_t)rem << M));
+}
+
+int32_t nqo_fingerprint_stale(uint64_t h, uint32_t W, uint32_t H, uint32_t H0) {
+  /* get_fingerprint after select_best_H (src/niqki_index.cpp:126-138) replaced
+   * the constructor's H0 by H: only H and M = W-H are updated there, mask_M and
+   * maximal_remainder keep their constructor values (:24-25), so the low part
+   * still has W-H0 bits and the saturation still counts from 2^H0-1, while the
+   * HyperLogLog part is shifted by the NEW M.  The two parts are ADDED (:285)
+   * and may overlap or leave [0, 2^W). */
+  uint32_t M = W - H;
+  uint32_t mask_m = ((uint32_t)1 << (W - H0)) - 1u;
+  int32_t lz = h ? __builtin_clzll(h) : 64;
+  int32_t rem = (int32_t)(((uint32_t)1 << H0) - 1u) - lz;
+  if (rem < 0) rem = 0;
+  return (int32_t)((uint32_t)(h & mask_m) + ((uint32_t)rem << M));
+}
+
+/* score_H: src/niqki_index.cpp:142-164, double arithmetic as written. */
+static double score_H(double x, int try_h, uint32_t W) {
+  double epsilon = 0.02;
+  double try_m = (double)(uint32_t)(W - (uint32_t)try_h); /* uint32 - int: unsigned, wraps for try_h > W */
+  double two_h = pow(2, try_h);
+  double ua = (((double)1 - pow(1 - epsilon, 1 / x)) * pow(2, 64));
+  double ia = log2(ua) + two_h - 64;
+  double ja = ua * pow(2, try_m - 64 - ia + two_h);
+  double ka;
+  if (ua < pow(2, 64 - two_h + 1)) ka = ua * pow(2, two_h - 64 - try_m - 1);
+  else ka = ia * pow(2, try_m) + ja;
+  double ub = ((double)1 - pow(epsilon, 1 / x)) * pow(2, 64);
+  double ib = log2(ub) + two_h - 64;
+  double jb = ub * pow(2, try_m - 64 - ib + two_h);
+  double kb;
+  if (ub < pow(2, 64 - two_h + 1)) kb = ub * pow(2, two_h - 64 - try_m - 1);
+  else kb = ib * pow(2, try_m) + jb;
+  return kb - ka;
+}
+
+uint32_t nqo_select_best_H(double genome_size, uint32_t S, uint32_t W, uint32_t H) {
+  /* src/niqki_index.cpp:126-138: the widest interval over try_h = 2..6 wins,
+   * the current H stays when no interval is positive (NaN compares false). */
+  double x = genome_size / (double)((uint64_t)1 << S);
+  double best = 0;
+  for (int try_h = 2; try_h < 7; try_h++) {
+    double v = score_H(x, try_h, W);
+    if (v > best) { best = v; H = (uint32_t)try_h; }
+  }
+  return H;
 }
 
 uint64_t nqo_hash_family(uint64_t x, uint32_t step) { /* :308-310 */
@@ -106,7 +154,7 @@ uint64_t nqo_sketch_accumulate(const nqo_params *p, const uint8_t *seq,
     rc = (rc >> 2) + (code_rc(c) << rc_shift); /* :233-236 */
     uint64_t canon = fw < rc ? fw : rc;        /* :345 */
     uint64_t slot = nqo_unrev64(canon) >> (64 - S); /* :347 */
-    int32_t fp = nqo_fingerprint(nqo_rev64(canon), p->W, p->H); /* :346,348 */
+    int32_t fp = nqo_fingerprint_stale(nqo_rev64(canon), p->W, p->H, p->H0 ? p->H0 : p->H); /* :346,348 */
     int32_t cur = sk[slot];
     if (cur == -1 || cur > fp) sk[slot] = fp; /* :350-355: min over fp */
   }
@@ -299,6 +347,7 @@ nqo_index *nqo_load_bytes(const uint8_t *buf, uint64_t len, uint64_t *consumed) 
   nqo_index *ix = (nqo_index *)calloc(1, sizeof(*ix));
   ix->p.S = hdr[0]; ix->p.K = hdr[1]; ix->p.H = hdr[2]; ix->p.W = hdr[3];
   ix->p.min_score = hdr[4];
+  ix->p.H0 = 0;
   ix->n_genomes = hdr[5];
   ix->n_buckets = ((uint64_t)1 << ix->p.S) << ix->p.W;
   ix->offsets = (uint64_t *)calloc(ix->n_buckets + 1, sizeof(uint64_t));

@@ -37,6 +37,8 @@ typedef struct nqo_params {
   uint32_t W;         /* fingerprint bits */
   uint32_t H;         /* HyperLogLog bits inside the fingerprint (M = W-H) */
   uint32_t min_score; /* (uint32)(min_fract * F), src/niqki_index.cpp:22 */
+  uint32_t H0;        /* 0, or the constructor's H when select_best_H (-G) replaced it
+                         afterwards: mask_M / maximal_remainder stay at H0's values */
 } nqo_params;
 
 /* src/niqki_index.cpp:22  min_score = min_fract*F  (double -> uint32 truncation) */
@@ -49,6 +51,14 @@ uint64_t nqo_unrev64(uint64_t x);
 /* src/niqki_index.cpp:277-287 (+ asm_log2 :199-206).  h==0 -> 0 (bsr UB in the
  * reference, observed result 0). */
 int32_t nqo_fingerprint(uint64_t h, uint32_t W, uint32_t H);
+
+/* get_fingerprint with the stale mask_M / maximal_remainder a `-G` run has:
+ * src/niqki_index.cpp:126-138 changes H and M only.  H0 = constructor's H. */
+int32_t nqo_fingerprint_stale(uint64_t h, uint32_t W, uint32_t H, uint32_t H0);
+
+/* select_best_H + score_H: src/niqki_index.cpp:126-164.  Returns the H the
+ * reference ends with (the given H when no candidate scores above 0). */
+uint32_t nqo_select_best_H(double genome_size, uint32_t S, uint32_t W, uint32_t H);
 
 /* src/niqki_index.cpp:308-310 */
 uint64_t nqo_hash_family(uint64_t x, uint32_t step);

@@ -24,7 +24,7 @@ u64p = C.POINTER(C.c_uint64)
 
 class Params(C.Structure):
     _fields_ = [("K", C.c_uint32), ("S", C.c_uint32), ("W", C.c_uint32),
-                ("H", C.c_uint32), ("min_score", C.c_uint32)]
+                ("H", C.c_uint32), ("min_score", C.c_uint32), ("H0", C.c_uint32)]
 
 
 class _Index(C.Structure):
@@ -56,6 +56,10 @@ def lib():
             f.argtypes = [C.c_uint64]
         L.nqo_fingerprint.restype = C.c_int32
         L.nqo_fingerprint.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.nqo_fingerprint_stale.restype = C.c_int32
+        L.nqo_fingerprint_stale.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.nqo_select_best_H.restype = C.c_uint32
+        L.nqo_select_best_H.argtypes = [C.c_double, C.c_uint32, C.c_uint32, C.c_uint32]
         L.nqo_hash_family.restype = C.c_uint64
         L.nqo_hash_family.argtypes = [C.c_uint64, C.c_uint32]
         L.nqo_sketch_accumulate.restype = C.c_uint64
@@ -103,8 +107,21 @@ def _seq(seq):
     return np.ascontiguousarray(seq, dtype=np.uint8)
 
 
-def make_params(K=31, S=15, W=12, H=4, J=0.0):
-    return Params(K, S, W, H, lib().nqo_min_score(J, S))
+def make_params(K=31, S=15, W=12, H=4, J=0.0, genome_size=0.0):
+    """genome_size != 0 applies the reference's -G (select_best_H after the constructor)."""
+    p = Params(K, S, W, H, lib().nqo_min_score(J, S), 0)
+    if genome_size:
+        p.H0 = H
+        p.H = lib().nqo_select_best_H(genome_size, S, W, H)
+    return p
+
+
+def select_best_H(genome_size, S, W, H):
+    return lib().nqo_select_best_H(genome_size, S, W, H)
+
+
+def fingerprint_stale(h, W, H, H0):
+    return lib().nqo_fingerprint_stale(h, W, H, H0)
 
 
 def rev64(x):
@@ -272,6 +289,8 @@ class Ref:
         L.ref_bucket_size.restype = C.c_uint64
         L.ref_bucket_size.argtypes = [C.c_void_p, C.c_uint64]
         L.ref_dump.argtypes = [C.c_void_p, C.c_char_p]
+        L.ref_select_best_H.restype = C.c_uint32
+        L.ref_select_best_H.argtypes = [C.c_void_p, C.c_double]
         self._L = L
         self.S, self.K, self.W, self.H = S, K, W, H
         self.F = 1 << S
@@ -285,6 +304,10 @@ class Ref:
 
     def min_score(self):
         return self._L.ref_min_score(self._h)
+
+    def select_best_H(self, genome_size):
+        self.H = self._L.ref_select_best_H(self._h, genome_size)
+        return self.H
 
     def rev64(self, x):
         return self._L.ref_rev64(self._h, x)

@@ -29,6 +29,13 @@ void *ref_create(uint32_t lF, uint32_t K, uint32_t W, uint32_t H,
 
 void ref_destroy(void *h) { delete static_cast<Index *>(h); }
 
+// select_best_H: src/niqki_index.cpp:126-138 (prints "I chosed H=...")
+uint32_t ref_select_best_H(void *h, double genome_size) {
+  Index *ix = static_cast<Index *>(h);
+  ix->select_best_H(genome_size);
+  return ix->H;
+}
+
 uint32_t ref_min_score(void *h) { return static_cast<Index *>(h)->min_score; }
 
 uint64_t ref_rev64(void *h, uint64_t x) { return static_cast<Index *>(h)->revhash64(x); }

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "niqki_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(niqki_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(niqki_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_all_exported(native):

@@ -75,6 +75,18 @@ def test_index_query_dump(workdir, gold):
     assert hashlib.md5(raw).hexdigest() == meta["cli"]["dump_md5"]
 
 
+def test_genome_size_option(workdir, gold):
+    """-G: select_best_H after the constructor; the dump header carries the chosen H."""
+    _, meta = gold
+    out = run(workdir, ["-I", "fof.txt", "-Q", "fof.txt", "-S", "10", "-G", "40000", "-J", "0.1", "-O", "hits_G.gz",
+                        "-D", "idxG.dump"])
+    assert "I chosed H=%d" % meta["cli"]["dumpG_header"][2] in out
+    assert_same_text(gunzip(workdir / "hits_G.gz").decode(), meta["cli"]["hits_G"])
+    raw = gunzip(workdir / "idxG.dump")
+    assert np.frombuffer(raw[:24], np.uint32).tolist() == meta["cli"]["dumpG_header"]
+    assert hashlib.md5(raw).hexdigest() == meta["cli"]["dumpG_md5"]
+
+
 def test_matrix(workdir, gold):
     _, meta = gold
     run(workdir, ["-M", "fof.txt", "-S", "10", "-O", "matrix.gz"])

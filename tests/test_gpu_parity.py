@@ -51,11 +51,13 @@ def test_synth_host_equals_device(native):
     e.close()
 
 
-@pytest.mark.parametrize("case", ["A", "D1", "D2", "D3", "D4"])
+@pytest.mark.parametrize("case", ["A", "D1", "D2", "D3", "D4", "G1", "G2", "G3"])
 def test_sketch_insert_query_vs_reference_goldens(native, po, gold, case):
     vec, meta = gold
     m = meta[case]
     e = native.Engine(K=m["K"], S=m["S"], W=m["W"], H=m["H"], J=m["J"])
+    if "G" in m:  # -G: select_best_H after the constructor (stale mask / saturation constants)
+        assert e.select_best_H(m["G"]) == m["H_final"]
     assert e.min_score == int(vec[case + "_min_score"][0])
     genomes = synth_case(native, m)
     sk = e.sketch(genomes)
@@ -68,20 +70,21 @@ def test_sketch_insert_query_vs_reference_goldens(native, po, gold, case):
     assert np.array_equal(hc, vec[case + "_hit_counts"])
     assert np.array_equal(hg, vec[case + "_hit_gids"])
     # dense counters against the oracle
-    p = po.make_params(m["K"], m["S"], m["W"], m["H"], m["J"])
+    p = po.make_params(m["K"], m["S"], m["W"], m["H"], m["J"], genome_size=m.get("G", 0.0))
     ix = po.Index(p, sk)
     cnt = e.query_counts(qsk)
     for q in range(qsk.shape[0]):
         assert np.array_equal(cnt[q].astype(np.uint32), ix.counts(qsk[q]))
-    # stored sketches read back
-    assert np.array_equal(e.get_sketches(0, len(genomes)), sk)
+    # stored sketches read back (cells outside [0, 2^W) are never stored: src/niqki_index.cpp:364)
+    assert np.array_equal(e.get_sketches(0, len(genomes)), np.where(sk < (1 << m["W"]), sk, -1))
     # dump payload byte-identical to the reference's (names appended by the host program)
     import hashlib
     raw = e.export_dump() + "".join("g%d\n" % i for i in range(len(genomes))).encode()
     assert len(raw) == m["dump_len"] and hashlib.md5(raw).hexdigest() == m["dump_md5"]
     # load the dump into a fresh handle and query again
     e2 = native.Engine.import_dump(raw)
-    assert e2.n_genomes == len(genomes) and (e2.K, e2.S, e2.W, e2.H) == (m["K"], m["S"], m["W"], m["H"])
+    assert e2.n_genomes == len(genomes)
+    assert (e2.K, e2.S, e2.W, e2.H) == (m["K"], m["S"], m["W"], m.get("H_final", m["H"]))
     assert e2.min_score == e.min_score
     off2, hc2, hg2 = e2.query(qsk)
     assert np.array_equal(off2, off) and np.array_equal(hc2, hc) and np.array_equal(hg2, hg)

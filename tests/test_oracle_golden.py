@@ -31,17 +31,35 @@ def test_hash_and_fingerprint_kats(po, gold):
         assert po.unrev64(po.rev64(x)) == x
 
 
+def test_select_best_H_and_stale_fingerprints(po, gold):
+    """-G: select_best_H / score_H (src/niqki_index.cpp:126-164) and get_fingerprint with the
+    constructor's stale mask_M / maximal_remainder, against the reference's own answers."""
+    vec, meta = gold
+    for S, W, H, G, chosen in meta["select_best_H"]:
+        assert po.select_best_H(G, S, W, H) == chosen, (S, W, H, G)
+    xs = vec["kat_x"].tolist()
+    for tag, (W, H0) in {"kat_fp_stale_w12_h4_g150": (12, 4), "kat_fp_stale_w12_h2_g5e6": (12, 2),
+                         "kat_fp_stale_w8_h5_g1e4": (8, 5)}.items():
+        v = vec[tag]
+        Hn = int(v[0])
+        assert Hn != H0
+        for i, x in enumerate(xs):
+            assert po.fingerprint_stale(x, W, Hn, H0) == int(v[1 + i]), (tag, hex(x))
+
+
 def test_min_score_truncation(po):
     assert po.lib().nqo_min_score(0.9, 10) == 921   # SURVEY.md 8a a9
     assert po.lib().nqo_min_score(0.1, 15) == 3276
     assert po.lib().nqo_min_score(0.0, 15) == 0
 
 
-@pytest.mark.parametrize("case", ["A", "D1", "D2", "D3", "D4"])
+@pytest.mark.parametrize("case", ["A", "D1", "D2", "D3", "D4", "G1", "G2", "G3"])
 def test_sketch_index_query_dump_vs_reference(po, native, gold, case):
     vec, meta = gold
     m = meta[case]
-    p = po.make_params(m["K"], m["S"], m["W"], m["H"], m["J"])
+    p = po.make_params(m["K"], m["S"], m["W"], m["H"], m["J"], genome_size=m.get("G", 0.0))
+    if "G" in m:
+        assert p.H == m["H_final"] != m["H"]
     assert p.min_score == int(vec[case + "_min_score"][0])
     genomes = synth_case(native, m)
     sk = np.stack([po.compute_sketch(p, g) for g in genomes])
