@@ -194,6 +194,56 @@ int niqki_query_sequences(niqki_index *ix, const uint8_t *seqs,
                           uint64_t *hit_off, uint32_t *hit_counts,
                           uint32_t *hit_gids, uint64_t capacity, int mem);
 
+/* ---- raw file bytes in: FASTA / FASTQ framing on the GPU -------------------
+ * Index::Biogetline (src/niqki_index.cpp:890-941) and the read loops of
+ * insert_file_whole / query_file_whole (:442-456, :505-519) and
+ * insert_file_lines / query_file_lines (:383-430): the caller hands over the
+ * (gunzipped) bytes of its files, the records are framed on the device and stay
+ * there as the "staged batch" of the handle; niqki_staged_* then sketch, insert
+ * or query it.  Framing is the reference's: FASTA = the first line of a file and
+ * every line starting with '>' is a header, all other lines are concatenated
+ * (nothing trimmed or upper-cased); FASTQ = 4-line records.  A record of at most
+ * K bases is skipped (:395,:423,:450,:512). */
+typedef struct niqki_raw_batch {
+  const uint8_t *raw;        /* bytes of n_files files back to back, in the memory space of the
+                                call (device: 4-byte aligned, NIQKI_SEQ_PAD readable bytes after) */
+  const uint64_t *file_off;  /* HOST array, n_files+1 offsets into raw */
+  const uint8_t *file_type;  /* HOST array, n_files: 'A' FASTA / 'Q' FASTQ (get_data_type, :944-952) */
+  uint32_t n_files;
+  uint32_t lines;            /* 0: one sketch per file (whole mode); 1: one sketch per record longer
+                                than K (lines mode, n_files must be 1) */
+  uint32_t final;            /* lines mode: raw reaches the end of the file; otherwise the last
+                                (possibly incomplete) record is left for the next call */
+  uint32_t max_entries;      /* lines mode: stop after this many sketches */
+} niqki_raw_batch;
+
+typedef struct niqki_stage_info {
+  uint32_t n_entry;    /* sketches the staged batch produces */
+  uint32_t n_rec;      /* records framed, short ones included */
+  uint64_t consumed;   /* raw bytes covered by the entries: a lines-mode stream resumes here
+                          (always the first byte of a header line, or the end) */
+  uint64_t seq_bytes;  /* sequence bytes staged */
+} niqki_stage_info;
+
+/* entry_hdr (HOST array of max_entries, lines mode, may be NULL): raw offset of the
+ * header line of each entry (names are the header lines, :395-400). */
+int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *batch, int mem_space,
+                    niqki_stage_info *info, uint64_t *entry_hdr);
+/* compute_sketch of every staged entry (n_entry x 2^S int32). */
+int niqki_staged_sketch(niqki_index *ix, int32_t *sketches, int mem_space);
+/* ... + insert_sketch: ids follow the entries (:396-401, :479-490). */
+int niqki_staged_insert(niqki_index *ix);
+/* ... + query_sketch per entry; outputs as niqki_query. */
+int niqki_staged_query(niqki_index *ix, uint64_t *hit_off, uint32_t *hit_counts,
+                       uint32_t *hit_gids, uint64_t capacity, int mem_space);
+/* Read the staged framing back (HOST arrays, any may be NULL): rec_off n_rec+1,
+ * seqs seq_bytes, entry_rec n_entry+1, hdr_pos n_rec.  For tests and diagnosis. */
+int niqki_staged_records(niqki_index *ix, uint64_t *rec_off, uint8_t *seqs,
+                         uint32_t *entry_rec, uint64_t *hdr_pos);
+/* Page-locked host memory for raw batches (plain malloc'ed memory works too, slower). */
+void *niqki_host_alloc(size_t bytes);
+void niqki_host_free(void *p);
+
 /* Counting loop of Index::query_range (src/niqki_index.cpp:570-597): for
  * target genomes t in [begin,end), counts[(t-begin)*stride + a] = number of
  * buckets holding both a and t (the reference's counts[a*batch + t-begin];
@@ -249,7 +299,8 @@ enum niqki_kernel_class {
   NIQKI_KC_GATHER = 2,   /* gather-histogram over the inverted index */
   NIQKI_KC_HITS = 3,     /* threshold + compaction + sort */
   NIQKI_KC_BUILD = 4,    /* insert transpose + CSR build */
-  NIQKI_KC_COUNT = 5
+  NIQKI_KC_INGEST = 5,   /* FASTA / FASTQ framing */
+  NIQKI_KC_COUNT = 6
 };
 
 /* When enabled, every launch of the classes above is bracketed by HIP events

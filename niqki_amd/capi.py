@@ -14,7 +14,7 @@ _LIB = os.path.join(_HERE, "lib", "libniqki_hip.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
 SEQ_PAD = 64
-KC_SKETCH, KC_DENSIFY, KC_GATHER, KC_HITS, KC_BUILD = 0, 1, 2, 3, 4
+KC_SKETCH, KC_DENSIFY, KC_GATHER, KC_HITS, KC_BUILD, KC_INGEST = 0, 1, 2, 3, 4, 5
 E_CAPACITY = 4
 
 
@@ -28,6 +28,17 @@ class Params(C.Structure):
     _fields_ = [("K", C.c_uint32), ("S", C.c_uint32), ("W", C.c_uint32), ("H", C.c_uint32),
                 ("min_score", C.c_uint32), ("slot_begin", C.c_uint32), ("slot_end", C.c_uint32),
                 ("device", C.c_int32), ("tile_genomes", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+class RawBatch(C.Structure):
+    _fields_ = [("raw", C.c_void_p), ("file_off", C.c_void_p), ("file_type", C.c_void_p),
+                ("n_files", C.c_uint32), ("lines", C.c_uint32), ("final", C.c_uint32),
+                ("max_entries", C.c_uint32)]
+
+
+class StageInfo(C.Structure):
+    _fields_ = [("n_entry", C.c_uint32), ("n_rec", C.c_uint32), ("consumed", C.c_uint64),
+                ("seq_bytes", C.c_uint64)]
 
 
 def lib_path():
@@ -70,6 +81,13 @@ ABI = [
     ("niqki_candidates_from_counts", _int, [_vp, _vp, _u32, _u64, _u32, _u32, _u32, _vp, _vp, _int]),
     ("niqki_query", _int, [_vp, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_query_sequences", _int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_stage_raw", _int, [_vp, C.POINTER(RawBatch), _int, C.POINTER(StageInfo), _vp]),
+    ("niqki_staged_sketch", _int, [_vp, _vp, _int]),
+    ("niqki_staged_insert", _int, [_vp]),
+    ("niqki_staged_query", _int, [_vp, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_staged_records", _int, [_vp, _vp, _vp, _vp, _vp]),
+    ("niqki_host_alloc", _vp, [C.c_size_t]),
+    ("niqki_host_free", None, [_vp]),
     ("niqki_matrix_range", _int, [_vp, _u32, _u32, _vp, _u64, _int]),
     ("niqki_export_dump", _int, [_vp, _vp, _u64, C.POINTER(_u64)]),
     ("niqki_import_dump", _int, [C.POINTER(Params), _vp, _u64, C.POINTER(_u64), C.POINTER(_vp)]),
@@ -288,6 +306,50 @@ class Engine:
         cap = capacity if capacity is not None else max(1024, nq * 64)
         return self._hits(lambda ho, hc, hg, c: self.L.niqki_query_sequences(
             self.h, _p(seqs), _p(off), nq, None, nq, _p(ho), _p(hc), _p(hg), c, MEM_HOST), nq, cap)
+
+    # -- raw file bytes, framed on the GPU (niqki_stage_raw and friends)
+    def stage_raw(self, files, types=None, lines=False, final=True, max_entries=16384):
+        """files: list of bytes-like (the gunzipped content of each file).  Returns
+        (StageInfo, entry_hdr) -- entry_hdr: raw offset of each entry's header line (lines mode)."""
+        blobs = [np.frombuffer(bytes(f), dtype=np.uint8) for f in files]
+        off = np.zeros(len(blobs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([b.size for b in blobs], dtype=np.uint64)
+        raw = np.concatenate(blobs + [np.zeros(0, np.uint8)]) if blobs else np.zeros(0, np.uint8)
+        ty = np.frombuffer(("".join(types) if types else "A" * len(blobs)).encode(), dtype=np.uint8).copy()
+        if ty.size == 0:
+            ty = np.zeros(1, np.uint8)
+        b = RawBatch(_p(raw) if raw.size else None, _p(off), _p(ty), len(blobs), int(bool(lines)), int(bool(final)),
+                     max_entries)
+        info = StageInfo()
+        hdr = np.zeros(max(max_entries, 1), dtype=np.uint64)
+        self._ck(self.L.niqki_stage_raw(self.h, C.byref(b), MEM_HOST, C.byref(info), _p(hdr) if lines else None))
+        self._staged = info
+        return info, hdr[:info.n_entry] if lines else None
+
+    def staged_records(self):
+        """(records as list of bytes, entry_rec, hdr_pos) of the staged batch."""
+        st = self._staged
+        rec_off = np.zeros(st.n_rec + 1, dtype=np.uint64)
+        seqs = np.zeros(max(st.seq_bytes, 1), dtype=np.uint8)
+        entry_rec = np.zeros(st.n_entry + 1, dtype=np.uint32)
+        hdr_pos = np.zeros(max(st.n_rec, 1), dtype=np.uint64)
+        self._ck(self.L.niqki_staged_records(self.h, _p(rec_off), _p(seqs), _p(entry_rec), _p(hdr_pos)))
+        recs = [seqs[int(rec_off[i]):int(rec_off[i + 1])].tobytes() for i in range(st.n_rec)]
+        return recs, entry_rec, hdr_pos[:st.n_rec]
+
+    def staged_sketch(self):
+        out = np.empty((self._staged.n_entry, self.F), dtype=np.int32)
+        self._ck(self.L.niqki_staged_sketch(self.h, _p(out), MEM_HOST))
+        return out
+
+    def staged_insert(self):
+        self._ck(self.L.niqki_staged_insert(self.h))
+
+    def staged_query(self, capacity=None):
+        nq = self._staged.n_entry
+        cap = capacity if capacity is not None else max(1024, nq * 64)
+        return self._hits(lambda ho, hc, hg, c: self.L.niqki_staged_query(
+            self.h, _p(ho), _p(hc), _p(hg), c, MEM_HOST), nq, cap)
 
     def matrix_range(self, begin, end):
         n = self.n_genomes

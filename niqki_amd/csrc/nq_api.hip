@@ -62,6 +62,14 @@ struct niqki_index {
 
   Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
       ws_misc, ws_stash;
+  // staged batch (niqki_stage_raw): framing results live in ws_seq / ws_recoff / ws_entry
+  Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr;
+  struct {
+    bool valid = false, sketched = false;
+    uint32_t n_entry = 0, n_rec = 0;
+    uint64_t seq_bytes = 0;
+    const uint32_t *entry_rec = nullptr;  // device, n_entry+1
+  } staged;
 
   bool prof = false;
   double prof_ms[NIQKI_KC_COUNT] = {0};
@@ -318,6 +326,49 @@ int hits_dev(niqki_index *ix, const uint16_t *counts, uint32_t nq, uint64_t stri
   return NIQKI_OK;
 }
 
+// Hits of nq sketches (host memory, or device-resident when sk_dev) into HOST arrays:
+// batches of query_batch sketches, hits appended in query order.
+int query_to_host(niqki_index *ix, const int32_t *sketches, bool sk_dev, uint32_t nq, uint64_t *hit_off,
+                  uint32_t *hit_counts, uint32_t *hit_gids, uint64_t capacity) {
+  int rc;
+  const uint32_t N = ix->built_n;
+  const uint64_t stride = ((uint64_t)N + 1) & ~1ull;
+  uint64_t base = 0;
+  bool overflow = false;
+  hit_off[0] = 0;
+  const uint32_t qb = ix->query_batch;
+  std::vector<unsigned long long> off(qb + 1);
+  for (uint32_t q0 = 0; q0 < nq; q0 += qb) {
+    const uint32_t n = std::min(qb, nq - q0);
+    if (!sk_dev && (rc = ensure(ix, ix->ws_sk, (size_t)n * ix->d.F * 4))) return rc;
+    if ((rc = ensure(ix, ix->ws_counts, std::max<size_t>((size_t)n * stride * 2, 2)))) return rc;
+    if ((rc = ensure(ix, ix->ws_hitoff, (size_t)(n + 1) * 8))) return rc;
+    const uint64_t room = overflow || base > capacity ? 0 : capacity - base;
+    if ((rc = ensure(ix, ix->ws_hc, (size_t)std::max<uint64_t>(room, 1) * 4))) return rc;
+    if ((rc = ensure(ix, ix->ws_hg, (size_t)std::max<uint64_t>(room, 1) * 4))) return rc;
+    const int32_t *d_sk = sketches + (size_t)q0 * ix->d.F;
+    if (!sk_dev) {
+      NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, d_sk, (size_t)n * ix->d.F * 4, hipMemcpyHostToDevice, ix->stream));
+      d_sk = (const int32_t *)ix->ws_sk.p;
+    }
+    if ((rc = counts_dev(ix, d_sk, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+    uint64_t total = 0;
+    rc = hits_dev(ix, (const uint16_t *)ix->ws_counts.p, n, stride, 0, N, (unsigned long long *)ix->ws_hitoff.p,
+                  (uint32_t *)ix->ws_hc.p, (uint32_t *)ix->ws_hg.p, room, true, &total);
+    if (rc && rc != NIQKI_E_CAPACITY) return rc;
+    NQ_HIP(ix, hipMemcpyAsync(off.data(), ix->ws_hitoff.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
+    if (rc == NIQKI_OK && total) {
+      NQ_HIP(ix, hipMemcpyAsync(hit_counts + base, ix->ws_hc.p, (size_t)total * 4, hipMemcpyDeviceToHost, ix->stream));
+      NQ_HIP(ix, hipMemcpyAsync(hit_gids + base, ix->ws_hg.p, (size_t)total * 4, hipMemcpyDeviceToHost, ix->stream));
+    }
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    if (rc == NIQKI_E_CAPACITY) overflow = true;
+    for (uint32_t i = 0; i < n; ++i) hit_off[q0 + i + 1] = base + off[i + 1];
+    base += off[n];
+  }
+  return overflow ? NIQKI_E_CAPACITY : NIQKI_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -416,7 +467,9 @@ void niqki_destroy(niqki_index *ix) {
   (void)hipSetDevice(ix->device);
   (void)hipStreamSynchronize(ix->stream);
   for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
-                 &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash})
+                 &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash,
+                 &ix->ws_raw, &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
+                 &ix->ws_hdrpos, &ix->ws_ehdr})
     if (b->p) (void)hipFree(b->p);
   if (ix->store) (void)hipFree(ix->store);
   if (ix->entries) (void)hipFree(ix->entries);
@@ -510,6 +563,7 @@ int niqki_sketch(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, 
   }
   const uint64_t total = rec_off[n_rec];
   int rc;
+  ix->staged.valid = false;  // the staging buffers are shared with niqki_stage_raw
   if ((rc = ensure(ix, ix->ws_seq, (size_t)total + NIQKI_SEQ_PAD))) return rc;
   if ((rc = ensure(ix, ix->ws_recoff, (size_t)(n_rec + 1) * 8))) return rc;
   if ((rc = ensure(ix, ix->ws_sk, sk_bytes))) return rc;
@@ -749,37 +803,7 @@ int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint64_t 
     return hits_dev(ix, (const uint16_t *)ix->ws_counts.p, nq, stride, 0, N, (unsigned long long *)hit_off,
                     hit_counts, hit_gids, capacity, false, nullptr);
   }
-  // host: batches of query_batch sketches, hits appended in query order
-  uint64_t base = 0;
-  bool overflow = false;
-  hit_off[0] = 0;
-  const uint32_t qb = ix->query_batch;
-  std::vector<unsigned long long> off(qb + 1);
-  for (uint32_t q0 = 0; q0 < nq; q0 += qb) {
-    const uint32_t n = std::min(qb, nq - q0);
-    if ((rc = ensure(ix, ix->ws_sk, (size_t)n * ix->d.F * 4))) return rc;
-    if ((rc = ensure(ix, ix->ws_counts, std::max<size_t>((size_t)n * stride * 2, 2)))) return rc;
-    if ((rc = ensure(ix, ix->ws_hitoff, (size_t)(n + 1) * 8))) return rc;
-    const uint64_t room = overflow || base > capacity ? 0 : capacity - base;
-    if ((rc = ensure(ix, ix->ws_hc, (size_t)std::max<uint64_t>(room, 1) * 4))) return rc;
-    if ((rc = ensure(ix, ix->ws_hg, (size_t)std::max<uint64_t>(room, 1) * 4))) return rc;
-    NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, sketches + (size_t)q0 * ix->d.F, (size_t)n * ix->d.F * 4, hipMemcpyHostToDevice, ix->stream));
-    if ((rc = counts_dev(ix, (const int32_t *)ix->ws_sk.p, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
-    uint64_t total = 0;
-    rc = hits_dev(ix, (const uint16_t *)ix->ws_counts.p, n, stride, 0, N, (unsigned long long *)ix->ws_hitoff.p,
-                  (uint32_t *)ix->ws_hc.p, (uint32_t *)ix->ws_hg.p, room, true, &total);
-    if (rc && rc != NIQKI_E_CAPACITY) return rc;
-    NQ_HIP(ix, hipMemcpyAsync(off.data(), ix->ws_hitoff.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
-    if (rc == NIQKI_OK && total) {
-      NQ_HIP(ix, hipMemcpyAsync(hit_counts + base, ix->ws_hc.p, (size_t)total * 4, hipMemcpyDeviceToHost, ix->stream));
-      NQ_HIP(ix, hipMemcpyAsync(hit_gids + base, ix->ws_hg.p, (size_t)total * 4, hipMemcpyDeviceToHost, ix->stream));
-    }
-    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
-    if (rc == NIQKI_E_CAPACITY) overflow = true;
-    for (uint32_t i = 0; i < n; ++i) hit_off[q0 + i + 1] = base + off[i + 1];
-    base += off[n];
-  }
-  return overflow ? NIQKI_E_CAPACITY : NIQKI_OK;
+  return query_to_host(ix, sketches, false, nq, hit_off, hit_counts, hit_gids, capacity);
 }
 
 int niqki_query_sequences(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, uint32_t n_rec,
@@ -817,6 +841,198 @@ int niqki_get_sketches(niqki_index *ix, uint32_t begin, uint32_t n, int32_t *ske
     NQ_HIP(ix, hipStreamSynchronize(ix->stream));
   }
   return NIQKI_OK;
+}
+
+int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_stage_info *info,
+                    uint64_t *entry_hdr) {
+  if (!ix || !b || !info) return NIQKI_E_INVALID;
+  if (b->n_files && (!b->file_off || !b->file_type)) return NIQKI_E_INVALID;
+  if (b->lines && b->n_files > 1) return fail(ix, NIQKI_E_INVALID, "lines mode frames one file per call");
+  if (b->lines && b->max_entries == 0) return fail(ix, NIQKI_E_INVALID, "max_entries must be > 0");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  ix->staged.valid = false;
+  ix->staged.sketched = false;
+  *info = niqki_stage_info{0, 0, 0, 0};
+  const uint32_t nf = b->n_files;
+  const uint64_t T = nf ? b->file_off[nf] : 0;
+  if (nf && !b->raw && T) return NIQKI_E_INVALID;
+  // chunk table: chunks never span two files
+  std::vector<uint8_t> meta((size_t)(nf + 1) * 12 + nf + 16);
+  uint64_t *h_off = (uint64_t *)meta.data();
+  uint32_t *h_first = (uint32_t *)(meta.data() + (size_t)(nf + 1) * 8);
+  uint8_t *h_type = meta.data() + (size_t)(nf + 1) * 12;
+  uint64_t chunks = 0;
+  for (uint32_t f = 0; f < nf; ++f) {
+    if (b->file_off[f + 1] < b->file_off[f]) return fail(ix, NIQKI_E_INVALID, "file_off must be non-decreasing");
+    if (b->file_type[f] != 'A' && b->file_type[f] != 'Q') return fail(ix, NIQKI_E_INVALID, "file_type must be 'A' or 'Q'");
+    h_off[f] = b->file_off[f];
+    h_first[f] = (uint32_t)chunks;
+    h_type[f] = b->file_type[f];
+    chunks += (b->file_off[f + 1] - b->file_off[f] + nq::kIngestChunk - 1) / nq::kIngestChunk;
+  }
+  if (chunks > 0x7FFFFFFFull) return fail(ix, NIQKI_E_INVALID, "raw batch too large");
+  h_off[nf] = T;
+  h_first[nf] = (uint32_t)chunks;
+  int rc;
+  const uint8_t *d_raw = b->raw;
+  if (mem == NIQKI_MEM_HOST) {
+    if ((rc = ensure(ix, ix->ws_raw, (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
+    if (T) NQ_HIP(ix, hipMemcpyAsync(ix->ws_raw.p, b->raw, T, hipMemcpyHostToDevice, ix->stream));
+    d_raw = (const uint8_t *)ix->ws_raw.p;
+  } else if ((uintptr_t)d_raw & 3) {
+    return fail(ix, NIQKI_E_INVALID, "device raw bytes must be 4-byte aligned");
+  }
+  if ((rc = ensure(ix, ix->ws_fmeta, meta.size()))) return rc;
+  if ((rc = ensure(ix, ix->ws_summ, std::max<size_t>((size_t)chunks * 20, 4)))) return rc;
+  if ((rc = ensure(ix, ix->ws_chunk, std::max<size_t>((size_t)chunks * 16, 4)))) return rc;
+  if ((rc = ensure(ix, ix->ws_fkept, (size_t)(nf + 1) * 8))) return rc;
+  if ((rc = ensure(ix, ix->ws_fnrec, (size_t)(nf + 1) * 4))) return rc;
+  if ((rc = ensure(ix, ix->ws_misc, 256))) return rc;
+  NQ_HIP(ix, hipMemcpyAsync(ix->ws_fmeta.p, meta.data(), meta.size(), hipMemcpyHostToDevice, ix->stream));
+  nq::IngestArgs a;
+  a.raw = d_raw;
+  a.file_off = (const uint64_t *)ix->ws_fmeta.p;
+  a.chunk_first = (const uint32_t *)((uint8_t *)ix->ws_fmeta.p + (size_t)(nf + 1) * 8);
+  a.file_type = (const uint8_t *)ix->ws_fmeta.p + (size_t)(nf + 1) * 12;
+  a.n_files = nf;
+  a.n_chunks = (uint32_t)chunks;
+  a.summ = (uint32_t *)ix->ws_summ.p;
+  a.chunk_out = (uint32_t *)ix->ws_chunk.p;
+  a.file_kept = (uint64_t *)ix->ws_fkept.p;
+  a.file_nrec = (uint32_t *)ix->ws_fnrec.p;
+  a.totals = (uint64_t *)ix->ws_misc.p;
+  a.seqs = nullptr;
+  a.rec_off = nullptr;
+  a.hdr_pos = nullptr;
+  uint64_t totals[2] = {0, 0};
+  {
+    Span sp(ix, NIQKI_KC_INGEST);
+    NQ_HIP(ix, nq::launch_ingest_scan(a, ix->stream));
+  }
+  NQ_HIP(ix, hipMemcpyAsync(totals, a.totals, 16, hipMemcpyDeviceToHost, ix->stream));
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));  // also: `meta` and the caller's raw bytes are consumed
+  if (totals[0] > 0xFFFFFFF0ull) return fail(ix, NIQKI_E_INVALID, "too many records in one batch");
+  const uint32_t n_rec = (uint32_t)totals[0];
+  const uint64_t kept = totals[1];
+  if ((rc = ensure(ix, ix->ws_recoff, (size_t)(n_rec + 1) * 8))) return rc;
+  if ((rc = ensure(ix, ix->ws_hdrpos, std::max<size_t>((size_t)n_rec * 8, 8)))) return rc;
+  if ((rc = ensure(ix, ix->ws_seq, (size_t)kept + 2 * NIQKI_SEQ_PAD))) return rc;
+  a.seqs = (uint8_t *)ix->ws_seq.p;
+  a.rec_off = (uint64_t *)ix->ws_recoff.p;
+  a.hdr_pos = (uint64_t *)ix->ws_hdrpos.p;
+  {
+    Span sp(ix, NIQKI_KC_INGEST);
+    NQ_HIP(ix, nq::launch_ingest_emit(a, ix->stream));
+  }
+  NQ_HIP(ix, hipMemcpyAsync(a.rec_off + n_rec, a.totals + 1, 8, hipMemcpyDeviceToDevice, ix->stream));
+  NQ_HIP(ix, hipMemsetAsync(a.seqs + kept, 0, NIQKI_SEQ_PAD, ix->stream));
+  uint32_t n_entry = nf;
+  uint64_t consumed = T;
+  const uint32_t *d_entry = a.file_nrec;  // whole mode: entry f = the records of file f
+  if (b->lines) {
+    const uint32_t n_use = b->final ? n_rec : (n_rec ? n_rec - 1 : 0);
+    if ((rc = ensure(ix, ix->ws_entry, (size_t)(b->max_entries + 1) * 4))) return rc;
+    if ((rc = ensure(ix, ix->ws_ehdr, (size_t)b->max_entries * 8))) return rc;
+    uint32_t *d_res = (uint32_t *)((uint8_t *)ix->ws_misc.p + 64);
+    NQ_HIP(ix, nq::launch_ingest_entries(a.rec_off, a.hdr_pos, n_use, ix->d.K, b->max_entries,
+                                         (uint32_t *)ix->ws_entry.p, (uint64_t *)ix->ws_ehdr.p, d_res, ix->stream));
+    uint32_t res[2] = {0, 0};
+    NQ_HIP(ix, hipMemcpyAsync(res, d_res, 8, hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    n_entry = res[0];
+    if (res[1] < n_rec)
+      NQ_HIP(ix, hipMemcpyAsync(&consumed, a.hdr_pos + res[1], 8, hipMemcpyDeviceToHost, ix->stream));
+    if (entry_hdr && n_entry)
+      NQ_HIP(ix, hipMemcpyAsync(entry_hdr, ix->ws_ehdr.p, (size_t)n_entry * 8, hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    d_entry = (const uint32_t *)ix->ws_entry.p;
+  }
+  ix->staged.valid = true;
+  ix->staged.n_entry = n_entry;
+  ix->staged.n_rec = n_rec;
+  ix->staged.seq_bytes = kept;
+  ix->staged.entry_rec = d_entry;
+  info->n_entry = n_entry;
+  info->n_rec = n_rec;
+  info->consumed = consumed;
+  info->seq_bytes = kept;
+  return NIQKI_OK;
+}
+
+namespace {
+// sketches of the staged entries into ws_sk (once per staged batch)
+int staged_sketch_ws(niqki_index *ix) {
+  if (!ix->staged.valid) return fail(ix, NIQKI_E_STATE, "no staged batch (niqki_stage_raw first)");
+  if (ix->staged.sketched) return NIQKI_OK;
+  const uint32_t n = ix->staged.n_entry;
+  int rc = ensure(ix, ix->ws_sk, std::max<size_t>((size_t)n * ix->d.F * 4, 4));
+  if (rc) return rc;
+  rc = sketch_dev(ix, (const uint8_t *)ix->ws_seq.p, (const uint64_t *)ix->ws_recoff.p, ix->staged.n_rec,
+                  ix->staged.entry_rec, n, (int32_t *)ix->ws_sk.p, ix->staged.seq_bytes);
+  if (rc) return rc;
+  ix->staged.sketched = true;
+  return NIQKI_OK;
+}
+}  // namespace
+
+int niqki_staged_sketch(niqki_index *ix, int32_t *sketches, int mem) {
+  if (!ix) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = staged_sketch_ws(ix);
+  if (rc) return rc;
+  const size_t bytes = (size_t)ix->staged.n_entry * ix->d.F * 4;
+  if (!bytes) return NIQKI_OK;
+  if (!sketches) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipMemcpyAsync(sketches, ix->ws_sk.p, bytes,
+                            mem == NIQKI_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ix->stream));
+  if (mem == NIQKI_MEM_HOST) NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  return NIQKI_OK;
+}
+
+int niqki_staged_insert(niqki_index *ix) {
+  if (!ix) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = staged_sketch_ws(ix);
+  if (rc) return rc;
+  return niqki_insert(ix, (const int32_t *)ix->ws_sk.p, ix->staged.n_entry, NIQKI_MEM_DEVICE);
+}
+
+int niqki_staged_query(niqki_index *ix, uint64_t *hit_off, uint32_t *hit_counts, uint32_t *hit_gids,
+                       uint64_t capacity, int mem) {
+  if (!ix || !hit_off) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = staged_sketch_ws(ix);
+  if (rc) return rc;
+  if (mem == NIQKI_MEM_DEVICE)
+    return niqki_query(ix, (const int32_t *)ix->ws_sk.p, ix->staged.n_entry, hit_off, hit_counts, hit_gids,
+                       capacity, NIQKI_MEM_DEVICE);
+  if ((rc = build_if_needed(ix))) return rc;
+  return query_to_host(ix, (const int32_t *)ix->ws_sk.p, true, ix->staged.n_entry, hit_off, hit_counts,
+                       hit_gids, capacity);
+}
+
+int niqki_staged_records(niqki_index *ix, uint64_t *rec_off, uint8_t *seqs, uint32_t *entry_rec,
+                         uint64_t *hdr_pos) {
+  if (!ix) return NIQKI_E_INVALID;
+  if (!ix->staged.valid) return fail(ix, NIQKI_E_STATE, "no staged batch (niqki_stage_raw first)");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  const auto &st = ix->staged;
+  if (rec_off) NQ_HIP(ix, hipMemcpyAsync(rec_off, ix->ws_recoff.p, (size_t)(st.n_rec + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
+  if (seqs && st.seq_bytes) NQ_HIP(ix, hipMemcpyAsync(seqs, ix->ws_seq.p, st.seq_bytes, hipMemcpyDeviceToHost, ix->stream));
+  if (entry_rec) NQ_HIP(ix, hipMemcpyAsync(entry_rec, st.entry_rec, (size_t)(st.n_entry + 1) * 4, hipMemcpyDeviceToHost, ix->stream));
+  if (hdr_pos && st.n_rec) NQ_HIP(ix, hipMemcpyAsync(hdr_pos, ix->ws_hdrpos.p, (size_t)st.n_rec * 8, hipMemcpyDeviceToHost, ix->stream));
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  return NIQKI_OK;
+}
+
+void *niqki_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void niqki_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int niqki_matrix_range(niqki_index *ix, uint32_t begin, uint32_t end, uint16_t *counts, uint64_t stride,

@@ -118,6 +118,34 @@ hipError_t launch_candidates(const uint16_t *counts, uint64_t stride, uint32_t n
 hipError_t launch_hits_count(const HitsArgs &a, hipStream_t stream);
 hipError_t launch_hits_emit(const HitsArgs &a, hipStream_t stream);
 
+// ---- FASTA / FASTQ framing (nq_ingest.hip) --------------------------------------
+constexpr uint32_t kIngestBlock = 256;
+constexpr uint32_t kIngestChunk = 8192;  // bytes per workgroup; chunks never span two files
+struct IngestArgs {
+  const uint8_t *raw;           // bytes of all files (16-byte aligned, >= 64 readable bytes after the end)
+  const uint64_t *file_off;     // n_files+1 offsets into raw
+  const uint8_t *file_type;     // n_files: 'A' (FASTA) or 'Q' (FASTQ)
+  const uint32_t *chunk_first;  // n_files+1: first chunk of each file
+  uint32_t n_files, n_chunks;
+  uint32_t *summ;               // n_chunks x 5, pass 1 -> 2
+  uint32_t *chunk_out;          // n_chunks x 4, pass 2 -> 3
+  uint64_t *file_kept;          // n_files+1: sequence bytes before each file (after launch_ingest_scan)
+  uint32_t *file_nrec;          // n_files+1: records before each file   (  "  )
+  uint64_t *totals;             // {records, sequence bytes}
+  uint8_t *seqs;                // out: record sequences back to back
+  uint64_t *rec_off;            // out: n_rec+1 (entry n_rec is written by the caller)
+  uint64_t *hdr_pos;            // out: raw offset of each record's header line
+};
+// passes 1+2 (census, per-file chaining, bases); then the caller sizes rec_off/hdr_pos
+// from totals[0] and runs pass 3
+hipError_t launch_ingest_scan(const IngestArgs &a, hipStream_t stream);
+hipError_t launch_ingest_emit(const IngestArgs &a, hipStream_t stream);
+// lines mode: records [0, n_use) longer than K -> entries (<= max_entries);
+// result = {n_entry, first record not consumed}; entry_rec gets n_entry+1 values
+hipError_t launch_ingest_entries(const uint64_t *rec_off, const uint64_t *hdr_pos, uint32_t n_use, uint32_t K,
+                                 uint32_t max_entries, uint32_t *entry_rec, uint64_t *entry_hdr,
+                                 uint32_t *result, hipStream_t stream);
+
 // ---- synthetic genomes (nq_synth.hip) ----------------------------------------
 hipError_t launch_synth(uint64_t seed, const uint32_t *family, const uint32_t *member,
                         const uint32_t *rate14, uint32_t n, uint64_t len, uint64_t stride,

@@ -258,6 +258,66 @@ class Index:
         return ix
 
 
+# ---- record framing ----------------------------------------------------------
+
+class _Stream:
+    """std::istream over a byte string, as far as getline / peek / eof go."""
+
+    def __init__(self, data):
+        self.d, self.pos, self.eofbit, self.failbit = bytes(data), 0, False, False
+
+    def getline(self, old):
+        if self.failbit or self.eofbit:          # sentry fails: the string keeps its content
+            self.failbit = True
+            return old
+        if self.pos >= len(self.d):              # nothing extracted
+            self.eofbit = self.failbit = True
+            return b""
+        j = self.d.find(b"\n", self.pos)
+        if j < 0:
+            line, self.pos, self.eofbit = self.d[self.pos:], len(self.d), True
+        else:
+            line, self.pos = self.d[self.pos:j], j + 1
+        return line
+
+    def peek(self):
+        if self.failbit or self.eofbit:
+            self.failbit = self.failbit or False
+            return -1
+        if self.pos >= len(self.d):
+            self.eofbit = True
+            return -1
+        b = self.d[self.pos]
+        return b - 256 if b >= 128 else b        # `char c = in->peek()` is signed: 0xFF == EOF
+
+
+def frame_records(data, type_, K):
+    """`while(!in.eof()) Biogetline(...)` of src/niqki_index.cpp:890-941 and its callers
+    (:390-403, :446-453): the (header line offset, header, sequence) of every record
+    LONGER THAN K, in file order."""
+    st = _Stream(data)
+    out = []
+    header = result = discard = b""
+    while not st.eofbit:
+        result = b""
+        hdr_at = st.pos
+        if type_ == "Q":
+            header = st.getline(header)
+            result = st.getline(result)
+            discard = st.getline(discard)
+            discard = st.getline(discard)
+        else:
+            header = st.getline(header)
+            c = st.peek()
+            while c != ord(">") and c != -1:
+                discard = st.getline(discard)
+                result += discard
+                c = st.peek()
+        if len(result) > K:
+            out.append((hdr_at, header, result))
+    return out
+
+
 # ---- the real reference (only where oracle/_ref was built) ------------------
 
 def have_ref():

@@ -6,7 +6,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import synth_case
+from conftest import family_spec, synth_case
 
 
 def test_hash_and_fingerprint_kats(po, gold):
@@ -155,6 +155,37 @@ def test_cli_golden_first_line_shape(gold):
     hits = meta["cli"]["hits"].splitlines()
     assert len(hits) == 12 and hits[0].startswith("syn00.fa syn00.fa:1 ")
     assert meta["cli"]["matrix"].startswith("##Names\tsyn00.fa\t")
+
+
+def test_record_framing_restatement_vs_reference_cli(po, native, gold):
+    """Pins oracle/pyoracle.py frame_records (Index::Biogetline + its callers' loops,
+    src/niqki_index.cpp:383-430, :890-941) on what the reference CLI printed for the
+    hand-made FASTA / FASTQ files with every framing oddity (lines mode, J=0: every
+    record lists all 12 genomes with its exact counts)."""
+    _, meta = gold
+    cli = meta["cli"]
+    fam, mem, rate = family_spec(4, 8)
+    genomes = [native.synth_genome_host(meta["seed"], int(f), int(m), int(r), 40000)
+               for f, m, r in zip(fam[:12], mem[:12], rate[:12])]
+    p = po.make_params(31, 10, 12, 4, 0.0)
+    ix = po.Index(p, np.stack([po.compute_sketch(p, g) for g in genomes]))
+    names = ["syn%02d.fa" % i for i in range(12)]
+    for key, ty in (("nasty_fa", "A"), ("nasty_fq", "Q")):
+        data = cli[key + "_input"].encode("latin1")
+        lines = []
+        for _, header, seq in po.frame_records(data, ty, 31):
+            hc, hg = ix.query(po.compute_sketch(p, seq))
+            lines.append(header.decode("latin1") + " " + "".join("%s:%g " % (names[g], c / 1024) for c, g in zip(hc, hg)))
+        assert "\n".join(lines) + "\n" == cli[key], key
+    # -i: the headers become the genome names
+    data = cli["nasty_fa_input"].encode("latin1")
+    recs = po.frame_records(data, "A", 31)
+    ix2 = po.Index(po.make_params(31, 10, 12, 4, 0.02), np.stack([po.compute_sketch(p, s) for _, _, s in recs]))
+    lines = []
+    for i, g in enumerate(genomes):
+        hc, hg = ix2.query(po.compute_sketch(p, g), min_score=20)
+        lines.append(names[i] + " " + "".join("%s:%g " % (recs[g_][1].decode("latin1"), c / 1024) for c, g_ in zip(hc, hg)))
+    assert "\n".join(lines) + "\n" == cli["nasty_idx"]
 
 
 def test_ecoli_pins_when_reference_present(po, gold):

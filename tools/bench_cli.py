@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""End-to-end timing of the `niqki` host program (niqki_amd/bin/niqki) on files:
+N synthetic genomes written as FASTA (70 columns, optionally gzip level 1), then
+  niqki -I fof -Q fof -J 0.1            (whole-file mode)
+and, with --reads R, a FASTA of R 150-base reads through -l (lines mode) against
+that index.  Prints one JSON line with wall times and rates.  File bytes are the
+inputs of the measurement, so they are written to --dir first (default /dev/shm:
+page cache speed, i.e. the storage is taken out of the picture)."""
+import argparse
+import gzip
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+BIN = os.path.join(ROOT, "niqki_amd", "bin", "niqki")
+
+
+def write_fasta(path, name, seq, gz):
+    rows = np.frombuffer(seq[: len(seq) // 70 * 70], np.uint8).reshape(-1, 70)
+    body = np.concatenate([rows, np.full((rows.shape[0], 1), 10, np.uint8)], axis=1).tobytes()
+    tail = bytes(seq[len(seq) // 70 * 70:])
+    data = b">" + name.encode() + b"\n" + body + (tail + b"\n" if tail else b"")
+    if gz:
+        with gzip.open(path, "wb", compresslevel=1) as f:
+            f.write(data)
+    else:
+        with open(path, "wb") as f:
+            f.write(data)
+    return len(data)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genomes", type=int, default=512)
+    ap.add_argument("--len", type=int, default=5_000_000)
+    ap.add_argument("--reads", type=int, default=0)
+    ap.add_argument("--gz", action="store_true")
+    ap.add_argument("--dir", default="/dev/shm/niqki_cli_bench")
+    ap.add_argument("--extra", default="", help="extra CLI options, space separated")
+    args = ap.parse_args()
+    import niqki_amd
+    shutil.rmtree(args.dir, ignore_errors=True)
+    os.makedirs(args.dir)
+    try:
+        names, raw_bytes = [], 0
+        for g in range(args.genomes):
+            seq = niqki_amd.synth_genome_host(11, g // 16, g % 16, 0 if g % 16 == 0 else 20 + 40 * (g % 16), args.len)
+            fn = os.path.join(args.dir, "g%05d.fa%s" % (g, ".gz" if args.gz else ""))
+            raw_bytes += write_fasta(fn, "g%05d" % g, seq, args.gz)
+            names.append(fn)
+        open(os.path.join(args.dir, "fof.txt"), "w").write("\n".join(names) + "\n")
+        extra = args.extra.split()
+        res = {"genomes": args.genomes, "len": args.len, "gz": args.gz, "fasta_bytes": raw_bytes}
+
+        def run(tag, cli):
+            t0 = time.time()
+            r = subprocess.run([BIN] + cli + extra, cwd=args.dir, capture_output=True, text=True, timeout=1800)
+            dt = time.time() - t0
+            if r.returncode != 0:
+                print(r.stdout[-2000:], r.stderr[-2000:], file=sys.stderr)
+                raise SystemExit(1)
+            res[tag + "_s"] = round(dt, 3)
+            return dt
+        dt = run("index_only", ["-I", "fof.txt", "-J", "0.1", "-O", "o1.gz"])
+        res["index_genomes_per_s"] = round(args.genomes / dt, 1)
+        res["index_fasta_GBps"] = round(raw_bytes / dt / 1e9, 3)
+        dt2 = run("index_query", ["-I", "fof.txt", "-Q", "fof.txt", "-J", "0.1", "-O", "o2.gz"])
+        res["query_genomes_per_s"] = round(args.genomes / max(dt2 - dt, 1e-9), 1)
+        if args.reads:
+            rng = np.random.default_rng(3)
+            src = niqki_amd.synth_genome_host(11, 0, 0, 0, args.len)
+            st = rng.integers(0, args.len - 150, args.reads)
+            with open(os.path.join(args.dir, "reads.fa"), "wb") as f:
+                for i in range(0, args.reads, 65536):
+                    blk = [b">r%d\n" % (i + j) + bytes(src[s:s + 150]) + b"\n" for j, s in enumerate(st[i:i + 65536])]
+                    f.write(b"".join(blk))
+            dt3 = run("index_lines", ["-I", "fof.txt", "-l", "reads.fa", "-S", "12", "-W", "10", "-J", "0.1", "-O", "o3.gz"])
+            dt4 = run("index_s12", ["-I", "fof.txt", "-S", "12", "-W", "10", "-J", "0.1", "-O", "o4.gz"])
+            res["reads_per_s"] = round(args.reads / max(dt3 - dt4, 1e-9), 1)
+        print(json.dumps(res))
+    finally:
+        shutil.rmtree(args.dir, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
