@@ -207,7 +207,10 @@ int niqki_query_sequences(niqki_index *ix, const uint8_t *seqs,
 typedef struct niqki_raw_batch {
   const uint8_t *raw;        /* bytes of n_files files back to back, in the memory space of the
                                 call (device: 4-byte aligned, NIQKI_SEQ_PAD readable bytes after) */
-  const uint64_t *file_off;  /* HOST array, n_files+1 offsets into raw */
+  const uint8_t *const *file_ptr; /* optional (host memory space only): HOST array of n_files host
+                                pointers, file f's bytes start at file_ptr[f]; raw is then ignored */
+  const uint64_t *file_off;  /* HOST array, n_files+1 offsets into raw (their differences are the
+                                file sizes when file_ptr is used) */
   const uint8_t *file_type;  /* HOST array, n_files: 'A' FASTA / 'Q' FASTQ (get_data_type, :944-952) */
   uint32_t n_files;
   uint32_t lines;            /* 0: one sketch per file (whole mode); 1: one sketch per record longer

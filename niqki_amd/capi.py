@@ -31,7 +31,7 @@ class Params(C.Structure):
 
 
 class RawBatch(C.Structure):
-    _fields_ = [("raw", C.c_void_p), ("file_off", C.c_void_p), ("file_type", C.c_void_p),
+    _fields_ = [("raw", C.c_void_p), ("file_ptr", C.c_void_p), ("file_off", C.c_void_p), ("file_type", C.c_void_p),
                 ("n_files", C.c_uint32), ("lines", C.c_uint32), ("final", C.c_uint32),
                 ("max_entries", C.c_uint32)]
 
@@ -308,9 +308,10 @@ class Engine:
             self.h, _p(seqs), _p(off), nq, None, nq, _p(ho), _p(hc), _p(hg), c, MEM_HOST), nq, cap)
 
     # -- raw file bytes, framed on the GPU (niqki_stage_raw and friends)
-    def stage_raw(self, files, types=None, lines=False, final=True, max_entries=16384):
+    def stage_raw(self, files, types=None, lines=False, final=True, max_entries=16384, scattered=False):
         """files: list of bytes-like (the gunzipped content of each file).  Returns
-        (StageInfo, entry_hdr) -- entry_hdr: raw offset of each entry's header line (lines mode)."""
+        (StageInfo, entry_hdr) -- entry_hdr: raw offset of each entry's header line (lines mode).
+        scattered: hand the files over as separate buffers (file_ptr) instead of one."""
         blobs = [np.frombuffer(bytes(f), dtype=np.uint8) for f in files]
         off = np.zeros(len(blobs) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([b.size for b in blobs], dtype=np.uint64)
@@ -318,8 +319,12 @@ class Engine:
         ty = np.frombuffer(("".join(types) if types else "A" * len(blobs)).encode(), dtype=np.uint8).copy()
         if ty.size == 0:
             ty = np.zeros(1, np.uint8)
-        b = RawBatch(_p(raw) if raw.size else None, _p(off), _p(ty), len(blobs), int(bool(lines)), int(bool(final)),
-                     max_entries)
+        ptrs = None
+        if scattered:
+            keep = [np.ascontiguousarray(x).copy() for x in blobs]
+            ptrs = (C.c_void_p * max(len(keep), 1))(*[k.ctypes.data for k in keep])
+        b = RawBatch(None if scattered or not raw.size else _p(raw), C.cast(ptrs, C.c_void_p) if scattered else None,
+                     _p(off), _p(ty), len(blobs), int(bool(lines)), int(bool(final)), max_entries)
         info = StageInfo()
         hdr = np.zeros(max(max_entries, 1), dtype=np.uint64)
         self._ck(self.L.niqki_stage_raw(self.h, C.byref(b), MEM_HOST, C.byref(info), _p(hdr) if lines else None))

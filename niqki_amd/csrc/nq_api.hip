@@ -855,7 +855,8 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   *info = niqki_stage_info{0, 0, 0, 0};
   const uint32_t nf = b->n_files;
   const uint64_t T = nf ? b->file_off[nf] : 0;
-  if (nf && !b->raw && T) return NIQKI_E_INVALID;
+  if (nf && !b->raw && !b->file_ptr && T) return NIQKI_E_INVALID;
+  if (b->file_ptr && mem != NIQKI_MEM_HOST) return fail(ix, NIQKI_E_INVALID, "file_ptr needs the host memory space");
   // chunk table: chunks never span two files
   std::vector<uint8_t> meta((size_t)(nf + 1) * 12 + nf + 16);
   uint64_t *h_off = (uint64_t *)meta.data();
@@ -877,7 +878,14 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   const uint8_t *d_raw = b->raw;
   if (mem == NIQKI_MEM_HOST) {
     if ((rc = ensure(ix, ix->ws_raw, (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
-    if (T) NQ_HIP(ix, hipMemcpyAsync(ix->ws_raw.p, b->raw, T, hipMemcpyHostToDevice, ix->stream));
+    if (b->file_ptr) {
+      for (uint32_t f = 0; f < nf; ++f) {
+        const uint64_t n = b->file_off[f + 1] - b->file_off[f];
+        if (n) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_raw.p + b->file_off[f], b->file_ptr[f], n, hipMemcpyHostToDevice, ix->stream));
+      }
+    } else if (T) {
+      NQ_HIP(ix, hipMemcpyAsync(ix->ws_raw.p, b->raw, T, hipMemcpyHostToDevice, ix->stream));
+    }
     d_raw = (const uint8_t *)ix->ws_raw.p;
   } else if ((uintptr_t)d_raw & 3) {
     return fail(ix, NIQKI_E_INVALID, "device raw bytes must be 4-byte aligned");

@@ -1,10 +1,16 @@
-// index_host.cpp -- file-level drivers of the `niqki` host program.  Reads
-// FASTA/FASTQ exactly like the reference (seqio.h), batches records, and calls
-// the gfx950 engine through the C ABI (include/niqki_hip.h).  No sketching,
-// counting or sorting happens on the host.
+// index_host.cpp -- file-level drivers of the `niqki` host program.  Moves the
+// bytes of the input files into page-locked memory and calls the gfx950 engine
+// through the C ABI (include/niqki_hip.h): record framing (the reference's
+// Biogetline), sketching, counting and sorting all happen on the GPU.
 #include "index_host.h"
 
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <unistd.h>
+
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 
 #include <cstdio>
 #include <cstring>
@@ -30,99 +36,161 @@ std::string fmt_double(double v) {
   snprintf(buf, sizeof buf, "%g", v);
   return buf;
 }
-constexpr size_t kBatchBytes = size_t(1) << 30;   // sequence bytes per GPU call
-constexpr size_t kBatchEntries = 16384;           // sketches per GPU call
+constexpr size_t kBatchBytes = size_t(1) << 30;   // dump import: bytes per GPU call
 
-// All records longer than K of one sequence file (insert_file_whole /
-// query_file_whole read loop, src/niqki_index.cpp:446-453, :510-515).
-std::vector<std::string> read_whole_file(const std::string &path, size_t K) {
-  std::vector<std::string> recs;
-  const char type = data_type(path);
-  GzReader fin(path);
-  std::string rec, header;
-  while (!fin.eof()) {
-    bio_getline(fin, rec, type, header, K);
-    if (rec.size() > K) recs.push_back(rec);
-  }
-  return recs;
-}
-
-// Reads (and gunzips) the files of a list on several threads -- the reference
-// does this part in its OpenMP region, one file per thread -- and hands them to
-// `consume` strictly in list order, so genome ids and output order are those of
-// a single-threaded run.
-template <typename Consume>
-void for_each_file_in_order(const std::vector<std::string> &paths, size_t K, Consume consume) {
-  unsigned threads = std::thread::hardware_concurrency();
-  threads = threads ? std::min(threads, 32u) : 4u;
-  const size_t window = (size_t)threads * 2;
-  for (size_t w0 = 0; w0 < paths.size(); w0 += window) {
-    const size_t w1 = std::min(paths.size(), w0 + window);
-    std::vector<std::vector<std::string>> recs(w1 - w0);
-    std::vector<std::string> errs(w1 - w0);
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < threads; ++t)
-      pool.emplace_back([&, t] {
-        for (size_t i = w0 + t; i < w1; i += threads) {
-          try { recs[i - w0] = read_whole_file(paths[i], K); } catch (const std::exception &e) { errs[i - w0] = e.what(); }
-        }
-      });
-    for (auto &th : pool) th.join();
-    for (size_t i = w0; i < w1; ++i) {
-      if (!errs[i - w0].empty()) throw std::runtime_error(errs[i - w0]);
-      consume(paths[i], recs[i - w0]);
-    }
-  }
-}
-}  // namespace
-
-// A batch of records on their way to the GPU: entry e = records
-// [entry_rec[e], entry_rec[e+1]) of seqs, name[e] its label.
-struct Index::Batch {
-  std::vector<uint8_t> seqs;
-  std::vector<uint64_t> rec_off{0};
-  std::vector<uint32_t> entry_rec{0};
-  std::vector<std::string> names;
-  void add_record(const std::string &s) {
-    seqs.insert(seqs.end(), s.begin(), s.end());
-    rec_off.push_back(seqs.size());
-  }
-  void end_entry(const std::string &name) {
-    entry_rec.push_back((uint32_t)(rec_off.size() - 1));
-    names.push_back(name);
-  }
-  size_t n_entries() const { return names.size(); }
-  bool full() const { return seqs.size() >= kBatchBytes || names.size() >= kBatchEntries; }
-  void clear() {
-    seqs.clear();
-    rec_off.assign(1, 0);
-    entry_rec.assign(1, 0);
-    names.clear();
+// ---- raw file bytes in page-locked memory --------------------------------------
+// The GPU frames the records (niqki_stage_raw), so the host only moves bytes:
+// files are read (and gunzipped) straight into page-locked buffers that the
+// library copies from by DMA.
+struct PinnedBuf {
+  uint8_t *p = nullptr;
+  size_t cap = 0, size = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf &) = delete;
+  PinnedBuf &operator=(const PinnedBuf &) = delete;
+  ~PinnedBuf() { niqki_host_free(p); }
+  void reserve(size_t n) {  // keeps the first `size` bytes
+    if (n <= cap) return;
+    const size_t want = std::max(n, cap + cap / 2);
+    uint8_t *q = (uint8_t *)niqki_host_alloc(want);
+    if (!q) throw std::runtime_error("page-locked allocation of " + std::to_string(want) + " bytes failed");
+    if (size) std::memcpy(q, p, size);
+    niqki_host_free(p);
+    p = q;
+    cap = want;
   }
 };
 
-// Runs the GPU call of a full batch on a helper thread while the caller parses
-// the next one; batches are flushed strictly one after another (the handle is
-// used by one thread at a time and output order is input order).
-class Index::Pipeline {
- public:
-  using Fn = void (Index::*)(Batch &);
-  Pipeline(Index *ix, Fn fn) : ix_(ix), fn_(fn) {}
-  ~Pipeline() { try { wait(); } catch (...) {} }
-  void submit(Batch &b) {
-    wait();
-    auto job = std::make_shared<Batch>(std::move(b));
-    b.clear();
-    pending_ = std::async(std::launch::async, [this, job] { (ix_->*fn_)(*job); });
+// Whole content of a file, gunzipped when it starts with the gzip magic (the
+// reference's zstr::ifstream auto-detects the same way, src/zstr.hpp:190-203).
+void read_file_bytes(const std::string &path, PinnedBuf &out) {
+  out.size = 0;
+  const int fd = ::open(path.c_str(), O_RDONLY);
+  if (fd < 0) throw std::runtime_error("cannot open '" + path + "'");
+  struct stat st;
+  if (fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("cannot stat '" + path + "'"); }
+  unsigned char magic[2] = {0, 0};
+  const ssize_t m = pread(fd, magic, 2, 0);
+  if (m == 2 && magic[0] == 0x1F && magic[1] == 0x8B) {
+    gzFile g = gzdopen(fd, "rb");  // owns fd from here
+    if (!g) { ::close(fd); throw std::runtime_error("cannot open '" + path + "'"); }
+    gzbuffer(g, 1 << 20);
+    out.reserve(std::max<size_t>((size_t)st.st_size * 4, size_t(1) << 20));
+    for (;;) {
+      if (out.size == out.cap) out.reserve(out.cap * 2);
+      const int n = gzread(g, out.p + out.size, (unsigned)std::min<size_t>(out.cap - out.size, 1u << 30));
+      if (n < 0) { gzclose(g); throw std::runtime_error("'" + path + "': gzip stream is damaged"); }
+      if (n == 0) break;
+      out.size += (size_t)n;
+    }
+    gzclose(g);
+    return;
   }
-  void wait() {
-    if (pending_.valid()) pending_.get();  // rethrows a failure of the helper thread
+  out.reserve(std::max<size_t>((size_t)st.st_size, 64));
+  for (;;) {  // regular files give st_size bytes; pipes and growing files are read to their end
+    if (out.size == out.cap) out.reserve(out.cap * 2);
+    const ssize_t n = ::read(fd, out.p + out.size, std::min<size_t>(out.cap - out.size, size_t(1) << 30));
+    if (n < 0) { ::close(fd); throw std::runtime_error("cannot read '" + path + "'"); }
+    if (n == 0) break;
+    out.size += (size_t)n;
+    if (out.size == (size_t)st.st_size && S_ISREG(st.st_mode)) break;
+  }
+  ::close(fd);
+}
+
+unsigned host_threads() {
+  if (const char *v = std::getenv("NIQKI_HOST_THREADS")) {
+    const int n = std::atoi(v);
+    if (n > 0) return (unsigned)std::min(n, 256);
+  }
+  const unsigned hw = std::thread::hardware_concurrency();
+  return hw ? std::min(hw, 32u) : 4u;
+}
+
+// Reads the files of a list on several threads -- the reference does this part in
+// its OpenMP region, one file per thread -- and hands them out strictly in list
+// order, so genome ids and output order are those of a single-threaded run.  A
+// reader takes a buffer BEFORE it takes the next file index, so the oldest
+// outstanding file always owns one and the consumer can never starve.
+class OrderedFileReader {
+ public:
+  struct File {
+    PinnedBuf buf;
+    std::string err;
+  };
+  OrderedFileReader(const std::vector<std::string> &paths, unsigned threads, size_t n_bufs)
+      : paths_(paths), bufs_(n_bufs), ready_(paths.size(), nullptr) {
+    for (auto &b : bufs_) free_.push_back(&b);
+    threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(paths.size(), 1));
+    for (unsigned t = 0; t < threads; ++t) pool_.emplace_back([this] { work(); });
+  }
+  ~OrderedFileReader() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_ = true;
+    }
+    cv_free_.notify_all();
+    for (auto &t : pool_) t.join();
+  }
+  // next file of the list, or nullptr after the last one; give it back with release()
+  File *next() {
+    std::unique_lock<std::mutex> g(mu_);
+    if (taken_ >= paths_.size()) return nullptr;
+    cv_ready_.wait(g, [&] { return ready_[taken_] != nullptr; });
+    File *f = ready_[taken_++];
+    if (!f->err.empty()) throw std::runtime_error(f->err);
+    return f;
+  }
+  void release(File *f) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      free_.push_back(f);
+    }
+    cv_free_.notify_one();
   }
 
  private:
-  Index *ix_;
-  Fn fn_;
-  std::future<void> pending_;
+  void work() {
+    for (;;) {
+      File *f;
+      size_t idx;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_free_.wait(g, [&] { return stop_ || issued_ >= paths_.size() || !free_.empty(); });
+        if (stop_ || issued_ >= paths_.size()) return;
+        f = free_.back();
+        free_.pop_back();
+        idx = issued_++;
+      }
+      f->err.clear();
+      try { read_file_bytes(paths_[idx], f->buf); } catch (const std::exception &e) { f->err = e.what(); f->buf.size = 0; }
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        ready_[idx] = f;
+      }
+      cv_ready_.notify_all();
+    }
+  }
+  const std::vector<std::string> &paths_;
+  std::deque<File> bufs_;
+  std::vector<File *> free_, ready_;
+  std::vector<std::thread> pool_;
+  std::mutex mu_;
+  std::condition_variable cv_free_, cv_ready_;
+  size_t issued_ = 0, taken_ = 0;
+  bool stop_ = false;
+};
+
+constexpr size_t kWholeBatchFiles = 128;               // files per GPU call (whole-file mode)
+constexpr size_t kWholeBatchBytes = size_t(3) << 29;   // ... or 1.5 GB
+constexpr size_t kReaderBufs = 2 * kWholeBatchFiles + 32;
+}  // namespace
+
+// Files of one GPU call (whole-file mode): one sketch per file.
+struct Index::Batch {
+  std::vector<OrderedFileReader::File *> files;
+  std::vector<std::string> names;
+  size_t bytes = 0;
 };
 
 void Index::check(int rc, const char *what) const {
@@ -222,17 +290,83 @@ query_output Index::query_sketch(const std::vector<int32_t> &sketch) const {
   return r;
 }
 
-// ---- insertion ---------------------------------------------------------------
+// ---- insertion / query drivers ---------------------------------------------------
+
+// stage the files of a batch: one entry per file (insert_file_whole / query_file_whole,
+// src/niqki_index.cpp:442-456, :505-519)
+void Index::stage_batch(Batch &b) {
+  const size_t n = b.files.size();
+  std::vector<const uint8_t *> ptr(n);
+  std::vector<uint64_t> off(n + 1, 0);
+  std::vector<uint8_t> type(n);
+  for (size_t i = 0; i < n; ++i) {
+    ptr[i] = b.files[i]->buf.p;
+    off[i + 1] = off[i] + b.files[i]->buf.size;
+    type[i] = (uint8_t)data_type(b.names[i]);
+  }
+  niqki_raw_batch rb{};
+  rb.file_ptr = ptr.data();
+  rb.file_off = off.data();
+  rb.file_type = type.data();
+  rb.n_files = (uint32_t)n;
+  niqki_stage_info info{};
+  check(niqki_stage_raw(h_, &rb, NIQKI_MEM_HOST, &info, nullptr), "niqki_stage_raw");
+}
 
 void Index::flush_insert(Batch &b) {
-  const size_t n = b.n_entries();
-  if (!n) return;
-  std::vector<int32_t> sk(n * (size_t)F);
-  check(niqki_sketch(h_, b.seqs.data(), b.rec_off.data(), (uint32_t)(b.rec_off.size() - 1), b.entry_rec.data(),
-                     (uint32_t)n, sk.data(), NIQKI_MEM_HOST), "niqki_sketch");
-  check(niqki_insert(h_, sk.data(), (uint32_t)n, NIQKI_MEM_HOST), "niqki_insert");
+  if (b.files.empty()) return;
+  stage_batch(b);
+  check(niqki_staged_insert(h_), "niqki_staged_insert");
   for (auto &nm : b.names) filenames.push_back(nm);
-  b.clear();
+}
+
+// hits of the staged entries, written in entry order
+void Index::output_staged(const std::vector<std::string> &names) {
+  const size_t n = names.size();
+  const uint64_t N = niqki_genome_count(h_);
+  uint64_t cap = std::max<uint64_t>(uint64_t(1) << 20, n * 64);
+  std::vector<uint64_t> off(n + 1);
+  std::vector<uint32_t> hc, hg;
+  for (;;) {
+    hc.resize(cap);
+    hg.resize(cap);
+    const int rc = niqki_staged_query(h_, off.data(), hc.data(), hg.data(), cap, NIQKI_MEM_HOST);
+    if (rc == NIQKI_E_CAPACITY && cap < n * N) { cap = std::max(off[n], cap * 2); continue; }
+    check(rc, "niqki_staged_query");
+    break;
+  }
+  query_output one;
+  for (size_t i = 0; i < n; ++i) {
+    one.clear();
+    for (uint64_t j = off[i]; j < off[i + 1]; ++j) one.push_back({hc[j], hg[j]});
+    output_query(one, names[i]);
+  }
+}
+
+void Index::flush_query(Batch &b) {
+  if (b.files.empty()) return;
+  stage_batch(b);
+  output_staged(b.names);
+}
+
+void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*flush)(Batch &)) {
+  OrderedFileReader rd(paths, host_threads(), kReaderBufs);
+  Batch b;
+  auto done = [&] {
+    (this->*flush)(b);
+    for (auto *f : b.files) rd.release(f);
+    b.files.clear();
+    b.names.clear();
+    b.bytes = 0;
+  };
+  size_t i = 0;
+  while (auto *f = rd.next()) {
+    b.files.push_back(f);
+    b.names.push_back(paths[i++]);
+    b.bytes += f->buf.size;
+    if (b.files.size() >= kWholeBatchFiles || b.bytes >= kWholeBatchBytes) done();
+  }
+  done();
 }
 
 void Index::insert_file_of_file_whole(const std::string &filestr) {
@@ -250,62 +384,7 @@ void Index::insert_file_of_file_whole(const std::string &filestr) {
     if (ref.size() > 2 && exists_test(ref)) paths.push_back(ref);
     ref.clear();
   }
-  Batch b;
-  Pipeline pipe(this, &Index::flush_insert);
-  for_each_file_in_order(paths, K, [&](const std::string &path, const std::vector<std::string> &recs) {
-    // insert_file_whole (:442-456): every record longer than K goes into ONE sketch
-    for (const auto &r : recs) b.add_record(r);
-    b.end_entry(path);
-    if (b.full()) pipe.submit(b);
-  });
-  pipe.submit(b);
-  pipe.wait();
-}
-
-void Index::insert_file_lines(const std::string &filestr) {
-  const char type = data_type(filestr);
-  GzReader in(filestr);
-  Batch b;
-  Pipeline pipe(this, &Index::flush_insert);
-  std::string ref, header;
-  while (!in.eof()) {
-    bio_getline(in, ref, type, header, K);
-    if (ref.size() > K) {  // :395: one entry per record, named by its header line
-      b.add_record(ref);
-      b.end_entry(header);
-      if (b.full()) pipe.submit(b);
-    }
-  }
-  pipe.submit(b);
-  pipe.wait();
-}
-
-// ---- query ---------------------------------------------------------------------
-
-void Index::flush_query(Batch &b) {
-  const size_t n = b.n_entries();
-  if (!n) return;
-  const uint64_t N = niqki_genome_count(h_);
-  uint64_t cap = std::max<uint64_t>(uint64_t(1) << 20, n * 64);
-  std::vector<uint64_t> off(n + 1);
-  std::vector<uint32_t> hc, hg;
-  for (;;) {
-    hc.resize(cap);
-    hg.resize(cap);
-    int rc = niqki_query_sequences(h_, b.seqs.data(), b.rec_off.data(), (uint32_t)(b.rec_off.size() - 1),
-                                   b.entry_rec.data(), (uint32_t)n, off.data(), hc.data(), hg.data(), cap,
-                                   NIQKI_MEM_HOST);
-    if (rc == NIQKI_E_CAPACITY && cap < n * N) { cap = std::max(off[n], cap * 2); continue; }
-    check(rc, "niqki_query_sequences");
-    break;
-  }
-  query_output one;
-  for (size_t i = 0; i < n; ++i) {
-    one.clear();
-    for (uint64_t j = off[i]; j < off[i + 1]; ++j) one.push_back({hc[j], hg[j]});
-    output_query(one, b.names[i]);
-  }
-  b.clear();
+  for_each_batch(paths, &Index::flush_insert);
 }
 
 void Index::query_file_of_file_whole(const std::string &filestr) {
@@ -317,34 +396,71 @@ void Index::query_file_of_file_whole(const std::string &filestr) {
     if (exists_test(ref)) paths.push_back(ref);  // :534
     ref.clear();
   }
-  Batch b;
-  Pipeline pipe(this, &Index::flush_query);
-  for_each_file_in_order(paths, K, [&](const std::string &path, const std::vector<std::string> &recs) {
-    for (const auto &r : recs) b.add_record(r);  // query_file_whole :505-519
-    b.end_entry(path);
-    if (b.full()) pipe.submit(b);
-  });
-  pipe.submit(b);
-  pipe.wait();
+  for_each_batch(paths, &Index::flush_query);
 }
 
-void Index::query_file_lines(const std::string &filestr) {
-  const char type = data_type(filestr);
+// One entry per record longer than K, named by its header line
+// (insert_file_lines / query_file_lines, :383-430).  The file is streamed through
+// one page-locked buffer; the GPU reports how far the complete records reach.
+void Index::stream_lines(const std::string &filestr, bool insert) {
+  const uint8_t type = (uint8_t)data_type(filestr);
   GzReader in(filestr);
-  Batch b;
-  Pipeline pipe(this, &Index::flush_query);
-  std::string ref, head;
-  while (!in.eof()) {
-    bio_getline(in, ref, type, head, K);
-    if (ref.size() > K) {
-      b.add_record(ref);
-      b.end_entry(head);
-      if (b.full()) pipe.submit(b);
+  // sketches of one call stay below 2 GB
+  const uint32_t max_entries = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(1024, (uint64_t(2) << 30) / ((uint64_t)F * 4)));
+  PinnedBuf buf;
+  size_t want = size_t(4) << 20;
+  bool eof = false;
+  std::vector<uint64_t> hdr(max_entries);
+  std::vector<std::string> names;
+  for (;;) {
+    buf.reserve(want);
+    while (!eof && buf.size < want) {
+      const size_t n = in.read(buf.p + buf.size, want - buf.size);
+      buf.size += n;
+      if (n == 0 || in.eof()) eof = true;
     }
+    const uint64_t off[2] = {0, buf.size};
+    niqki_raw_batch rb{};
+    rb.raw = buf.p;
+    rb.file_off = off;
+    rb.file_type = &type;
+    rb.n_files = 1;
+    rb.lines = 1;
+    rb.final = eof ? 1 : 0;
+    rb.max_entries = max_entries;
+    niqki_stage_info info{};
+    check(niqki_stage_raw(h_, &rb, NIQKI_MEM_HOST, &info, hdr.data()), "niqki_stage_raw");
+    if (info.n_entry) {
+      names.clear();
+      for (uint32_t e = 0; e < info.n_entry; ++e) {
+        const uint8_t *b = buf.p + hdr[e];
+        const uint8_t *nl = (const uint8_t *)memchr(b, '\n', buf.size - hdr[e]);
+        names.emplace_back((const char *)b, nl ? (size_t)(nl - b) : (size_t)(buf.size - hdr[e]));
+      }
+      if (insert) {
+        check(niqki_staged_insert(h_), "niqki_staged_insert");
+        for (auto &nm : names) filenames.push_back(nm);
+      } else {
+        output_staged(names);
+      }
+    }
+    if (eof && info.consumed == buf.size) break;
+    if (info.consumed == 0) {  // not one complete record in the buffer yet
+      want = std::max(want * 2, buf.size * 2);
+      continue;
+    }
+    std::memmove(buf.p, buf.p + info.consumed, buf.size - info.consumed);
+    buf.size -= info.consumed;
+    // aim at max_entries records per call, with some slack
+    const double per_entry = (double)info.consumed / std::max<uint32_t>(info.n_entry, 1);
+    want = (size_t)std::min<double>(double(size_t(1) << 29), std::max<double>(double(size_t(1) << 20), per_entry * max_entries * 1.1));
+    want = std::max(want, buf.size + (size_t(1) << 16));
   }
-  pipe.submit(b);
-  pipe.wait();
 }
+
+void Index::insert_file_lines(const std::string &filestr) { stream_lines(filestr, true); }
+
+void Index::query_file_lines(const std::string &filestr) { stream_lines(filestr, false); }
 
 void Index::output_query(const query_output &toprint, const std::string &queryname) {
   if (pretty_printing) {  // :546-553

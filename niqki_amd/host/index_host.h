@@ -54,9 +54,12 @@ class Index {
 
  private:
   struct Batch;
-  class Pipeline;
+  void stage_batch(Batch &b);
   void flush_insert(Batch &b);
   void flush_query(Batch &b);
+  void for_each_batch(const std::vector<std::string> &paths, void (Index::*flush)(Batch &));
+  void output_staged(const std::vector<std::string> &names);
+  void stream_lines(const std::string &filestr, bool insert);
   void check(int rc, const char *what) const;
   niqki_index *h_ = nullptr;
 };

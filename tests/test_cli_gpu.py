@@ -50,7 +50,7 @@ def gunzip(path):
 
 def assert_same_text(got, exp):
     """Identical tokens; Jaccard values within 1e-6 (they are equal: same %g of exact counts)."""
-    gl, el = got.splitlines(), exp.splitlines()
+    gl, el = got.split("\n"), exp.split("\n")   # not splitlines(): a header may hold a '\r'
     assert len(gl) == len(el)
     for a, b in zip(gl, el):
         if a == b:
@@ -85,6 +85,51 @@ def test_genome_size_option(workdir, gold):
     raw = gunzip(workdir / "idxG.dump")
     assert np.frombuffer(raw[:24], np.uint32).tolist() == meta["cli"]["dumpG_header"]
     assert hashlib.md5(raw).hexdigest() == meta["cli"]["dumpG_md5"]
+
+
+def test_record_framing_oddities(workdir, gold):
+    """Hand-made FASTA / FASTQ files with every framing oddity (CRLF, blank lines, consecutive
+    headers, '>' inside lines, first line without '>', 0xFF at a line start, no final newline,
+    FASTQ record without quality lines): same text as the reference CLI, lines mode both ways."""
+    _, meta = gold
+    cli = meta["cli"]
+    (workdir / "nasty.fa").write_bytes(cli["nasty_fa_input"].encode("latin1"))
+    (workdir / "nasty.fq").write_bytes(cli["nasty_fq_input"].encode("latin1"))
+    run(workdir, ["-I", "fof.txt", "-l", "nasty.fa", "-S", "10", "-J", "0", "-O", "nasty_fa.gz"])
+    assert_same_text(gunzip(workdir / "nasty_fa.gz").decode("latin1"), cli["nasty_fa"])
+    run(workdir, ["-I", "fof.txt", "-l", "nasty.fq", "-S", "10", "-J", "0", "-O", "nasty_fq.gz"])
+    assert_same_text(gunzip(workdir / "nasty_fq.gz").decode("latin1"), cli["nasty_fq"])
+    run(workdir, ["-i", "nasty.fa", "-Q", "fof.txt", "-S", "10", "-J", "0.02", "-O", "nasty_idx.gz"])
+    assert_same_text(gunzip(workdir / "nasty_idx.gz").decode("latin1"), cli["nasty_idx"])
+
+
+def test_gzip_inputs_and_many_files(workdir, gold):
+    """gzip-compressed genome files and a list longer than one GPU batch give the same
+    hits as the plain files."""
+    import shutil
+    _, meta = gold
+    names = (workdir / "fof.txt").read_text().split()
+    big = []
+    for rep in range(25):   # 300 files > kWholeBatchFiles
+        for n in names:
+            dst = "r%02d_%s.gz" % (rep, n)
+            if not (workdir / dst).exists():
+                with gzip.open(workdir / dst, "wb", compresslevel=1) as f:
+                    f.write((workdir / n).read_bytes())
+            big.append(dst)
+    (workdir / "big.txt").write_text("\n".join(big) + "\n")
+    run(workdir, ["-I", "big.txt", "-Q", "fof.txt", "-S", "10", "-J", "0.1", "-O", "big.gz"])
+    got = gunzip(workdir / "big.gz").decode().splitlines()
+    exp = meta["cli"]["hits"].splitlines()
+    assert len(got) == len(exp) == 12
+    for g, e in zip(got, exp):
+        # every hit of the plain run appears 25 times (once per copy), same value
+        eh = dict(t.rsplit(":", 1) for t in e.split(" ")[1:] if t)
+        gh = [t.rsplit(":", 1) for t in g.split(" ")[1:] if t]
+        assert len(gh) == 25 * len(eh)
+        for name, val in gh:
+            base = name.split("_", 1)[1][:-3]
+            assert eh[base] == val
 
 
 def test_matrix(workdir, gold):
