@@ -412,6 +412,17 @@ class Engine:
         self._ck(self.L.niqki_synth_genomes(self.h, seed, _p(family), _p(member), _p(rate14), n,
                                             length, stride, _p(out), MEM_DEVICE))
 
+    def stage_raw_dev(self, raw, file_off, types, lines=False, final=True, max_entries=16384):
+        """raw: device bytes (torch tensor / address); file_off, types: host numpy arrays."""
+        off = np.ascontiguousarray(file_off, dtype=np.uint64)
+        ty = np.ascontiguousarray(types, dtype=np.uint8)
+        b = RawBatch(_p(raw), None, _p(off), _p(ty), off.size - 1, int(bool(lines)), int(bool(final)), max_entries)
+        info = StageInfo()
+        hdr = np.zeros(max(max_entries, 1), dtype=np.uint64)
+        self._ck(self.L.niqki_stage_raw(self.h, C.byref(b), MEM_DEVICE, C.byref(info), _p(hdr) if lines else None))
+        self._staged = info
+        return info, hdr[:info.n_entry] if lines else None
+
     def sketch_dev(self, seqs, rec_off, n_rec, sketches, entry_rec=None, n_entry=None):
         self._ck(self.L.niqki_sketch(self.h, _p(seqs), _p(rec_off), n_rec, _p(entry_rec),
                                      n_rec if n_entry is None else n_entry, _p(sketches), MEM_DEVICE))
