@@ -8,6 +8,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -104,7 +105,7 @@ unsigned host_threads() {
     if (n > 0) return (unsigned)std::min(n, 256);
   }
   const unsigned hw = std::thread::hardware_concurrency();
-  return hw ? std::min(hw, 32u) : 4u;
+  return hw ? std::min(hw, 64u) : 4u;
 }
 
 // Reads the files of a list on several threads -- the reference does this part in
@@ -118,9 +119,17 @@ class OrderedFileReader {
     PinnedBuf buf;
     std::string err;
   };
+  // The page-locked buffers are shared by all readers of the process (index phase, then
+  // query phase) and never freed: locking and unlocking 1.5 GB of pages costs more than
+  // reading the files, and the process ends right after its last phase.
+  static std::deque<File> &pool(size_t n) {
+    static std::deque<File> *p = new std::deque<File>();
+    while (p->size() < n) p->emplace_back();
+    return *p;
+  }
   OrderedFileReader(const std::vector<std::string> &paths, unsigned threads, size_t n_bufs)
-      : paths_(paths), bufs_(n_bufs), ready_(paths.size(), nullptr) {
-    for (auto &b : bufs_) free_.push_back(&b);
+      : paths_(paths), bufs_(pool(n_bufs)), ready_(paths.size(), nullptr) {
+    for (size_t i = 0; i < n_bufs; ++i) free_.push_back(&bufs_[n_bufs - 1 - i]);  // LIFO: low indices first
     threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(paths.size(), 1));
     for (unsigned t = 0; t < threads; ++t) pool_.emplace_back([this] { work(); });
   }
@@ -172,7 +181,7 @@ class OrderedFileReader {
     }
   }
   const std::vector<std::string> &paths_;
-  std::deque<File> bufs_;
+  std::deque<File> &bufs_;
   std::vector<File *> free_, ready_;
   std::vector<std::thread> pool_;
   std::mutex mu_;
@@ -350,23 +359,37 @@ void Index::flush_query(Batch &b) {
 }
 
 void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*flush)(Batch &)) {
+  using clk = std::chrono::steady_clock;
+  const bool timing = std::getenv("NIQKI_HOST_TIMING") != nullptr;  // where the wall time goes, on stderr
+  double t_wait = 0, t_gpu = 0;
+  const auto t_begin = clk::now();
   OrderedFileReader rd(paths, host_threads(), kReaderBufs);
   Batch b;
   auto done = [&] {
+    const auto t0 = clk::now();
     (this->*flush)(b);
+    t_gpu += std::chrono::duration<double>(clk::now() - t0).count();
     for (auto *f : b.files) rd.release(f);
     b.files.clear();
     b.names.clear();
     b.bytes = 0;
   };
   size_t i = 0;
-  while (auto *f = rd.next()) {
+  for (;;) {
+    const auto t0 = clk::now();
+    auto *f = rd.next();
+    t_wait += std::chrono::duration<double>(clk::now() - t0).count();
+    if (!f) break;
     b.files.push_back(f);
     b.names.push_back(paths[i++]);
     b.bytes += f->buf.size;
     if (b.files.size() >= kWholeBatchFiles || b.bytes >= kWholeBatchBytes) done();
   }
   done();
+  if (timing)
+    std::cerr << "[niqki timing] " << paths.size() << " files: total "
+              << std::chrono::duration<double>(clk::now() - t_begin).count() << " s, waiting for file bytes " << t_wait
+              << " s, GPU calls (copy + frame + sketch + insert/query + output) " << t_gpu << " s" << std::endl;
 }
 
 void Index::insert_file_of_file_whole(const std::string &filestr) {
