@@ -87,23 +87,26 @@ __device__ void densify_lds(uint32_t *sk, const Derived &d, uint32_t *s_flag) {
   uint32_t empty = s_flag[0];
   if (empty == 0 || empty == F) return;
   uint32_t step = 0, idle = 0;
-  const uint32_t vmask = d.R - 1u;
   while (true) {
-    // propose
+    // propose: an empty cell remembers the smallest source cell that points at it (the
+    // first writer of the reference's ascending loop); occupied cells hold values below
+    // 2^31 and are left alone by the min.  No assumption on the value range: after
+    // niqki_select_best_H cells may exceed 2^W.
     for (uint32_t i = tid; i < F; i += BLOCK) {
       uint32_t v = sk[i];
       if (v < 0x80000000u) {
         // hash_family(v, step) % F, src/niqki_index.cpp:308-310,:319 (low bits only)
         uint32_t t = ((uint32_t)unrev64(v) + step * (uint32_t)rev64(v)) & (F - 1u);
-        atomicMin(&sk[t], 0x80000000u | (i << d.W) | v);
+        atomicMin(&sk[t], 0x80000000u | i);
       }
     }
     __syncthreads();
-    // resolve
+    // resolve: copy from the winning source (occupied since before this pass, so no
+    // other thread writes it now)
     uint32_t filled = 0;
     for (uint32_t i = tid; i < F; i += BLOCK) {
       uint32_t v = sk[i];
-      if (v >= 0x80000000u && v != kEmpty32) { sk[i] = v & vmask; ++filled; }
+      if (v >= 0x80000000u && v != kEmpty32) { sk[i] = sk[v & 0x7FFFFFFFu]; ++filled; }
     }
     if (filled) atomicAdd(&s_flag[1], filled);
     __syncthreads();

@@ -1,0 +1,88 @@
+"""GPU: randomized differential test of the whole path against the oracle over the
+parameter space the ABI accepts (K 1..31, S 1..15, W <= 15, H <= W, S+W <= 30):
+sketch (incl. densification and the inputs on which the reference never returns),
+insert, dense counters, thresholded + ordered hits, matrix, dump bytes, -G."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def random_record(rng, L, dirty):
+    s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].copy()
+    if dirty and L:
+        k = max(1, L // 40)
+        s[rng.integers(0, L, k)] = np.frombuffer(b"NnacgtRY-*\r", np.uint8)[rng.integers(0, 11, k)]
+    return s
+
+
+def mutate(rng, s, rate):
+    t = s.copy()
+    m = rng.random(t.size) < rate
+    t[m] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(m.sum()))]
+    return t
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_parameters_vs_oracle(native, po, seed):
+    rng = np.random.default_rng(1000 + seed)
+    K = int(rng.integers(1, 32)) if seed % 3 else 31
+    S = int(rng.integers(1, 13))
+    W = int(rng.integers(1, min(15, 22 - S) + 1))
+    H = int(rng.integers(0, min(W, 6) + 1))
+    J = float(rng.choice([0.0, 0.05, 0.3, 0.9]))
+    p = po.make_params(K, S, W, H, J)
+    e = native.Engine(K=K, S=S, W=W, H=H, J=J)
+    # genomes: a few families so that hits exist, lengths from "shorter than K" upwards
+    base = [random_record(rng, int(rng.integers(max(K, 40), 6000)), dirty=seed % 2 == 1) for _ in range(3)]
+    genomes = []
+    for b in base:
+        genomes.append(b)
+        for r in (0.002, 0.02, 0.1):
+            genomes.append(mutate(rng, b, r))
+    genomes += [random_record(rng, L, False) for L in (0, K - 1 if K > 1 else 0, K, K + 1, K + 2, 64)]
+    exp_sk = np.stack([po.densify(p, po.sketch_accumulate(p, g))[0] for g in genomes])
+    sk = e.sketch(genomes)
+    assert np.array_equal(sk, exp_sk), (K, S, W, H)
+    e.insert(sk)
+    ix = po.Index(p, exp_sk)
+    queries = np.stack([exp_sk[i] for i in (0, 1, 5, 9, len(genomes) - 1)] +
+                       [po.densify(p, po.sketch_accumulate(p, mutate(rng, base[0], 0.05)))[0]])
+    cnt = e.query_counts(queries)
+    off, hc, hg = e.query(queries)
+    for q in range(queries.shape[0]):
+        assert np.array_equal(cnt[q].astype(np.uint32), ix.counts(queries[q])), (q, K, S, W, H)
+        ec, eg = ix.query(queries[q])
+        assert np.array_equal(hc[off[q]:off[q + 1]], ec) and np.array_equal(hg[off[q]:off[q + 1]], eg)
+    n = len(genomes)
+    assert np.array_equal(e.matrix_range(0, n), ix.matrix_range(0, n).T)
+    assert e.export_dump() == ix.dump_bytes()
+    e.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_select_best_h_random(native, po, seed):
+    """-G with random constructor parameters: the stale-constant fingerprints of the sketches
+    and everything downstream equal the oracle's (itself pinned on the reference)."""
+    rng = np.random.default_rng(2000 + seed)
+    K = int(rng.integers(8, 32))
+    S = int(rng.integers(2, 11))
+    W = int(rng.integers(6, min(15, 22 - S) + 1))
+    H = int(rng.integers(0, 6))
+    G = float(rng.choice([1.0, 150.0, 3e4, 5e6, 1e9]))
+    p = po.make_params(K, S, W, H, 0.1, genome_size=G)
+    e = native.Engine(K=K, S=S, W=W, H=H, J=0.1)
+    assert e.select_best_H(G) == p.H
+    base = random_record(rng, 4000, False)
+    genomes = [base] + [mutate(rng, base, r) for r in (0.01, 0.05, 0.2)] + [random_record(rng, 900, True)]
+    exp_sk = np.stack([po.densify(p, po.sketch_accumulate(p, g))[0] for g in genomes])
+    sk = e.sketch(genomes)
+    assert np.array_equal(sk, exp_sk), (K, S, W, H, G, p.H)
+    e.insert(sk)
+    ix = po.Index(p, exp_sk)
+    off, hc, hg = e.query(exp_sk)
+    for q in range(len(genomes)):
+        ec, eg = ix.query(exp_sk[q])
+        assert np.array_equal(hc[off[q]:off[q + 1]], ec) and np.array_equal(hg[off[q]:off[q + 1]], eg)
+    assert e.export_dump() == ix.dump_bytes()
+    e.close()
