@@ -443,6 +443,224 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
   for (uint32_t i = tid; i < d.F; i += BLOCK) out[i] = sk[i];
 }
 
+
+// ---- short records: one wavefront per sketch -----------------------------------------
+// A 150-base read holds ~120 k-mers but its densification takes ~350 passes
+// (SURVEY.md 8a a8), so the short-record kernel is built around the passes: one wave
+// owns one sketch, nothing is synchronised across waves, and a pass costs two LDS round
+// trips.  Each occupied cell of the sketch becomes an ENTRY held in registers
+// (up to kReadEntries per lane): T = running low word of hash_family(v, step) (the target
+// is T mod F and T += B per pass, B = low word of revhash64(v), src/niqki_index.cpp:308-310),
+// mi = smallest cell index known to hold v.  A pass: every entry proposes
+// 2^31 | mi to its target cell with an LDS min (occupied cells hold values below 2^31
+// and stay as they are, the smallest source index wins = the first writer of the
+// reference's ascending loop, :313-331); then every entry reads its target back, and the
+// one that finds its own proposal writes the value and lowers its mi.  Copies of a value
+// propose the same target, so the entries present at the start are all that ever
+// matter; two entries with the same value are harmless (the lower index always wins).
+constexpr uint32_t kReadEntries = 16;                 // entries per lane
+constexpr uint32_t kReadMaxEntries = 64 * kReadEntries;
+constexpr uint32_t kReadTile = 512;                   // positions coded per tile
+
+static size_t sketch_reads_lds_bytes(const Derived &d) {
+  // sketch cells + entry list (cell, value) + position codes + code table
+  return (size_t)d.F * 4 + (size_t)kReadMaxEntries * 8 + kReadTile + 256 + 64;
+}
+
+// plain pass over all cells (more occupied cells than register entries: long records,
+// few passes)
+__device__ void densify_wave_cells(uint32_t *sk, const Derived &d, uint32_t empty) {
+  const uint32_t F = d.F, lane = threadIdx.x;
+  uint32_t step = 0, idle = 0;
+  for (;;) {
+    for (uint32_t i = lane; i < F; i += 64) {
+      const uint32_t v = sk[i];
+      if (v < 0x80000000u) {
+        const uint32_t t = ((uint32_t)unrev64(v) + step * (uint32_t)rev64(v)) & (F - 1u);
+        atomicMin(&sk[t], 0x80000000u | i);
+      }
+    }
+    __syncthreads();
+    uint32_t filled = 0;
+    for (uint32_t i = lane; i < F; i += 64) {
+      const uint32_t v = sk[i];
+      if (v >= 0x80000000u && v != kEmpty32) { sk[i] = sk[v & 0x7FFFFFFFu]; ++filled; }
+    }
+    __syncthreads();
+    uint32_t tot = filled;
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) tot += __shfl_xor(tot, dd, 64);
+    empty -= tot;
+    ++step;
+    idle = tot ? 0u : idle + 1u;
+    if (empty == 0 || idle >= F) break;
+  }
+}
+
+
+// all LDS traffic of the wave issued so far has completed, and the compiler keeps the
+// accesses on either side apart (one wave: the LDS serves its instructions in order)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The passes over R register entries per lane (entry e = k*64 + lane of elist).
+template <int R>
+__device__ __forceinline__ void densify_wave_entries(uint32_t *sk, const uint32_t *elist, uint32_t n_ent,
+                                                     uint32_t F, uint32_t empty) {
+  const uint32_t lane = threadIdx.x, Fm = F - 1u;
+  uint32_t T[R], B[R], mk[R], V[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const uint32_t e = (uint32_t)k * 64u + lane;
+    const bool valid = e < n_ent;
+    const uint32_t v = valid ? elist[2 * e + 1] : 0u;
+    V[k] = v;
+    mk[k] = valid ? (0x80000000u | elist[2 * e]) : kEmpty32;  // a min with "empty" changes nothing
+    T[k] = (uint32_t)unrev64(v);
+    B[k] = (uint32_t)rev64(v);
+  }
+  uint32_t idle = 0;
+  for (;;) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) atomicMin(&sk[T[k] & Fm], mk[k]);
+    wave_lds_sync();
+    // all targets are read back before any winner writes: every read sees the surviving
+    // proposal of its cell, which names exactly one entry
+    uint32_t back[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) back[k] = sk[T[k] & Fm];
+    wave_lds_sync();
+    uint32_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const uint32_t t = T[k] & Fm;
+      const bool won = back[k] == mk[k] && mk[k] != kEmpty32;
+      if (won) {
+        sk[t] = V[k];
+        const uint32_t m = 0x80000000u | t;
+        mk[k] = m < mk[k] ? m : mk[k];
+      }
+      tot += (uint32_t)__popcll(__ballot(won));
+      T[k] += B[k];
+    }
+    wave_lds_sync();
+    empty -= tot;
+    idle = tot ? 0u : idle + 1u;
+    if (empty == 0 || idle >= F) break;
+  }
+}
+
+__global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  const Derived &d = a.d;
+  const uint32_t F = d.F, lane = threadIdx.x;
+  uint32_t *sk = smem;                                       // F cells
+  uint32_t *elist = smem + F;                                // kReadMaxEntries x {cell, value}
+  uint8_t *codes = (uint8_t *)(elist + 2 * kReadMaxEntries); // kReadTile position codes
+  uint8_t *lut = codes + kReadTile;                          // 256-byte code table
+  const uint32_t entry = blockIdx.x;
+  const uint32_t K = d.K, Km1 = d.K - 1u;
+
+  for (uint32_t i = lane; i < 256; i += 64) lut[i] = code_entry(i);
+  if (a.accumulate) {
+    const uint32_t *src = (const uint32_t *)a.sketches + (uint64_t)entry * F;
+    for (uint32_t i = lane; i < F; i += 64) sk[i] = src[i];
+  } else {
+    for (uint32_t i = lane; i < F; i += 64) sk[i] = kEmpty32;
+  }
+  __syncthreads();
+
+  // ---- k-mers: positions are coded tile by tile (forward code | rc code << 2 per position,
+  // "positional codes" of DESIGN.md), every lane then assembles whole k-mers from K codes ----
+  if (a.seqs != nullptr) {
+    const uint32_t r0 = a.entry_rec ? a.entry_rec[entry] : entry;
+    const uint32_t r1 = a.entry_rec ? a.entry_rec[entry + 1] : entry + 1;
+    for (uint32_t rec = r0; rec < r1; ++rec) {
+      const uint64_t b0 = a.rec_off[rec], b1 = a.rec_off[rec + 1];
+      const uint64_t len = b1 - b0;
+      if (len <= K) continue;                 // src/niqki_index.cpp:395,:450
+      const uint64_t n_kmers = len - K;       // last k-mer skipped, :342
+      const uint8_t *base = a.seqs + b0;
+      // the K-1 prefix digits are zeroed together when one of them is no base (:255-273)
+      uint32_t ok = 1;
+      if (lane < Km1) ok = (lut[base[lane]] >> 6) & 1u;
+      ok = __all(ok) ? 1u : 0u;
+      const uint32_t per_tile = kReadTile - Km1;   // k-mers served by one tile of positions
+      for (uint64_t k0 = 0; k0 < n_kmers; k0 += per_tile) {
+        __syncthreads();  // the previous tile's codes are no longer read
+        for (uint32_t j = lane; j < kReadTile; j += 64) {
+          const uint64_t pos = k0 + j;
+          uint32_t c = 0;
+          if (pos < len) {
+            const uint32_t e = lut[base[pos]];
+            if (pos < Km1) {
+              const uint32_t dgt = ok ? ((e >> 4) & 3u) : 0u;
+              c = dgt | ((3u - dgt) << 2);      // digit and its complement (rcb, :240-250)
+            } else {
+              c = e & 15u;                       // rolling tables (:114-123, :211-221)
+            }
+          }
+          codes[j] = (uint8_t)c;
+        }
+        __syncthreads();
+        const uint64_t left = n_kmers - k0;
+        const uint32_t n_here = left < per_tile ? (uint32_t)left : per_tile;
+        for (uint32_t q = lane; q < ((n_here + 63u) & ~63u); q += 64) {
+          const bool live = q < n_here;
+          uint64_t fw = 0, rc = 0;
+          if (live) {
+            for (uint32_t j = 0; j < K; ++j) {
+              const uint32_t c = codes[q + j];
+              fw = (fw << 2) | (c & 3u);
+              rc |= (uint64_t)(c >> 2) << (2u * j);
+            }
+          }
+          const uint64_t canon = fw < rc ? fw : rc;   // :345
+          sketch_update(canon, d, sk, live);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  uint32_t *out = (uint32_t *)a.sketches + (uint64_t)entry * F;
+  if (a.densify) {
+    // ---- entries: occupied cells in ascending order, dealt round-robin to the lanes ----
+    uint32_t n_ent = 0;
+    for (uint32_t c0 = 0; c0 < F; c0 += 64) {
+      const uint32_t c = c0 + lane;
+      const uint32_t v = c < F ? sk[c] : kEmpty32;
+      const uint64_t bal = __ballot(v != kEmpty32);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+      const uint32_t at = n_ent + rank;
+      if (v != kEmpty32 && at < kReadMaxEntries) { elist[2 * at] = c; elist[2 * at + 1] = v; }
+      n_ent += (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    const uint32_t empty0 = F - n_ent;
+    if (empty0 != 0 && n_ent != 0) {
+      if (n_ent > kReadMaxEntries) {
+        densify_wave_cells(sk, d, empty0);
+      } else {
+        const uint32_t rounds = (n_ent + 63u) >> 6;   // wave uniform
+        if (rounds <= 1) densify_wave_entries<1>(sk, elist, n_ent, F, empty0);
+        else if (rounds <= 2) densify_wave_entries<2>(sk, elist, n_ent, F, empty0);
+        else if (rounds <= 3) densify_wave_entries<3>(sk, elist, n_ent, F, empty0);
+        else if (rounds <= 4) densify_wave_entries<4>(sk, elist, n_ent, F, empty0);
+        else if (rounds <= 6) densify_wave_entries<6>(sk, elist, n_ent, F, empty0);
+        else if (rounds <= 8) densify_wave_entries<8>(sk, elist, n_ent, F, empty0);
+        else if (rounds <= 12) densify_wave_entries<12>(sk, elist, n_ent, F, empty0);
+        else densify_wave_entries<16>(sk, elist, n_ent, F, empty0);
+      }
+    }
+    __syncthreads();
+  }
+  for (uint32_t i = lane; i < F; i += 64) out[i] = sk[i];
+}
+
 static size_t sketch_lds_bytes(const Derived &d, bool distinct, uint32_t ring_waves) {
   return (size_t)d.F * 4 + 16 + 256 + (distinct ? (size_t)d.R * 12 : 0) + (size_t)ring_waves * kRingAlloc * 8;
 }
@@ -454,6 +672,18 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   // Launch shape by the average input length of a sketch: a 256-thread workgroup for
   // reads, else 1024 threads with chunks of 32 / 128 / 512 k-mers per lane (long chunks
   // amortise the K-1 warm-up steps, short ones keep all lanes busy on short records).
+  // reads: one wavefront per sketch when the sketch and its entry list leave room for
+  // several waves per CU (NIQKI_SKETCH_WAVE=0 switches this shape off)
+  {
+    const char *wv = std::getenv("NIQKI_SKETCH_WAVE");
+    const size_t wl = sketch_reads_lds_bytes(a.d);
+    if (avg_len <= 4096 && a.splits == 1 && wl <= 40 * 1024 && !(wv && std::atoi(wv) == 0)) {
+      hipError_t e = hipFuncSetAttribute((const void *)sketch_reads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(sketch_reads_kernel, dim3(n_entry), dim3(64), wl, stream, a);
+      return hipGetLastError();
+    }
+  }
   const bool short_records = avg_len < 16384;
   // distinct-value densification where its tables leave room for >= 2 workgroups per CU
   // after niqki_select_best_H the fingerprint parts may overlap and leave [0, 2^W): the
