@@ -330,26 +330,36 @@ void Index::flush_insert(Batch &b) {
 }
 
 // hits of the staged entries, written in entry order
-void Index::output_staged(const std::vector<std::string> &names) {
-  const size_t n = names.size();
+// hits of the staged entries
+void Index::query_staged(size_t n, Hits &h) {
   const uint64_t N = niqki_genome_count(h_);
   uint64_t cap = std::max<uint64_t>(uint64_t(1) << 20, n * 64);
-  std::vector<uint64_t> off(n + 1);
-  std::vector<uint32_t> hc, hg;
+  h.off.resize(n + 1);
   for (;;) {
-    hc.resize(cap);
-    hg.resize(cap);
-    const int rc = niqki_staged_query(h_, off.data(), hc.data(), hg.data(), cap, NIQKI_MEM_HOST);
-    if (rc == NIQKI_E_CAPACITY && cap < n * N) { cap = std::max(off[n], cap * 2); continue; }
+    h.hc.resize(cap);
+    h.hg.resize(cap);
+    const int rc = niqki_staged_query(h_, h.off.data(), h.hc.data(), h.hg.data(), cap, NIQKI_MEM_HOST);
+    if (rc == NIQKI_E_CAPACITY && cap < n * N) { cap = std::max(h.off[n], cap * 2); continue; }
     check(rc, "niqki_staged_query");
     break;
   }
+}
+
+// ... written in entry order
+void Index::write_hits(const Hits &h) {
   query_output one;
-  for (size_t i = 0; i < n; ++i) {
+  for (size_t i = 0; i < h.names.size(); ++i) {
     one.clear();
-    for (uint64_t j = off[i]; j < off[i + 1]; ++j) one.push_back({hc[j], hg[j]});
-    output_query(one, names[i]);
+    for (uint64_t j = h.off[i]; j < h.off[i + 1]; ++j) one.push_back({h.hc[j], h.hg[j]});
+    output_query(one, h.names[i]);
   }
+}
+
+void Index::output_staged(const std::vector<std::string> &names) {
+  Hits h;
+  h.names = names;
+  query_staged(names.size(), h);
+  write_hits(h);
 }
 
 void Index::flush_query(Batch &b) {
@@ -422,63 +432,190 @@ void Index::query_file_of_file_whole(const std::string &filestr) {
   for_each_batch(paths, &Index::flush_query);
 }
 
-// One entry per record longer than K, named by its header line
-// (insert_file_lines / query_file_lines, :383-430).  The file is streamed through
-// one page-locked buffer; the GPU reports how far the complete records reach.
+// ---- lines mode: reader thread -> GPU calls (caller's thread) -> writer thread ------
+namespace {
+
+// End of the last complete record in buf[0, size): the reader cuts its pieces there, so
+// every piece holds whole records (the GPU frames them; this is only a safe place to cut).
+// FASTA: a line that starts with '>' begins a record.  FASTQ: records are 4 lines, and a
+// piece starts at a record, so the cut is after a multiple of 4 newlines.  0 = none yet.
+size_t record_cut(const uint8_t *buf, size_t size, char type) {
+  if (type == 'Q') {
+    size_t lines = 0, cut = 0;
+    const uint8_t *p = buf, *end = buf + size;
+    while (p < end) {
+      const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+      if (!nl) break;
+      p = nl + 1;
+      if ((++lines & 3) == 0) cut = (size_t)(p - buf);
+    }
+    return cut;
+  }
+  size_t hi = size;
+  while (hi > 1) {
+    const uint8_t *gt = (const uint8_t *)memrchr(buf + 1, '>', hi - 1);
+    if (!gt) return 0;
+    if (gt[-1] == '\n') return (size_t)(gt - buf);
+    hi = (size_t)(gt - buf);
+  }
+  return 0;
+}
+
+// Small blocking queue for handing buffers between the stages.
+template <typename T>
+class Channel {
+ public:
+  void push(T v) {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      q_.push_back(std::move(v));
+    }
+    cv_.notify_all();
+  }
+  T pop() {
+    std::unique_lock<std::mutex> g(mu_);
+    cv_.wait(g, [&] { return !q_.empty(); });
+    T v = std::move(q_.front());
+    q_.pop_front();
+    return v;
+  }
+
+ private:
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::deque<T> q_;
+};
+
+struct Piece {
+  PinnedBuf buf;
+  bool last = false;
+  std::string err;
+};
+
+}  // namespace
+
+// One entry per record longer than K, named by its header line (insert_file_lines /
+// query_file_lines, :383-430).  A reader thread streams the file into page-locked pieces
+// that end at a record boundary, this thread runs the GPU calls, a writer thread formats
+// and compresses the hits: the three overlap, output order is input order.
 void Index::stream_lines(const std::string &filestr, bool insert) {
-  const uint8_t type = (uint8_t)data_type(filestr);
-  GzReader in(filestr);
+  const char type = data_type(filestr);
+  const uint8_t type_u8 = (uint8_t)type;
   // sketches of one call stay below 2 GB
   const uint32_t max_entries = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(1024, (uint64_t(2) << 30) / ((uint64_t)F * 4)));
-  PinnedBuf buf;
-  size_t want = size_t(4) << 20;
-  bool eof = false;
+  constexpr size_t kPieces = 3;
+  std::deque<Piece> pieces(kPieces);
+  Channel<Piece *> free_q, ready_q;
+  for (auto &pc : pieces) free_q.push(&pc);
+
+  std::thread reader([&] {
+    std::vector<uint8_t> carry;
+    size_t target = size_t(8) << 20;
+    bool eof = false;
+    try {
+      GzReader in(filestr);
+      while (!eof) {
+        Piece *pc = free_q.pop();
+        if (!pc) return;  // the consumer gave up
+        pc->err.clear();
+        pc->last = false;
+        pc->buf.size = 0;
+        pc->buf.reserve(std::max(target, carry.size()) + (size_t(1) << 16));
+        std::memcpy(pc->buf.p, carry.data(), carry.size());
+        pc->buf.size = carry.size();
+        carry.clear();
+        size_t cut = 0;
+        for (;;) {
+          while (!eof && pc->buf.size < target) {
+            const size_t n = in.read(pc->buf.p + pc->buf.size, target - pc->buf.size);
+            pc->buf.size += n;
+            if (n == 0 || in.eof()) eof = true;
+          }
+          if (eof) { cut = pc->buf.size; break; }
+          cut = record_cut(pc->buf.p, pc->buf.size, type);
+          if (cut) break;
+          target *= 2;  // not one complete record yet: a longer piece
+          pc->buf.reserve(target + (size_t(1) << 16));
+        }
+        carry.assign(pc->buf.p + cut, pc->buf.p + pc->buf.size);
+        pc->buf.size = cut;
+        pc->last = eof;
+        ready_q.push(pc);
+      }
+    } catch (const std::exception &e) {
+      Piece *pc = free_q.pop();
+      if (pc) { pc->err = e.what(); pc->last = true; pc->buf.size = 0; ready_q.push(pc); }
+    }
+  });
+
+  Channel<Hits *> out_q;
+  Channel<Hits *> out_free;
+  std::deque<Hits> results(4);
+  for (auto &r : results) out_free.push(&r);
+  std::string writer_err;
+  std::thread writer([&] {
+    for (;;) {
+      Hits *h = out_q.pop();
+      if (!h) return;
+      try { if (writer_err.empty()) write_hits(*h); } catch (const std::exception &e) { writer_err = e.what(); }
+      out_free.push(h);
+    }
+  });
+
+  std::string err;
   std::vector<uint64_t> hdr(max_entries);
-  std::vector<std::string> names;
-  for (;;) {
-    buf.reserve(want);
-    while (!eof && buf.size < want) {
-      const size_t n = in.read(buf.p + buf.size, want - buf.size);
-      buf.size += n;
-      if (n == 0 || in.eof()) eof = true;
+  try {
+    for (bool last = false; !last;) {
+      Piece *pc = ready_q.pop();
+      last = pc->last;
+      if (!pc->err.empty()) throw std::runtime_error(pc->err);
+      size_t at = 0;
+      do {
+        const uint64_t off[2] = {0, pc->buf.size - at};
+        niqki_raw_batch rb{};
+        rb.raw = pc->buf.p + at;
+        rb.file_off = off;
+        rb.file_type = &type_u8;
+        rb.n_files = 1;
+        rb.lines = 1;
+        rb.final = 1;  // pieces hold whole records
+        rb.max_entries = max_entries;
+        niqki_stage_info info{};
+        check(niqki_stage_raw(h_, &rb, NIQKI_MEM_HOST, &info, hdr.data()), "niqki_stage_raw");
+        if (info.n_entry) {
+          Hits *h = insert ? nullptr : out_free.pop();
+          std::vector<std::string> local;
+          std::vector<std::string> &names = h ? h->names : local;
+          names.clear();
+          const uint8_t *base = pc->buf.p + at;
+          const size_t left = pc->buf.size - at;
+          for (uint32_t e = 0; e < info.n_entry; ++e) {
+            const uint8_t *b = base + hdr[e];
+            const uint8_t *nl = (const uint8_t *)memchr(b, '\n', left - hdr[e]);
+            names.emplace_back((const char *)b, nl ? (size_t)(nl - b) : (size_t)(left - hdr[e]));
+          }
+          if (insert) {
+            check(niqki_staged_insert(h_), "niqki_staged_insert");
+            for (auto &nm : names) filenames.push_back(nm);
+          } else {
+            try { query_staged(info.n_entry, *h); } catch (...) { out_free.push(h); throw; }
+            out_q.push(h);
+          }
+        }
+        if (info.consumed == 0 && info.n_entry == 0) break;  // nothing but a header without end
+        at += info.consumed;
+      } while (at < pc->buf.size);
+      free_q.push(pc);
     }
-    const uint64_t off[2] = {0, buf.size};
-    niqki_raw_batch rb{};
-    rb.raw = buf.p;
-    rb.file_off = off;
-    rb.file_type = &type;
-    rb.n_files = 1;
-    rb.lines = 1;
-    rb.final = eof ? 1 : 0;
-    rb.max_entries = max_entries;
-    niqki_stage_info info{};
-    check(niqki_stage_raw(h_, &rb, NIQKI_MEM_HOST, &info, hdr.data()), "niqki_stage_raw");
-    if (info.n_entry) {
-      names.clear();
-      for (uint32_t e = 0; e < info.n_entry; ++e) {
-        const uint8_t *b = buf.p + hdr[e];
-        const uint8_t *nl = (const uint8_t *)memchr(b, '\n', buf.size - hdr[e]);
-        names.emplace_back((const char *)b, nl ? (size_t)(nl - b) : (size_t)(buf.size - hdr[e]));
-      }
-      if (insert) {
-        check(niqki_staged_insert(h_), "niqki_staged_insert");
-        for (auto &nm : names) filenames.push_back(nm);
-      } else {
-        output_staged(names);
-      }
-    }
-    if (eof && info.consumed == buf.size) break;
-    if (info.consumed == 0) {  // not one complete record in the buffer yet
-      want = std::max(want * 2, buf.size * 2);
-      continue;
-    }
-    std::memmove(buf.p, buf.p + info.consumed, buf.size - info.consumed);
-    buf.size -= info.consumed;
-    // aim at max_entries records per call, with some slack
-    const double per_entry = (double)info.consumed / std::max<uint32_t>(info.n_entry, 1);
-    want = (size_t)std::min<double>(double(size_t(1) << 29), std::max<double>(double(size_t(1) << 20), per_entry * max_entries * 1.1));
-    want = std::max(want, buf.size + (size_t(1) << 16));
+  } catch (const std::exception &e) {
+    err = e.what();
+    free_q.push(nullptr);  // releases a reader that waits for a buffer
   }
+  reader.join();
+  out_q.push(nullptr);
+  writer.join();
+  if (!err.empty()) throw std::runtime_error(err);
+  if (!writer_err.empty()) throw std::runtime_error(writer_err);
 }
 
 void Index::insert_file_lines(const std::string &filestr) { stream_lines(filestr, true); }

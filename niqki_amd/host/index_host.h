@@ -58,6 +58,13 @@ class Index {
   void flush_insert(Batch &b);
   void flush_query(Batch &b);
   void for_each_batch(const std::vector<std::string> &paths, void (Index::*flush)(Batch &));
+  struct Hits {  // hits of a batch of entries: (count, gid) runs hc/hg[off[i] .. off[i+1]) for names[i]
+    std::vector<std::string> names;
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> hc, hg;
+  };
+  void query_staged(size_t n, Hits &h);
+  void write_hits(const Hits &h);
   void output_staged(const std::vector<std::string> &names);
   void stream_lines(const std::string &filestr, bool insert);
   void check(int rc, const char *what) const;

@@ -132,6 +132,44 @@ def test_gzip_inputs_and_many_files(workdir, gold):
             assert eh[base] == val
 
 
+@pytest.mark.parametrize("fmt", ["fa", "fq"])
+def test_lines_mode_streams_many_pieces(workdir, native, gold, fmt):
+    """A read file several pieces long (reader thread -> GPU -> writer thread): names, order and
+    hits equal those of the record-level ABI path on the same reads."""
+    _, meta = gold
+    fam, mem, rate = family_spec(4, 8)
+    genomes = [native.synth_genome_host(meta["seed"], int(f), int(m), int(r), 40000)
+               for f, m, r in zip(fam[:12], mem[:12], rate[:12])]
+    rng = np.random.default_rng(17)
+    n = 150_000
+    which = rng.integers(0, 12, n)
+    start = rng.integers(0, 40000 - 150, n)
+    reads = [genomes[w][s:s + 150] for w, s in zip(which, start)]
+    path = workdir / ("many.%s" % fmt)
+    with open(path, "wb") as f:
+        for i, r in enumerate(reads):
+            if fmt == "fa":
+                f.write(b">read%d\n" % i + bytes(r) + b"\n")
+            else:
+                f.write(b"@read%d\n" % i + bytes(r) + b"\n+\n" + b"I" * 150 + b"\n")
+    assert path.stat().st_size > (20 << 20)   # > 2 pieces of 8 MB
+    run(workdir, ["-I", "fof.txt", "-l", path.name, "-S", "10", "-W", "10", "-J", "0.05", "-O", "many.gz"])
+    got = gunzip(workdir / "many.gz").decode().split("\n")
+    e = native.Engine(K=31, S=10, W=10, H=4, J=0.05)
+    e.insert(e.sketch(genomes))
+    names = (workdir / "fof.txt").read_text().split()
+    off, hc, hg = e.query_sequences(reads)
+    e.close()
+    assert len(got) == n + 1 and got[-1] == ""
+    head = b">" if fmt == "fa" else b"@"
+    for i in range(0, n, 997):   # every 997th line in full, all names below
+        exp = (head + b"read%d" % i).decode() + " " + "".join(
+            "%s:%g " % (names[g], c / 1024) for c, g in zip(hc[off[i]:off[i + 1]], hg[off[i]:off[i + 1]]))
+        assert got[i] == exp, i
+    assert [g.split(" ", 1)[0] for g in got[:n]] == [(head + b"read%d" % i).decode() for i in range(n)]
+    assert sum(len(g.split(" ")) - 2 for g in got[:n]) == int(off[-1])   # total hits
+
+
 def test_matrix(workdir, gold):
     _, meta = gold
     run(workdir, ["-M", "fof.txt", "-S", "10", "-O", "matrix.gz"])
