@@ -9,6 +9,7 @@ from collections import defaultdict
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = name.split("(")[0]
     return name[-90:]
 
