@@ -8,7 +8,7 @@ K=31 S=15 W=12 (H=4, J=0.1 -> min_score 3276), synthetic 5 Mbp genomes.
 One "step" = one pass of the hot path (k-mer rolling hash -> HyperMinHash
 sketch -> densification -> gather-histogram over the inverted index ->
 threshold + ordered hits) over one batch of query genomes whose bases are
-already resident in HBM.  N > 1 (torch.distributed.run, one rank per GPU over
+already resident in HBM (a ring of distinct batches, step i uses batch i mod ring).  N > 1 (torch.distributed.run, one rank per GPU over
 RCCL): the index is sharded by sketch-slot range, the per-genome hit vectors are
 summed across ranks by a reduce-scatter (niqki_amd/dist.py); total work is
 fixed, so scaling is "strong".
@@ -64,7 +64,9 @@ def main():
     ap.add_argument("--steps", type=int, default=9)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genomes", type=int, default=100_000)
-    ap.add_argument("--batch", type=int, default=1000, help="query genomes per step (whole job)")
+    ap.add_argument("--batch", type=int, default=4000, help="query genomes per step (whole job)")
+    ap.add_argument("--ring", type=int, default=3,
+                    help="distinct query batches kept resident in HBM; step i uses batch i mod ring")
     ap.add_argument("--len", type=int, default=5_000_000)
     ap.add_argument("--family", type=int, default=100)
     ap.add_argument("--seed", type=int, default=20261003)
@@ -154,9 +156,10 @@ def main():
     log("[rank %d] index: %d genomes, tile %d, built in %.1f s" % (rank, eng.n_genomes, eng.tile_genomes(), t_index))
     del seqbuf
 
-    # ---- query inputs resident in HBM: (warmup+steps) batches, this rank's share ----
+    # ---- query inputs resident in HBM: a ring of distinct batches, this rank's share ----
     per = (args.batch + world - 1) // world
-    n_batches = args.warmup + args.steps
+    n_steps_all = args.warmup + args.steps
+    n_batches = max(1, min(n_steps_all, args.ring))
     qseq = torch.zeros(n_batches * per * stride_b + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
     for bi in range(n_batches):
         q = bi * per * world + rank * per + np.arange(per)
@@ -166,7 +169,7 @@ def main():
     d_ro = rec_offsets(per)
     qsk = torch.empty((n_batches, per, F), dtype=torch.int32, device=dev)
     cap = per * 4096
-    hit_off = torch.zeros((n_batches, per + 1), dtype=torch.int64, device=dev)
+    hit_off = torch.zeros((n_steps_all, per + 1), dtype=torch.int64, device=dev)
     hc = torch.zeros(cap, dtype=torch.int32, device=dev)
     hg = torch.zeros(cap, dtype=torch.int32, device=dev)
     stride = (N + 1) & ~1
@@ -174,14 +177,15 @@ def main():
     sq = ShardedQuery(eng, N, F, dev, exchange=args.exchange) if use_dist else None
     eng.synchronize()
 
-    def step(bi):
+    def step(si):
+        bi = si % n_batches
         base = qseq[bi * per * stride_b:]
         eng.sketch_dev(base, d_ro, per, qsk[bi])
         if use_dist:
-            sq.step(qsk[bi], hit_off[bi], hc, hg, cap)
+            sq.step(qsk[bi], hit_off[si], hc, hg, cap)
         else:
             eng.query_counts_dev(qsk[bi], per, counts, stride)
-            eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[bi], hc, hg, cap)
+            eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[si], hc, hg, cap)
 
     def barrier():
         if use_dist:
@@ -201,8 +205,8 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for bi in range(args.warmup, n_batches):
-        step(bi)
+    for si in range(args.warmup, n_steps_all):
+        step(si)
     eng.synchronize()
     torch.cuda.synchronize()
     barrier()
@@ -219,7 +223,8 @@ def main():
     # ---- roofline of the gather kernel: algorithmic bytes 4T + 20F per query ----
     f_local = se - sb
     T = 0
-    for bi in range(args.warmup, n_batches):
+    for si in range(args.warmup, n_steps_all):
+        bi = si % n_batches
         if use_dist:
             allsk = sq.exchange_sketches(qsk[bi])
             T += int(eng.gathered_dev(allsk, per * world).sum())
@@ -304,7 +309,7 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
     p = po.make_params(K, S, W, H, J)
     cores = po.lib().nqo_max_threads()
     n_s = int(min(per, max(8, 2 * cores)))
-    bi = args.warmup
+    bi = args.warmup % qsk.shape[0]   # the batch the first timed step used
     seqs = qseq[bi * per * stride_b: bi * per * stride_b + n_s * stride_b].cpu().numpy()
     rec = np.stack([seqs[i * stride_b:i * stride_b + L] for i in range(n_s)])
     rec_off = (np.arange(n_s + 1) * L).astype(np.uint64)
