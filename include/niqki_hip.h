@@ -203,7 +203,10 @@ int niqki_query_sequences(niqki_index *ix, const uint8_t *seqs,
  * or query it.  Framing is the reference's: FASTA = the first line of a file and
  * every line starting with '>' is a header, all other lines are concatenated
  * (nothing trimmed or upper-cased); FASTQ = 4-line records.  A record of at most
- * K bases is skipped (:395,:423,:450,:512). */
+ * K bases is skipped (:395,:423,:450,:512).  The staged batch stays usable until the
+ * next niqki_stage_raw or the next HOST-memory niqki_sketch / niqki_query_sequences
+ * on the handle (they share its staging buffers; niqki_staged_* then report
+ * NIQKI_E_STATE); every other call leaves it alone. */
 typedef struct niqki_raw_batch {
   const uint8_t *raw;        /* bytes of n_files files back to back, in the memory space of the
                                 call (device: 4-byte aligned, NIQKI_SEQ_PAD readable bytes after) */

@@ -63,7 +63,7 @@ struct niqki_index {
   Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
       ws_misc, ws_stash;
   // staged batch (niqki_stage_raw): framing results live in ws_seq / ws_recoff / ws_entry
-  Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr;
+  Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk;
   struct {
     bool valid = false, sketched = false;
     uint32_t n_entry = 0, n_rec = 0;
@@ -469,7 +469,7 @@ void niqki_destroy(niqki_index *ix) {
   for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
                  &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash,
                  &ix->ws_raw, &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
-                 &ix->ws_hdrpos, &ix->ws_ehdr})
+                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk})
     if (b->p) (void)hipFree(b->p);
   if (ix->store) (void)hipFree(ix->store);
   if (ix->entries) (void)hipFree(ix->entries);
@@ -968,15 +968,16 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
 }
 
 namespace {
-// sketches of the staged entries into ws_sk (once per staged batch)
+// sketches of the staged entries into their own buffer (once per staged batch; the other
+// entry points keep using ws_sk, so they cannot disturb a staged batch)
 int staged_sketch_ws(niqki_index *ix) {
   if (!ix->staged.valid) return fail(ix, NIQKI_E_STATE, "no staged batch (niqki_stage_raw first)");
   if (ix->staged.sketched) return NIQKI_OK;
   const uint32_t n = ix->staged.n_entry;
-  int rc = ensure(ix, ix->ws_sk, std::max<size_t>((size_t)n * ix->d.F * 4, 4));
+  int rc = ensure(ix, ix->ws_stsk, std::max<size_t>((size_t)n * ix->d.F * 4, 4));
   if (rc) return rc;
   rc = sketch_dev(ix, (const uint8_t *)ix->ws_seq.p, (const uint64_t *)ix->ws_recoff.p, ix->staged.n_rec,
-                  ix->staged.entry_rec, n, (int32_t *)ix->ws_sk.p, ix->staged.seq_bytes);
+                  ix->staged.entry_rec, n, (int32_t *)ix->ws_stsk.p, ix->staged.seq_bytes);
   if (rc) return rc;
   ix->staged.sketched = true;
   return NIQKI_OK;
@@ -991,7 +992,7 @@ int niqki_staged_sketch(niqki_index *ix, int32_t *sketches, int mem) {
   const size_t bytes = (size_t)ix->staged.n_entry * ix->d.F * 4;
   if (!bytes) return NIQKI_OK;
   if (!sketches) return NIQKI_E_INVALID;
-  NQ_HIP(ix, hipMemcpyAsync(sketches, ix->ws_sk.p, bytes,
+  NQ_HIP(ix, hipMemcpyAsync(sketches, ix->ws_stsk.p, bytes,
                             mem == NIQKI_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ix->stream));
   if (mem == NIQKI_MEM_HOST) NQ_HIP(ix, hipStreamSynchronize(ix->stream));
   return NIQKI_OK;
@@ -1002,7 +1003,7 @@ int niqki_staged_insert(niqki_index *ix) {
   NQ_HIP(ix, hipSetDevice(ix->device));
   int rc = staged_sketch_ws(ix);
   if (rc) return rc;
-  return niqki_insert(ix, (const int32_t *)ix->ws_sk.p, ix->staged.n_entry, NIQKI_MEM_DEVICE);
+  return niqki_insert(ix, (const int32_t *)ix->ws_stsk.p, ix->staged.n_entry, NIQKI_MEM_DEVICE);
 }
 
 int niqki_staged_query(niqki_index *ix, uint64_t *hit_off, uint32_t *hit_counts, uint32_t *hit_gids,
@@ -1012,10 +1013,10 @@ int niqki_staged_query(niqki_index *ix, uint64_t *hit_off, uint32_t *hit_counts,
   int rc = staged_sketch_ws(ix);
   if (rc) return rc;
   if (mem == NIQKI_MEM_DEVICE)
-    return niqki_query(ix, (const int32_t *)ix->ws_sk.p, ix->staged.n_entry, hit_off, hit_counts, hit_gids,
+    return niqki_query(ix, (const int32_t *)ix->ws_stsk.p, ix->staged.n_entry, hit_off, hit_counts, hit_gids,
                        capacity, NIQKI_MEM_DEVICE);
   if ((rc = build_if_needed(ix))) return rc;
-  return query_to_host(ix, (const int32_t *)ix->ws_sk.p, true, ix->staged.n_entry, hit_off, hit_counts,
+  return query_to_host(ix, (const int32_t *)ix->ws_stsk.p, true, ix->staged.n_entry, hit_off, hit_counts,
                        hit_gids, capacity);
 }
 

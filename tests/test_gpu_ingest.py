@@ -203,6 +203,18 @@ def test_staged_insert_and_query_equal_the_record_path(native, po):
     off2, hc2, hg2 = b.query_sequences(genomes[:5])
     assert np.array_equal(off, off2) and np.array_equal(hc, hc2) and np.array_equal(hg, hg2)
     assert off[-1] > 5
+    # other calls in between do not disturb the staged batch ...
+    a.stage_raw(files[:5], None)
+    sk5 = a.staged_sketch()
+    a.query(b.get_sketches(0, 12))
+    a.densify(np.full((3, 1024), -1, np.int32))
+    off3, hc3, hg3 = a.staged_query()
+    assert np.array_equal(off3, off2) and np.array_equal(hc3, hc2) and np.array_equal(hg3, hg2)
+    assert np.array_equal(a.staged_sketch(), sk5)
+    # ... except a host-memory sketch call, which takes the staging buffers: reported, not wrong
+    a.sketch(genomes[:2])
+    with pytest.raises(native.NiqkiError):
+        a.staged_query()
     # lines mode on the same bytes: one entry per record
     reads = b"".join(b">r%d\n" % i + genomes[i % 12][100 * i:100 * i + 150] + b"\n" for i in range(200))
     info, hdr = a.stage_raw([reads], None, lines=True, final=True, max_entries=4096)
