@@ -458,7 +458,7 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
 // one that finds its own proposal writes the value and lowers its mi.  Copies of a value
 // propose the same target, so the entries present at the start are all that ever
 // matter; two entries with the same value are harmless (the lower index always wins).
-constexpr uint32_t kReadEntries = 16;                 // entries per lane
+constexpr uint32_t kReadEntries = 6;                  // entries per lane (384: reads up to ~400 bases)
 constexpr uint32_t kReadMaxEntries = 64 * kReadEntries;
 constexpr uint32_t kReadTile = 512;                   // positions coded per tile
 
@@ -650,10 +650,8 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
         else if (rounds <= 2) densify_wave_entries<2>(sk, elist, n_ent, F, empty0);
         else if (rounds <= 3) densify_wave_entries<3>(sk, elist, n_ent, F, empty0);
         else if (rounds <= 4) densify_wave_entries<4>(sk, elist, n_ent, F, empty0);
-        else if (rounds <= 6) densify_wave_entries<6>(sk, elist, n_ent, F, empty0);
-        else if (rounds <= 8) densify_wave_entries<8>(sk, elist, n_ent, F, empty0);
-        else if (rounds <= 12) densify_wave_entries<12>(sk, elist, n_ent, F, empty0);
-        else densify_wave_entries<16>(sk, elist, n_ent, F, empty0);
+        else densify_wave_entries<6>(sk, elist, n_ent, F, empty0);
+        static_assert(kReadEntries == 6, "dispatch above covers 1..6 rounds");
       }
     }
     __syncthreads();
