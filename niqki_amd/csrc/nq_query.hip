@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256) void hits_compact_kernel(HitsArgs a) {
   __shared__ uint32_t s_before;
   const uint32_t q = blockIdx.x / a.n_blk, b = blockIdx.x % a.n_blk;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (a.blk_counts[blockIdx.x] == 0) return;  // nothing above the threshold in this block (uniform)
   if (tid == 0) {
     uint32_t before = 0;
     for (uint32_t i = 0; i < b; ++i) before += a.blk_counts[(uint64_t)q * a.n_blk + i];
