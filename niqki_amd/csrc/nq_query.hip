@@ -355,9 +355,15 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     case 1: NQ_BY_TILES(1024, 8); break;
     case 2: NQ_BY_TILES(1024, 32); break;
     case 3: NQ_BY_TILES(512, 16); break;
+    case 4: NQ_BY_TILES(256, 16); break;
+    case 5: NQ_BY_TILES(128, 16); break;
     case 11: NQ_BY_TILES(1024, 16, 1); break;      // ablations, see MODE
     case 16: NQ_BY_TILES(1024, 16, 6); break;
-    default: NQ_BY_TILES(1024, 16); break;
+    default:
+      // small tiles (short-read indexes): counters of <= 24 KB leave room for several
+      // workgroups per CU, and 4 waves per query then beat 16 (tools/bench_reads.py)
+      if (v.tile <= 12288) NQ_BY_TILES(256, 16); else NQ_BY_TILES(1024, 16);
+      break;
   }
 #undef NQ_BY_TILES
 #undef NQ_GATHER_LDS

@@ -499,6 +499,9 @@ struct Piece {
 // that end at a record boundary, this thread runs the GPU calls, a writer thread formats
 // and compresses the hits: the three overlap, output order is input order.
 void Index::stream_lines(const std::string &filestr, bool insert) {
+  using clk = std::chrono::steady_clock;
+  const auto t_begin = clk::now();
+  uint64_t n_entries_total = 0;
   const char type = data_type(filestr);
   const uint8_t type_u8 = (uint8_t)type;
   // sketches of one call stay below 2 GB
@@ -582,6 +585,7 @@ void Index::stream_lines(const std::string &filestr, bool insert) {
         rb.max_entries = max_entries;
         niqki_stage_info info{};
         check(niqki_stage_raw(h_, &rb, NIQKI_MEM_HOST, &info, hdr.data()), "niqki_stage_raw");
+        n_entries_total += info.n_entry;
         if (info.n_entry) {
           Hits *h = insert ? nullptr : out_free.pop();
           std::vector<std::string> local;
@@ -616,6 +620,9 @@ void Index::stream_lines(const std::string &filestr, bool insert) {
   writer.join();
   if (!err.empty()) throw std::runtime_error(err);
   if (!writer_err.empty()) throw std::runtime_error(writer_err);
+  if (std::getenv("NIQKI_HOST_TIMING"))
+    std::cerr << "[niqki timing] lines mode: " << n_entries_total << " entries in "
+              << std::chrono::duration<double>(clk::now() - t_begin).count() << " s" << std::endl;
 }
 
 void Index::insert_file_lines(const std::string &filestr) { stream_lines(filestr, true); }
