@@ -116,6 +116,23 @@ def test_chunk_boundaries(native, po, size):
     check_whole(native, po, files, ["A"] * len(files))
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_framing_fuzz(native, po, seed):
+    """Files of random bytes from an alphabet rich in newlines, '>', 0xFF, '\\r' and NULs, as
+    FASTA and as FASTQ: records are framed where the reference's reader loop frames them."""
+    rng = np.random.default_rng(100 + seed)
+    alphabet = np.frombuffer(b"ACGTACGTACGTacgtN\n\n>\xff\r\x00@+ ", np.uint8)
+    files, types = [], []
+    for i in range(24):
+        n = int(rng.integers(0, 40000)) if i % 4 else int(rng.integers(0, 300))
+        p_nl = float(rng.choice([0.002, 0.02, 0.2]))
+        body = alphabet[rng.integers(0, alphabet.size, n)].copy()
+        body[rng.random(n) < p_nl] = ord("\n")
+        files.append(bytes(body))
+        types.append("A" if i % 2 == 0 else "Q")
+    check_whole(native, po, files, types, K=int(rng.integers(3, 32)), S=6)
+
+
 def test_single_line_genome_and_many_small_files(native, po):
     rng = np.random.default_rng(3)
     big = b">g\n" + rand_seq(rng, 300_000) + b"\n"           # one 300 kbp line
