@@ -191,6 +191,11 @@ def main():
         if use_dist:
             dist.barrier()
 
+    if use_dist and sq.exchange == "sparse":
+        # exchange calibration (untimed, not a warm-up step): every resident batch once, so that
+        # a candidate list that does not fit is seen before anything is timed
+        for bi in range(n_batches):
+            step(bi)
     for bi in range(args.warmup):
         step(bi)
     eng.synchronize()
