@@ -174,7 +174,9 @@ def main():
     hg = torch.zeros(cap, dtype=torch.int32, device=dev)
     stride = (N + 1) & ~1
     counts = torch.zeros((per * world, stride), dtype=torch.int16, device=dev)
-    sq = ShardedQuery(eng, N, F, dev, exchange=args.exchange) if use_dist else None
+    # 256 candidates per query and shard (a family has 100 members); the calibration pass below
+    # switches to the dense exchange if any list overflows
+    sq = ShardedQuery(eng, N, F, dev, exchange=args.exchange, cand_cap=256) if use_dist else None
     eng.synchronize()
 
     def step(si):
