@@ -170,6 +170,28 @@ def test_lines_mode_streams_many_pieces(workdir, native, gold, fmt):
     assert sum(len(g.split(" ")) - 2 for g in got[:n]) == int(off[-1])   # total hits
 
 
+def test_reference_example_data(tmp_path, gold):
+    """BASELINE.json configs[0]: the nine E. coli genomes the reference ships as its example
+    (data fixtures in tests/golden/ecoli), default parameters (K=31 S=15 W=12): --matrix gives the
+    README's matrix, index + query the reference CLI's hits, the dump its bytes."""
+    _, meta = gold
+    exp = meta["ecoli_cli"]
+    edir = os.path.join(ROOT, "tests", "golden", "ecoli")
+    run(edir, ["-M", "file_of_file.txt", "-O", str(tmp_path / "m.gz")])
+    assert_same_text(gunzip(tmp_path / "m.gz").decode(), exp["matrix"])
+    assert "ecoli01p.fa.gz\t1\t0.967773\t0.938019\t" in exp["matrix"]       # README.md:118-128
+    run(edir, ["-I", "file_of_file.txt", "-Q", "file_of_file.txt", "-J", "0.8", "-O", str(tmp_path / "h.gz"),
+               "-D", str(tmp_path / "d.gz")])
+    assert_same_text(gunzip(tmp_path / "h.gz").decode(), exp["hits_J0.8"])
+    h = hashlib.md5()
+    n = 0
+    with gzip.open(tmp_path / "d.gz", "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+            n += len(blk)
+    assert n == exp["dump_len"] and h.hexdigest() == exp["dump_md5"]
+
+
 def test_matrix(workdir, gold):
     _, meta = gold
     run(workdir, ["-M", "fof.txt", "-S", "10", "-O", "matrix.gz"])

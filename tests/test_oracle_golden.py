@@ -188,14 +188,11 @@ def test_record_framing_restatement_vs_reference_cli(po, native, gold):
     assert "\n".join(lines) + "\n" == cli["nasty_idx"]
 
 
-def test_ecoli_pins_when_reference_present(po, gold):
-    """the 9 shipped E. coli genomes (only in the build
-    container, where /root/reference exists)."""
+def test_ecoli_pins(po, gold):
+    """the 9 E. coli genomes the reference ships (tests/golden/ecoli)."""
     import gzip
     import os
-    d = "/root/reference/resources"
-    if not os.path.isdir(d):
-        pytest.skip("reference resources not present")
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ecoli")   # data fixtures
     _, meta = gold
     m = meta["ecoli"]
     p = po.make_params(31, 15, 12, 4, 0.0)
@@ -214,3 +211,10 @@ def test_ecoli_pins_when_reference_present(po, gold):
     assert hg.tolist() == m["q1_gids"]
     # README matrix value (README.md:118-128): ecoli01p vs 02p = 31712/32768
     assert "%g" % (31712 / 32768) == "0.967773"
+    # the whole matrix the reference CLI printed for these files (query_matrix / query_range,
+    # src/niqki_index.cpp:570-628: min_score 0.1*F, rows in list order, trailing tabs)
+    mat = ix.matrix_range(0, 9)
+    text = "##Names\t" + "".join(f + "\t" for f in m["files"]) + "\n"
+    for a in range(9):
+        text += m["files"][a] + "\t" + "".join("%g\t" % ((mat[a, t] / 32768) if mat[a, t] >= 3276 else 0.0) for t in range(9)) + "\n"
+    assert text == meta["ecoli_cli"]["matrix"]
