@@ -46,18 +46,29 @@ constexpr size_t kBatchBytes = size_t(1) << 30;   // dump import: bytes per GPU 
 struct PinnedBuf {
   uint8_t *p = nullptr;
   size_t cap = 0, size = 0;
+  bool locked = false;  // page-locked (else plain memory: the copies still work, slower)
   PinnedBuf() = default;
   PinnedBuf(const PinnedBuf &) = delete;
   PinnedBuf &operator=(const PinnedBuf &) = delete;
-  ~PinnedBuf() { niqki_host_free(p); }
+  ~PinnedBuf() { release(); }
+  void release() {
+    if (locked) niqki_host_free(p); else std::free(p);
+    p = nullptr;
+  }
   void reserve(size_t n) {  // keeps the first `size` bytes
     if (n <= cap) return;
     const size_t want = std::max(n, cap + cap / 2);
+    bool q_locked = true;
     uint8_t *q = (uint8_t *)niqki_host_alloc(want);
-    if (!q) throw std::runtime_error("page-locked allocation of " + std::to_string(want) + " bytes failed");
+    if (!q) {  // e.g. a low locked-memory limit
+      q = (uint8_t *)std::malloc(want);
+      q_locked = false;
+      if (!q) throw std::runtime_error("allocation of " + std::to_string(want) + " bytes failed");
+    }
     if (size) std::memcpy(q, p, size);
-    niqki_host_free(p);
+    release();
     p = q;
+    locked = q_locked;
     cap = want;
   }
 };

@@ -108,7 +108,11 @@ def test_north_star_parameters_vs_reference_goldens(native, po, gold):
     e.close()
 
 
-def test_short_and_edge_reads_vs_reference_goldens(native, gold):
+@pytest.mark.parametrize("wave_kernel", ["1", "0"])
+def test_short_and_edge_reads_vs_reference_goldens(native, gold, wave_kernel, monkeypatch):
+    """Both launch shapes of the short-record path: one wavefront per sketch (default) and the
+    256-thread workgroup per sketch it replaced (still used for S >= 13 / 4-16 kbp records)."""
+    monkeypatch.setenv("NIQKI_SKETCH_WAVE", wave_kernel)
     vec, meta = gold
     m = meta["C"]
     e = native.Engine(K=m["K"], S=m["S"], W=m["W"], H=m["H"])
