@@ -59,11 +59,12 @@ struct niqki_index {
   int gather_variant = 0;
   uint64_t record_len_hint = 0;  // avg bytes per sketch for device-side batches (0 = read it back)
   uint32_t query_batch = 1024;
+  int query_order = 1;           // option: order the queries of a launch for cache locality
 
   Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
       ws_misc, ws_stash;
   // staged batch (niqki_stage_raw): framing results live in ws_seq / ws_recoff / ws_entry
-  Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk;
+  Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk, ws_order;
   struct {
     bool valid = false, sketched = false;
     uint32_t n_entry = 0, n_rec = 0;
@@ -276,11 +277,21 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *
     rc = ensure(ix, ix->ws_stash, (size_t)std::min(nq, chunk) * (ix->n_tiles - 1) * f_local * sizeof(nq::Entry));
     if (rc) return rc;
   }
+  // locality order of each launch: worth its probe on large indexes and real batches
+  const bool ordered = ix->query_order && !ix->direct && chunk <= 4096 && ix->built_n >= 16384 &&
+                       ix->built_n < (1u << 20) - 1 && f_local >= 1024;
+  if (ordered && (rc = ensure(ix, ix->ws_order, (size_t)chunk * 8))) return rc;
   for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
     const uint32_t n = std::min(chunk, nq - q0);
     Span sp(ix, NIQKI_KC_GATHER);
+    const uint32_t *order = nullptr;
+    if (ordered && n >= 64) {
+      uint32_t *keys = (uint32_t *)ix->ws_order.p;
+      NQ_HIP(ix, nq::launch_order(view(ix), sketches + (size_t)q0 * ix->d.F, n, keys, keys + chunk, ix->stream));
+      order = keys + chunk;
+    }
     NQ_HIP(ix, nq::launch_gather(view(ix), sketches + (size_t)q0 * ix->d.F, n, counts + (size_t)q0 * stride, stride,
-                                 (nq::Entry *)ix->ws_stash.p, ix->gather_variant, ix->stream));
+                                 (nq::Entry *)ix->ws_stash.p, order, ix->gather_variant, ix->stream));
   }
   return NIQKI_OK;
 }
@@ -458,6 +469,7 @@ int niqki_create(const niqki_params *params, niqki_index **out) {
   if ((e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking)) != hipSuccess) return bail(NIQKI_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   ix->own_stream = true;
   if (const char *v = std::getenv("NIQKI_GATHER_VARIANT")) ix->gather_variant = std::atoi(v);
+  if (const char *v = std::getenv("NIQKI_QUERY_ORDER")) ix->query_order = std::atoi(v) != 0;
   *out = ix;
   return NIQKI_OK;
 }
@@ -469,7 +481,7 @@ void niqki_destroy(niqki_index *ix) {
   for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
                  &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash,
                  &ix->ws_raw, &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
-                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk})
+                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order})
     if (b->p) (void)hipFree(b->p);
   if (ix->store) (void)hipFree(ix->store);
   if (ix->entries) (void)hipFree(ix->entries);
@@ -515,6 +527,7 @@ int niqki_synchronize(niqki_index *ix) {
 int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
   if (!ix || !key) return NIQKI_E_INVALID;
   if (!std::strcmp(key, "gather_variant")) { ix->gather_variant = (int)value; return NIQKI_OK; }
+  if (!std::strcmp(key, "query_order")) { ix->query_order = value != 0; return NIQKI_OK; }
   if (!std::strcmp(key, "query_batch")) { if (value < 1) return NIQKI_E_INVALID; ix->query_batch = (uint32_t)value; return NIQKI_OK; }
   if (!std::strcmp(key, "tile_genomes")) {
     if (value < 0 || value > 65536 || (value & 63)) return fail(ix, NIQKI_E_INVALID, "tile_genomes must be a multiple of 64, <= 65536");

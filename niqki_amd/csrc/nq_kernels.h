@@ -91,9 +91,13 @@ hipError_t launch_import(const Derived &d, const uint32_t *words, const uint64_t
 // gather-histogram: counts[q*stride + g] for all genomes (u16), one workgroup
 // per (query, tile).
 // stash: nq x (n_tiles-1) x f_local Entry scratch (unused for n_tiles == 1)
+// order: nullptr, or the locality order of the batch from launch_order (nq <= 4096, CSR layout)
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq,
-                         uint16_t *counts, uint64_t stride, Entry *stash, int variant,
-                         hipStream_t stream);
+                         uint16_t *counts, uint64_t stride, Entry *stash, const uint32_t *order,
+                         int variant, hipStream_t stream);
+// keys / order: nq words of scratch each
+hipError_t launch_order(const IndexView &v, const int32_t *sketches, uint32_t nq, uint32_t *keys,
+                        uint32_t *order, hipStream_t stream);
 hipError_t launch_gathered(const IndexView &v, const int32_t *sketches, uint32_t nq,
                            unsigned long long *per_query, hipStream_t stream);
 

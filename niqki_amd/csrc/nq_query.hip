@@ -293,13 +293,104 @@ __device__ __forceinline__ void walk_tile_direct(const IndexView &v, const int32
   }
 }
 
+
+// ---- locality order of a query batch -----------------------------------------------------
+// Queries that hit the same genomes read the same table and bucket lines.  When they run on
+// the same XCD at the same time those lines are fetched from HBM once (measured: 13 % off the
+// launch when the 4 queries of a family sit 8 blocks apart).  So a batch is ordered by its
+// best probable hit: probe_kernel counts the first kProbeSlots slots only and takes the genome
+// with the most hits as the query's key, order_kernel sorts (key, query), and gather_kernel
+// maps sorted neighbours to one XCD.  Only the order of the work changes, never a result.
+constexpr uint32_t kXcds = 8;
+constexpr uint32_t kOrderGroup = 8;
+constexpr uint32_t kProbeSlots = 16;
+constexpr uint32_t kOrderMax = 4096;   // queries per launch (12 index bits next to a 20-bit key)
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void probe_kernel(IndexView v, const int32_t *sketches, uint32_t *keys) {
+  extern __shared__ __align__(16) uint32_t cnt[];
+  __shared__ uint32_t s_best;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const int32_t *sk = sketches + (uint64_t)q * v.d.F + v.d.slot_begin;
+  const uint32_t n_probe = v.f_local < kProbeSlots ? v.f_local : kProbeSlots;
+  if (tid == 0) s_best = 0;
+  for (uint32_t t = 0; t < v.n_tiles; ++t) {
+    const uint32_t g0 = t * v.tile;
+    const uint32_t n_t = (v.n_genomes - g0) < v.tile ? (v.n_genomes - g0) : v.tile;
+    const uint32_t n_words = (n_t + 1) / 2;
+    for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
+    __syncthreads();
+    const uint16_t *gl = v.gids + v.tile_base[t];
+    for (uint32_t s = wave; s < n_probe; s += BLOCK / 64) {
+      const int32_t fp = sk[s];
+      if (fp < 0 || (uint32_t)fp >= v.d.R) continue;  // wave uniform
+      const Entry e = v.entries[((uint64_t)s * v.d.R + (uint32_t)fp) * v.n_tiles + t];
+      const uint16_t *b = gl + ((uint64_t)e.start << v.align_log2);
+      for (uint32_t o = lane; o < e.len; o += 64) bump(cnt, b[o]);
+    }
+    __syncthreads();
+    uint32_t best = 0;  // count << 20 | gid
+    for (uint32_t i = tid; i < n_words; i += BLOCK) {
+      const uint32_t w = cnt[i];
+      const uint32_t a = ((w & 0xFFFFu) << 20) | (g0 + 2 * i);
+      const uint32_t b2 = ((w >> 16) << 20) | (g0 + 2 * i + 1);
+      best = best > a ? best : a;
+      best = best > b2 ? best : b2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t y = __shfl_xor(best, o, 64);
+      best = best > y ? best : y;
+    }
+    if (lane == 0) atomicMax(&s_best, best);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const uint32_t c = s_best >> 20;
+    const uint32_t key = c >= 2 ? (s_best & 0xFFFFFu) : 0xFFFFFu;  // unrelated queries: one group at the end
+    keys[q] = (key << 12) | q;
+  }
+}
+
+// keys[0..nq) -> order[0..nq): ascending (key, query index); one workgroup, bitonic in LDS
+__global__ __launch_bounds__(1024) void order_kernel(const uint32_t *keys, uint32_t nq, uint32_t *order) {
+  __shared__ uint32_t a[kOrderMax];
+  const uint32_t tid = threadIdx.x;
+  for (uint32_t i = tid; i < kOrderMax; i += 1024) a[i] = i < nq ? keys[i] : 0xFFFFFFFFu;
+  __syncthreads();
+  for (uint32_t k = 2; k <= kOrderMax; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = tid; i < kOrderMax; i += 1024) {
+        const uint32_t l = i ^ j;
+        if (l > i) {
+          const uint32_t x = a[i], y = a[l];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) { a[i] = y; a[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = tid; i < nq; i += 1024) order[i] = a[i] & 0xFFFu;
+}
+
 // One workgroup per query; the genome tiles are walked one after another with
 // the tile's hit counters (packed u16 pairs) in LDS.
 template <int BLOCK, int UNROLL, int NT, int MODE = 0>
 __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_t *sketches,
-                                                       uint16_t *counts, uint64_t stride, Entry *stash) {
+                                                       uint16_t *counts, uint64_t stride, Entry *stash,
+                                                       const uint32_t *order, uint32_t nq) {
   extern __shared__ __align__(16) uint32_t cnt[];
-  const uint32_t q = blockIdx.x;
+  uint32_t q = blockIdx.x;
+  if (order) {
+    // Locality order (see order_queries below): block b runs on XCD b % 8 as the (b / 8)-th
+    // workgroup of that XCD; kOrderGroup consecutive entries of the sorted order share an XCD
+    // and sit next to each other in its dispatch queue.
+    const uint32_t x = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
+    const uint32_t i = ((k / kOrderGroup) * kXcds + x) * kOrderGroup + k % kOrderGroup;
+    if (i >= nq) return;  // padding block (uniform)
+    q = order[i];
+  }
   const uint32_t tid = threadIdx.x;
   const int32_t *sk = sketches + (uint64_t)q * v.d.F + v.d.slot_begin;
   Item *queue = (Item *)(cnt + (v.tile + 1) / 2);  // behind the counters: kQueue items per wave
@@ -329,11 +420,24 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
   }
 }
 
+hipError_t launch_order(const IndexView &v, const int32_t *sketches, uint32_t nq, uint32_t *keys,
+                        uint32_t *order, hipStream_t stream) {
+  if (nq == 0 || nq > kOrderMax || v.direct || v.n_genomes >= (1u << 20) - 1) return hipErrorInvalidValue;
+  const size_t lds = (size_t)((v.tile + 1) / 2) * 4;
+  hipError_t e = hipFuncSetAttribute((const void *)probe_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(probe_kernel<1024>, dim3(nq), dim3(1024), lds, stream, v, sketches, keys);
+  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, keys, nq, order);
+  return hipGetLastError();
+}
+
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq, uint16_t *counts,
-                         uint64_t stride, Entry *stash, int variant, hipStream_t stream) {
+                         uint64_t stride, Entry *stash, const uint32_t *order, int variant, hipStream_t stream) {
   if (nq == 0 || v.n_tiles == 0) return hipSuccess;
 #define NQ_GATHER_LDS(B) ((size_t)((v.tile + 1) / 2) * 4 + (size_t)(B / 64) * kQueue * sizeof(Item))
-  dim3 grid(nq);
+  // with a locality order the grid is padded to whole groups on every XCD
+  const uint32_t per_round = kXcds * kOrderGroup;
+  dim3 grid(order ? (nq + per_round - 1) / per_round * per_round : nq);
   hipError_t e;
 #define NQ_LAUNCH_GATHER(B, U, NT, ...)                                                          \
   do {                                                                                           \
@@ -341,7 +445,7 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     const size_t lds = NQ_GATHER_LDS(B);                                                         \
     e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                               \
-    hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, v, sketches, counts, stride, stash);       \
+    hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, v, sketches, counts, stride, stash, order, nq); \
   } while (0)
 #define NQ_BY_TILES(B, U, ...)                                                                   \
   do {                                                                                           \

@@ -501,3 +501,38 @@ def test_maximum_fingerprint_width_and_full_tile(native, po, index_layout):
         assert np.array_equal(hc[int(off[i]):int(off[i + 1])], ehc) and np.array_equal(hg[int(off[i]):int(off[i + 1])], ehg)
     assert e.tile_genomes() == 65536
     e.close()
+
+
+def test_locality_order_changes_nothing(native, po):
+    """Large index + batch: the gather kernel runs the queries in locality order (probe of the
+    first slots -> sort -> XCD-aware block mapping).  Same counters and hits as with the option
+    off and as the oracle, for batch sizes around the group padding."""
+    rng = np.random.default_rng(21)
+    S, W, N = 10, 8, 20000
+    F = 1 << S
+    base = rng.integers(0, 1 << W, (40, F)).astype(np.int32)
+    sk = base[rng.integers(0, 40, N)].copy()                      # 40 families of identical-ish sketches
+    noise = rng.random((N, F)) < 0.3
+    sk[noise] = rng.integers(0, 1 << W, int(noise.sum()))
+    sk[rng.random((N, F)) < 0.01] = -1
+    e = native.Engine(K=31, S=S, W=W, H=3, J=0.3)
+    for a in range(0, N, 4000):
+        e.insert(sk[a:a + 4000])
+    p = po.make_params(31, S, W, 3, 0.3)
+    ix = po.Index(p, sk)
+    for nq in (64, 100, 513):
+        q = base[rng.integers(0, 40, nq)].copy()
+        m = rng.random((nq, F)) < 0.2
+        q[m] = rng.integers(0, 1 << W, int(m.sum()))
+        q[nq // 2] = -1                                            # a query without any hit
+        e.set_option("query_order", 1)
+        c1 = e.query_counts(q)
+        h1 = e.query(q)
+        e.set_option("query_order", 0)
+        c0 = e.query_counts(q)
+        h0 = e.query(q)
+        assert np.array_equal(c1, c0)
+        assert all(np.array_equal(x, y) for x, y in zip(h1, h0))
+        for i in (0, 1, nq // 2, nq - 1):
+            assert np.array_equal(c1[i].astype(np.uint32), ix.counts(q[i])), (nq, i)
+    e.close()

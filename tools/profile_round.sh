@@ -16,7 +16,7 @@ done
 cd $R
 python tools/prof_summary.py $OUT/kt > gpurun_out/${TAG}_kernel_trace_summary.txt
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_rocprofv3_kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_128B; do python tools/prof_summary.py $OUT/$c | grep -E "^==|gather_kernel|sketch_kernel|hits_|build_kernel"; done > gpurun_out/${TAG}_pmc_summary.txt
+for c in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_128B; do python tools/prof_summary.py $OUT/$c | grep -E "^==|gather_kernel|probe_kernel|order_kernel|sketch_kernel|hits_|build_kernel"; done > gpurun_out/${TAG}_pmc_summary.txt
 cp $OUT/kt.json gpurun_out/${TAG}_bench_under_rocprof.json
 rm -rf $OUT
 cat gpurun_out/${TAG}_pmc_summary.txt | cut -c1-200; head -12 gpurun_out/${TAG}_kernel_trace_summary.txt | cut -c1-170
