@@ -110,7 +110,9 @@ int niqki_synchronize(niqki_index *ix);
  * "bucket_align_log2" (-1 = choose, 0..6: buckets start on multiples of 2^a ids),
  * "min_score", "record_len_hint" (average bytes per sketch of NIQKI_MEM_DEVICE
  * batches, so that niqki_sketch need not read rec_off back to pick a launch
- * shape; 0 = read it back). */
+ * shape; 0 = read it back), "query_order" (1 = default: the queries of a launch
+ * are processed in an order that puts similar ones on the same XCD; results are
+ * unaffected; 0 = input order). */
 int niqki_set_option(niqki_index *ix, const char *key, int64_t value);
 
 /* Pre-sizes the sketch store for n_genomes (optional; the store grows). */
