@@ -13,7 +13,10 @@
 // table access (the other tiles' entries are parked in a coalesced stash), then
 // the wave walks the 64 buckets one after another, all lanes reading consecutive
 // u16 genome ids of one 128-byte aligned bucket.  HBM-bound by design:
-// algorithmic bytes per query = 4T + 20F.
+// algorithmic bytes per query = 4T + 20F.  On large indexes the
+// queries of a launch are first put into a locality order (probe_kernel,
+// order_kernel): similar queries then run on the same XCD at the same time and
+// share their table and bucket lines through its L2.
 #include "nq_kernels.h"
 
 namespace nq {
