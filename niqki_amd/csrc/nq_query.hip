@@ -131,16 +131,21 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
     }
   };
 
+  // software pipeline: table look-ups run two iterations ahead of the walk, fingerprints
+  // three (a pass over short buckets has little walk work to hide a look-up behind)
   uint32_t it = wave;
   int32_t fp0 = load_fp(it);
   int32_t fp1 = load_fp(it + NW);
+  int32_t fp2 = load_fp(it + 2 * NW);
   Look cur = lookup(it, fp0);
   bool cur_ok = valid_of(it, fp0);
+  Look nxt = lookup(it + NW, fp1);
+  bool nxt_ok = valid_of(it + NW, fp1);
 
   for (; it < n_it; it += NW) {
-    const Look nxt = lookup(it + NW, fp1);
-    const bool nxt_ok = valid_of(it + NW, fp1);
-    fp1 = load_fp(it + 2 * NW);
+    const Look nxt2 = lookup(it + 2 * NW, fp2);
+    const bool nxt2_ok = valid_of(it + 2 * NW, fp2);
+    fp2 = load_fp(it + 3 * NW);
     uint32_t pos = cur.e[0].start, rem = cur_ok ? cur.e[0].len : 0u;
     const uint32_t step = 64u >> a;  // units per 64 ids (align_log2 <= 6)
     if (STASH_OUT) {
@@ -151,7 +156,7 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
           my_stash[(uint64_t)(k - 1) * v.f_local + s] = Entry{cur.e[k].start, cur_ok ? cur.e[k].len : 0u};
       }
     }
-    if (MODE == 6) { sink += pos ^ rem; cur = nxt; cur_ok = nxt_ok; continue; }
+    if (MODE == 6) { sink += pos ^ rem; cur = nxt; cur_ok = nxt_ok; nxt = nxt2; nxt_ok = nxt2_ok; continue; }
     // cut the 64 buckets into chunks of <= 64 ids, at most 3 per lane and round
     // (q_count < 64 here, so at most 63 + 192 items are ever queued)
     do {
@@ -178,6 +183,8 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
     } while (__any(rem != 0));
     cur = nxt;
     cur_ok = nxt_ok;
+    nxt = nxt2;
+    nxt_ok = nxt2_ok;
   }
   if (q_count) {  // the last partial batch
     Item x = wq[(q_head + lane) & (kQueue - 1)];
