@@ -110,10 +110,14 @@ void read_file_bytes(const std::string &path, PinnedBuf &out) {
   ::close(fd);
 }
 
+// file-reader threads: NIQKI_HOST_THREADS, else OMP_NUM_THREADS (what sizes the reference's
+// reader pool, its files being read inside an OpenMP region), else min(hardware threads, 64)
 unsigned host_threads() {
-  if (const char *v = std::getenv("NIQKI_HOST_THREADS")) {
-    const int n = std::atoi(v);
-    if (n > 0) return (unsigned)std::min(n, 256);
+  for (const char *name : {"NIQKI_HOST_THREADS", "OMP_NUM_THREADS"}) {
+    if (const char *v = std::getenv(name)) {
+      const int n = std::atoi(v);
+      if (n > 0) return (unsigned)std::min(n, 256);
+    }
   }
   const unsigned hw = std::thread::hardware_concurrency();
   return hw ? std::min(hw, 64u) : 4u;
