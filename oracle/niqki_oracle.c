@@ -154,7 +154,7 @@ uint64_t nqo_sketch_accumulate(const nqo_params *p, const uint8_t *seq,
     rc = (rc >> 2) + (code_rc(c) << rc_shift); /* :233-236 */
     uint64_t canon = fw < rc ? fw : rc;        /* :345 */
     uint64_t slot = nqo_unrev64(canon) >> (64 - S); /* :347 */
-    int32_t fp = nqo_fingerprint_stale(nqo_rev64(canon), p->W, p->H, p->H0 ? p->H0 : p->H); /* :346,348 */
+    int32_t fp = nqo_fingerprint_stale(nqo_rev64(canon), p->W, p->H, p->H0p1 ? p->H0p1 - 1 : p->H); /* :346,348 */
     int32_t cur = sk[slot];
     if (cur == -1 || cur > fp) sk[slot] = fp; /* :350-355: min over fp */
   }
@@ -347,7 +347,7 @@ nqo_index *nqo_load_bytes(const uint8_t *buf, uint64_t len, uint64_t *consumed) 
   nqo_index *ix = (nqo_index *)calloc(1, sizeof(*ix));
   ix->p.S = hdr[0]; ix->p.K = hdr[1]; ix->p.H = hdr[2]; ix->p.W = hdr[3];
   ix->p.min_score = hdr[4];
-  ix->p.H0 = 0;
+  ix->p.H0p1 = 0;
   ix->n_genomes = hdr[5];
   ix->n_buckets = ((uint64_t)1 << ix->p.S) << ix->p.W;
   ix->offsets = (uint64_t *)calloc(ix->n_buckets + 1, sizeof(uint64_t));

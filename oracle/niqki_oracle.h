@@ -37,8 +37,8 @@ typedef struct nqo_params {
   uint32_t W;         /* fingerprint bits */
   uint32_t H;         /* HyperLogLog bits inside the fingerprint (M = W-H) */
   uint32_t min_score; /* (uint32)(min_fract * F), src/niqki_index.cpp:22 */
-  uint32_t H0;        /* 0, or the constructor's H when select_best_H (-G) replaced it
-                         afterwards: mask_M / maximal_remainder stay at H0's values */
+  uint32_t H0p1;      /* 0, or 1 + the constructor's H when select_best_H (-G) replaced it
+                         afterwards: mask_M / maximal_remainder stay at that H's values */
 } nqo_params;
 
 /* src/niqki_index.cpp:22  min_score = min_fract*F  (double -> uint32 truncation) */

@@ -24,7 +24,7 @@ u64p = C.POINTER(C.c_uint64)
 
 class Params(C.Structure):
     _fields_ = [("K", C.c_uint32), ("S", C.c_uint32), ("W", C.c_uint32),
-                ("H", C.c_uint32), ("min_score", C.c_uint32), ("H0", C.c_uint32)]
+                ("H", C.c_uint32), ("min_score", C.c_uint32), ("H0p1", C.c_uint32)]
 
 
 class _Index(C.Structure):
@@ -111,7 +111,7 @@ def make_params(K=31, S=15, W=12, H=4, J=0.0, genome_size=0.0):
     """genome_size != 0 applies the reference's -G (select_best_H after the constructor)."""
     p = Params(K, S, W, H, lib().nqo_min_score(J, S), 0)
     if genome_size:
-        p.H0 = H
+        p.H0p1 = H + 1
         p.H = lib().nqo_select_best_H(genome_size, S, W, H)
     return p
 

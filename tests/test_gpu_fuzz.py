@@ -5,7 +5,11 @@ insert, dense counters, thresholded + ordered hits, matrix, dump bytes, -G."""
 import numpy as np
 import pytest
 
+import os
+
 pytestmark = pytest.mark.gpu
+# NIQKI_FUZZ_SCALE=k runs k times as many seeds (one-off campaigns; the default stays small)
+SCALE = int(os.environ.get("NIQKI_FUZZ_SCALE", "1"))
 
 
 def random_record(rng, L, dirty):
@@ -23,7 +27,7 @@ def mutate(rng, s, rate):
     return t
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * SCALE))
 def test_random_parameters_vs_oracle(native, po, seed):
     rng = np.random.default_rng(1000 + seed)
     K = int(rng.integers(1, 32)) if seed % 3 else 31
@@ -60,7 +64,7 @@ def test_random_parameters_vs_oracle(native, po, seed):
     e.close()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 * SCALE))
 def test_select_best_h_random(native, po, seed):
     """-G with random constructor parameters: the stale-constant fingerprints of the sketches
     and everything downstream equal the oracle's (itself pinned on the reference)."""

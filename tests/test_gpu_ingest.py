@@ -6,7 +6,10 @@ CLI's own output for the nasty files."""
 import numpy as np
 import pytest
 
+import os
+
 pytestmark = pytest.mark.gpu
+SCALE = int(os.environ.get("NIQKI_FUZZ_SCALE", "1"))   # one-off campaigns: more fuzz seeds
 
 CHUNK = 8192  # nq::kIngestChunk
 
@@ -116,7 +119,7 @@ def test_chunk_boundaries(native, po, size):
     check_whole(native, po, files, ["A"] * len(files))
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 * SCALE))
 def test_framing_fuzz(native, po, seed):
     """Files of random bytes from an alphabet rich in newlines, '>', 0xFF, '\\r' and NULs, as
     FASTA and as FASTQ: records are framed where the reference's reader loop frames them."""

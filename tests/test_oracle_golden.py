@@ -39,7 +39,7 @@ def test_select_best_H_and_stale_fingerprints(po, gold):
         assert po.select_best_H(G, S, W, H) == chosen, (S, W, H, G)
     xs = vec["kat_x"].tolist()
     for tag, (W, H0) in {"kat_fp_stale_w12_h4_g150": (12, 4), "kat_fp_stale_w12_h2_g5e6": (12, 2),
-                         "kat_fp_stale_w8_h5_g1e4": (8, 5)}.items():
+                         "kat_fp_stale_w8_h5_g1e4": (8, 5), "kat_fp_stale_w10_h0_g1": (10, 0)}.items():
         v = vec[tag]
         Hn = int(v[0])
         assert Hn != H0
