@@ -108,6 +108,8 @@ int niqki_synchronize(niqki_index *ix);
  * "tile_genomes" (multiple of 64, <= 65536; takes effect at the next build),
  * "index_layout" (0 = choose, 1 = CSR entries + id lists, 2 = bucket lines),
  * "bucket_align_log2" (-1 = choose, 0..6: buckets start on multiples of 2^a ids),
+ * "tile_stripe" (1 = default: with several tiles genome g goes to tile g mod tiles, so a
+ * run of related genomes is spread over all tiles; 0 = tiles are ranges of genome ids),
  * "min_score", "record_len_hint" (average bytes per sketch of NIQKI_MEM_DEVICE
  * batches, so that niqki_sketch need not read rec_off back to pick a launch
  * shape; 0 = read it back), "query_order" (1 = default: the queries of a launch

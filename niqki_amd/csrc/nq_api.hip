@@ -52,6 +52,8 @@ struct niqki_index {
   uint16_t *lines = nullptr;       // bucket-line table (direct layout)
   size_t lines_bytes = 0;
   uint32_t direct = 0;             // layout of the built index
+  uint32_t stripe = 0;             // tiles are dealt round-robin (CSR layout)
+  int stripe_opt = 1;              // option: 1 = stripe when there are several tiles
   int layout_opt = 0;              // option: 0 = choose, 1 = CSR entries + id lists, 2 = bucket lines
   int bucket_align = -1;           // option: log2 ids per bucket alignment unit, -1 = choose
   bool built = false;
@@ -185,6 +187,7 @@ nq::IndexView view(const niqki_index *ix) {
   v.f_local = ix->d.slot_end - ix->d.slot_begin;
   v.align_log2 = ix->align_log2;
   v.direct = ix->direct;
+  v.stripe = ix->stripe;
   v.lines = ix->lines;
   v.cap = ix->cap;
   v.store = ix->store;
@@ -527,6 +530,7 @@ int niqki_synchronize(niqki_index *ix) {
 int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
   if (!ix || !key) return NIQKI_E_INVALID;
   if (!std::strcmp(key, "gather_variant")) { ix->gather_variant = (int)value; return NIQKI_OK; }
+  if (!std::strcmp(key, "tile_stripe")) { ix->stripe_opt = value != 0; ix->built = false; return NIQKI_OK; }
   if (!std::strcmp(key, "query_order")) { ix->query_order = value != 0; return NIQKI_OK; }
   if (!std::strcmp(key, "query_batch")) { if (value < 1) return NIQKI_E_INVALID; ix->query_batch = (uint32_t)value; return NIQKI_OK; }
   if (!std::strcmp(key, "tile_genomes")) {
@@ -719,6 +723,10 @@ int niqki_build(niqki_index *ix) {
   ix->built_n = N;
   ix->align_log2 = (uint32_t)al;
   ix->direct = direct ? 1u : 0u;
+  // CSR layout: genomes are dealt to the tiles round-robin (option "tile_stripe", default on)
+  int stripe = ix->stripe_opt;
+  if (const char *v = std::getenv("NIQKI_TILE_STRIPE")) stripe = std::atoi(v);
+  ix->stripe = (!direct && stripe != 0 && n_tiles > 1 && n_tiles <= 64) ? 1u : 0u;
   if (n_tiles == 0) { ix->built = true; return NIQKI_OK; }
   {
     Span sp(ix, NIQKI_KC_BUILD);

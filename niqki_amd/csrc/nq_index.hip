@@ -113,9 +113,9 @@ __global__ void build_kernel(IndexView v, uint32_t *slot_units, Entry *entries, 
   const bool direct = v.direct != 0;
   uint32_t *cur = smem + (size_t)wave * R * (direct ? 2 : 1);
   uint32_t *ovs = cur + R;  // bucket lines: overflow start (units) per fingerprint
-  const uint32_t g0 = t * v.tile;
-  const uint32_t n_t = (v.n_genomes - g0) < v.tile ? (v.n_genomes - g0) : v.tile;
-  const uint16_t *row = v.store + (uint64_t)s * v.cap + g0;
+  const uint32_t n_t = tile_count(v, t);
+  const uint16_t *srow = v.store + (uint64_t)s * v.cap;
+  auto row_at = [&](uint32_t i) -> uint32_t { return srow[tile_gid(v, t, i)]; };  // i-th genome of the tile
   // ids a bucket keeps outside its line / units they need
   auto units_of = [&](uint32_t h) -> uint32_t {
     if (direct) return h > kLineIds ? (h - kLineIds + 63) >> 6 : 0u;
@@ -124,7 +124,7 @@ __global__ void build_kernel(IndexView v, uint32_t *slot_units, Entry *entries, 
 
   for (uint32_t i = lane; i < R; i += 64) cur[i] = 0;
   for (uint32_t i = lane; i < n_t; i += 64) {
-    uint32_t fp = row[i];
+    uint32_t fp = row_at(i);
     if (fp != kEmpty16) atomicAdd(&cur[fp], 1u);
   }
   if (!FILL) {
@@ -163,7 +163,7 @@ __global__ void build_kernel(IndexView v, uint32_t *slot_units, Entry *entries, 
   const uint64_t lt_mask = (1ULL << lane) - 1ULL;
   for (uint32_t base = 0; base < n_t; base += 64) {
     uint32_t i = base + lane;
-    uint32_t fp = (i < n_t) ? (uint32_t)row[i] : (uint32_t)kEmpty16;
+    uint32_t fp = (i < n_t) ? row_at(i) : (uint32_t)kEmpty16;
     bool valid = fp != kEmpty16;
     uint64_t peers = __ballot(valid);
     for (uint32_t b = 0; b < W; ++b) {
@@ -275,6 +275,28 @@ __device__ __forceinline__ void bucket_copy(const IndexView &v, uint32_t t, uint
     for (uint32_t j = 0; j < e.len; ++j) out[pos++] = t * v.tile + gl[j];
   }
 }
+// striped tiles: the bucket's ids in ascending GLOBAL order are a merge of the tiles' lists
+// (each ascending in its local ids)
+constexpr uint32_t kMaxTilesMerge = 64;
+__device__ __forceinline__ void bucket_merge(const IndexView &v, uint32_t s, uint32_t fp, uint32_t *out,
+                                             unsigned long long &pos) {
+  const Entry *e = v.entries + ((uint64_t)s * v.d.R + fp) * v.n_tiles;
+  uint32_t at[kMaxTilesMerge];
+  for (uint32_t t = 0; t < v.n_tiles; ++t) at[t] = 0;
+  for (;;) {
+    uint32_t best = 0xFFFFFFFFu, bt = 0;
+    for (uint32_t t = 0; t < v.n_tiles; ++t) {
+      if (at[t] < e[t].len) {
+        const uint16_t *gl = v.gids + v.tile_base[t] + ((uint64_t)e[t].start << v.align_log2);
+        const uint32_t g = tile_gid(v, t, gl[at[t]]);
+        if (g < best) { best = g; bt = t; }
+      }
+    }
+    if (best == 0xFFFFFFFFu) break;
+    out[pos++] = best;
+    ++at[bt];
+  }
+}
 
 __global__ __launch_bounds__(256) void export_slot_ids_kernel(IndexView v, unsigned long long *slot_word) {
   const uint32_t lane = threadIdx.x & 63;
@@ -316,7 +338,8 @@ __global__ __launch_bounds__(256) void export_kernel(IndexView v, const unsigned
     unsigned long long pos = running + incl - x;
     if (fp < R) {
       out[pos++] = size;
-      for (uint32_t t = 0; t < v.n_tiles; ++t) bucket_copy(v, t, s, fp, out, pos);
+      if (v.stripe && v.n_tiles > 1) bucket_merge(v, s, fp, out, pos);
+      else for (uint32_t t = 0; t < v.n_tiles; ++t) bucket_copy(v, t, s, fp, out, pos);
     }
     running += __shfl(incl, 63, 64);
   }

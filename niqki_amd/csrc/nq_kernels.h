@@ -25,7 +25,8 @@ hipError_t launch_fill_u32(uint32_t *p, uint64_t n, uint32_t v, hipStream_t stre
 
 // ---- sketch store + inverted index (nq_index.hip) ---------------------------
 // Sketch store: u16 [F_local][cap], slot major; 0xFFFF = empty/invalid cell.
-// Inverted index over genome tiles (tile t = genomes [t*T, min((t+1)*T, N))):
+// Inverted index over genome tiles (tile t = genomes [t*T, min((t+1)*T, N)), or, striped,
+// the genomes g with g % n_tiles == t in ascending order):
 //   entries  Entry [F_local][R][n_tiles]   bucket (slot, fp) of every tile side by
 //                                          side, so ONE lookup serves all tiles
 //   gids     u16, tile t at gids + tile_base[t]; a bucket starts at
@@ -53,6 +54,9 @@ struct IndexView {
   uint32_t f_local;  // slot_end - slot_begin
   uint32_t align_log2;
   uint32_t direct;   // bucket-line layout
+  uint32_t stripe;   // genomes are dealt to the tiles round-robin (tile = gid % n_tiles, local id =
+                     // gid / n_tiles) instead of in ranges: a run of related genomes is spread over
+                     // all tiles, which keeps their buckets short in every tile
   const uint16_t *lines;
   uint64_t cap;      // row stride of the sketch store (genomes)
   const uint16_t *store;
@@ -61,6 +65,16 @@ struct IndexView {
   const uint64_t *tile_base;   // n_tiles+1 (in ids), device
   const uint32_t *slot_units;  // n_tiles x (f_local+1): units before slot s of tile t
 };
+
+// genomes of tile t / global id of its i-th genome
+NQ_HD uint32_t tile_count(const IndexView &v, uint32_t t) {
+  if (v.stripe) return v.n_genomes > t ? (v.n_genomes - t + v.n_tiles - 1) / v.n_tiles : 0u;
+  const uint32_t g0 = t * v.tile;
+  return (v.n_genomes - g0) < v.tile ? (v.n_genomes - g0) : v.tile;
+}
+NQ_HD uint32_t tile_gid(const IndexView &v, uint32_t t, uint32_t i) {
+  return v.stripe ? i * v.n_tiles + t : t * v.tile + i;
+}
 
 hipError_t launch_store_insert(const Derived &d, const int32_t *sketches, uint32_t n,
                                uint16_t *store, uint64_t cap, uint32_t first_gid,

@@ -325,8 +325,7 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(IndexView v, const int32_t
   const uint32_t n_probe = v.f_local < kProbeSlots ? v.f_local : kProbeSlots;
   if (tid == 0) s_best = 0;
   for (uint32_t t = 0; t < v.n_tiles; ++t) {
-    const uint32_t g0 = t * v.tile;
-    const uint32_t n_t = (v.n_genomes - g0) < v.tile ? (v.n_genomes - g0) : v.tile;
+    const uint32_t n_t = tile_count(v, t);
     const uint32_t n_words = (n_t + 1) / 2;
     for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
     __syncthreads();
@@ -342,8 +341,8 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(IndexView v, const int32_t
     uint32_t best = 0;  // count << 20 | gid
     for (uint32_t i = tid; i < n_words; i += BLOCK) {
       const uint32_t w = cnt[i];
-      const uint32_t a = ((w & 0xFFFFu) << 20) | (g0 + 2 * i);
-      const uint32_t b2 = ((w >> 16) << 20) | (g0 + 2 * i + 1);
+      const uint32_t a = ((w & 0xFFFFu) << 20) | tile_gid(v, t, 2 * i);
+      const uint32_t b2 = ((w >> 16) << 20) | tile_gid(v, t, 2 * i + 1);
       best = best > a ? best : a;
       best = best > b2 ? best : b2;
     }
@@ -406,8 +405,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
   Item *queue = (Item *)(cnt + (v.tile + 1) / 2);  // behind the counters: kQueue items per wave
   uint32_t sink = 0;
   for (uint32_t t = 0; t < v.n_tiles; ++t) {
-    const uint32_t g0 = t * v.tile;
-    const uint32_t n_t = (v.n_genomes - g0) < v.tile ? (v.n_genomes - g0) : v.tile;
+    const uint32_t n_t = tile_count(v, t);
     const uint32_t n_words = (n_t + 1) / 2;
     for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
     __syncthreads();
@@ -421,11 +419,19 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     }
     if (MODE != 0) cnt[tid % n_words] ^= sink;
     __syncthreads();
-    // dense counter row of this tile: u16 counts[q*stride + g0 + i], written as the packed words
-    uint32_t *out = (uint32_t *)(counts + (uint64_t)q * stride + g0);
-    const uint32_t full = n_t / 2;
-    for (uint32_t i = tid; i < full; i += BLOCK) out[i] = cnt[i];
-    if ((n_t & 1u) && tid == 0) counts[(uint64_t)q * stride + g0 + n_t - 1] = (uint16_t)(cnt[full] & 0xFFFFu);
+    uint16_t *row = counts + (uint64_t)q * stride;
+    if (v.stripe && v.n_tiles > 1) {
+      // striped tiles: the tile's i-th counter belongs to genome i * n_tiles + t
+      for (uint32_t i = tid; i < n_t; i += BLOCK)
+        row[tile_gid(v, t, i)] = (uint16_t)(cnt[i >> 1] >> ((i & 1u) * 16u));
+    } else {
+      // dense counter row of this tile: u16 counts[q*stride + g0 + i], written as the packed words
+      const uint32_t g0 = t * v.tile;
+      uint32_t *out = (uint32_t *)(row + g0);
+      const uint32_t full = n_t / 2;
+      for (uint32_t i = tid; i < full; i += BLOCK) out[i] = cnt[i];
+      if ((n_t & 1u) && tid == 0) row[g0 + n_t - 1] = (uint16_t)(cnt[full] & 0xFFFFu);
+    }
     __syncthreads();
   }
 }

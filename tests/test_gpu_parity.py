@@ -11,11 +11,12 @@ from conftest import family_spec, synth_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["csr", "lines"])
+@pytest.fixture(autouse=True, params=["csr", "csr_ranges", "lines"])
 def index_layout(request, monkeypatch):
-    """Every test runs under both index layouts: CSR entries +
-    id lists, and bucket lines."""
-    monkeypatch.setenv("NIQKI_INDEX_LAYOUT", "1" if request.param == "csr" else "2")
+    """Every test runs under the index layouts of DESIGN.md section 3: CSR entries + id lists
+    with striped tiles (default) or with tiles as ranges of genome ids, and bucket lines."""
+    monkeypatch.setenv("NIQKI_INDEX_LAYOUT", "2" if request.param == "lines" else "1")
+    monkeypatch.setenv("NIQKI_TILE_STRIPE", "0" if request.param == "csr_ranges" else "1")
     return request.param
 
 
