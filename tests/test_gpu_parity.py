@@ -537,3 +537,31 @@ def test_locality_order_changes_nothing(native, po):
         for i in (0, 1, nq // 2, nq - 1):
             assert np.array_equal(c1[i].astype(np.uint32), ix.counts(q[i])), (nq, i)
     e.close()
+
+
+def test_more_genomes_than_one_tile_holds(native, po):
+    """70 000 genomes: two real counter tiles of the default size (u16 tile-local ids), striped or
+    as ranges: dense counters, ordered hits and the dump bytes against the oracle."""
+    rng = np.random.default_rng(33)
+    S, W, N = 6, 8, 70000
+    F = 1 << S
+    fam = rng.integers(0, 1 << W, (300, F)).astype(np.int32)
+    sk = fam[np.arange(N) // 234].copy()                 # runs of 234 related genomes
+    noise = rng.random((N, F)) < 0.35
+    sk[noise] = rng.integers(0, 1 << W, int(noise.sum()))
+    e = native.Engine(K=31, S=S, W=W, H=3, J=0.5)
+    for a in range(0, N, 10000):
+        e.insert(sk[a:a + 10000])
+    assert e.tile_genomes() < N                            # really more than one tile
+    p = po.make_params(31, S, W, 3, 0.5)
+    ix = po.Index(p, sk)
+    q = np.concatenate([fam[[0, 7, 299]], sk[[0, 65535, 65536, N - 1]], rng.integers(0, 1 << W, (2, F)).astype(np.int32)])
+    cnt = e.query_counts(q)
+    off, hc, hg = e.query(q)
+    for i in range(q.shape[0]):
+        assert np.array_equal(cnt[i].astype(np.uint32), ix.counts(q[i])), i
+        ehc, ehg = ix.query(q[i])
+        assert np.array_equal(hc[off[i]:off[i + 1]], ehc) and np.array_equal(hg[off[i]:off[i + 1]], ehg), i
+    assert off[3] - off[0] > 300                           # the family queries do have hits
+    assert e.export_dump() == ix.dump_bytes()
+    e.close()
