@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--steps", type=int, default=9)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genomes", type=int, default=100_000)
-    ap.add_argument("--batch", type=int, default=4000, help="query genomes per step (whole job)")
+    ap.add_argument("--batch", type=int, default=4096, help="query genomes per step (whole job)")
     ap.add_argument("--ring", type=int, default=3,
                     help="distinct query batches kept resident in HBM; step i uses batch i mod ring")
     ap.add_argument("--len", type=int, default=5_000_000)
