@@ -258,6 +258,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, (K, S, W, H, J))
 
+    # bytes a rank sends per step in the exchange (sketch slices, then the candidate lists or the
+    # dense counters): with the step time this bounds the average xGMI rate per GPU
+    xbytes = None
+    if use_dist:
+        g1 = (world - 1) / world
+        nq_all = per * world
+        xbytes = per * F * 4 * g1                                   # all_to_all of F/G-slot sketch slices
+        if sq.exchange == "sparse":
+            xbytes += nq_all * sq.cand_cap * 4 * g1 + nq_all * 4 * g1    # all_gather of candidates + their counts
+            xbytes += nq_all * world * sq.cand_cap * 4 * g1              # reduce_scatter of the candidates' partial counts
+        else:
+            xbytes += nq_all * (stride // 2) * 4 * g1                    # dense u16 counters as int32 pairs
     if rank == 0:
         n_queries = args.steps * per * world
         out = {
@@ -280,6 +292,8 @@ def main():
                 "index_genomes": N, "query_batch": per * world, "genome_len": L,
                 "parallelism": "slot-shard x%d (%s exchange)" % (world, sq.exchange) if use_dist else "1 GPU",
                 "exchange_overflow": bool(int(sq.overflow.item())) if use_dist else False,
+                "exchange_bytes_per_rank_per_step": xbytes,
+                "exchange_avg_gbs_per_rank": (xbytes / (dt / args.steps) / 1e9) if xbytes else None,
                 "tile_genomes": eng.tile_genomes(), "index_build_s": round(t_index, 2),
                 "hits_per_query": total_hits / max(1, args.steps * per), "hit_overflow": overflow,
             },
