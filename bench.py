@@ -176,7 +176,7 @@ def main():
     counts = torch.zeros((per * world, stride), dtype=torch.int16, device=dev)
     # 256 candidates per query and shard (a family has 100 members); the calibration pass below
     # switches to the dense exchange if any list overflows
-    sq = ShardedQuery(eng, N, F, dev, exchange=args.exchange, cand_cap=256) if use_dist else None
+    sq = ShardedQuery(eng, N, F, dev, exchange=args.exchange, cand_cap=256, compact_sketches=True) if use_dist else None
     eng.synchronize()
 
     def step(si):
@@ -264,7 +264,7 @@ def main():
     if use_dist:
         g1 = (world - 1) / world
         nq_all = per * world
-        xbytes = per * F * 4 * g1                                   # all_to_all of F/G-slot sketch slices
+        xbytes = per * F * 2 * g1                                   # all_to_all of F/G-slot sketch slices (int16)
         if sq.exchange == "sparse":
             xbytes += nq_all * sq.cand_cap * 4 * g1 + nq_all * 4 * g1    # all_gather of candidates + their counts
             xbytes += nq_all * world * sq.cand_cap * 4 * g1              # reduce_scatter of the candidates' partial counts

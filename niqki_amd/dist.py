@@ -44,7 +44,7 @@ def padded_batch(nq, world):
 
 class ShardedQuery:
     def __init__(self, engine, n_genomes, F, device, group=None, exchange="auto", min_score=None,
-                 cand_cap=1024):
+                 cand_cap=1024, compact_sketches=False):
         self.e = engine
         self.group = group
         self.rank = dist.get_rank(group)
@@ -55,6 +55,9 @@ class ShardedQuery:
         self.device = device
         self.min_score = engine.min_score if min_score is None else min_score
         self.cand_cap = cand_cap
+        # sketch cells are -1 or a fingerprint below 2^W <= 2^15: they travel as int16 when the
+        # caller says so (not after niqki_select_best_H, whose cells may exceed 2^W)
+        self.compact = compact_sketches
         if exchange == "auto":
             exchange = "sparse" if self.min_score >= 4 * self.world else "reduce_scatter"
         if exchange == "sparse" and self.min_score < self.world:
@@ -81,9 +84,11 @@ class ShardedQuery:
             dist.all_gather_into_tensor(allsk, local_sketches.contiguous(), group=self.group)
             return allsk
         w = self.F // G
-        send = local_sketches.view(per, G, w).permute(1, 0, 2).contiguous()      # [dest][q][slot in dest's range]
-        recv = self._buf("skrecv", (G, per, w), torch.int32)                        # [source][q][my slots]
-        dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+        wire = torch.int16 if self.compact else torch.int32
+        send = local_sketches.view(per, G, w).permute(1, 0, 2).to(wire).contiguous()  # [dest][q][slot in dest's range]
+        recv = self._buf("skrecv", (G, per, w), wire)                                  # [source][q][my slots]
+        # pure data movement: as bytes (neither RCCL nor gloo has a 16-bit integer type)
+        dist.all_to_all_single(recv.view(-1).view(torch.uint8), send.view(-1).view(torch.uint8), group=self.group)
         sb = self.rank * w
         allsk.view(G, per, self.F)[:, :, sb:sb + w] = recv
         return allsk

@@ -83,7 +83,8 @@ def _worker(rank, world, port, exchange, ret):
     F = 1 << S
     sb, se = slot_range(rank, world, F)
     eng = OracleShard(po, p, sk, sb, se)
-    sq = ShardedQuery(eng, N, F, torch.device("cpu"), exchange=exchange, cand_cap=64 if exchange == "sparse" else 8)
+    sq = ShardedQuery(eng, N, F, torch.device("cpu"), exchange=exchange.split("+")[0],
+                      cand_cap=64 if exchange.startswith("sparse") else 8, compact_sketches=exchange.endswith("+i16"))
     per = padded_batch(NQ, world)
     mine = torch.from_numpy(q[rank * per:(rank + 1) * per].copy())
     hit_off = torch.zeros(per + 1, dtype=torch.int64)
@@ -97,7 +98,7 @@ def _worker(rank, world, port, exchange, ret):
         lo, hi = int(hit_off[i]), int(hit_off[i + 1])
         ok &= np.array_equal(hc[lo:hi].numpy().astype(np.uint32), ehc)
         ok &= np.array_equal(hg[lo:hi].numpy().astype(np.uint32), ehg)
-    if exchange == "sparse":
+    if exchange.startswith("sparse"):
         ok &= int(sq.overflow.item()) == 0
         # a capacity that is too small must be reported, never silently wrong
         sq2 = ShardedQuery(eng, N, F, torch.device("cpu"), exchange="sparse", cand_cap=1)
@@ -115,7 +116,7 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize("exchange", ["reduce_scatter", "all_to_all", "sparse"])
+@pytest.mark.parametrize("exchange", ["reduce_scatter", "all_to_all", "sparse", "sparse+i16"])
 def test_slot_sharded_query_world2(exchange):
     world = 2
     mgr = mp.Manager()
