@@ -104,9 +104,9 @@ int niqki_set_stream(niqki_index *ix, void *hip_stream);
 void *niqki_get_stream(const niqki_index *ix);
 int niqki_synchronize(niqki_index *ix);
 
-/* Tuning knobs (no reference counterpart): "gather_variant", "query_batch",
+/* Tuning knobs (no reference counterpart; none of them changes a result):
+ * "gather_variant" (launch shape of the gather kernel, 0 = choose .. 5), "query_batch",
  * "tile_genomes" (multiple of 64, <= 65536; takes effect at the next build),
- * "index_layout" (0 = choose, 1 = CSR entries + id lists, 2 = bucket lines),
  * "bucket_align_log2" (-1 = choose, 0..6: buckets start on multiples of 2^a ids),
  * "tile_stripe" (1 = default: with several tiles genome g goes to tile g mod tiles, so a
  * run of related genomes is spread over all tiles; 0 = tiles are ranges of genome ids),
@@ -157,8 +157,9 @@ int niqki_build(niqki_index *ix);
 /* Counting half of Index::query_sketch (src/niqki_index.cpp:652-661): for
  * query q, counts[q*stride + g] = number of this shard's slots whose bucket
  * holds genome g.  uint16 counters like the reference's lF<=15 branch.
- * stride >= genome_count (in elements), even.  This is the per-genome hit
- * vector the multi-GPU path sums across slot shards. */
+ * stride >= genome_count (in elements), even; a NIQKI_MEM_DEVICE `counts` must be
+ * 4-byte aligned (rows are written as packed u16 pairs).  This is the per-genome
+ * hit vector the multi-GPU path sums across slot shards. */
 int niqki_query_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq,
                        uint16_t *counts, uint64_t stride, int mem);
 
@@ -272,7 +273,9 @@ int niqki_export_dump(niqki_index *ix, uint8_t *buf, uint64_t capacity,
 /* Loading constructor (src/niqki_index.cpp:63-90) from the gunzipped bytes of
  * a dump (names excluded; *consumed = offset of the first name byte).  The
  * parameters stored in the dump override those given (like :67-72), except
- * device / tile_genomes / slot range, which are taken from `params`. */
+ * device / tile_genomes / slot range, which are taken from `params`: a handle
+ * created with a slot range keeps only its own slots of the dump (one shard of
+ * a multi-GPU index), the bytes of the other slots are walked and skipped. */
 int niqki_import_dump(const niqki_params *params, const uint8_t *buf,
                       uint64_t len, uint64_t *consumed, niqki_index **out);
 
@@ -284,9 +287,11 @@ int niqki_export_dump_header(niqki_index *ix, uint8_t header[24]);
 int niqki_export_dump_layout(niqki_index *ix, uint64_t *slot_bytes);
 int niqki_export_dump_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end,
                             uint8_t *buf, uint64_t capacity, uint64_t *size);
-/* niqki_import_begin creates the handle from the header; niqki_import_slots takes
- * the payload of whole slots [slot_begin, slot_end) in order (*consumed = bytes
- * used); after the last slot the handle is a normal index (built on first use). */
+/* niqki_import_begin creates the handle from the header (slot range from `params`,
+ * as above); niqki_import_slots takes the payload of whole slots [slot_begin,
+ * slot_end) in order (*consumed = bytes used; slots outside the handle's range are
+ * validated and dropped); after the last slot the handle is a normal index (built
+ * on first use). */
 int niqki_import_begin(const niqki_params *params, const uint8_t header[24], niqki_index **out);
 int niqki_import_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end,
                        const uint8_t *buf, uint64_t len, uint64_t *consumed);

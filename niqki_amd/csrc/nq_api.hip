@@ -49,12 +49,8 @@ struct niqki_index {
   uint64_t *tile_base = nullptr;   // n_tiles+1, device
   uint32_t *slot_units = nullptr;  // n_tiles x (f_local+1), device
   size_t entries_bytes = 0, gids_bytes = 0, tile_base_bytes = 0, slot_units_bytes = 0;
-  uint16_t *lines = nullptr;       // bucket-line table (direct layout)
-  size_t lines_bytes = 0;
-  uint32_t direct = 0;             // layout of the built index
-  uint32_t stripe = 0;             // tiles are dealt round-robin (CSR layout)
+  uint32_t stripe = 0;             // tiles are dealt round-robin
   int stripe_opt = 1;              // option: 1 = stripe when there are several tiles
-  int layout_opt = 0;              // option: 0 = choose, 1 = CSR entries + id lists, 2 = bucket lines
   int bucket_align = -1;           // option: log2 ids per bucket alignment unit, -1 = choose
   bool built = false;
 
@@ -186,9 +182,7 @@ nq::IndexView view(const niqki_index *ix) {
   v.n_tiles = ix->n_tiles;
   v.f_local = ix->d.slot_end - ix->d.slot_begin;
   v.align_log2 = ix->align_log2;
-  v.direct = ix->direct;
   v.stripe = ix->stripe;
-  v.lines = ix->lines;
   v.cap = ix->cap;
   v.store = ix->store;
   v.entries = ix->entries;
@@ -271,17 +265,18 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *
   if (rc) return rc;
   if (nq == 0) return NIQKI_OK;
   if (stride < ix->built_n || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
+  if ((uintptr_t)counts & 3) return fail(ix, NIQKI_E_INVALID, "counts must be 4-byte aligned (rows are written as packed u16 pairs)");
   if (ix->built_n == 0) return NIQKI_OK;
   // launches of at most `chunk` queries bound the per-query stash (one Entry per
   // slot and extra tile) whatever the caller's batch size is
   const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
   const uint32_t chunk = ix->n_tiles > 1 ? 4096u : nq;
-  if (ix->n_tiles > 1 && !ix->direct) {
+  if (ix->n_tiles > 1) {
     rc = ensure(ix, ix->ws_stash, (size_t)std::min(nq, chunk) * (ix->n_tiles - 1) * f_local * sizeof(nq::Entry));
     if (rc) return rc;
   }
   // locality order of each launch: worth its probe on large indexes and real batches
-  const bool ordered = ix->query_order && !ix->direct && chunk <= 4096 && ix->built_n >= 16384 &&
+  const bool ordered = ix->query_order && chunk <= 4096 && ix->built_n >= 16384 &&
                        ix->built_n < (1u << 20) - 1 && f_local >= 1024;
   if (ordered && (rc = ensure(ix, ix->ws_order, (size_t)chunk * 8))) return rc;
   for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
@@ -471,7 +466,8 @@ int niqki_create(const niqki_params *params, niqki_index **out) {
   ix->device = dev;
   if ((e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking)) != hipSuccess) return bail(NIQKI_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   ix->own_stream = true;
-  if (const char *v = std::getenv("NIQKI_GATHER_VARIANT")) ix->gather_variant = std::atoi(v);
+  if (const char *v = std::getenv("NIQKI_GATHER_VARIANT"))
+    if (nq::gather_variant_valid(std::atoi(v))) ix->gather_variant = std::atoi(v);
   if (const char *v = std::getenv("NIQKI_QUERY_ORDER")) ix->query_order = std::atoi(v) != 0;
   *out = ix;
   return NIQKI_OK;
@@ -488,7 +484,6 @@ void niqki_destroy(niqki_index *ix) {
     if (b->p) (void)hipFree(b->p);
   if (ix->store) (void)hipFree(ix->store);
   if (ix->entries) (void)hipFree(ix->entries);
-  if (ix->lines) (void)hipFree(ix->lines);
   if (ix->gids) (void)hipFree(ix->gids);
   if (ix->tile_base) (void)hipFree(ix->tile_base);
   if (ix->slot_units) (void)hipFree(ix->slot_units);
@@ -529,19 +524,18 @@ int niqki_synchronize(niqki_index *ix) {
 
 int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
   if (!ix || !key) return NIQKI_E_INVALID;
-  if (!std::strcmp(key, "gather_variant")) { ix->gather_variant = (int)value; return NIQKI_OK; }
+  if (!std::strcmp(key, "gather_variant")) {
+    // launch shapes 0 (choose) .. 5; the measurement-only variants exist in ABLATION builds alone
+    if (!nq::gather_variant_valid((int)value)) return fail(ix, NIQKI_E_INVALID, "unknown gather_variant");
+    ix->gather_variant = (int)value;
+    return NIQKI_OK;
+  }
   if (!std::strcmp(key, "tile_stripe")) { ix->stripe_opt = value != 0; ix->built = false; return NIQKI_OK; }
   if (!std::strcmp(key, "query_order")) { ix->query_order = value != 0; return NIQKI_OK; }
   if (!std::strcmp(key, "query_batch")) { if (value < 1) return NIQKI_E_INVALID; ix->query_batch = (uint32_t)value; return NIQKI_OK; }
   if (!std::strcmp(key, "tile_genomes")) {
     if (value < 0 || value > 65536 || (value & 63)) return fail(ix, NIQKI_E_INVALID, "tile_genomes must be a multiple of 64, <= 65536");
     ix->p.tile_genomes = (uint32_t)value;
-    ix->built = false;
-    return NIQKI_OK;
-  }
-  if (!std::strcmp(key, "index_layout")) {
-    if (value < 0 || value > 2) return fail(ix, NIQKI_E_INVALID, "index_layout: 0 = choose, 1 = CSR, 2 = bucket lines");
-    ix->layout_opt = (int)value;
     ix->built = false;
     return NIQKI_OK;
   }
@@ -668,31 +662,16 @@ int niqki_build(niqki_index *ix) {
   if (const char *v = std::getenv("NIQKI_TILE_GENOMES")) tile = (uint32_t)std::atoi(v);
   if (tile == 0 || tile > 65536 || (tile & 63)) {
     // as few tiles as the 16-bit tile-local ids and the LDS counter array allow
-    // (65472: a bucket length must fit the u16 length field of a bucket line)
     uint32_t nt = std::max<uint32_t>(1, (N + 65471) / 65472);
     tile = ((N + nt - 1) / nt + 63) / 64 * 64;
     if (tile == 0) tile = 64;
   }
   const uint32_t n_tiles = (N + tile - 1) / tile;
-  // Layout.  CSR (entries + id lists) by default.  Bucket lines (one 128-byte line per
-  // (tile, slot, fingerprint), found from the fingerprint alone) fetch ~35 % fewer lines
-  // per query but measured no faster on MI355X (the walk is instruction-issue bound,
-  // DESIGN.md 4.4) at twice the memory, so they are opt-in: index_layout = 2.
-  int layout = ix->layout_opt;
-  if (const char *v = std::getenv("NIQKI_INDEX_LAYOUT")) layout = std::atoi(v);
-  const size_t lines_bytes = ((size_t)f_local * ix->d.R + 1) * 128 * n_tiles;
-  if (layout != 2) layout = 1;
-  if (layout == 2 && tile > 65472) return fail(ix, NIQKI_E_INVALID, "bucket lines need tile_genomes <= 65472");
-  if (layout == 2 && (size_t)ix->d.R * 8 > 160 * 1024)  // the build keeps two words per fingerprint in LDS
-    return fail(ix, NIQKI_E_INVALID, "bucket lines need W <= 14");
-  const bool direct = layout == 2;
-  // CSR: 128-byte aligned buckets pay off once buckets are long (big tiles); for small
-  // tiles the padding would dominate the id array.  Bucket lines: the overflow parts are
-  // always 128-byte aligned.
+  // 128-byte aligned buckets pay off once buckets are long (big tiles); for small tiles the
+  // padding would dominate the id array.
   int al = ix->bucket_align;
   if (const char *v = std::getenv("NIQKI_BUCKET_ALIGN_LOG2")) al = std::atoi(v);
   if (al < 0 || al > 6) al = tile >= 16384 ? 6 : (tile >= 2048 ? 3 : 0);
-  if (direct) al = 6;
   auto grow = [&](void **p, size_t &have, size_t want) -> int {
     want = std::max<size_t>(want, 256);
     if (want <= have) return NIQKI_OK;
@@ -702,31 +681,18 @@ int niqki_build(niqki_index *ix) {
     have = want;
     return NIQKI_OK;
   };
-  auto drop = [&](void **p, size_t &have) -> int {
-    if (*p) NQ_HIP(ix, hipFree(*p));
-    *p = nullptr; have = 0;
-    return NIQKI_OK;
-  };
   int rc;
-  if (direct) {
-    if ((rc = drop((void **)&ix->entries, ix->entries_bytes))) return rc;
-    if ((rc = grow((void **)&ix->lines, ix->lines_bytes, lines_bytes))) return rc;
-    NQ_HIP(ix, hipMemsetAsync(ix->lines, 0, lines_bytes, ix->stream));
-  } else {
-    if ((rc = drop((void **)&ix->lines, ix->lines_bytes))) return rc;
-    if ((rc = grow((void **)&ix->entries, ix->entries_bytes, (size_t)f_local * ix->d.R * n_tiles * sizeof(nq::Entry)))) return rc;
-  }
+  if ((rc = grow((void **)&ix->entries, ix->entries_bytes, (size_t)f_local * ix->d.R * n_tiles * sizeof(nq::Entry)))) return rc;
   if ((rc = grow((void **)&ix->slot_units, ix->slot_units_bytes, (size_t)n_tiles * (f_local + 1) * 4))) return rc;
   if ((rc = grow((void **)&ix->tile_base, ix->tile_base_bytes, (size_t)(n_tiles + 1) * 8))) return rc;
   ix->tile = tile;
   ix->n_tiles = n_tiles;
   ix->built_n = N;
   ix->align_log2 = (uint32_t)al;
-  ix->direct = direct ? 1u : 0u;
-  // CSR layout: genomes are dealt to the tiles round-robin (option "tile_stripe", default on)
+  // genomes are dealt to the tiles round-robin (option "tile_stripe", default on)
   int stripe = ix->stripe_opt;
   if (const char *v = std::getenv("NIQKI_TILE_STRIPE")) stripe = std::atoi(v);
-  ix->stripe = (!direct && stripe != 0 && n_tiles > 1 && n_tiles <= 64) ? 1u : 0u;
+  ix->stripe = (stripe != 0 && n_tiles > 1 && n_tiles <= 64) ? 1u : 0u;
   if (n_tiles == 0) { ix->built = true; return NIQKI_OK; }
   {
     Span sp(ix, NIQKI_KC_BUILD);
@@ -743,7 +709,7 @@ int niqki_build(niqki_index *ix) {
   if ((rc = grow((void **)&ix->gids, ix->gids_bytes, (size_t)total_ids * 2 + 512))) return rc;
   {
     Span sp(ix, NIQKI_KC_BUILD);
-    NQ_HIP(ix, nq::launch_build_fill(view(ix), ix->entries, ix->gids, ix->lines, ix->stream));
+    NQ_HIP(ix, nq::launch_build_fill(view(ix), ix->entries, ix->gids, ix->stream));
   }
   ix->built = true;
   return NIQKI_OK;
@@ -1193,14 +1159,14 @@ int niqki_import_begin(const niqki_params *params, const uint8_t header[24], niq
   std::memcpy(hdr, header, 24);
   niqki_params p = *params;
   p.S = hdr[0]; p.K = hdr[1]; p.H = hdr[2]; p.W = hdr[3]; p.min_score = hdr[4];
-  p.slot_begin = p.slot_end = 0;
+  // slot_begin / slot_end stay the caller's: a slot shard loads only its own slots of the dump
   niqki_index *ix = nullptr;
   int rc = niqki_create(&p, &ix);
   if (rc) return rc;
   const uint32_t N = hdr[5];
   rc = reserve_store(ix, std::max<uint32_t>(N, 1));
   hipError_t e = hipSuccess;
-  if (!rc) e = hipMemsetAsync(ix->store, 0xFF, (size_t)ix->d.F * ix->cap * 2, ix->stream);
+  if (!rc) e = hipMemsetAsync(ix->store, 0xFF, (size_t)(ix->d.slot_end - ix->d.slot_begin) * ix->cap * 2, ix->stream);
   if (rc || e != hipSuccess) {
     g_create_err = rc ? ix->err : std::string(hipGetErrorString(e));
     niqki_destroy(ix);
@@ -1233,17 +1199,24 @@ int niqki_import_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end, 
   if (w > n_words) return fail(ix, NIQKI_E_INVALID, "dump payload ends inside a bucket");
   slot_word[n_slots] = w;
   if (consumed) *consumed = w * 4;
-  if (n_slots == 0) return NIQKI_OK;
+  // the part of [slot_begin, slot_end) this shard owns (all of it for a whole-range handle)
+  const uint32_t own0 = std::max(slot_begin, ix->d.slot_begin), own1 = std::min(slot_end, ix->d.slot_end);
+  if (own0 >= own1) return NIQKI_OK;
+  const uint32_t n_own = own1 - own0;
+  const uint64_t w0 = slot_word[own0 - slot_begin], w1 = slot_word[own1 - slot_begin];
+  std::vector<uint64_t> own_word(slot_word.begin() + (own0 - slot_begin), slot_word.begin() + (own1 - slot_begin) + 1);
+  for (auto &x : own_word) x -= w0;
   int rc;
-  if ((rc = ensure(ix, ix->ws_counts, std::max<uint64_t>(w * 4, 4)))) return rc;
-  if ((rc = ensure(ix, ix->ws_misc, (size_t)(n_slots + 1) * 8 + 8))) return rc;
+  if ((rc = ensure(ix, ix->ws_counts, std::max<uint64_t>((w1 - w0) * 4, 4)))) return rc;
+  if ((rc = ensure(ix, ix->ws_misc, (size_t)(n_own + 1) * 8 + 8))) return rc;
   uint8_t *d_slot = (uint8_t *)ix->ws_misc.p;
-  uint32_t *d_bad = (uint32_t *)(d_slot + (size_t)(n_slots + 1) * 8);
-  NQ_HIP(ix, hipMemcpyAsync(ix->ws_counts.p, buf, w * 4, hipMemcpyHostToDevice, ix->stream));
-  NQ_HIP(ix, hipMemcpyAsync(d_slot, slot_word.data(), (size_t)(n_slots + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+  uint32_t *d_bad = (uint32_t *)(d_slot + (size_t)(n_own + 1) * 8);
+  NQ_HIP(ix, hipMemcpyAsync(ix->ws_counts.p, buf + w0 * 4, (w1 - w0) * 4, hipMemcpyHostToDevice, ix->stream));
+  NQ_HIP(ix, hipMemcpyAsync(d_slot, own_word.data(), (size_t)(n_own + 1) * 8, hipMemcpyHostToDevice, ix->stream));
   NQ_HIP(ix, hipMemsetAsync(d_bad, 0, 4, ix->stream));
+  // rows of the store are shard-local slots
   NQ_HIP(ix, nq::launch_import(ix->d, (const uint32_t *)ix->ws_counts.p, (const uint64_t *)d_slot, ix->store, ix->cap,
-                               ix->n_genomes, d_bad, slot_begin, n_slots, ix->stream));
+                               ix->n_genomes, d_bad, own0 - ix->d.slot_begin, n_own, ix->stream));
   uint32_t bad = 0;
   NQ_HIP(ix, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ix->stream));
   NQ_HIP(ix, hipStreamSynchronize(ix->stream));

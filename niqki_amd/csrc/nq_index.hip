@@ -93,16 +93,9 @@ hipError_t launch_store_read(const Derived &d, const uint16_t *store, uint64_t c
 
 // ---- index build: one wave per (tile, slot) row, stable counting sort on fp ----
 // FILL = false: units (1 << align_log2 ids) the row needs -> slot_units[t][s]
-// FILL = true : CSR layout: entries {start, len} of every fingerprint + the ascending id
-//               lists; bucket-line layout: the first 60 ids, the length and the overflow
-//               start in the bucket's own line, the rest in the overflow array
-__device__ __forceinline__ uint64_t line_index(const IndexView &v, uint32_t t, uint32_t s, uint32_t fp) {
-  return (uint64_t)t * ((uint64_t)v.f_local * v.d.R + 1) + (uint64_t)s * v.d.R + fp;
-}
-
+// FILL = true : entries {start, len} of every fingerprint + the ascending id lists
 template <bool FILL>
-__global__ void build_kernel(IndexView v, uint32_t *slot_units, Entry *entries, uint16_t *gids, uint16_t *lines,
-                             uint32_t wpb) {
+__global__ void build_kernel(IndexView v, uint32_t *slot_units, Entry *entries, uint16_t *gids, uint32_t wpb) {
   extern __shared__ __align__(16) uint32_t smem[];
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const uint64_t task = (uint64_t)blockIdx.x * wpb + wave;
@@ -110,17 +103,11 @@ __global__ void build_kernel(IndexView v, uint32_t *slot_units, Entry *entries, 
   const uint32_t t = (uint32_t)(task / v.f_local), s = (uint32_t)(task % v.f_local);
   const uint32_t R = v.d.R, W = v.d.W, a = v.align_log2;
   const uint32_t round = (1u << a) - 1u;
-  const bool direct = v.direct != 0;
-  uint32_t *cur = smem + (size_t)wave * R * (direct ? 2 : 1);
-  uint32_t *ovs = cur + R;  // bucket lines: overflow start (units) per fingerprint
+  uint32_t *cur = smem + (size_t)wave * R;
   const uint32_t n_t = tile_count(v, t);
   const uint16_t *srow = v.store + (uint64_t)s * v.cap;
   auto row_at = [&](uint32_t i) -> uint32_t { return srow[tile_gid(v, t, i)]; };  // i-th genome of the tile
-  // ids a bucket keeps outside its line / units they need
-  auto units_of = [&](uint32_t h) -> uint32_t {
-    if (direct) return h > kLineIds ? (h - kLineIds + 63) >> 6 : 0u;
-    return (h + round) >> a;
-  };
+  auto units_of = [&](uint32_t h) -> uint32_t { return (h + round) >> a; };  // units a bucket of h ids needs
 
   for (uint32_t i = lane; i < R; i += 64) cur[i] = 0;
   for (uint32_t i = lane; i < n_t; i += 64) {
@@ -143,23 +130,12 @@ __global__ void build_kernel(IndexView v, uint32_t *slot_units, Entry *entries, 
     uint32_t incl = wave_incl_scan(x, lane);
     uint32_t excl = running + incl - x;
     if (fp < R) {
-      if (direct) {
-        cur[fp] = 0;  // ids placed so far
-        ovs[fp] = base_units + excl;
-        if (h) {
-          uint16_t *ln = lines + line_index(v, t, s, fp) * 64;
-          ln[kLineLen] = (uint16_t)h;
-          ln[kLineOvf] = (uint16_t)((base_units + excl) & 0xFFFFu);
-          ln[kLineOvf + 1] = (uint16_t)((base_units + excl) >> 16);
-        }
-      } else {
-        cur[fp] = excl << a;  // cursor, in ids, relative to the row's first unit
-        entries[((uint64_t)s * R + fp) * v.n_tiles + t] = Entry{base_units + excl, h};
-      }
+      cur[fp] = excl << a;  // cursor, in ids, relative to the row's first unit
+      entries[((uint64_t)s * R + fp) * v.n_tiles + t] = Entry{base_units + excl, h};
     }
     running += __shfl(incl, 63, 64);
   }
-  uint16_t *gl = gids + v.tile_base[t] + (direct ? 0ull : ((uint64_t)base_units << a));
+  uint16_t *gl = gids + v.tile_base[t] + ((uint64_t)base_units << a);
   const uint64_t lt_mask = (1ULL << lane) - 1ULL;
   for (uint32_t base = 0; base < n_t; base += 64) {
     uint32_t i = base + lane;
@@ -175,13 +151,7 @@ __global__ void build_kernel(IndexView v, uint32_t *slot_units, Entry *entries, 
       uint32_t rank = __popcll(peers & lt_mask);
       uint32_t cnt = __popcll(peers);
       uint32_t p = cur[fp];
-      if (direct) {
-        const uint32_t k = p + rank;  // position inside the bucket
-        if (k < kLineIds) lines[line_index(v, t, s, fp) * 64 + k] = (uint16_t)i;
-        else gl[((uint64_t)ovs[fp] << 6) + (k - kLineIds)] = (uint16_t)i;
-      } else {
-        gl[p + rank] = (uint16_t)i;
-      }
+      gl[p + rank] = (uint16_t)i;
       if (rank == cnt - 1) cur[fp] = p + cnt;
     }
   }
@@ -217,7 +187,7 @@ __global__ void tile_base_kernel(uint64_t *tile_base, uint32_t n_tiles) {
 }
 
 static void build_shape(const IndexView &v, uint32_t &wpb, size_t &lds, uint64_t &blocks) {
-  size_t per_wave = (size_t)v.d.R * 4 * (v.direct ? 2 : 1);
+  size_t per_wave = (size_t)v.d.R * 4;
   wpb = (uint32_t)(65536 / per_wave);
   if (wpb > 4) wpb = 4;
   if (wpb < 1) wpb = 1;
@@ -235,14 +205,13 @@ hipError_t launch_build_sizes(const IndexView &v, uint32_t *slot_units, uint64_t
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(build_kernel<false>, dim3((uint32_t)blocks), dim3(64 * wpb), lds, stream, v, slot_units,
-                     (Entry *)nullptr, (uint16_t *)nullptr, (uint16_t *)nullptr, wpb);
+                     (Entry *)nullptr, (uint16_t *)nullptr, wpb);
   hipLaunchKernelGGL(slot_scan_kernel, dim3(v.n_tiles), dim3(1024), 0, stream, v, slot_units, tile_base);
   hipLaunchKernelGGL(tile_base_kernel, dim3(1), dim3(64), 0, stream, tile_base, v.n_tiles);
   return hipGetLastError();
 }
 
-hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids, uint16_t *lines,
-                             hipStream_t stream) {
+hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids, hipStream_t stream) {
   if ((uint64_t)v.n_tiles * v.f_local == 0) return hipSuccess;
   uint32_t wpb; size_t lds; uint64_t blocks;
   build_shape(v, wpb, lds, blocks);
@@ -250,30 +219,20 @@ hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(build_kernel<true>, dim3((uint32_t)blocks), dim3(64 * wpb), lds, stream, v,
-                     (uint32_t *)v.slot_units, entries, gids, lines, wpb);
+                     (uint32_t *)v.slot_units, entries, gids, wpb);
   return hipGetLastError();
 }
 
 // ---- dump stream export (src/niqki_index.cpp:42-55) ----
 // slot_word[s] = word position of bucket (s, 0): s*R buckets' size words + the ids before it.
-// length / i-th id of bucket (t, s, fp) in either layout
 __device__ __forceinline__ uint32_t bucket_len(const IndexView &v, uint32_t t, uint32_t s, uint32_t fp) {
-  if (v.direct) return v.lines[line_index(v, t, s, fp) * 64 + kLineLen];
   return v.entries[((uint64_t)s * v.d.R + fp) * v.n_tiles + t].len;
 }
 __device__ __forceinline__ void bucket_copy(const IndexView &v, uint32_t t, uint32_t s, uint32_t fp, uint32_t *out,
                                             unsigned long long &pos) {
-  if (v.direct) {
-    const uint16_t *ln = v.lines + line_index(v, t, s, fp) * 64;
-    const uint32_t len = ln[kLineLen];
-    const uint32_t ovf = (uint32_t)ln[kLineOvf] | ((uint32_t)ln[kLineOvf + 1] << 16);
-    const uint16_t *gl = v.gids + v.tile_base[t] + ((uint64_t)ovf << 6);
-    for (uint32_t j = 0; j < len; ++j) out[pos++] = t * v.tile + (j < kLineIds ? ln[j] : gl[j - kLineIds]);
-  } else {
-    const Entry e = v.entries[((uint64_t)s * v.d.R + fp) * v.n_tiles + t];
-    const uint16_t *gl = v.gids + v.tile_base[t] + ((uint64_t)e.start << v.align_log2);
-    for (uint32_t j = 0; j < e.len; ++j) out[pos++] = t * v.tile + gl[j];
-  }
+  const Entry e = v.entries[((uint64_t)s * v.d.R + fp) * v.n_tiles + t];
+  const uint16_t *gl = v.gids + v.tile_base[t] + ((uint64_t)e.start << v.align_log2);
+  for (uint32_t j = 0; j < e.len; ++j) out[pos++] = t * v.tile + gl[j];
 }
 // striped tiles: the bucket's ids in ascending GLOBAL order are a merge of the tiles' lists
 // (each ascending in its local ids)

@@ -37,27 +37,16 @@ struct Entry {
   uint32_t start;  // in units of (1 << align_log2) ids
   uint32_t len;
 };
-// "Bucket line" layout (direct != 0), used when its table fits the memory budget:
-//   lines  u16 [n_tiles][F_local*R + 1][64]   one 128-byte line per (tile, slot, fp),
-//          found from the fingerprint alone (no lookup table): ids[0..59] = the first
-//          60 tile-local ids of the bucket, [60] = bucket length, [62..63] = u32 start
-//          (in 64-id units) of the rest of the bucket inside the tile's overflow array
-//          (gids / tile_base as above, align_log2 = 6).  Line F_local*R is all zero.
-constexpr uint32_t kLineIds = 60;   // ids stored inline
-constexpr uint32_t kLineLen = 60;   // u16 index of the length field
-constexpr uint32_t kLineOvf = 62;   // u16 index of the low half of the overflow start
 struct IndexView {
   Derived d;
   uint32_t n_genomes;
-  uint32_t tile;     // T, genomes per tile (multiple of 64, <= 65536; <= 65472 with bucket lines)
+  uint32_t tile;     // T, genomes per tile (multiple of 64, <= 65536)
   uint32_t n_tiles;
   uint32_t f_local;  // slot_end - slot_begin
   uint32_t align_log2;
-  uint32_t direct;   // bucket-line layout
   uint32_t stripe;   // genomes are dealt to the tiles round-robin (tile = gid % n_tiles, local id =
                      // gid / n_tiles) instead of in ranges: a run of related genomes is spread over
                      // all tiles, which keeps their buckets short in every tile
-  const uint16_t *lines;
   uint64_t cap;      // row stride of the sketch store (genomes)
   const uint16_t *store;
   const Entry *entries;
@@ -86,8 +75,7 @@ hipError_t launch_store_read(const Derived &d, const uint16_t *store, uint64_t c
 hipError_t launch_build_sizes(const IndexView &v, uint32_t *slot_units, uint64_t *tile_base,
                               hipStream_t stream);
 // Build, phase 2: entries + gids (gids sized from tile_base[n_tiles]).
-hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids, uint16_t *lines,
-                             hipStream_t stream);
+hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids, hipStream_t stream);
 // dump stream (src/niqki_index.cpp:42-55) of a whole-range index.
 // layout: slot_word[s] (F+1 entries) = word position of bucket (s, 0) in the stream
 // (header excluded); export: the words of slots [s0, s1) into `out` (word 0 = first
@@ -105,10 +93,12 @@ hipError_t launch_import(const Derived &d, const uint32_t *words, const uint64_t
 // gather-histogram: counts[q*stride + g] for all genomes (u16), one workgroup
 // per (query, tile).
 // stash: nq x (n_tiles-1) x f_local Entry scratch (unused for n_tiles == 1)
-// order: nullptr, or the locality order of the batch from launch_order (nq <= 4096, CSR layout)
+// order: nullptr, or the locality order of the batch from launch_order (nq <= 4096)
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq,
                          uint16_t *counts, uint64_t stride, Entry *stash, const uint32_t *order,
                          int variant, hipStream_t stream);
+// launch shapes selectable through the "gather_variant" option (0 = choose)
+bool gather_variant_valid(int variant);
 // keys / order: nq words of scratch each
 hipError_t launch_order(const IndexView &v, const int32_t *sketches, uint32_t nq, uint32_t *keys,
                         uint32_t *order, hipStream_t stream);

@@ -82,7 +82,8 @@ __device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t 
 // wave-private LDS queue, so the walk always runs on full batches of 64 chunks
 // whatever the bucket lengths are.
 // MODE is a measurement aid (results are wrong for MODE != 0): 1 = no LDS
-// atomics, 6 = lookups only.
+// atomics, 6 = lookups only.  MODE != 0 is instantiated only in -DNQ_ABLATION builds;
+// the shipped library cannot be switched into it.
 template <int BLOCK, int UNROLL, int NT, bool STASH_OUT, bool STASH_IN, int MODE>
 __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk, uint32_t q, uint32_t t,
                                           uint32_t *cnt, Item *queue, Entry *stash, uint32_t &sink) {
@@ -193,117 +194,6 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
   }
 }
 
-// Bucket-line layout: one pass of a workgroup over all slots of one tile.  The
-// line of bucket (slot, fp) is addressed from the fingerprint alone, so there is no
-// lookup and one dependent memory level: every lane loads its slot's fingerprint
-// (two iterations ahead), then the wave reads the 64 lines one after another, lane l
-// taking the u16 at index l -- ids 0..59, the bucket length at 60, the overflow start
-// at 62..63 -- UNROLL lines per round trip, two rounds in flight.  Ids beyond the
-// first 60 of a bucket live in the tile's overflow array and go through the same
-// wave-private chunk queue as in the CSR walk.
-template <int BLOCK, int UNROLL, int MODE>
-__device__ __forceinline__ void walk_tile_direct(const IndexView &v, const int32_t *sk, uint32_t t, uint32_t *cnt,
-                                                 Item *queue, uint32_t &sink) {
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  constexpr uint32_t NW = BLOCK / 64;
-  const uint32_t R = v.d.R;
-  const uint32_t n_it = (v.f_local + 63) / 64;
-  const uint32_t zero_line = v.f_local * R;  // all-zero line: length 0
-  const uint16_t *lines = v.lines + (uint64_t)t * ((uint64_t)zero_line + 1) * 64;
-  const uint16_t *gl = v.gids + v.tile_base[t];
-  Item *wq = queue + wave * kQueue;
-  uint32_t q_head = 0, q_count = 0;  // wave-uniform
-
-  auto load_fp = [&](uint32_t it) -> int32_t {
-    const uint32_t s = it * 64 + lane;
-    return sk[s < v.f_local ? s : v.f_local - 1];
-  };
-  auto line_of = [&](uint32_t it, int32_t fp) -> uint32_t {
-    const uint32_t s = it * 64 + lane;
-    const bool ok = it < n_it && s < v.f_local && fp >= 0 && (uint32_t)fp < R;  // src/niqki_index.cpp:654
-    return ok ? s * R + (uint32_t)fp : zero_line;
-  };
-  auto drain = [&]() {
-    while (q_count >= 64) {
-      const Item x = wq[(q_head + lane) & (kQueue - 1)];
-      q_head = (q_head + 64) & (kQueue - 1);
-      q_count -= 64;
-      walk64<UNROLL, MODE>(gl, 6, x.pos, x.len, lane, cnt, sink);
-    }
-  };
-
-  uint32_t it = wave;
-  int32_t fp1 = load_fp(it + NW);
-  uint32_t li = line_of(it, load_fp(it));
-  for (; it < n_it; it += NW) {
-    const uint32_t li_next = line_of(it + NW, fp1);
-    fp1 = load_fp(it + 2 * NW);
-    uint32_t pos = 0, rem = 0;  // this lane's slot: overflow start (64-id units) / ids left there
-    if (MODE == 6) { sink += li; li = li_next; continue; }
-
-    uint32_t ga[UNROLL], gb[UNROLL];
-    auto fetch = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const uint32_t b = __builtin_amdgcn_readlane(li, j0 + u);
-        g[u] = (lines + (uint64_t)b * 64)[lane];
-      }
-    };
-    auto apply = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
-#pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const uint32_t len = __builtin_amdgcn_readlane(g[u], kLineLen);
-        const uint32_t nin = len < kLineIds ? len : kLineIds;
-        if (MODE == 1) { if (lane < nin) sink ^= g[u]; }
-        else bump_if(cnt, g[u] & 0xFFFFu, lane < nin, lane);
-        if (len > kLineIds) {  // wave-uniform: hand the rest of the bucket to lane j0+u
-          const uint32_t ovf = __builtin_amdgcn_readlane(g[u], kLineOvf) |
-                               (__builtin_amdgcn_readlane(g[u], kLineOvf + 1) << 16);
-          if (lane == j0 + u) { pos = ovf; rem = len - kLineIds; }
-        }
-      }
-    };
-    fetch(0, ga);
-#pragma unroll
-    for (uint32_t j0 = 0; j0 < 64; j0 += 2 * UNROLL) {
-      fetch(j0 + UNROLL, gb);
-      apply(j0, ga);
-      if (j0 + 2 * UNROLL < 64) fetch(j0 + 2 * UNROLL, ga);
-      apply(j0 + UNROLL, gb);
-    }
-    // overflow parts: chunks of <= 64 ids through the queue (q_count < 64 here)
-    while (__any(rem != 0)) {
-      uint32_t nch = (rem + 63) >> 6;
-      if (nch > 3) nch = 3;
-      uint32_t incl = nch;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        uint32_t y = __shfl_up(incl, o, 64);
-        if (lane >= (uint32_t)o) incl += y;
-      }
-      const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-      uint32_t slot = q_head + q_count + incl - nch;
-#pragma unroll
-      for (uint32_t k = 0; k < 3; ++k)
-        if (k < nch) {
-          const uint32_t left = rem - 64 * k;
-          wq[(slot + k) & (kQueue - 1)] = Item{pos + k, left < 64 ? left : 64u};
-        }
-      q_count += total;
-      pos += nch;
-      rem -= rem < 192 ? rem : 192u;
-      drain();
-    }
-    li = li_next;
-  }
-  if (q_count) {  // the last partial batch
-    Item x = wq[(q_head + lane) & (kQueue - 1)];
-    if (lane >= q_count) x = Item{0u, 0u};
-    walk64<UNROLL, MODE>(gl, 6, x.pos, x.len, lane, cnt, sink);
-  }
-}
-
-
 // ---- locality order of a query batch -----------------------------------------------------
 // Queries that hit the same genomes read the same table and bucket lines.  When they run on
 // the same XCD at the same time those lines are fetched from HBM once (measured: 13 % off the
@@ -409,9 +299,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     const uint32_t n_words = (n_t + 1) / 2;
     for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
     __syncthreads();
-    if (NT == 0) {
-      walk_tile_direct<BLOCK, UNROLL, MODE>(v, sk, t, cnt, queue, sink);
-    } else if (NT >= 2) {
+    if (NT >= 2) {
       if (t == 0) walk_tile<BLOCK, UNROLL, NT, true, false, MODE>(v, sk, q, t, cnt, queue, stash, sink);
       else walk_tile<BLOCK, UNROLL, NT, false, true, MODE>(v, sk, q, t, cnt, queue, stash, sink);
     } else {
@@ -438,13 +326,20 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
 
 hipError_t launch_order(const IndexView &v, const int32_t *sketches, uint32_t nq, uint32_t *keys,
                         uint32_t *order, hipStream_t stream) {
-  if (nq == 0 || nq > kOrderMax || v.direct || v.n_genomes >= (1u << 20) - 1) return hipErrorInvalidValue;
+  if (nq == 0 || nq > kOrderMax || v.n_genomes >= (1u << 20) - 1) return hipErrorInvalidValue;
   const size_t lds = (size_t)((v.tile + 1) / 2) * 4;
   hipError_t e = hipFuncSetAttribute((const void *)probe_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(probe_kernel<1024>, dim3(nq), dim3(1024), lds, stream, v, sketches, keys);
   hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, keys, nq, order);
   return hipGetLastError();
+}
+
+bool gather_variant_valid(int variant) {
+#ifdef NQ_ABLATION
+  if (variant == 11 || variant == 16) return true;
+#endif
+  return variant >= 0 && variant <= 5;
 }
 
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq, uint16_t *counts,
@@ -465,8 +360,7 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
   } while (0)
 #define NQ_BY_TILES(B, U, ...)                                                                   \
   do {                                                                                           \
-    if (v.direct) NQ_LAUNCH_GATHER(B, U, 0, ##__VA_ARGS__);                                      \
-    else if (v.n_tiles == 2) NQ_LAUNCH_GATHER(B, U, 2, ##__VA_ARGS__);                                \
+    if (v.n_tiles == 2) NQ_LAUNCH_GATHER(B, U, 2, ##__VA_ARGS__);                                \
     else if (v.n_tiles == 3) NQ_LAUNCH_GATHER(B, U, 3, ##__VA_ARGS__);                           \
     else if (v.n_tiles == 4) NQ_LAUNCH_GATHER(B, U, 4, ##__VA_ARGS__);                           \
     else NQ_LAUNCH_GATHER(B, U, 1, ##__VA_ARGS__);                                               \
@@ -477,8 +371,10 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     case 3: NQ_BY_TILES(512, 16); break;
     case 4: NQ_BY_TILES(256, 16); break;
     case 5: NQ_BY_TILES(128, 16); break;
-    case 11: NQ_BY_TILES(1024, 16, 1); break;      // ablations, see MODE
+#ifdef NQ_ABLATION  // measurement builds only (make ABLATION=1): these variants return wrong counters
+    case 11: NQ_BY_TILES(1024, 16, 1); break;
     case 16: NQ_BY_TILES(1024, 16, 6); break;
+#endif
     default:
       // small tiles (short-read indexes): counters of <= 24 KB leave room for several
       // workgroups per CU, and 4 waves per query then beat 16 (tools/bench_reads.py)
@@ -501,13 +397,8 @@ __global__ __launch_bounds__(256) void gathered_kernel(IndexView v, const int32_
   for (uint32_t s = threadIdx.x; s < v.f_local; s += blockDim.x) {
     int32_t fp = sk[s];
     if (fp >= 0 && (uint32_t)fp < R) {
-      if (v.direct) {
-        for (uint32_t t = 0; t < v.n_tiles; ++t)
-          sum += v.lines[((uint64_t)t * ((uint64_t)v.f_local * R + 1) + (uint64_t)s * R + (uint32_t)fp) * 64 + kLineLen];
-      } else {
-        const Entry *p = v.entries + ((uint64_t)s * R + (uint32_t)fp) * v.n_tiles;
-        for (uint32_t t = 0; t < v.n_tiles; ++t) sum += p[t].len;
-      }
+      const Entry *p = v.entries + ((uint64_t)s * R + (uint32_t)fp) * v.n_tiles;
+      for (uint32_t t = 0; t < v.n_tiles; ++t) sum += p[t].len;
     }
   }
   atomicAdd(&per_query[q], sum);
@@ -539,28 +430,41 @@ __global__ __launch_bounds__(256) void hits_count_kernel(HitsArgs a) {
   if (threadIdx.x == 0) a.blk_counts[blockIdx.x] = s_sum;
 }
 
-// exclusive scan of blk_counts (nq*n_blk entries) in place + hit_off[q]; single workgroup
+// hit_off[q] = exclusive prefix over queries of the per-query hit totals (blk_counts keeps the
+// per-block counts; hits_compact_kernel forms a block's prefix inside its query itself).
+// Single workgroup: per-thread partial sums over a run of queries, one wave-level scan of the 16
+// wave totals, then the runs again.  n_blk is small (N / 4096), so a thread reads its queries' rows
+// directly.
 __global__ __launch_bounds__(1024) void hits_scan_kernel(HitsArgs a) {
-  __shared__ unsigned long long part[1024];
-  const uint64_t n = (uint64_t)a.nq * a.n_blk;
-  const uint32_t tid = threadIdx.x;
-  const uint64_t per = (n + 1023) / 1024;
-  const uint64_t lo = tid * per, hi = (lo + per < n) ? lo + per : n;
+  __shared__ unsigned long long wave_tot[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t per = (a.nq + 1023) / 1024;
+  const uint32_t lo = tid * per < a.nq ? tid * per : a.nq;
+  const uint32_t hi = lo + per < a.nq ? lo + per : a.nq;
   unsigned long long sum = 0;
-  for (uint64_t i = lo; i < hi; ++i) sum += a.blk_counts[i];
-  part[tid] = sum;
-  __syncthreads();
-  if (tid == 0) {
-    unsigned long long run = 0;
-    for (uint32_t i = 0; i < 1024; ++i) { unsigned long long x = part[i]; part[i] = run; run += x; }
-    a.hit_off[a.nq] = run;
+  for (uint32_t q = lo; q < hi; ++q)
+    for (uint32_t b = 0; b < a.n_blk; ++b) sum += a.blk_counts[(uint64_t)q * a.n_blk + b];
+  unsigned long long incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long y = __shfl_up(incl, o, 64);
+    if (lane >= (uint32_t)o) incl += y;
   }
+  if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();
-  unsigned long long run = part[tid];
-  for (uint64_t i = lo; i < hi; ++i) {
-    if (i % a.n_blk == 0) a.hit_off[i / a.n_blk] = run;
-    run += a.blk_counts[i];
+  unsigned long long base = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 16; ++w) {
+    const unsigned long long x = wave_tot[w];
+    if (w < wave) base += x;
+    total += x;
   }
+  unsigned long long run = base + incl - sum;
+  for (uint32_t q = lo; q < hi; ++q) {
+    a.hit_off[q] = run;
+    for (uint32_t b = 0; b < a.n_blk; ++b) run += a.blk_counts[(uint64_t)q * a.n_blk + b];
+  }
+  if (tid == 0) a.hit_off[a.nq] = total;
 }
 
 // Each (query, block) writes its hits at the mirrored position so that a

@@ -687,7 +687,10 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   // after niqki_select_best_H the fingerprint parts may overlap and leave [0, 2^W): the
   // value-indexed tables and the filter's ordering argument need the regular form
   const bool regular = a.d.mask_m == (1u << a.d.M) - 1u && a.d.max_rem == (1u << a.d.H) - 1u;
-  a.distinct = (regular && short_records && sketch_lds_bytes(a.d, true, 0) <= 64 * 1024) ? 1u : 0u;
+  // ... and cells this launch produced itself: a caller's sketch (niqki_densify, accumulate) may hold
+  // any value, the value-indexed tables only values below 2^W
+  const bool own_cells = a.seqs != nullptr && !a.accumulate;
+  a.distinct = (regular && own_cells && short_records && sketch_lds_bytes(a.d, true, 0) <= 64 * 1024) ? 1u : 0u;
   // candidate filter: long records only (the kernel picks its strength per sketch);
   // NIQKI_SKETCH_FILTER=0 switches it off
   // NIQKI_SKETCH_FILTER: 0 = off, unset/1 = automatic, n >= 2 = force n-1 leading zeros (tests)

@@ -107,6 +107,7 @@ class ShardedQuery:
             dist.all_to_all_single(recv.view(-1), words.reshape(-1), group=self.group)
             torch.sum(recv, dim=0, out=out)
         else:
+            # (also the fallback of an overflowing sparse step)
             dist.reduce_scatter_tensor(out.view(-1), words.reshape(-1), group=self.group)
         return out.view(torch.int16)
 
@@ -125,7 +126,8 @@ class ShardedQuery:
         ncand_all = self._buf("ncand_all", (G, nq), torch.int32)
         dist.all_gather_into_tensor(cand_all.view(-1), cand.view(-1), group=self.group)
         dist.all_gather_into_tensor(ncand_all.view(-1), ncand, group=self.group)
-        self.overflow |= (ncand_all > C).any().to(torch.int32)
+        self._step_overflow = (ncand_all > C).any().to(torch.int32)
+        self.overflow |= self._step_overflow
         # union per query: the G lists side by side (duplicates are harmless)
         union = cand_all.permute(1, 0, 2).reshape(nq, G * C)                    # [q][G*C], -1 = no candidate
         valid = union >= 0
@@ -148,15 +150,30 @@ class ShardedQuery:
         red[:, 0] = torch.where(v0 >= 32768, v0 - 65536, v0).to(torch.int16)
         return red
 
-    def step(self, local_sketches, hit_off, hit_counts, hit_gids, capacity):
+    def step(self, local_sketches, hit_off, hit_counts, hit_gids, capacity, check_overflow=True):
         """One query batch.  local_sketches: [per, F] int32 of this rank's share.
-        Fills hit_off[per+1] (int64), hit_counts / hit_gids (int32, capacity)."""
+        Fills hit_off[per+1] (int64), hit_counts / hit_gids (int32, capacity).
+
+        The engine's kernels and the torch ops / collectives of this module must run on ONE
+        stream: the engine is (re)bound to torch's current stream here (a handle's own stream is
+        non-blocking and orders against nothing else).  A sparse step whose candidate lists
+        overflow is redone with the dense exchange (one 4-byte read-back per step;
+        check_overflow=False leaves the check to the caller, who then must test `overflow`)."""
+        if self.device.type == "cuda" and hasattr(self.e, "set_stream"):
+            self.e.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         per = local_sketches.shape[0]
         nq = per * self.world
         allsk = self.exchange_sketches(local_sketches)
         counts = self._buf("counts", (nq, self.stride), torch.int16)
         self.e.query_counts_dev(allsk, nq, counts, self.stride)
-        red = self.reduce_candidates(counts) if self.exchange == "sparse" else self.reduce_counts(counts)
+        if self.exchange == "sparse":
+            red = self.reduce_candidates(counts)
+            if check_overflow:
+                # every rank sees the same all-gathered list sizes, so all ranks take the same branch
+                if int(self._step_overflow.item()):
+                    red = self.reduce_counts(counts)
+        else:
+            red = self.reduce_counts(counts)
         self.e.hits_from_counts_dev(red, per, self.stride, 0, self.N, hit_off, hit_counts, hit_gids,
                                     capacity)
         return red

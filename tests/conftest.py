@@ -56,3 +56,24 @@ def family_spec(n_fam, n_mem, lo=16, hi=820, fam0=0):
             mem.append(k)
             rate.append(0 if k == 0 else int(round(lo * (hi / lo) ** ((k - 1) / max(n_mem - 2, 1)))))
     return np.array(fam, np.uint32), np.array(mem, np.uint32), np.array(rate, np.uint32)
+
+
+def make_cli_workdir(td, native, meta):
+    """The synthetic input files of the CLI goldens (oracle/make_goldens.py wrote the reference
+    CLI's outputs for exactly these): 12 FASTA genomes of 40 kbp, their list, 30 reads."""
+    fam, mem, rate = family_spec(4, 8)
+    genomes = [native.synth_genome_host(meta["seed"], int(f), int(m), int(r), 40000)
+               for f, m, r in zip(fam, mem, rate)]
+    names = []
+    for i, g in enumerate(genomes[:12]):
+        fn = "syn%02d.fa" % i
+        with open(td / fn, "wb") as f:
+            f.write(b">syn%02d\n" % i)
+            for a in range(0, len(g), 70):
+                f.write(bytes(g[a:a + 70]) + b"\n")
+        names.append(fn)
+    (td / "fof.txt").write_text("\n".join(names) + "\n")
+    with open(td / "reads.fa", "wb") as f:
+        for i in range(30):
+            f.write(b">read%d some text\n" % i + bytes(genomes[i % 12][200 * i:200 * i + 150]) + b"\n")
+    return td

@@ -90,20 +90,27 @@ def _worker(rank, world, port, exchange, ret):
     hit_off = torch.zeros(per + 1, dtype=torch.int64)
     hc = torch.zeros(per * N, dtype=torch.int32)
     hg = torch.zeros(per * N, dtype=torch.int32)
-    sq.step(mine, hit_off, hc, hg, per * N)
     whole = po.Index(p, sk)
-    ok = True
-    for i in range(per):
-        ehc, ehg = whole.query(q[rank * per + i], min_score=5)
-        lo, hi = int(hit_off[i]), int(hit_off[i + 1])
-        ok &= np.array_equal(hc[lo:hi].numpy().astype(np.uint32), ehc)
-        ok &= np.array_equal(hg[lo:hi].numpy().astype(np.uint32), ehg)
+
+    def answers_match():
+        good = True
+        for i in range(per):
+            ehc, ehg = whole.query(q[rank * per + i], min_score=5)
+            lo, hi = int(hit_off[i]), int(hit_off[i + 1])
+            good &= np.array_equal(hc[lo:hi].numpy().astype(np.uint32), ehc)
+            good &= np.array_equal(hg[lo:hi].numpy().astype(np.uint32), ehg)
+        return good
+
+    sq.step(mine, hit_off, hc, hg, per * N)
+    ok = answers_match()
     if exchange.startswith("sparse"):
         ok &= int(sq.overflow.item()) == 0
-        # a capacity that is too small must be reported, never silently wrong
+        # a capacity that is too small is reported and the step redone densely: never silently wrong
         sq2 = ShardedQuery(eng, N, F, torch.device("cpu"), exchange="sparse", cand_cap=1)
+        hit_off.zero_()
         sq2.step(mine, hit_off, hc, hg, per * N)
         ok &= int(sq2.overflow.item()) == 1
+        ok &= answers_match()
     ret[rank] = bool(ok)
     dist.destroy_process_group()
 

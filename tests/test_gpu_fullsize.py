@@ -1,0 +1,145 @@
+"""GPU parity at BASELINE.json's full size: configs[2] = 100 000 synthetic 5 Mbp genomes indexed,
+K=31 S=15 W=12 H=4 J=0.1, queried with the bench's own query genomes.
+
+The oracle cannot sketch 500 Gbp, so the test is anchored in two steps, both bit-exact:
+  * sketches: a sample of the index genomes and every checked query genome is re-sketched by
+    the oracle from the same synthetic bytes (host generator == device generator);
+  * index + counting loop + threshold + order (src/niqki_index.cpp:652-666, :685): the stored
+    sketches are read back in seven blocks of <= 16 384 genomes, each block becomes an oracle
+    index (the oracle's own insert + CSR), and the oracle's counters of ALL 100 000 columns are
+    compared with niqki_query_counts; the oracle's thresholded, ordered hit lists built from
+    those columns are compared with niqki_query's.
+"""
+import numpy as np
+import pytest
+
+import bench
+
+pytestmark = pytest.mark.gpu
+
+N, L, FAMILY, SEED = 100_000, 5_000_000, 100, 20261003
+K, S, W, H, J = 31, 15, 12, 4, 0.1
+F = 1 << S
+NQ = 64            # checked queries (dense columns + hit lists)
+NQ_SKETCH = 6      # of which re-sketched by the oracle (0.1 s of CPU each)
+BLOCK = 16384
+
+
+@pytest.fixture(scope="module")
+def big(native):
+    """The bench's index and its first query batch, built exactly as bench.py builds them."""
+    import torch
+    dev = torch.device("cuda")
+    e = native.Engine(K=K, S=S, W=W, H=H, J=J)
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    e.set_option("record_len_hint", L)
+    e.reserve(N)
+    n_fam = N // FAMILY
+    GB = 256
+    t32 = lambda a: torch.from_numpy(a.astype(np.int64)).to(torch.int32).to(dev)  # noqa: E731
+    seq = torch.zeros(GB * L + native.SEQ_PAD, dtype=torch.uint8, device=dev)
+    sk = torch.empty((GB, F), dtype=torch.int32, device=dev)
+    ro = torch.from_numpy(np.arange(GB + 1, dtype=np.int64) * L).to(dev)
+    for g0 in range(0, N, GB):
+        n = min(GB, N - g0)
+        fam, mem, rate = bench.genome_spec(np.arange(g0, g0 + n), n_fam, FAMILY)
+        e.synth_dev(SEED, t32(fam), t32(mem), t32(rate), n, L, L, seq)
+        e.sketch_dev(seq, ro if n == GB else torch.from_numpy(np.arange(n + 1, dtype=np.int64) * L).to(dev), n, sk)
+        e.insert_dev(sk, n)
+    e.build()
+    # queries 0..NQ-1 of the bench's first batch (every 10th from a family that is not indexed)
+    qfam, qmem, qrate = bench.query_spec(np.arange(NQ), n_fam)
+    e.synth_dev(SEED, t32(qfam), t32(qmem), t32(qrate), NQ, L, L, seq)
+    qsk = torch.empty((NQ, F), dtype=torch.int32, device=dev)
+    e.sketch_dev(seq, torch.from_numpy(np.arange(NQ + 1, dtype=np.int64) * L).to(dev), NQ, qsk)
+    e.synchronize()
+    qseq = seq[:NQ_SKETCH * L].cpu().numpy().reshape(NQ_SKETCH, L).copy()
+    del seq
+    yield e, qsk.cpu().numpy(), qseq, (qfam, qmem, qrate)
+    e.close()
+
+
+def test_config3_sketches_of_index_and_queries_vs_oracle(native, po, big):
+    e, qsk, qseq, _ = big
+    p = po.make_params(K, S, W, H, J)
+    for i in range(NQ_SKETCH):
+        assert np.array_equal(qsk[i], po.compute_sketch(p, qseq[i])), i
+    # indexed genomes: first, last, a family ancestor and a 5 % member, from the host generator
+    n_fam = N // FAMILY
+    for g in (0, 4_299, 65_471, N - 1):
+        fam, mem, rate = bench.genome_spec(np.array([g]), n_fam, FAMILY)
+        seq = native.synth_genome_host(SEED, int(fam[0]), int(mem[0]), int(rate[0]), L)
+        assert np.array_equal(e.get_sketches(g, 1)[0], po.compute_sketch(p, seq)), g
+
+
+def test_config3_all_columns_and_hit_lists_vs_oracle(native, po, big):
+    e, qsk, _, (qfam, _, _) = big
+    assert e.n_genomes == N and e.tile_genomes() < N          # two counter tiles, striped
+    p = po.make_params(K, S, W, H, J)
+    assert p.min_score == 3276 == e.min_score
+    got = e.query_counts(qsk)                                   # [NQ][N] u16 through the C ABI
+    exp = np.zeros((NQ, N), np.uint32)
+    for b0 in range(0, N, BLOCK):
+        n = min(BLOCK, N - b0)
+        sub = e.get_sketches(b0, n)
+        ix = po.Index(p, sub)
+        for q in range(NQ):
+            exp[q, b0:b0 + n] = ix.counts(qsk[q])
+        del ix, sub
+    assert np.array_equal(got.astype(np.uint32), exp)
+    # threshold + order from the oracle's columns: greater<pair<count, gid>>, :662-666, :685
+    off, hc, hg = e.query(qsk)
+    n_with_hits = 0
+    for q in range(NQ):
+        gids = np.nonzero(exp[q] >= p.min_score)[0]
+        order = np.lexsort((-gids.astype(np.int64), -exp[q, gids].astype(np.int64)))
+        ec, eg = exp[q, gids][order], gids[order].astype(np.uint32)
+        lo, hi = int(off[q]), int(off[q + 1])
+        assert np.array_equal(hc[lo:hi], ec) and np.array_equal(hg[lo:hi], eg), q
+        n_with_hits += len(gids) > 0
+        if qfam[q] < N // FAMILY:                              # mutant of an indexed family: hits stay inside it
+            assert len(gids) > 0 and (gids // FAMILY == qfam[q]).all(), q
+        else:
+            assert len(gids) == 0, q
+    assert n_with_hits >= NQ * 8 // 10
+    # the oracle's own threshold/sort (nqo_hits_from_counts) agrees with the numpy restatement
+    L_ = po.lib()
+    row = np.ascontiguousarray(exp[0])
+    oc, og = np.empty(N, np.uint32), np.empty(N, np.uint32)
+    k = L_.nqo_hits_from_counts(row.ctypes.data, N, p.min_score, oc.ctypes.data, og.ctypes.data, N)
+    assert np.array_equal(oc[:k], hc[int(off[0]):int(off[1])]) and np.array_equal(og[:k], hg[int(off[0]):int(off[1])])
+
+
+def test_candidates_from_counts_vs_numpy(native):
+    """niqki_candidates_from_counts (the sparse multi-GPU exchange's first step): ids with
+    counter >= threshold, any order, -1 padding, n_cand exact also when the list overflows."""
+    import torch
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(12)
+    e = native.Engine(K=31, S=8, W=8, H=4)
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    for n_gids, stride, cap, thr in ((1000, 1000, 64, 40), (70001, 70002, 256, 3), (513, 600, 8, 1), (64, 64, 64, 0),
+                                     (300, 300, 16, 65535)):
+        nq = 7
+        c = rng.integers(0, 60, (nq, stride)).astype(np.uint16)
+        c[0, :] = 0                       # no candidate
+        c[1, :n_gids] = thr               # every genome exactly at the threshold (overflows cap)
+        c[2, :n_gids] = max(thr, 1) - 1   # every genome just below it
+        c[3, n_gids:] = 65535             # columns beyond n_gids never count
+        c[4, 0] = c[4, n_gids - 1] = 65535
+        d_c = torch.from_numpy(c.view(np.int16)).to(dev)
+        cand = torch.full((nq, cap), 7, dtype=torch.int32, device=dev)
+        ncand = torch.zeros(nq, dtype=torch.int32, device=dev)
+        e.candidates_dev(d_c, nq, stride, n_gids, thr, cap, cand, ncand)
+        e.synchronize()
+        cand, ncand = cand.cpu().numpy(), ncand.cpu().numpy()
+        for q in range(nq):
+            want = np.nonzero(c[q, :n_gids] >= thr)[0]
+            assert ncand[q] == len(want), (q, n_gids, thr)
+            k = min(len(want), cap)
+            assert (cand[q, k:] == -1).all()
+            got = cand[q, :k]
+            assert len(set(got.tolist())) == k and set(got.tolist()) <= set(want.tolist())
+            if len(want) <= cap:
+                assert sorted(got.tolist()) == want.tolist()
+    e.close()

@@ -11,12 +11,11 @@ from conftest import family_spec, synth_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["csr", "csr_ranges", "lines"])
-def index_layout(request, monkeypatch):
-    """Every test runs under the index layouts of DESIGN.md section 3: CSR entries + id lists
-    with striped tiles (default) or with tiles as ranges of genome ids, and bucket lines."""
-    monkeypatch.setenv("NIQKI_INDEX_LAYOUT", "2" if request.param == "lines" else "1")
-    monkeypatch.setenv("NIQKI_TILE_STRIPE", "0" if request.param == "csr_ranges" else "1")
+@pytest.fixture(autouse=True, params=["striped", "ranges"])
+def tile_layout(request, monkeypatch):
+    """Every test runs under both tilings of DESIGN.md section 3: genomes dealt to the counter
+    tiles round-robin (default) or tiles as ranges of genome ids."""
+    monkeypatch.setenv("NIQKI_TILE_STRIPE", "0" if request.param == "ranges" else "1")
     return request.param
 
 
@@ -457,7 +456,7 @@ def test_streaming_dump_and_load_equal_the_whole_buffer_forms(native, po):
     e.close()
 
 
-def test_maximum_fingerprint_width_and_full_tile(native, po, index_layout):
+def test_maximum_fingerprint_width_and_full_tile(native, po):
     """Corners of the supported range: W = 15 (2^15 fingerprints per slot, one build wave
     needs 128 KB of LDS) and a counter tile of 65536 genomes (160 KB of LDS)."""
     # W = 15, H = 7: sketches from sequences, then index + query against the oracle
@@ -469,28 +468,19 @@ def test_maximum_fingerprint_width_and_full_tile(native, po, index_layout):
     sk = e.sketch(g)
     assert np.array_equal(sk, np.stack([po.compute_sketch(p, x) for x in g]))
     e.insert(sk)
-    if index_layout == "lines":  # its build keeps two LDS words per fingerprint: W <= 14
-        with pytest.raises(native.NiqkiError):
-            e.build()
-    else:
-        ix = po.Index(p, sk)
-        off, hc, hg = e.query(sk[:3])
-        for i in range(3):
-            ehc, ehg = ix.query(sk[i])
-            assert np.array_equal(hc[int(off[i]):int(off[i + 1])], ehc) and np.array_equal(hg[int(off[i]):int(off[i + 1])], ehg)
+    ix = po.Index(p, sk)
+    off, hc, hg = e.query(sk[:3])
+    for i in range(3):
+        ehc, ehg = ix.query(sk[i])
+        assert np.array_equal(hc[int(off[i]):int(off[i + 1])], ehc) and np.array_equal(hg[int(off[i]):int(off[i + 1])], ehg)
     e.close()
-    # one tile of 65536 genomes (CSR layout only: a bucket line's length field is 16 bits)
+    # one tile of 65536 genomes
     S, W, N = 4, 6, 65536
     rng = np.random.default_rng(9)
     sk = rng.integers(0, 1 << W, (N, 1 << S)).astype(np.int32)
     e = native.Engine(K=31, S=S, W=W, H=3, min_score_value=14, tile_genomes=65536)
     e.insert(sk)
     q = sk[[0, 65535, 31000]]
-    if index_layout == "lines":
-        with pytest.raises(native.NiqkiError):
-            e.build()
-        e.close()
-        return
     p2 = po.make_params(31, S, W, 3, 0.0)
     p2.min_score = 14
     ix = po.Index(p2, sk)

@@ -2,6 +2,7 @@
 reference produced (oracle/make_goldens.py -> tests/golden/).  This is what pins
 the oracle."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -218,3 +219,27 @@ def test_ecoli_pins(po, gold):
     for a in range(9):
         text += m["files"][a] + "\t" + "".join("%g\t" % ((mat[a, t] / 32768) if mat[a, t] >= 3276 else 0.0) for t in range(9)) + "\n"
     assert text == meta["ecoli_cli"]["matrix"]
+
+
+def test_reference_binary_loads_our_dump_fixture(tmp_path, po, native, gold):
+    """Drop-in check of the dump format in the other direction, in the build container: the REAL
+    reference binary (oracle/_ref/niqki_ref, compiled from /root/reference by oracle/Makefile;
+    it never travels to the GPU box) loads tests/golden/ours_cli_dump.gz -- the multi-member
+    gzip dump OUR host program wrote on a GPU box (tools/make_dump_fixture.py; the GPU suite
+    checks that the program still writes it) -- and answers like it does from its own dump."""
+    import gzip
+    import shutil
+    import subprocess
+    from conftest import GOLD, make_cli_workdir
+    fixture = os.path.join(GOLD, "ours_cli_dump.gz")
+    if not os.path.exists(po.REF_BIN_PATH):
+        pytest.skip("oracle/_ref/niqki_ref not built (no /root/reference here)")
+    assert os.path.exists(fixture)
+    _, meta = gold
+    td = make_cli_workdir(tmp_path, native, meta)
+    shutil.copy(fixture, td / "ours.dump")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([po.REF_BIN_PATH, "-L", "ours.dump", "-Q", "fof.txt", "-O", "ref_on_ours.gz"], cwd=td,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert gzip.open(td / "ref_on_ours.gz", "rb").read().decode() == meta["cli"]["hits_loaded"]
