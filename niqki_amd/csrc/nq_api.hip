@@ -58,11 +58,12 @@ struct niqki_index {
   uint64_t record_len_hint = 0;  // avg bytes per sketch for device-side batches (0 = read it back)
   uint32_t query_batch = 1024;
   int query_order = 1;           // option: order the queries of a launch for cache locality
+  int lookup_prepass = -1;       // option: slot-major table look-up pre-pass: -1 = when it pays, 0 = never, 1 = whenever usable
 
   Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
       ws_misc, ws_stash;
   // staged batch (niqki_stage_raw): framing results live in ws_seq / ws_recoff / ws_entry
-  Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk, ws_order;
+  Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk, ws_order, ws_blocked, ws_pre;
   struct {
     bool valid = false, sketched = false;
     uint32_t n_entry = 0, n_rec = 0;
@@ -270,8 +271,18 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *
   // launches of at most `chunk` queries bound the per-query stash (one Entry per
   // slot and extra tile) whatever the caller's batch size is
   const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
-  const uint32_t chunk = ix->n_tiles > 1 ? 4096u : nq;
-  if (ix->n_tiles > 1) {
+  const nq::IndexView v = view(ix);
+  // Table look-ups: inside the gather kernel (one random table line per query and slot), or
+  // by the slot-major pre-pass, which streams the whole table once per launch: it pays when
+  // the launch's random lines (128 bytes each) outweigh twice the table.
+  bool pre = ix->lookup_prepass != 0 && nq::launch_lookup_usable(v) && (((uintptr_t)(sketches + ix->d.slot_begin)) & 15) == 0;
+  if (pre && ix->lookup_prepass < 0)
+    pre = (uint64_t)std::min(nq, 4096u) * 128 >= 2ull * ix->d.R * ix->n_tiles * sizeof(nq::Entry);
+  const uint32_t chunk = (ix->n_tiles > 1 || pre) ? 4096u : nq;
+  if (pre) {
+    if ((rc = ensure(ix, ix->ws_blocked, nq::lookup_blocked_bytes(v, std::min(nq, chunk))))) return rc;
+    if ((rc = ensure(ix, ix->ws_pre, nq::lookup_pre_bytes(v, std::min(nq, chunk))))) return rc;
+  } else if (ix->n_tiles > 1) {
     rc = ensure(ix, ix->ws_stash, (size_t)std::min(nq, chunk) * (ix->n_tiles - 1) * f_local * sizeof(nq::Entry));
     if (rc) return rc;
   }
@@ -288,8 +299,11 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *
       NQ_HIP(ix, nq::launch_order(view(ix), sketches + (size_t)q0 * ix->d.F, n, keys, keys + chunk, ix->stream));
       order = keys + chunk;
     }
-    NQ_HIP(ix, nq::launch_gather(view(ix), sketches + (size_t)q0 * ix->d.F, n, counts + (size_t)q0 * stride, stride,
-                                 (nq::Entry *)ix->ws_stash.p, order, ix->gather_variant, ix->stream));
+    if (pre)
+      NQ_HIP(ix, nq::launch_lookup(v, sketches + (size_t)q0 * ix->d.F, n, ix->ws_blocked.p, (uint32_t *)ix->ws_pre.p, ix->stream));
+    NQ_HIP(ix, nq::launch_gather(v, sketches + (size_t)q0 * ix->d.F, n, counts + (size_t)q0 * stride, stride,
+                                 pre ? (nq::Entry *)ix->ws_pre.p : (nq::Entry *)ix->ws_stash.p, order, ix->gather_variant,
+                                 pre, ix->stream));
   }
   return NIQKI_OK;
 }
@@ -469,6 +483,7 @@ int niqki_create(const niqki_params *params, niqki_index **out) {
   if (const char *v = std::getenv("NIQKI_GATHER_VARIANT"))
     if (nq::gather_variant_valid(std::atoi(v))) ix->gather_variant = std::atoi(v);
   if (const char *v = std::getenv("NIQKI_QUERY_ORDER")) ix->query_order = std::atoi(v) != 0;
+  if (const char *v = std::getenv("NIQKI_LOOKUP_PREPASS")) ix->lookup_prepass = std::atoi(v);
   *out = ix;
   return NIQKI_OK;
 }
@@ -480,7 +495,7 @@ void niqki_destroy(niqki_index *ix) {
   for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
                  &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash,
                  &ix->ws_raw, &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
-                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order})
+                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order, &ix->ws_blocked, &ix->ws_pre})
     if (b->p) (void)hipFree(b->p);
   if (ix->store) (void)hipFree(ix->store);
   if (ix->entries) (void)hipFree(ix->entries);
@@ -532,6 +547,11 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
   }
   if (!std::strcmp(key, "tile_stripe")) { ix->stripe_opt = value != 0; ix->built = false; return NIQKI_OK; }
   if (!std::strcmp(key, "query_order")) { ix->query_order = value != 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "lookup_prepass")) {
+    if (value < -1 || value > 1) return fail(ix, NIQKI_E_INVALID, "lookup_prepass: -1 = when it pays, 0 = never, 1 = whenever usable");
+    ix->lookup_prepass = (int)value;
+    return NIQKI_OK;
+  }
   if (!std::strcmp(key, "query_batch")) { if (value < 1) return NIQKI_E_INVALID; ix->query_batch = (uint32_t)value; return NIQKI_OK; }
   if (!std::strcmp(key, "tile_genomes")) {
     if (value < 0 || value > 65536 || (value & 63)) return fail(ix, NIQKI_E_INVALID, "tile_genomes must be a multiple of 64, <= 65536");

@@ -94,9 +94,17 @@ hipError_t launch_import(const Derived &d, const uint32_t *words, const uint64_t
 // per (query, tile).
 // stash: nq x (n_tiles-1) x f_local Entry scratch (unused for n_tiles == 1)
 // order: nullptr, or the locality order of the batch from launch_order (nq <= 4096)
+// pre: `stash` holds the packed words of launch_lookup for ALL tiles (sketches are then unused)
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq,
                          uint16_t *counts, uint64_t stride, Entry *stash, const uint32_t *order,
-                         int variant, hipStream_t stream);
+                         int variant, bool pre, hipStream_t stream);
+// Slot-major look-up pre-pass for a launch of nq <= 4096 queries (nq_query.hip): fills
+// pre[q][tile][slot] from the table read once.  blocked / pre: scratch of the sizes below.
+bool launch_lookup_usable(const IndexView &v);
+size_t lookup_blocked_bytes(const IndexView &v, uint32_t nq);
+size_t lookup_pre_bytes(const IndexView &v, uint32_t nq);
+hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t nq, void *blocked, uint32_t *pre,
+                         hipStream_t stream);
 // launch shapes selectable through the "gather_variant" option (0 = choose)
 bool gather_variant_valid(int variant);
 // keys / order: nq words of scratch each

@@ -84,28 +84,34 @@ __device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t 
 // MODE is a measurement aid (results are wrong for MODE != 0): 1 = no LDS
 // atomics, 6 = lookups only.  MODE != 0 is instantiated only in -DNQ_ABLATION builds;
 // the shipped library cannot be switched into it.
-template <int BLOCK, int UNROLL, int NT, bool STASH_OUT, bool STASH_IN, int MODE>
+//   PRE      : entries come from the slot-major look-up pre-pass (lookup_kernel below): one
+//              packed word per (query, tile, slot) = bucket start relative to the slot's first
+//              unit << 16 | length, read coalesced; no table access in this kernel at all.
+template <int BLOCK, int UNROLL, int NT, bool STASH_OUT, bool STASH_IN, int MODE, bool PRE = false>
 __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk, uint32_t q, uint32_t t,
-                                          uint32_t *cnt, Item *queue, Entry *stash, uint32_t &sink) {
+                                          uint32_t *cnt, Item *queue, Entry *stash, uint32_t &sink,
+                                          const uint32_t *pre = nullptr) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   constexpr uint32_t NW = BLOCK / 64;
   constexpr int NE = STASH_OUT ? NT : 1;  // entries fetched per lookup
   const uint32_t R = v.d.R, a = v.align_log2;
   const uint32_t n_it = (v.f_local + 63) / 64;
   const uint16_t *gl = v.gids + v.tile_base[t];
-  Entry *my_stash = stash + (uint64_t)q * (v.n_tiles - 1) * v.f_local;
+  Entry *my_stash = PRE ? nullptr : stash + (uint64_t)q * (v.n_tiles - 1) * v.f_local;
+  const uint32_t *my_pre = PRE ? pre + ((uint64_t)q * v.n_tiles + t) * v.f_local : nullptr;
+  const uint32_t *my_units = v.slot_units + (uint64_t)t * (v.f_local + 1);
   Item *wq = queue + wave * kQueue;
   uint32_t q_head = 0, q_count = 0;  // wave-uniform
 
   struct Look { Entry e[NE]; };
   auto slot_ok = [&](uint32_t it) -> bool { return it < n_it && it * 64 + lane < v.f_local; };
   auto load_fp = [&](uint32_t it) -> int32_t {
-    if (STASH_IN) return 0;
+    if (STASH_IN || PRE) return 0;
     const uint32_t s = it * 64 + lane;
     return sk[s < v.f_local ? s : v.f_local - 1];
   };
   auto valid_of = [&](uint32_t it, int32_t fp) -> bool {
-    if (STASH_IN) return slot_ok(it);
+    if (STASH_IN || PRE) return slot_ok(it);
     return slot_ok(it) && fp >= 0 && (uint32_t)fp < R;  // src/niqki_index.cpp:654
   };
   // unconditional loads from clamped addresses: they stay in flight across the walk
@@ -113,7 +119,10 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
     Look L;
     uint32_t s = it * 64 + lane;
     if (s >= v.f_local) s = v.f_local - 1;
-    if (STASH_IN) {
+    if (PRE) {
+      const uint32_t w = my_pre[s];
+      L.e[0] = Entry{my_units[s] + (w >> 16), w & 0xFFFFu};
+    } else if (STASH_IN) {
       L.e[0] = my_stash[(uint64_t)(t - 1) * v.f_local + s];
     } else {
       const bool ok = fp >= 0 && (uint32_t)fp < R;
@@ -194,6 +203,147 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
   }
 }
 
+// ---- slot-major look-up pre-pass ---------------------------------------------------------
+// In gather_kernel's own look-up every (query, slot) costs one random 128-byte table line of
+// which 8 * n_tiles bytes are used: 4.2 MB of a 14 MB query at the north-star shape.  For a real
+// batch the table is better read ONCE, slot by slot, for all queries of the launch:
+//   block_kernel   sketches [nq][F] int32 -> blocked u16 fingerprints [f_local/8][nq][8]
+//                  (0xFFFF = no valid fingerprint), a 64-query x 128-slot transpose through LDS;
+//   lookup_kernel  one workgroup per block of 8 slots: each slot's entry row (R x n_tiles x 8
+//                  bytes, contiguous) is staged in LDS with coalesced loads, every thread looks up
+//                  its (<= 4) queries there and keeps the results in registers; after the 8 slots
+//                  it stores, per (query, tile), 8 packed words = 32 contiguous bytes of
+//                  pre[q][t][s].  The four workgroups that complete one 128-byte line of `pre`
+//                  are neighbours in one XCD's dispatch order, so the line is assembled in that
+//                  XCD's L2 before it is written back.
+// Packed word: (bucket start - first unit of its slot) << 16 | length; launch_lookup_usable()
+// says whether both halves fit 16 bits for the index at hand.
+// HBM traffic per launch: the table once + 2 bytes per (query, slot) in and 4 * n_tiles out,
+// instead of 128 bytes per (query, slot).
+constexpr uint32_t kXcds = 8;
+constexpr uint32_t kPreSlots = 8;        // slots per lookup workgroup
+constexpr uint32_t kPreQ = 4;            // queries per thread (1024 threads: launches of <= 4096)
+constexpr uint32_t kPreBlock = 1024;
+
+__global__ __launch_bounds__(256) void block_kernel(Derived d, const int32_t *sketches, uint32_t nq, uint32_t f_local,
+                                                   uint4 *blocked) {
+  __shared__ uint4 tile[64][17];          // [query][slot block], padded
+  const uint32_t tid = threadIdx.x;
+  const uint32_t q0 = blockIdx.y * 64, b0 = blockIdx.x * 16;   // 16 slot blocks = 128 slots
+  const uint32_t n_blk = f_local / kPreSlots;
+  for (uint32_t i = tid; i < 64 * 16; i += 256) {
+    const uint32_t qq = i / 16, bb = i % 16;                   // consecutive lanes: consecutive slot blocks of one query
+    const uint32_t q = q0 + qq, b = b0 + bb;
+    uint4 out = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (q < nq && b < n_blk) {
+      const int4 *src = (const int4 *)(sketches + (uint64_t)q * d.F + d.slot_begin + (uint64_t)b * kPreSlots);
+      const int4 a = src[0], c = src[1];
+      auto h = [&](int32_t x) -> uint32_t { return (x >= 0 && (uint32_t)x < d.R) ? (uint32_t)x : 0xFFFFu; };  // :654
+      out = make_uint4(h(a.x) | (h(a.y) << 16), h(a.z) | (h(a.w) << 16), h(c.x) | (h(c.y) << 16), h(c.z) | (h(c.w) << 16));
+    }
+    tile[qq][bb] = out;
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < 64 * 16; i += 256) {
+    const uint32_t bb = i / 64, qq = i % 64;                   // consecutive lanes: consecutive queries of one slot block
+    const uint32_t q = q0 + qq, b = b0 + bb;
+    if (q < nq && b < n_blk) blocked[(uint64_t)b * nq + q] = tile[qq][bb];
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const uint4 *blocked, uint32_t nq, uint32_t *pre) {
+  extern __shared__ __align__(16) uint4 row[];   // one slot's entries: R * NT * 8 bytes
+  const uint32_t tid = threadIdx.x;
+  const uint32_t n_blk = v.f_local / kPreSlots;
+  // XCD-aware order: block ids x, x+8, x+16, x+24 (one XCD, adjacent in its queue) take the four
+  // slot blocks that share the 128-byte lines of `pre`
+  const uint32_t x = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
+  const uint32_t sb = ((k / 4) * kXcds + x) * 4 + (k % 4);
+  if (sb >= n_blk) return;   // padding block (uniform)
+  const uint32_t R = v.d.R;
+  uint32_t fpw[kPreQ][4];    // this thread's queries: 8 u16 fingerprints each
+#pragma unroll
+  for (uint32_t j = 0; j < kPreQ; ++j) {
+    const uint32_t q = tid + j * kPreBlock;
+    const uint4 w = q < nq ? blocked[(uint64_t)sb * nq + q] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    fpw[j][0] = w.x; fpw[j][1] = w.y; fpw[j][2] = w.z; fpw[j][3] = w.w;
+  }
+  uint32_t res[kPreQ][NT][kPreSlots];
+  const uint32_t row_vec = R * NT / 2;           // uint4 per row (two entries each)
+#pragma unroll
+  for (uint32_t i = 0; i < kPreSlots; ++i) {
+    const uint32_t s = sb * kPreSlots + i;
+    const uint4 *src = (const uint4 *)(v.entries + (uint64_t)s * R * NT);
+    __syncthreads();                              // the previous slot's look-ups are done
+    for (uint32_t o = tid; o < row_vec; o += kPreBlock) row[o] = src[o];
+    __syncthreads();
+    const Entry *e = (const Entry *)row;
+#pragma unroll
+    for (uint32_t j = 0; j < kPreQ; ++j) {
+      const uint32_t fp = (fpw[j][i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
+      const bool ok = fp != 0xFFFFu;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const Entry en = e[(ok ? fp : 0u) * NT + t];
+        const uint32_t base = v.slot_units[(uint64_t)t * (v.f_local + 1) + s];
+        res[j][t][i] = ok ? (((en.start - base) << 16) | en.len) : 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < kPreQ; ++j) {
+    const uint32_t q = tid + j * kPreBlock;
+    if (q < nq) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        uint4 *dst = (uint4 *)(pre + ((uint64_t)q * NT + t) * v.f_local + (uint64_t)sb * kPreSlots);
+        dst[0] = make_uint4(res[j][t][0], res[j][t][1], res[j][t][2], res[j][t][3]);
+        dst[1] = make_uint4(res[j][t][4], res[j][t][5], res[j][t][6], res[j][t][7]);
+      }
+    }
+  }
+}
+
+// Can the pre-pass serve this index?  Tiles 1..4, whole slot blocks, a row that fits LDS, and
+// both halves of the packed word within 16 bits (bucket lengths <= tile, starts relative to
+// the slot <= tile / unit + R units).
+bool launch_lookup_usable(const IndexView &v) {
+  if (v.n_tiles < 1 || v.n_tiles > 4 || v.f_local % kPreSlots) return false;
+  if ((size_t)v.d.R * v.n_tiles * sizeof(Entry) > 144 * 1024) return false;
+  if (v.tile > 65535u) return false;
+  return (uint64_t)(v.tile >> v.align_log2) + v.d.R + 1 <= 65535u;
+}
+
+size_t lookup_blocked_bytes(const IndexView &v, uint32_t nq) { return (size_t)v.f_local * nq * 2; }
+size_t lookup_pre_bytes(const IndexView &v, uint32_t nq) { return (size_t)v.f_local * nq * v.n_tiles * 4; }
+
+hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t nq, void *blocked, uint32_t *pre,
+                         hipStream_t stream) {
+  if (nq == 0 || nq > kPreQ * kPreBlock || !launch_lookup_usable(v)) return hipErrorInvalidValue;
+  const uint32_t n_blk = v.f_local / kPreSlots;
+  hipLaunchKernelGGL(block_kernel, dim3((n_blk + 15) / 16, (nq + 63) / 64), dim3(256), 0, stream, v.d, sketches, nq,
+                     v.f_local, (uint4 *)blocked);
+  const size_t lds = (size_t)v.d.R * v.n_tiles * sizeof(Entry);
+  const uint32_t per_round = kXcds * 4;
+  const uint32_t grid = (n_blk + per_round - 1) / per_round * per_round;
+  hipError_t e;
+#define NQ_LAUNCH_LOOKUP(NT)                                                                       \
+  do {                                                                                             \
+    e = hipFuncSetAttribute((const void *)lookup_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                                 \
+    hipLaunchKernelGGL(lookup_kernel<NT>, dim3(grid), dim3(kPreBlock), lds, stream, v, (const uint4 *)blocked, nq, pre); \
+  } while (0)
+  switch (v.n_tiles) {
+    case 1: NQ_LAUNCH_LOOKUP(1); break;
+    case 2: NQ_LAUNCH_LOOKUP(2); break;
+    case 3: NQ_LAUNCH_LOOKUP(3); break;
+    default: NQ_LAUNCH_LOOKUP(4); break;
+  }
+#undef NQ_LAUNCH_LOOKUP
+  return hipGetLastError();
+}
+
 // ---- locality order of a query batch -----------------------------------------------------
 // Queries that hit the same genomes read the same table and bucket lines.  When they run on
 // the same XCD at the same time those lines are fetched from HBM once (measured: 13 % off the
@@ -201,7 +351,6 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
 // best probable hit: probe_kernel counts the first kProbeSlots slots only and takes the genome
 // with the most hits as the query's key, order_kernel sorts (key, query), and gather_kernel
 // maps sorted neighbours to one XCD.  Only the order of the work changes, never a result.
-constexpr uint32_t kXcds = 8;
 constexpr uint32_t kOrderGroup = 8;
 constexpr uint32_t kProbeSlots = 16;
 constexpr uint32_t kOrderMax = 4096;   // queries per launch (12 index bits next to a 20-bit key)
@@ -275,6 +424,7 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *keys, uint3
 
 // One workgroup per query; the genome tiles are walked one after another with
 // the tile's hit counters (packed u16 pairs) in LDS.
+// NT = -1: every tile's entries come from the look-up pre-pass (`stash` then holds its packed words)
 template <int BLOCK, int UNROLL, int NT, int MODE = 0>
 __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_t *sketches,
                                                        uint16_t *counts, uint64_t stride, Entry *stash,
@@ -291,7 +441,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     q = order[i];
   }
   const uint32_t tid = threadIdx.x;
-  const int32_t *sk = sketches + (uint64_t)q * v.d.F + v.d.slot_begin;
+  const int32_t *sk = NT < 0 ? nullptr : sketches + (uint64_t)q * v.d.F + v.d.slot_begin;
   Item *queue = (Item *)(cnt + (v.tile + 1) / 2);  // behind the counters: kQueue items per wave
   uint32_t sink = 0;
   for (uint32_t t = 0; t < v.n_tiles; ++t) {
@@ -299,7 +449,9 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     const uint32_t n_words = (n_t + 1) / 2;
     for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
     __syncthreads();
-    if (NT >= 2) {
+    if constexpr (NT < 0) {
+      walk_tile<BLOCK, UNROLL, 1, false, false, MODE, true>(v, sk, q, t, cnt, queue, nullptr, sink, (const uint32_t *)stash);
+    } else if constexpr (NT >= 2) {
       if (t == 0) walk_tile<BLOCK, UNROLL, NT, true, false, MODE>(v, sk, q, t, cnt, queue, stash, sink);
       else walk_tile<BLOCK, UNROLL, NT, false, true, MODE>(v, sk, q, t, cnt, queue, stash, sink);
     } else {
@@ -343,7 +495,8 @@ bool gather_variant_valid(int variant) {
 }
 
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq, uint16_t *counts,
-                         uint64_t stride, Entry *stash, const uint32_t *order, int variant, hipStream_t stream) {
+                         uint64_t stride, Entry *stash, const uint32_t *order, int variant, bool pre,
+                         hipStream_t stream) {
   if (nq == 0 || v.n_tiles == 0) return hipSuccess;
 #define NQ_GATHER_LDS(B) ((size_t)((v.tile + 1) / 2) * 4 + (size_t)(B / 64) * kQueue * sizeof(Item))
   // with a locality order the grid is padded to whole groups on every XCD
@@ -360,7 +513,8 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
   } while (0)
 #define NQ_BY_TILES(B, U, ...)                                                                   \
   do {                                                                                           \
-    if (v.n_tiles == 2) NQ_LAUNCH_GATHER(B, U, 2, ##__VA_ARGS__);                                \
+    if (pre) NQ_LAUNCH_GATHER(B, U, -1, ##__VA_ARGS__);                                           \
+    else if (v.n_tiles == 2) NQ_LAUNCH_GATHER(B, U, 2, ##__VA_ARGS__);                           \
     else if (v.n_tiles == 3) NQ_LAUNCH_GATHER(B, U, 3, ##__VA_ARGS__);                           \
     else if (v.n_tiles == 4) NQ_LAUNCH_GATHER(B, U, 4, ##__VA_ARGS__);                           \
     else NQ_LAUNCH_GATHER(B, U, 1, ##__VA_ARGS__);                                               \

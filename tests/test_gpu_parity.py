@@ -11,11 +11,14 @@ from conftest import family_spec, synth_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["striped", "ranges"])
+@pytest.fixture(autouse=True, params=["striped", "ranges", "striped+prepass", "ranges+prepass"])
 def tile_layout(request, monkeypatch):
-    """Every test runs under both tilings of DESIGN.md section 3: genomes dealt to the counter
-    tiles round-robin (default) or tiles as ranges of genome ids."""
-    monkeypatch.setenv("NIQKI_TILE_STRIPE", "0" if request.param == "ranges" else "1")
+    """Every test runs under both tilings of DESIGN.md section 3 (genomes dealt to the counter
+    tiles round-robin = default, or tiles as ranges of genome ids) and under both table look-up
+    paths of the gather kernel: inside the kernel, or by the slot-major pre-pass (forced wherever
+    the index shape allows it; the default picks by batch size)."""
+    monkeypatch.setenv("NIQKI_TILE_STRIPE", "0" if request.param.startswith("ranges") else "1")
+    monkeypatch.setenv("NIQKI_LOOKUP_PREPASS", "1" if request.param.endswith("prepass") else "0")
     return request.param
 
 
