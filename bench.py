@@ -51,7 +51,7 @@ def query_spec(q, n_fam):
     """Query q: a fresh mutant (member id >= 2^20) of a pseudo-random indexed
     family; every 10th query comes from a family that is not indexed."""
     h = (q.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(33)
-    fam = (h % np.uint64(n_fam)).astype(np.uint32)
+    fam = (h % np.uint64(min(n_fam, int(os.environ.get("NIQKI_BENCH_QFAM") or n_fam)))).astype(np.uint32)
     fam = np.where(q % 10 == 9, n_fam + q, fam).astype(np.uint32)
     mem = ((1 << 20) + q).astype(np.uint32)
     rate = (16 + (h >> np.uint64(8)) % np.uint64(400)).astype(np.uint32)

@@ -251,9 +251,12 @@ __global__ __launch_bounds__(256) void block_kernel(Derived d, const int32_t *sk
   }
 }
 
-template <int NT>
+// DOUBLE: two row buffers in LDS; the next slot's row is fetched into registers before the
+// look-ups of the current one and stored behind them, so HBM latency hides behind the LDS work
+// and a slot costs one barrier (needs 2 rows <= LDS and a row of <= 4 x 16 bytes per thread).
+template <int NT, bool DOUBLE>
 __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const uint4 *blocked, uint32_t nq, uint32_t *pre) {
-  extern __shared__ __align__(16) uint4 row[];   // one slot's entries: R * NT * 8 bytes
+  extern __shared__ __align__(16) uint4 row[];   // one (or two) slots' entries: R * NT * 8 bytes each
   const uint32_t tid = threadIdx.x;
   const uint32_t n_blk = v.f_local / kPreSlots;
   // XCD-aware order: block ids x, x+8, x+16, x+24 (one XCD, adjacent in its queue) take the four
@@ -262,6 +265,26 @@ __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const ui
   const uint32_t sb = ((k / 4) * kXcds + x) * 4 + (k % 4);
   if (sb >= n_blk) return;   // padding block (uniform)
   const uint32_t R = v.d.R;
+  const uint32_t row_vec = R * NT / 2;           // uint4 per row (two entries each)
+  constexpr uint32_t kVec = 4;                   // DOUBLE: uint4 per thread and row
+  auto row_src = [&](uint32_t i) { return (const uint4 *)(v.entries + (uint64_t)(sb * kPreSlots + i) * R * NT); };
+  uint4 nxt[kVec];
+  auto fetch = [&](uint32_t i) {
+    const uint4 *src = row_src(i);
+#pragma unroll
+    for (uint32_t u = 0; u < kVec; ++u) {
+      const uint32_t o = tid + u * kPreBlock;
+      nxt[u] = src[o < row_vec ? o : 0];
+    }
+  };
+  auto stage = [&](uint4 *dst) {
+#pragma unroll
+    for (uint32_t u = 0; u < kVec; ++u) {
+      const uint32_t o = tid + u * kPreBlock;
+      if (o < row_vec) dst[o] = nxt[u];
+    }
+  };
+  if (DOUBLE) fetch(0);
   uint32_t fpw[kPreQ][4];    // this thread's queries: 8 u16 fingerprints each
 #pragma unroll
   for (uint32_t j = 0; j < kPreQ; ++j) {
@@ -269,16 +292,22 @@ __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const ui
     const uint4 w = q < nq ? blocked[(uint64_t)sb * nq + q] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
     fpw[j][0] = w.x; fpw[j][1] = w.y; fpw[j][2] = w.z; fpw[j][3] = w.w;
   }
+  if (DOUBLE) { stage(row); __syncthreads(); }
   uint32_t res[kPreQ][NT][kPreSlots];
-  const uint32_t row_vec = R * NT / 2;           // uint4 per row (two entries each)
 #pragma unroll
   for (uint32_t i = 0; i < kPreSlots; ++i) {
     const uint32_t s = sb * kPreSlots + i;
-    const uint4 *src = (const uint4 *)(v.entries + (uint64_t)s * R * NT);
-    __syncthreads();                              // the previous slot's look-ups are done
-    for (uint32_t o = tid; o < row_vec; o += kPreBlock) row[o] = src[o];
-    __syncthreads();
-    const Entry *e = (const Entry *)row;
+    const uint4 *cur = row;
+    if (DOUBLE) {
+      cur = row + (size_t)(i & 1u) * row_vec;
+      if (i + 1 < kPreSlots) fetch(i + 1);
+    } else {
+      const uint4 *src = row_src(i);
+      __syncthreads();                            // the previous slot's look-ups are done
+      for (uint32_t o = tid; o < row_vec; o += kPreBlock) row[o] = src[o];
+      __syncthreads();
+    }
+    const Entry *e = (const Entry *)cur;
 #pragma unroll
     for (uint32_t j = 0; j < kPreQ; ++j) {
       const uint32_t fp = (fpw[j][i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
@@ -289,6 +318,10 @@ __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const ui
         const uint32_t base = v.slot_units[(uint64_t)t * (v.f_local + 1) + s];
         res[j][t][i] = ok ? (((en.start - base) << 16) | en.len) : 0u;
       }
+    }
+    if (DOUBLE && i + 1 < kPreSlots) {
+      stage(row + (size_t)((i + 1) & 1u) * row_vec);   // last read two barriers ago
+      __syncthreads();
     }
   }
 #pragma unroll
@@ -324,16 +357,19 @@ hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t n
   const uint32_t n_blk = v.f_local / kPreSlots;
   hipLaunchKernelGGL(block_kernel, dim3((n_blk + 15) / 16, (nq + 63) / 64), dim3(256), 0, stream, v.d, sketches, nq,
                      v.f_local, (uint4 *)blocked);
-  const size_t lds = (size_t)v.d.R * v.n_tiles * sizeof(Entry);
+  const size_t row_bytes = (size_t)v.d.R * v.n_tiles * sizeof(Entry);
+  const bool dbl = 2 * row_bytes <= 150 * 1024 && row_bytes <= 4 * 16 * (size_t)kPreBlock;
+  const size_t lds = dbl ? 2 * row_bytes : row_bytes;
   const uint32_t per_round = kXcds * 4;
   const uint32_t grid = (n_blk + per_round - 1) / per_round * per_round;
   hipError_t e;
-#define NQ_LAUNCH_LOOKUP(NT)                                                                       \
+#define NQ_LAUNCH_LOOKUP2(NT, D)                                                                   \
   do {                                                                                             \
-    e = hipFuncSetAttribute((const void *)lookup_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    e = hipFuncSetAttribute((const void *)lookup_kernel<NT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                                 \
-    hipLaunchKernelGGL(lookup_kernel<NT>, dim3(grid), dim3(kPreBlock), lds, stream, v, (const uint4 *)blocked, nq, pre); \
+    hipLaunchKernelGGL((lookup_kernel<NT, D>), dim3(grid), dim3(kPreBlock), lds, stream, v, (const uint4 *)blocked, nq, pre); \
   } while (0)
+#define NQ_LAUNCH_LOOKUP(NT) do { if (dbl) NQ_LAUNCH_LOOKUP2(NT, true); else NQ_LAUNCH_LOOKUP2(NT, false); } while (0)
   switch (v.n_tiles) {
     case 1: NQ_LAUNCH_LOOKUP(1); break;
     case 2: NQ_LAUNCH_LOOKUP(2); break;
@@ -341,6 +377,7 @@ hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t n
     default: NQ_LAUNCH_LOOKUP(4); break;
   }
 #undef NQ_LAUNCH_LOOKUP
+#undef NQ_LAUNCH_LOOKUP2
   return hipGetLastError();
 }
 
@@ -567,28 +604,46 @@ hipError_t launch_gathered(const IndexView &v, const int32_t *sketches, uint32_t
 
 // ---- hits: threshold, compaction in descending gid order, stable sort on count ----
 
-// blk_counts[q][b] = number of genomes of block b with count >= min_score
-__global__ __launch_bounds__(256) void hits_count_kernel(HitsArgs a) {
+// blk_counts[q][b] = number of genomes of block b with count >= min_score, and the query's total
+// in hit_off[q] (scanned into offsets by hits_scan_kernel).  One workgroup per query: wave w takes
+// blocks w, w+16, ...; a lane reads 8 counters (16 bytes) at a time.
+__global__ __launch_bounds__(1024) void hits_count_kernel(HitsArgs a) {
   __shared__ uint32_t s_sum;
-  const uint32_t q = blockIdx.x / a.n_blk, b = blockIdx.x % a.n_blk;
+  const uint32_t q = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_sum = 0;
   __syncthreads();
   const uint16_t *row = a.counts + (uint64_t)q * a.stride + a.gid_begin;
-  const uint32_t lo = b * kHitsBlk;
-  const uint32_t hi = (lo + kHitsBlk < a.n_gids) ? lo + kHitsBlk : a.n_gids;
-  uint32_t c = 0;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) c += (row[i] >= a.min_score);
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-  if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&s_sum, c);
+  const bool vec = (((uintptr_t)row) & 15) == 0;   // uniform
+  uint32_t mine = 0;
+  for (uint32_t b = wave; b < a.n_blk; b += 16) {
+    const uint32_t lo = b * kHitsBlk;
+    const uint32_t hi = (lo + kHitsBlk < a.n_gids) ? lo + kHitsBlk : a.n_gids;
+    uint32_t c = 0;
+    if (vec) {
+      for (uint32_t i = lo + lane * 8; i < hi; i += 512) {
+        if (i + 8 <= hi) {
+          const uint4 w = *(const uint4 *)(row + i);
+          const uint32_t x[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) c += ((x[k] & 0xFFFFu) >= a.min_score) + ((x[k] >> 16) >= a.min_score);
+        } else {
+          for (uint32_t j = i; j < hi; ++j) c += (row[j] >= a.min_score);
+        }
+      }
+    } else {
+      for (uint32_t i = lo + lane; i < hi; i += 64) c += (row[i] >= a.min_score);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if (lane == 0) { a.blk_counts[(uint64_t)q * a.n_blk + b] = c; mine += c; }
+  }
+  if (lane == 0 && mine) atomicAdd(&s_sum, mine);
   __syncthreads();
-  if (threadIdx.x == 0) a.blk_counts[blockIdx.x] = s_sum;
+  if (threadIdx.x == 0) a.hit_off[q] = s_sum;
 }
 
-// hit_off[q] = exclusive prefix over queries of the per-query hit totals (blk_counts keeps the
-// per-block counts; hits_compact_kernel forms a block's prefix inside its query itself).
-// Single workgroup: per-thread partial sums over a run of queries, one wave-level scan of the 16
-// wave totals, then the runs again.  n_blk is small (N / 4096), so a thread reads its queries' rows
-// directly.
+// hit_off[0..nq): per-query totals -> exclusive prefix, hit_off[nq] = grand total.  One workgroup:
+// every thread scans a run of queries, the 16 wave totals are combined through LDS.
 __global__ __launch_bounds__(1024) void hits_scan_kernel(HitsArgs a) {
   __shared__ unsigned long long wave_tot[16];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -596,8 +651,7 @@ __global__ __launch_bounds__(1024) void hits_scan_kernel(HitsArgs a) {
   const uint32_t lo = tid * per < a.nq ? tid * per : a.nq;
   const uint32_t hi = lo + per < a.nq ? lo + per : a.nq;
   unsigned long long sum = 0;
-  for (uint32_t q = lo; q < hi; ++q)
-    for (uint32_t b = 0; b < a.n_blk; ++b) sum += a.blk_counts[(uint64_t)q * a.n_blk + b];
+  for (uint32_t q = lo; q < hi; ++q) sum += a.hit_off[q];
   unsigned long long incl = sum;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -615,8 +669,9 @@ __global__ __launch_bounds__(1024) void hits_scan_kernel(HitsArgs a) {
   }
   unsigned long long run = base + incl - sum;
   for (uint32_t q = lo; q < hi; ++q) {
+    const unsigned long long x = a.hit_off[q];
     a.hit_off[q] = run;
-    for (uint32_t b = 0; b < a.n_blk; ++b) run += a.blk_counts[(uint64_t)q * a.n_blk + b];
+    run += x;
   }
   if (tid == 0) a.hit_off[a.nq] = total;
 }
@@ -759,7 +814,7 @@ hipError_t launch_candidates(const uint16_t *counts, uint64_t stride, uint32_t n
 
 hipError_t launch_hits_count(const HitsArgs &a, hipStream_t stream) {
   if (a.nq == 0 || a.n_blk == 0) return hipSuccess;
-  hipLaunchKernelGGL(hits_count_kernel, dim3(a.nq * a.n_blk), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(hits_count_kernel, dim3(a.nq), dim3(1024), 0, stream, a);
   hipLaunchKernelGGL(hits_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
   return hipGetLastError();
 }

@@ -87,6 +87,10 @@ def test_config3_all_columns_and_hit_lists_vs_oracle(native, po, big):
             exp[q, b0:b0 + n] = ix.counts(qsk[q])
         del ix, sub
     assert np.array_equal(got.astype(np.uint32), exp)
+    # the same through the slot-major look-up pre-pass (what a 4096-query launch uses by default)
+    e.set_option("lookup_prepass", 1)
+    assert np.array_equal(e.query_counts(qsk), got)
+    e.set_option("lookup_prepass", -1)
     # threshold + order from the oracle's columns: greater<pair<count, gid>>, :662-666, :685
     off, hc, hg = e.query(qsk)
     n_with_hits = 0

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(1024) void sector_kernel(const uint16_t *tab, uint6
   auto fetch = [&](int r, uint32_t (&g)[UNROLL]) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const uint64_t line = mix(wave * 1315423911ULL + (uint64_t)(r * UNROLL + u)) % n_lines;  // wave-uniform
+      const uint64_t line = mix(wave * 1315423911ULL + (uint64_t)(r * UNROLL + u)) & (n_lines - 1);  // wave-uniform; n_lines = 2^k
       g[u] = (tab + line * 64)[idx];
     }
   };
