@@ -114,10 +114,10 @@ int niqki_synchronize(niqki_index *ix);
  * batches, so that niqki_sketch need not read rec_off back to pick a launch
  * shape; 0 = read it back), "query_order" (1 = default: the queries of a launch
  * are processed in an order that puts similar ones on the same XCD; results are
- * unaffected; 0 = input order), "lookup_prepass" (-1 = default: the index table is
- * read once per launch, slot by slot, for all its queries when that moves fewer bytes
- * than one random table line per query and slot; 0 = never; 1 = whenever the index
- * shape allows). */
+ * unaffected; 0 = input order), "lookup_prepass" (1 = the index table is walked
+ * once per launch, slot block by slot block, for all its queries instead of one random
+ * table line per query and slot inside the gather kernel, wherever the index shape
+ * allows: less HBM traffic, no faster on MI355X, so the default (-1, like 0) is off). */
 int niqki_set_option(niqki_index *ix, const char *key, int64_t value);
 
 /* Pre-sizes the sketch store for n_genomes (optional; the store grows). */

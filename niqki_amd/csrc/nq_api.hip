@@ -43,7 +43,7 @@ struct niqki_index {
   uint32_t n_genomes = 0;
 
   // inverted index
-  uint32_t tile = 0, n_tiles = 0, built_n = 0, align_log2 = 0;
+  uint32_t tile = 0, n_tiles = 0, built_n = 0, align_log2 = 0, padded = 0;
   nq::Entry *entries = nullptr;
   uint16_t *gids = nullptr;
   uint64_t *tile_base = nullptr;   // n_tiles+1, device
@@ -63,7 +63,7 @@ struct niqki_index {
   Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
       ws_misc, ws_stash;
   // staged batch (niqki_stage_raw): framing results live in ws_seq / ws_recoff / ws_entry
-  Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk, ws_order, ws_blocked, ws_pre;
+  Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk, ws_order, ws_pre;
   struct {
     bool valid = false, sketched = false;
     uint32_t n_entry = 0, n_rec = 0;
@@ -183,6 +183,7 @@ nq::IndexView view(const niqki_index *ix) {
   v.n_tiles = ix->n_tiles;
   v.f_local = ix->d.slot_end - ix->d.slot_begin;
   v.align_log2 = ix->align_log2;
+  v.padded = ix->padded;
   v.stripe = ix->stripe;
   v.cap = ix->cap;
   v.store = ix->store;
@@ -273,14 +274,15 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *
   const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
   const nq::IndexView v = view(ix);
   // Table look-ups: inside the gather kernel (one random table line per query and slot), or
-  // by the slot-major pre-pass, which streams the whole table once per launch: it pays when
-  // the launch's random lines (128 bytes each) outweigh twice the table.
+  // by the slot-major pre-pass, which walks the table once per launch for all its queries.
   bool pre = ix->lookup_prepass != 0 && nq::launch_lookup_usable(v) && (((uintptr_t)(sketches + ix->d.slot_begin)) & 15) == 0;
-  if (pre && ix->lookup_prepass < 0)
-    pre = (uint64_t)std::min(nq, 4096u) * 128 >= 2ull * ix->d.R * ix->n_tiles * sizeof(nq::Entry);
+  // Measured at the north-star shape (profiles/r02_*): the pre-pass takes 19 % of the HBM traffic
+  // off a launch but not its time -- both forms are bound by the number of random line requests a
+  // CU keeps in flight, and inside the gather kernel the look-ups overlap with the bucket walk.
+  // So the default keeps them there; the pre-pass is opt-in (lookup_prepass = 1).
+  if (ix->lookup_prepass < 0) pre = false;
   const uint32_t chunk = (ix->n_tiles > 1 || pre) ? 4096u : nq;
   if (pre) {
-    if ((rc = ensure(ix, ix->ws_blocked, nq::lookup_blocked_bytes(v, std::min(nq, chunk))))) return rc;
     if ((rc = ensure(ix, ix->ws_pre, nq::lookup_pre_bytes(v, std::min(nq, chunk))))) return rc;
   } else if (ix->n_tiles > 1) {
     rc = ensure(ix, ix->ws_stash, (size_t)std::min(nq, chunk) * (ix->n_tiles - 1) * f_local * sizeof(nq::Entry));
@@ -300,7 +302,7 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *
       order = keys + chunk;
     }
     if (pre)
-      NQ_HIP(ix, nq::launch_lookup(v, sketches + (size_t)q0 * ix->d.F, n, ix->ws_blocked.p, (uint32_t *)ix->ws_pre.p, ix->stream));
+      NQ_HIP(ix, nq::launch_lookup(v, sketches + (size_t)q0 * ix->d.F, n, (uint32_t *)ix->ws_pre.p, ix->stream));
     NQ_HIP(ix, nq::launch_gather(v, sketches + (size_t)q0 * ix->d.F, n, counts + (size_t)q0 * stride, stride,
                                  pre ? (nq::Entry *)ix->ws_pre.p : (nq::Entry *)ix->ws_stash.p, order, ix->gather_variant,
                                  pre, ix->stream));
@@ -495,7 +497,7 @@ void niqki_destroy(niqki_index *ix) {
   for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
                  &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash,
                  &ix->ws_raw, &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
-                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order, &ix->ws_blocked, &ix->ws_pre})
+                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order, &ix->ws_pre})
     if (b->p) (void)hipFree(b->p);
   if (ix->store) (void)hipFree(ix->store);
   if (ix->entries) (void)hipFree(ix->entries);
@@ -681,8 +683,8 @@ int niqki_build(niqki_index *ix) {
   uint32_t tile = ix->p.tile_genomes;
   if (const char *v = std::getenv("NIQKI_TILE_GENOMES")) tile = (uint32_t)std::atoi(v);
   if (tile == 0 || tile > 65536 || (tile & 63)) {
-    // as few tiles as the 16-bit tile-local ids and the LDS counter array allow
-    uint32_t nt = std::max<uint32_t>(1, (N + 65471) / 65472);
+    // as few tiles as the 16-bit tile-local ids (padding ids included) and the LDS counter array allow
+    uint32_t nt = std::max<uint32_t>(1, (N + nq::kPadMaxTile - 1) / nq::kPadMaxTile);
     tile = ((N + nt - 1) / nt + 63) / 64 * 64;
     if (tile == 0) tile = 64;
   }
@@ -709,6 +711,8 @@ int niqki_build(niqki_index *ix) {
   ix->n_tiles = n_tiles;
   ix->built_n = N;
   ix->align_log2 = (uint32_t)al;
+  // line-aligned buckets carry padding ids behind their last id (see IndexView::padded)
+  ix->padded = (al == 6 && tile <= nq::kPadMaxTile) ? 1u : 0u;
   // genomes are dealt to the tiles round-robin (option "tile_stripe", default on)
   int stripe = ix->stripe_opt;
   if (const char *v = std::getenv("NIQKI_TILE_STRIPE")) stripe = std::atoi(v);
@@ -727,6 +731,10 @@ int niqki_build(niqki_index *ix) {
   const uint64_t total_ids = tb[n_tiles];
   // + pad: the gather kernel reads up to 64 ids from a bucket's start whatever its length
   if ((rc = grow((void **)&ix->gids, ix->gids_bytes, (size_t)total_ids * 2 + 512))) return rc;
+  if (ix->padded) {
+    Span sp(ix, NIQKI_KC_BUILD);
+    NQ_HIP(ix, nq::launch_pad_fill(ix->gids, total_ids, tile, ix->stream));
+  }
   {
     Span sp(ix, NIQKI_KC_BUILD);
     NQ_HIP(ix, nq::launch_build_fill(view(ix), ix->entries, ix->gids, ix->stream));

@@ -12,6 +12,8 @@
 // the reference produces single-threaded.
 #include "nq_kernels.h"
 
+#include <algorithm>
+
 namespace nq {
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, uint32_t lane) {
@@ -171,8 +173,8 @@ __global__ __launch_bounds__(1024) void slot_scan_kernel(IndexView v, uint32_t *
   if (tid == 0) {
     uint64_t run = 0;
     for (uint32_t i = 0; i < 1024; ++i) { uint64_t x = part[i]; part[i] = run; run += x; }
-    u[v.f_local] = (uint32_t)run;
-    totals[t + 1] = run << v.align_log2;
+    u[v.f_local] = (uint32_t)run;   // padded layout: also the unit of the tile's spare padding line
+    totals[t + 1] = (run + (v.padded ? 1u : 0u)) << v.align_log2;
   }
   __syncthreads();
   uint64_t run = part[tid];
@@ -220,6 +222,24 @@ hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids,
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(build_kernel<true>, dim3((uint32_t)blocks), dim3(64 * wpb), lds, stream, v,
                      (uint32_t *)v.slot_units, entries, gids, wpb);
+  return hipGetLastError();
+}
+
+// padded layout: position p of every 128-byte line holds id tile + 2p until the fill overwrites it
+__global__ __launch_bounds__(256) void pad_fill_kernel(uint4 *gids, uint64_t n_vec, uint32_t tile) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    const uint32_t p = (uint32_t)(i & 7u) * 8u;   // first of this vector's 8 positions in its line
+    auto pair = [&](uint32_t k) { return (tile + 2u * (p + k)) | ((tile + 2u * (p + k + 1)) << 16); };
+    gids[i] = make_uint4(pair(0), pair(2), pair(4), pair(6));
+  }
+}
+
+hipError_t launch_pad_fill(uint16_t *gids, uint64_t n_ids, uint32_t tile, hipStream_t stream) {
+  if (n_ids == 0) return hipSuccess;
+  const uint64_t n_vec = n_ids / 8;
+  const uint64_t blocks = std::min<uint64_t>((n_vec + 255) / 256, 16384);
+  hipLaunchKernelGGL(pad_fill_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, (uint4 *)gids, n_vec, tile);
   return hipGetLastError();
 }
 

@@ -44,6 +44,10 @@ struct IndexView {
   uint32_t n_tiles;
   uint32_t f_local;  // slot_end - slot_begin
   uint32_t align_log2;
+  uint32_t padded;   // 128-byte aligned buckets whose unused tail positions hold padding ids: position p of
+                     // a line holds id tile + 2p, which the gather kernel counts into 64 dummy words behind
+                     // the tile's counters -- its bucket walk then needs no per-lane length test.  Every
+                     // tile's id array ends with one line of padding only (the walk's "no chunk").
   uint32_t stripe;   // genomes are dealt to the tiles round-robin (tile = gid % n_tiles, local id =
                      // gid / n_tiles) instead of in ranges: a run of related genomes is spread over
                      // all tiles, which keeps their buckets short in every tile
@@ -76,6 +80,10 @@ hipError_t launch_build_sizes(const IndexView &v, uint32_t *slot_units, uint64_t
                               hipStream_t stream);
 // Build, phase 2: entries + gids (gids sized from tile_base[n_tiles]).
 hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids, hipStream_t stream);
+// padded layout: the padding pattern over the whole id array (n_ids a multiple of 64), before the fill
+hipError_t launch_pad_fill(uint16_t *gids, uint64_t n_ids, uint32_t tile, hipStream_t stream);
+constexpr uint32_t kPadWords = 64;        // dummy counter words of a padded tile
+constexpr uint32_t kPadMaxTile = 65408;   // tile + 2 * 63 must fit 16 bits
 // dump stream (src/niqki_index.cpp:42-55) of a whole-range index.
 // layout: slot_word[s] (F+1 entries) = word position of bucket (s, 0) in the stream
 // (header excluded); export: the words of slots [s0, s1) into `out` (word 0 = first
@@ -98,13 +106,11 @@ hipError_t launch_import(const Derived &d, const uint32_t *words, const uint64_t
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq,
                          uint16_t *counts, uint64_t stride, Entry *stash, const uint32_t *order,
                          int variant, bool pre, hipStream_t stream);
-// Slot-major look-up pre-pass for a launch of nq <= 4096 queries (nq_query.hip): fills
-// pre[q][tile][slot] from the table read once.  blocked / pre: scratch of the sizes below.
+// Slot-major look-up pre-pass for the queries of a launch (nq_query.hip): fills
+// pre[q][tile][slot] (lookup_pre_bytes of scratch) from the table streamed once.
 bool launch_lookup_usable(const IndexView &v);
-size_t lookup_blocked_bytes(const IndexView &v, uint32_t nq);
 size_t lookup_pre_bytes(const IndexView &v, uint32_t nq);
-hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t nq, void *blocked, uint32_t *pre,
-                         hipStream_t stream);
+hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t nq, uint32_t *pre, hipStream_t stream);
 // launch shapes selectable through the "gather_variant" option (0 = choose)
 bool gather_variant_valid(int variant);
 // keys / order: nq words of scratch each

@@ -43,7 +43,10 @@ constexpr uint32_t kQueue = 256;  // items per wave-private LDS work queue
 // u16 ids of one chunk, UNROLL chunks per round trip, two rounds in flight (the
 // loads of round r+1 are issued before the LDS atomics of round r; unconditional
 // loads, lanes past a chunk's end read what follows it and are masked).
-template <int UNROLL, int MODE>
+// PAD (padded index, IndexView::padded): every chunk is a whole 128-byte line whose positions past
+// the bucket's end hold padding ids (a dummy counter word per position), so all 64 lanes count
+// what they read and the lengths are not needed here.
+template <int UNROLL, int MODE, bool PAD = false>
 __device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t pos, uint32_t len,
                                        uint32_t lane, uint32_t *cnt, uint32_t &sink) {
   uint32_t ga[UNROLL], gb[UNROLL];
@@ -57,6 +60,11 @@ __device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t 
   auto apply = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
+      if (PAD && MODE == 0) {
+        // word (g >> 1), increment 1 or 1 << 16: 1 + (g & 1) * 0xFFFF
+        atomicAdd((uint32_t *)((char *)cnt + ((g[u] << 1) & 0x3FFFCu)), __umul24(g[u] & 1u, 0xFFFFu) + 1u);
+        continue;
+      }
       const uint32_t l = __builtin_amdgcn_readlane(len, j0 + u);
       if (MODE == 1) { if (lane < l) sink ^= g[u]; }
       else bump_if(cnt, g[u], lane < l, lane);
@@ -87,7 +95,7 @@ __device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t 
 //   PRE      : entries come from the slot-major look-up pre-pass (lookup_kernel below): one
 //              packed word per (query, tile, slot) = bucket start relative to the slot's first
 //              unit << 16 | length, read coalesced; no table access in this kernel at all.
-template <int BLOCK, int UNROLL, int NT, bool STASH_OUT, bool STASH_IN, int MODE, bool PRE = false>
+template <int BLOCK, int UNROLL, int NT, bool STASH_OUT, bool STASH_IN, int MODE, bool PRE = false, bool PAD = false>
 __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk, uint32_t q, uint32_t t,
                                           uint32_t *cnt, Item *queue, Entry *stash, uint32_t &sink,
                                           const uint32_t *pre = nullptr) {
@@ -137,7 +145,7 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
       const Item x = wq[(q_head + lane) & (kQueue - 1)];
       q_head = (q_head + 64) & (kQueue - 1);
       q_count -= 64;
-      walk64<UNROLL, MODE>(gl, a, x.pos, x.len, lane, cnt, sink);
+      walk64<UNROLL, MODE, PAD>(gl, a, x.pos, x.len, lane, cnt, sink);
     }
   };
 
@@ -196,188 +204,114 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
     nxt = nxt2;
     nxt_ok = nxt2_ok;
   }
-  if (q_count) {  // the last partial batch
+  if (q_count) {  // the last partial batch; "no chunk" = the tile's spare line of padding ids
     Item x = wq[(q_head + lane) & (kQueue - 1)];
-    if (lane >= q_count) x = Item{0u, 0u};
-    walk64<UNROLL, MODE>(gl, a, x.pos, x.len, lane, cnt, sink);
+    if (lane >= q_count) x = Item{PAD ? my_units[v.f_local] : 0u, 0u};
+    walk64<UNROLL, MODE, PAD>(gl, a, x.pos, x.len, lane, cnt, sink);
   }
 }
 
 // ---- slot-major look-up pre-pass ---------------------------------------------------------
 // In gather_kernel's own look-up every (query, slot) costs one random 128-byte table line of
 // which 8 * n_tiles bytes are used: 4.2 MB of a 14 MB query at the north-star shape.  For a real
-// batch the table is better read ONCE, slot by slot, for all queries of the launch:
-//   block_kernel   sketches [nq][F] int32 -> blocked u16 fingerprints [f_local/8][nq][8]
-//                  (0xFFFF = no valid fingerprint), a 64-query x 128-slot transpose through LDS;
-//   lookup_kernel  one workgroup per block of 8 slots: each slot's entry row (R x n_tiles x 8
-//                  bytes, contiguous) is staged in LDS with coalesced loads, every thread looks up
-//                  its (<= 4) queries there and keeps the results in registers; after the 8 slots
-//                  it stores, per (query, tile), 8 packed words = 32 contiguous bytes of
-//                  pre[q][t][s].  The four workgroups that complete one 128-byte line of `pre`
-//                  are neighbours in one XCD's dispatch order, so the line is assembled in that
-//                  XCD's L2 before it is written back.
+// batch the table is better walked slot block by slot block for all queries of the launch:
+//   lookup_kernel  one workgroup = PS consecutive slots x 256 queries (one per thread).  A thread
+//                  reads its query's PS fingerprints (one whole 128-byte line of the sketch for
+//                  PS = 32), looks each one up with one 8 * n_tiles byte load, 8 slots in flight
+//                  at a time, packs the results and stores, per tile, PS words = one whole line
+//                  of pre[q][t][s].
+// All workgroups of one slot block (nq / 256 of them) are neighbours in one XCD's dispatch order
+// (block ids x, x+8, ...): they run at the same time on that XCD and walk the block's rows in
+// the same order, so a table line is fetched from HBM once and served from the XCD's L2 to the
+// other queries that need it (4096 queries into 512 lines per slot).
 // Packed word: (bucket start - first unit of its slot) << 16 | length; launch_lookup_usable()
 // says whether both halves fit 16 bits for the index at hand.
-// HBM traffic per launch: the table once + 2 bytes per (query, slot) in and 4 * n_tiles out,
+// HBM traffic per launch: the table once + 4 bytes per (query, slot) in and 4 * n_tiles out,
 // instead of 128 bytes per (query, slot).
 constexpr uint32_t kXcds = 8;
-constexpr uint32_t kPreSlots = 8;        // slots per lookup workgroup
-constexpr uint32_t kPreQ = 4;            // queries per thread (1024 threads: launches of <= 4096)
-constexpr uint32_t kPreBlock = 1024;
+constexpr uint32_t kPreBlock = 256;      // queries per lookup workgroup, one per thread
+constexpr uint32_t kPreFlight = 8;       // look-ups in flight per thread
 
-__global__ __launch_bounds__(256) void block_kernel(Derived d, const int32_t *sketches, uint32_t nq, uint32_t f_local,
-                                                   uint4 *blocked) {
-  __shared__ uint4 tile[64][17];          // [query][slot block], padded
+template <int NT, int PS>
+__global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const int32_t *sketches, uint32_t nq,
+                                                           uint32_t n_qchunk, uint32_t *pre) {
   const uint32_t tid = threadIdx.x;
-  const uint32_t q0 = blockIdx.y * 64, b0 = blockIdx.x * 16;   // 16 slot blocks = 128 slots
-  const uint32_t n_blk = f_local / kPreSlots;
-  for (uint32_t i = tid; i < 64 * 16; i += 256) {
-    const uint32_t qq = i / 16, bb = i % 16;                   // consecutive lanes: consecutive slot blocks of one query
-    const uint32_t q = q0 + qq, b = b0 + bb;
-    uint4 out = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    if (q < nq && b < n_blk) {
-      const int4 *src = (const int4 *)(sketches + (uint64_t)q * d.F + d.slot_begin + (uint64_t)b * kPreSlots);
-      const int4 a = src[0], c = src[1];
-      auto h = [&](int32_t x) -> uint32_t { return (x >= 0 && (uint32_t)x < d.R) ? (uint32_t)x : 0xFFFFu; };  // :654
-      out = make_uint4(h(a.x) | (h(a.y) << 16), h(a.z) | (h(a.w) << 16), h(c.x) | (h(c.y) << 16), h(c.z) | (h(c.w) << 16));
-    }
-    tile[qq][bb] = out;
-  }
-  __syncthreads();
-  for (uint32_t i = tid; i < 64 * 16; i += 256) {
-    const uint32_t bb = i / 64, qq = i % 64;                   // consecutive lanes: consecutive queries of one slot block
-    const uint32_t q = q0 + qq, b = b0 + bb;
-    if (q < nq && b < n_blk) blocked[(uint64_t)b * nq + q] = tile[qq][bb];
-  }
-}
-
-// DOUBLE: two row buffers in LDS; the next slot's row is fetched into registers before the
-// look-ups of the current one and stored behind them, so HBM latency hides behind the LDS work
-// and a slot costs one barrier (needs 2 rows <= LDS and a row of <= 4 x 16 bytes per thread).
-template <int NT, bool DOUBLE>
-__global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const uint4 *blocked, uint32_t nq, uint32_t *pre) {
-  extern __shared__ __align__(16) uint4 row[];   // one (or two) slots' entries: R * NT * 8 bytes each
-  const uint32_t tid = threadIdx.x;
-  const uint32_t n_blk = v.f_local / kPreSlots;
-  // XCD-aware order: block ids x, x+8, x+16, x+24 (one XCD, adjacent in its queue) take the four
-  // slot blocks that share the 128-byte lines of `pre`
+  const uint32_t n_sb = v.f_local / PS;
   const uint32_t x = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
-  const uint32_t sb = ((k / 4) * kXcds + x) * 4 + (k % 4);
-  if (sb >= n_blk) return;   // padding block (uniform)
+  const uint32_t sb = (k / n_qchunk) * kXcds + x;
+  if (sb >= n_sb) return;   // padding block (uniform)
+  const uint32_t q = (k % n_qchunk) * kPreBlock + tid;
+  if (q >= nq) return;      // no barrier below
   const uint32_t R = v.d.R;
-  const uint32_t row_vec = R * NT / 2;           // uint4 per row (two entries each)
-  constexpr uint32_t kVec = 4;                   // DOUBLE: uint4 per thread and row
-  auto row_src = [&](uint32_t i) { return (const uint4 *)(v.entries + (uint64_t)(sb * kPreSlots + i) * R * NT); };
-  uint4 nxt[kVec];
-  auto fetch = [&](uint32_t i) {
-    const uint4 *src = row_src(i);
+  // this thread's fingerprints (src/niqki_index.cpp:654: anything outside [0, R) has no bucket)
+  int32_t fp[PS];
+  {
+    const int4 *src = (const int4 *)(sketches + (uint64_t)q * v.d.F + v.d.slot_begin + (uint64_t)sb * PS);
 #pragma unroll
-    for (uint32_t u = 0; u < kVec; ++u) {
-      const uint32_t o = tid + u * kPreBlock;
-      nxt[u] = src[o < row_vec ? o : 0];
+    for (int u = 0; u < PS / 4; ++u) {
+      const int4 a = src[u];
+      fp[4 * u] = a.x; fp[4 * u + 1] = a.y; fp[4 * u + 2] = a.z; fp[4 * u + 3] = a.w;
     }
-  };
-  auto stage = [&](uint4 *dst) {
-#pragma unroll
-    for (uint32_t u = 0; u < kVec; ++u) {
-      const uint32_t o = tid + u * kPreBlock;
-      if (o < row_vec) dst[o] = nxt[u];
-    }
-  };
-  if (DOUBLE) fetch(0);
-  uint32_t fpw[kPreQ][4];    // this thread's queries: 8 u16 fingerprints each
-#pragma unroll
-  for (uint32_t j = 0; j < kPreQ; ++j) {
-    const uint32_t q = tid + j * kPreBlock;
-    const uint4 w = q < nq ? blocked[(uint64_t)sb * nq + q] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-    fpw[j][0] = w.x; fpw[j][1] = w.y; fpw[j][2] = w.z; fpw[j][3] = w.w;
   }
-  if (DOUBLE) { stage(row); __syncthreads(); }
-  uint32_t res[kPreQ][NT][kPreSlots];
+  uint32_t res[NT][PS];
 #pragma unroll
-  for (uint32_t i = 0; i < kPreSlots; ++i) {
-    const uint32_t s = sb * kPreSlots + i;
-    const uint4 *cur = row;
-    if (DOUBLE) {
-      cur = row + (size_t)(i & 1u) * row_vec;
-      if (i + 1 < kPreSlots) fetch(i + 1);
-    } else {
-      const uint4 *src = row_src(i);
-      __syncthreads();                            // the previous slot's look-ups are done
-      for (uint32_t o = tid; o < row_vec; o += kPreBlock) row[o] = src[o];
-      __syncthreads();
+  for (int i0 = 0; i0 < PS; i0 += kPreFlight) {
+    Entry en[kPreFlight][NT];
+#pragma unroll
+    for (int j = 0; j < (int)kPreFlight; ++j) {   // all loads of the group first
+      const int i = i0 + j;
+      const bool ok = fp[i] >= 0 && (uint32_t)fp[i] < R;
+      const Entry *e = v.entries + ((uint64_t)(sb * PS + i) * R + (ok ? (uint32_t)fp[i] : 0u)) * NT;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) en[j][t] = e[t];
     }
-    const Entry *e = (const Entry *)cur;
 #pragma unroll
-    for (uint32_t j = 0; j < kPreQ; ++j) {
-      const uint32_t fp = (fpw[j][i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu;
-      const bool ok = fp != 0xFFFFu;
+    for (int j = 0; j < (int)kPreFlight; ++j) {
+      const int i = i0 + j;
+      const bool ok = fp[i] >= 0 && (uint32_t)fp[i] < R;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const Entry en = e[(ok ? fp : 0u) * NT + t];
-        const uint32_t base = v.slot_units[(uint64_t)t * (v.f_local + 1) + s];
-        res[j][t][i] = ok ? (((en.start - base) << 16) | en.len) : 0u;
+        const uint32_t base = v.slot_units[(uint64_t)t * (v.f_local + 1) + sb * PS + i];
+        res[t][i] = ok ? (((en[j][t].start - base) << 16) | en[j][t].len) : 0u;
       }
-    }
-    if (DOUBLE && i + 1 < kPreSlots) {
-      stage(row + (size_t)((i + 1) & 1u) * row_vec);   // last read two barriers ago
-      __syncthreads();
     }
   }
 #pragma unroll
-  for (uint32_t j = 0; j < kPreQ; ++j) {
-    const uint32_t q = tid + j * kPreBlock;
-    if (q < nq) {
+  for (int t = 0; t < NT; ++t) {
+    uint4 *dst = (uint4 *)(pre + ((uint64_t)q * NT + t) * v.f_local + (uint64_t)sb * PS);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        uint4 *dst = (uint4 *)(pre + ((uint64_t)q * NT + t) * v.f_local + (uint64_t)sb * kPreSlots);
-        dst[0] = make_uint4(res[j][t][0], res[j][t][1], res[j][t][2], res[j][t][3]);
-        dst[1] = make_uint4(res[j][t][4], res[j][t][5], res[j][t][6], res[j][t][7]);
-      }
-    }
+    for (int u = 0; u < PS / 4; ++u) dst[u] = make_uint4(res[t][4 * u], res[t][4 * u + 1], res[t][4 * u + 2], res[t][4 * u + 3]);
   }
 }
 
-// Can the pre-pass serve this index?  Tiles 1..4, whole slot blocks, a row that fits LDS, and
-// both halves of the packed word within 16 bits (bucket lengths <= tile, starts relative to
-// the slot <= tile / unit + R units).
+static uint32_t lookup_slots(const IndexView &v) { return v.n_tiles <= 2 ? 32u : 16u; }
+
+// Can the pre-pass serve this index?  Tiles 1..4, whole slot blocks, and both halves of the
+// packed word within 16 bits (bucket lengths <= tile, starts relative to the slot <= tile / unit
+// + R units).
 bool launch_lookup_usable(const IndexView &v) {
-  if (v.n_tiles < 1 || v.n_tiles > 4 || v.f_local % kPreSlots) return false;
-  if ((size_t)v.d.R * v.n_tiles * sizeof(Entry) > 144 * 1024) return false;
+  if (v.n_tiles < 1 || v.n_tiles > 4 || v.f_local % lookup_slots(v)) return false;
   if (v.tile > 65535u) return false;
   return (uint64_t)(v.tile >> v.align_log2) + v.d.R + 1 <= 65535u;
 }
 
-size_t lookup_blocked_bytes(const IndexView &v, uint32_t nq) { return (size_t)v.f_local * nq * 2; }
 size_t lookup_pre_bytes(const IndexView &v, uint32_t nq) { return (size_t)v.f_local * nq * v.n_tiles * 4; }
 
-hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t nq, void *blocked, uint32_t *pre,
-                         hipStream_t stream) {
-  if (nq == 0 || nq > kPreQ * kPreBlock || !launch_lookup_usable(v)) return hipErrorInvalidValue;
-  const uint32_t n_blk = v.f_local / kPreSlots;
-  hipLaunchKernelGGL(block_kernel, dim3((n_blk + 15) / 16, (nq + 63) / 64), dim3(256), 0, stream, v.d, sketches, nq,
-                     v.f_local, (uint4 *)blocked);
-  const size_t row_bytes = (size_t)v.d.R * v.n_tiles * sizeof(Entry);
-  const bool dbl = 2 * row_bytes <= 150 * 1024 && row_bytes <= 4 * 16 * (size_t)kPreBlock;
-  const size_t lds = dbl ? 2 * row_bytes : row_bytes;
-  const uint32_t per_round = kXcds * 4;
-  const uint32_t grid = (n_blk + per_round - 1) / per_round * per_round;
-  hipError_t e;
-#define NQ_LAUNCH_LOOKUP2(NT, D)                                                                   \
-  do {                                                                                             \
-    e = hipFuncSetAttribute((const void *)lookup_kernel<NT, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (e != hipSuccess) return e;                                                                 \
-    hipLaunchKernelGGL((lookup_kernel<NT, D>), dim3(grid), dim3(kPreBlock), lds, stream, v, (const uint4 *)blocked, nq, pre); \
-  } while (0)
-#define NQ_LAUNCH_LOOKUP(NT) do { if (dbl) NQ_LAUNCH_LOOKUP2(NT, true); else NQ_LAUNCH_LOOKUP2(NT, false); } while (0)
+hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t nq, uint32_t *pre, hipStream_t stream) {
+  if (nq == 0 || !launch_lookup_usable(v)) return hipErrorInvalidValue;
+  const uint32_t ps = lookup_slots(v);
+  const uint32_t n_sb = v.f_local / ps, n_qchunk = (nq + kPreBlock - 1) / kPreBlock;
+  const uint64_t grid = (uint64_t)((n_sb + kXcds - 1) / kXcds * kXcds) * n_qchunk;
+  if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+#define NQ_LAUNCH_LOOKUP(NT, PS) \
+  hipLaunchKernelGGL((lookup_kernel<NT, PS>), dim3((uint32_t)grid), dim3(kPreBlock), 0, stream, v, sketches, nq, n_qchunk, pre)
   switch (v.n_tiles) {
-    case 1: NQ_LAUNCH_LOOKUP(1); break;
-    case 2: NQ_LAUNCH_LOOKUP(2); break;
-    case 3: NQ_LAUNCH_LOOKUP(3); break;
-    default: NQ_LAUNCH_LOOKUP(4); break;
+    case 1: NQ_LAUNCH_LOOKUP(1, 32); break;
+    case 2: NQ_LAUNCH_LOOKUP(2, 32); break;
+    case 3: NQ_LAUNCH_LOOKUP(3, 16); break;
+    default: NQ_LAUNCH_LOOKUP(4, 16); break;
   }
 #undef NQ_LAUNCH_LOOKUP
-#undef NQ_LAUNCH_LOOKUP2
   return hipGetLastError();
 }
 
@@ -462,7 +396,7 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *keys, uint3
 // One workgroup per query; the genome tiles are walked one after another with
 // the tile's hit counters (packed u16 pairs) in LDS.
 // NT = -1: every tile's entries come from the look-up pre-pass (`stash` then holds its packed words)
-template <int BLOCK, int UNROLL, int NT, int MODE = 0>
+template <int BLOCK, int UNROLL, int NT, int MODE = 0, bool PAD = false>
 __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_t *sketches,
                                                        uint16_t *counts, uint64_t stride, Entry *stash,
                                                        const uint32_t *order, uint32_t nq) {
@@ -479,7 +413,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
   }
   const uint32_t tid = threadIdx.x;
   const int32_t *sk = NT < 0 ? nullptr : sketches + (uint64_t)q * v.d.F + v.d.slot_begin;
-  Item *queue = (Item *)(cnt + (v.tile + 1) / 2);  // behind the counters: kQueue items per wave
+  Item *queue = (Item *)(cnt + (v.tile + 1) / 2 + (PAD ? kPadWords : 0u));  // behind the counters: kQueue items per wave
   uint32_t sink = 0;
   for (uint32_t t = 0; t < v.n_tiles; ++t) {
     const uint32_t n_t = tile_count(v, t);
@@ -487,12 +421,12 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
     __syncthreads();
     if constexpr (NT < 0) {
-      walk_tile<BLOCK, UNROLL, 1, false, false, MODE, true>(v, sk, q, t, cnt, queue, nullptr, sink, (const uint32_t *)stash);
+      walk_tile<BLOCK, UNROLL, 1, false, false, MODE, true, PAD>(v, sk, q, t, cnt, queue, nullptr, sink, (const uint32_t *)stash);
     } else if constexpr (NT >= 2) {
-      if (t == 0) walk_tile<BLOCK, UNROLL, NT, true, false, MODE>(v, sk, q, t, cnt, queue, stash, sink);
-      else walk_tile<BLOCK, UNROLL, NT, false, true, MODE>(v, sk, q, t, cnt, queue, stash, sink);
+      if (t == 0) walk_tile<BLOCK, UNROLL, NT, true, false, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink);
+      else walk_tile<BLOCK, UNROLL, NT, false, true, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink);
     } else {
-      walk_tile<BLOCK, UNROLL, 1, false, false, MODE>(v, sk, q, t, cnt, queue, stash, sink);
+      walk_tile<BLOCK, UNROLL, 1, false, false, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink);
     }
     if (MODE != 0) cnt[tid % n_words] ^= sink;
     __syncthreads();
@@ -535,7 +469,7 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
                          uint64_t stride, Entry *stash, const uint32_t *order, int variant, bool pre,
                          hipStream_t stream) {
   if (nq == 0 || v.n_tiles == 0) return hipSuccess;
-#define NQ_GATHER_LDS(B) ((size_t)((v.tile + 1) / 2) * 4 + (size_t)(B / 64) * kQueue * sizeof(Item))
+#define NQ_GATHER_LDS(B) ((size_t)((v.tile + 1) / 2 + (v.padded ? kPadWords : 0u)) * 4 + (size_t)(B / 64) * kQueue * sizeof(Item))
   // with a locality order the grid is padded to whole groups on every XCD
   const uint32_t per_round = kXcds * kOrderGroup;
   dim3 grid(order ? (nq + per_round - 1) / per_round * per_round : nq);
@@ -569,7 +503,9 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     default:
       // small tiles (short-read indexes): counters of <= 24 KB leave room for several
       // workgroups per CU, and 4 waves per query then beat 16 (tools/bench_reads.py)
-      if (v.tile <= 12288) NQ_BY_TILES(256, 16); else NQ_BY_TILES(1024, 16);
+      if (v.tile <= 12288) NQ_BY_TILES(256, 16);
+      else if (v.padded) NQ_BY_TILES(1024, 16, 0, true);   // padded index: mask-free bucket walk
+      else NQ_BY_TILES(1024, 16);
       break;
   }
 #undef NQ_BY_TILES

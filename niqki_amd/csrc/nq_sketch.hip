@@ -20,19 +20,18 @@
 
 namespace nq {
 
-// Per-byte code table, built in LDS by the first 256 threads (one dword per byte value).
-//   bits 1:0    forward code of the rolling update   (:114-123  A0 C1 G2 T3, else 0)
-//   bits 3:2    reverse-complement code of the update (:211-221 A3 C2 G1, else 0)
-//   bits 5:4    case-insensitive digit of the K-1 prefix (:255-273)
-//   bit  6      byte is a legal prefix character (ACGTacgt)
-//   bits 29:28  the reverse-complement code again, where the K = 31 roll ORs it into the high word
-__device__ __forceinline__ uint32_t code_entry(uint32_t c) {
+// Per-byte code table, built in LDS by the first 256 threads.
+//   bits 1:0  forward code of the rolling update   (:114-123  A0 C1 G2 T3, else 0)
+//   bits 3:2  reverse-complement code of the update (:211-221 A3 C2 G1, else 0)
+//   bits 5:4  case-insensitive digit of the K-1 prefix (:255-273)
+//   bit  6    byte is a legal prefix character (ACGTacgt)
+__device__ __forceinline__ uint8_t code_entry(uint32_t c) {
   uint32_t fwd = c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
   uint32_t rc = c == 'A' ? 3u : c == 'C' ? 2u : c == 'G' ? 1u : 0u;
   uint32_t u = c & 0xDFu;  // fold lower case onto upper case
   uint32_t ok = (u == 'A' || u == 'C' || u == 'G' || u == 'T') ? 1u : 0u;
   uint32_t pd = u == 'C' ? 1u : u == 'G' ? 2u : u == 'T' ? 3u : 0u;
-  return fwd | (rc << 2) | ((ok ? pd : 0u) << 4) | (ok << 6) | (rc << 28);
+  return (uint8_t)(fwd | (rc << 2) | ((ok ? pd : 0u) << 4) | (ok << 6));
 }
 
 // 16 bytes of a byte stream that starts at an arbitrary address: the stream is
@@ -191,17 +190,7 @@ __device__ void densify_lds_distinct(uint32_t *sk, const Derived &d, uint32_t *s
 template <int KFIX>
 __device__ __forceinline__ uint64_t roll_step(uint32_t e, uint64_t &fw, uint64_t &rc, const Derived &d,
                                               uint32_t rc_shift) {
-  if (KFIX == 31) {
-    // 62-bit words as 32-bit halves: funnel shifts (v_alignbit) instead of 64-bit shifts, and the
-    // table entry carries the reverse-complement code at the bit position it lands on (60 = 32 + 28)
-    uint32_t fl = (uint32_t)fw, fh = (uint32_t)(fw >> 32), rl = (uint32_t)rc, rh = (uint32_t)(rc >> 32);
-    fh = __builtin_amdgcn_alignbit(fh, fl, 30) & 0x3FFFFFFFu;
-    fl = (fl << 2) | (e & 3u);
-    rl = __builtin_amdgcn_alignbit(rh, rl, 2);
-    rh = (rh >> 2) | (e & 0x30000000u);
-    fw = ((uint64_t)fh << 32) | fl;
-    rc = ((uint64_t)rh << 32) | rl;
-  } else if (KFIX) {
+  if (KFIX) {
     constexpr uint64_t mask = (1ULL << (2 * KFIX)) - 1ULL;
     fw = ((fw << 2) | (uint64_t)(e & 3u)) & mask;
     rc = (rc >> 2) | ((uint64_t)((e >> 2) & 3u) << (2 * KFIX - 2));
@@ -228,7 +217,7 @@ __device__ __forceinline__ uint32_t rev64_hi(uint64_t canon) {
 }
 
 constexpr uint32_t kRing = 128;  // candidate k-mers per wave-private ring (filtered path)
-constexpr uint32_t kRingAlloc = kRing;
+constexpr uint32_t kRingAlloc = kRing + 64;  // + one scratch slot per lane
 
 // All records of one sketch, this workgroup's share of the chunks.
 // FILTER (long inputs only): a k-mer whose hash has fewer than T leading zeros
@@ -238,7 +227,7 @@ constexpr uint32_t kRingAlloc = kRing;
 // wave-private ring and finished 64 at a time.  The caller re-runs the records
 // unfiltered if any slot is still empty afterwards, so the result is exact.
 template <int BLOCK, int GROUPS, int KFIX, bool FILTER>
-__device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part, uint32_t *sk, const uint32_t *lut,
+__device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part, uint32_t *sk, const uint8_t *lut,
                              uint64_t *ring_base, uint32_t thr) {
   const Derived &d = a.d;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -340,12 +329,11 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
           for (int j = 0; j < 16; ++j) en[j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
         }
         auto filtered = [&](uint64_t canon, uint32_t hh) {
-          const bool pass = hh < thr;
-          const uint64_t bal = __ballot(pass);
-          if (pass) {  // ring position = tail + rank among the passing lanes (mbcnt adds its third operand)
-            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, q_tail));
-            ring[pos & (kRing - 1)] = canon;
-          }
+          const uint64_t bal = __ballot(hh < thr);
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+          // every lane stores: candidates into the ring, the others into a scratch
+          // slot of their own behind it (cheaper than masking the store)
+          ring[hh < thr ? ((q_tail + rank) & (kRing - 1)) : kRing + lane] = canon;
           const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)__popcll(bal));
           q_tail = (q_tail + n) & (kRing - 1);
           q_count += n;
@@ -384,8 +372,8 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
   const Derived &d = a.d;
   uint32_t *sk = smem;                              // F cells
   uint32_t *s_flag = smem + d.F;                    // 4 words
-  uint32_t *lut = smem + d.F + 4;                   // 256 dwords
-  uint32_t *aux = smem + d.F + 4 + 256;             // distinct-value tables or the filter rings
+  uint8_t *lut = (uint8_t *)(smem + d.F + 4);       // 256 bytes
+  uint32_t *aux = smem + d.F + 4 + 64;              // distinct-value tables or the filter rings
   const uint32_t tid = threadIdx.x;
   const uint32_t entry = blockIdx.x / a.splits;
   const uint32_t part = blockIdx.x % a.splits;
@@ -572,11 +560,11 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
   uint32_t *sk = smem;                                       // F cells
   uint32_t *elist = smem + F;                                // kReadMaxEntries x {cell, value}
   uint8_t *codes = (uint8_t *)(elist + 2 * kReadMaxEntries); // kReadTile position codes
-  uint8_t *lut = codes + kReadTile;                          // 256-byte code table (low byte of code_entry)
+  uint8_t *lut = codes + kReadTile;                          // 256-byte code table
   const uint32_t entry = blockIdx.x;
   const uint32_t K = d.K, Km1 = d.K - 1u;
 
-  for (uint32_t i = lane; i < 256; i += 64) lut[i] = (uint8_t)code_entry(i);
+  for (uint32_t i = lane; i < 256; i += 64) lut[i] = code_entry(i);
   if (a.accumulate) {
     const uint32_t *src = (const uint32_t *)a.sketches + (uint64_t)entry * F;
     for (uint32_t i = lane; i < F; i += 64) sk[i] = src[i];
@@ -672,7 +660,7 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
 }
 
 static size_t sketch_lds_bytes(const Derived &d, bool distinct, uint32_t ring_waves) {
-  return (size_t)d.F * 4 + 16 + 1024 + (distinct ? (size_t)d.R * 12 : 0) + (size_t)ring_waves * kRingAlloc * 8;
+  return (size_t)d.F * 4 + 16 + 256 + (distinct ? (size_t)d.R * 12 : 0) + (size_t)ring_waves * kRingAlloc * 8;
 }
 
 hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_len,
