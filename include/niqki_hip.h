@@ -309,6 +309,58 @@ int niqki_get_sketches(niqki_index *ix, uint32_t begin, uint32_t n,
 int niqki_query_gathered(niqki_index *ix, const int32_t *sketches, uint32_t nq,
                          uint64_t *gathered_per_query, int mem);
 
+/* ---- one index over several GPUs: slot-range shards -----------------------------
+ * No reference counterpart (the reference is one process on one host); this is how
+ * Index::insert_sketch / Index::query_sketch (src/niqki_index.cpp:362-370, :633-687)
+ * run when the F x 2^W inverted index is split by sketch-slot range over the GPUs
+ * of a node.  Rank r of `world` owns slots niqki_group_slot_range(r) of EVERY
+ * genome: a handle created with that slot range is one shard.  The hit count of a
+ * genome is a sum over slots, so a batch needs one exchange of partial results,
+ * done with RCCL over xGMI inside the library (librccl is loaded when the first
+ * group is made).  Results are exactly those of one whole-range handle.
+ *
+ * A niqki_group is the set of ranks that live in the calling process:
+ *   - one rank per process (n_local = 1, first_rank = this process' rank; `id` made
+ *     once by niqki_group_new_id and carried to every process by the caller), or
+ *   - all ranks in one process (n_local = world, first_rank = 0, id may be NULL).
+ *     Shards of such a group may even share a device (tests; emulating G shards on
+ *     one GPU): device-to-device copies then stand in for the collectives.
+ * The per-rank arrays of the calls below have n_local entries, rank first_rank + i at
+ * index i; sketch buffers are device memory of that rank's GPU, work is enqueued on
+ * the shard handles' streams.  Calls are collective: every process of the group makes
+ * the same calls in the same order. */
+typedef struct niqki_group niqki_group; /* opaque */
+#define NIQKI_GROUP_ID_BYTES 128
+
+void niqki_group_slot_range(uint32_t rank, uint32_t world, uint32_t S, uint32_t *slot_begin,
+                            uint32_t *slot_end);
+int niqki_group_new_id(uint8_t id[NIQKI_GROUP_ID_BYTES]);
+/* The shards must agree in K, S, W, min_score and genome count and own the slot ranges
+ * of their ranks.  On failure niqki_last_error(shards[0]) says why. */
+int niqki_group_create(niqki_index *const *shards, uint32_t n_local, uint32_t first_rank,
+                       uint32_t world, const uint8_t *id, niqki_group **out);
+void niqki_group_destroy(niqki_group *g); /* the shard handles stay the caller's */
+const char *niqki_group_last_error(const niqki_group *g);
+/* "exchange": 0 = choose (sparse when min_score >= 4 * world), 1 = sparse (candidate
+ * genomes only), 2 = dense (reduce-scatter of whole hit vectors); "cand_cap": candidate
+ * ids per query and rank of the sparse form (a step whose lists overflow is redone
+ * densely, never answered wrongly). */
+int niqki_group_set_option(niqki_group *g, const char *key, int64_t value);
+/* "overflows" (sparse steps redone densely so far), "rccl" (1 = RCCL transport),
+ * "sparse" (1 = the sparse exchange is selected). */
+int niqki_group_get_stat(const niqki_group *g, const char *key, uint64_t *value);
+/* Index::insert_sketch for a batch of world * per sketches of which rank r holds rows
+ * [r*per, (r+1)*per) (local_sketches[i]: per x 2^S int32, device memory); the first
+ * n_total rows of the batch (rank major) get the next genome ids, the rest is padding. */
+int niqki_group_insert(niqki_group *g, const int32_t *const *local_sketches, uint32_t per,
+                       uint32_t n_total);
+/* Index::query_sketch for such a batch: rank r receives the hits of ITS rows against the
+ * whole index -- hit_off[i] per+1 offsets, hit_counts[i] / hit_gids[i] capacity entries
+ * each, in the memory space `mem` (as niqki_query). */
+int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint32_t per,
+                      uint64_t *const *hit_off, uint32_t *const *hit_counts,
+                      uint32_t *const *hit_gids, uint64_t capacity, int mem);
+
 /* ---- measurement support -------------------------------------------------- */
 
 enum niqki_kernel_class {
@@ -318,7 +370,8 @@ enum niqki_kernel_class {
   NIQKI_KC_HITS = 3,     /* threshold + compaction + sort */
   NIQKI_KC_BUILD = 4,    /* insert transpose + CSR build */
   NIQKI_KC_INGEST = 5,   /* FASTA / FASTQ framing */
-  NIQKI_KC_COUNT = 6
+  NIQKI_KC_EXCHANGE = 6, /* slot-shard exchange: slice packing, candidate kernels, collectives */
+  NIQKI_KC_COUNT = 7
 };
 
 /* When enabled, every launch of the classes above is bracketed by HIP events

@@ -14,7 +14,8 @@ _LIB = os.path.join(_HERE, "lib", "libniqki_hip.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
 SEQ_PAD = 64
-KC_SKETCH, KC_DENSIFY, KC_GATHER, KC_HITS, KC_BUILD, KC_INGEST = 0, 1, 2, 3, 4, 5
+KC_SKETCH, KC_DENSIFY, KC_GATHER, KC_HITS, KC_BUILD, KC_INGEST, KC_EXCHANGE = 0, 1, 2, 3, 4, 5, 6
+GROUP_ID_BYTES = 128
 E_CAPACITY = 4
 
 
@@ -98,6 +99,15 @@ ABI = [
     ("niqki_import_slots", _int, [_vp, _u32, _u32, _vp, _u64, C.POINTER(_u64)]),
     ("niqki_get_sketches", _int, [_vp, _u32, _u32, _vp, _int]),
     ("niqki_query_gathered", _int, [_vp, _vp, _u32, _vp, _int]),
+    ("niqki_group_slot_range", None, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
+    ("niqki_group_new_id", _int, [_vp]),
+    ("niqki_group_create", _int, [_vp, _u32, _u32, _u32, _vp, C.POINTER(_vp)]),
+    ("niqki_group_destroy", None, [_vp]),
+    ("niqki_group_last_error", C.c_char_p, [_vp]),
+    ("niqki_group_set_option", _int, [_vp, C.c_char_p, _i64]),
+    ("niqki_group_get_stat", _int, [_vp, C.c_char_p, C.POINTER(_u64)]),
+    ("niqki_group_insert", _int, [_vp, _vp, _u32, _u32]),
+    ("niqki_group_query", _int, [_vp, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_profile_enable", _int, [_vp, _int]),
     ("niqki_profile_reset", _int, [_vp]),
     ("niqki_profile_read", _int, [_vp, _int, C.POINTER(_dbl), C.POINTER(_u64)]),
@@ -453,3 +463,90 @@ class Engine:
         out = np.zeros(nq, dtype=np.uint64)
         self._ck(self.L.niqki_query_gathered(self.h, _p(sketches), nq, _p(out), MEM_DEVICE))
         return out
+
+
+def group_slot_range(rank, world, S):
+    b, e = _u32(0), _u32(0)
+    lib().niqki_group_slot_range(rank, world, S, C.byref(b), C.byref(e))
+    return b.value, e.value
+
+
+def group_new_id():
+    """128 opaque bytes naming a group about to be formed (rank 0 makes them, the caller carries
+    them to the other processes)."""
+    buf = np.zeros(GROUP_ID_BYTES, dtype=np.uint8)
+    rc = lib().niqki_group_new_id(buf.ctypes.data)
+    if rc:
+        raise NiqkiError(rc, "niqki_group_new_id: " + lib().niqki_status_string(rc).decode())
+    return buf
+
+
+class Group:
+    """The ranks of a slot-sharded index that live in this process (niqki_group_*):
+    engines[i] is rank first_rank + i, created with group_slot_range(rank, world, S)."""
+
+    def __init__(self, engines, first_rank=0, world=None, group_id=None):
+        self.L = lib()
+        self.engines = list(engines)
+        self.n_local = len(self.engines)
+        self.first = first_rank
+        self.world = self.n_local if world is None else world
+        hs = (_vp * self.n_local)(*[e.h for e in self.engines])
+        idp = None if group_id is None else np.ascontiguousarray(group_id, dtype=np.uint8).ctypes.data
+        g = _vp()
+        rc = self.L.niqki_group_create(C.cast(hs, _vp), self.n_local, first_rank, self.world, idp, C.byref(g))
+        if rc:
+            raise NiqkiError(rc, "%s (%s)" % (self.L.niqki_status_string(rc).decode(),
+                                              self.L.niqki_last_error(self.engines[0].h).decode()))
+        self.g = g
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.L.niqki_group_destroy(self.g)
+            self.g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, allow=()):
+        if rc and rc not in allow:
+            raise NiqkiError(rc, "%s (%s)" % (self.L.niqki_status_string(rc).decode(),
+                                              self.L.niqki_group_last_error(self.g).decode()))
+        return rc
+
+    def set_option(self, key, value):
+        self._ck(self.L.niqki_group_set_option(self.g, key.encode(), int(value)))
+
+    def stat(self, key):
+        v = _u64(0)
+        self._ck(self.L.niqki_group_get_stat(self.g, key.encode(), C.byref(v)))
+        return v.value
+
+    def _ptrs(self, xs):
+        return C.cast((_vp * self.n_local)(*[_p(x) for x in xs]), _vp)
+
+    def insert_dev(self, local_sketches, per, n_total):
+        """local_sketches: per local rank a device tensor / address of per x F int32."""
+        self._ck(self.L.niqki_group_insert(self.g, self._ptrs(local_sketches), per, n_total))
+
+    def query_dev(self, local_sketches, per, hit_off, hit_counts, hit_gids, capacity):
+        """Per-rank device outputs (torch tensors / addresses): hit_off[i] int64 [per+1]."""
+        self._ck(self.L.niqki_group_query(self.g, self._ptrs(local_sketches), per, self._ptrs(hit_off),
+                                          self._ptrs(hit_counts), self._ptrs(hit_gids), capacity, MEM_DEVICE))
+
+    def query(self, local_sketches, per, capacity=None):
+        """Device sketches in, numpy hits out: list of (off, counts, gids) per local rank."""
+        cap = capacity if capacity is not None else max(1024, per * 64)
+        while True:
+            off = [np.zeros(per + 1, dtype=np.uint64) for _ in range(self.n_local)]
+            hc = [np.empty(max(cap, 1), dtype=np.uint32) for _ in range(self.n_local)]
+            hg = [np.empty(max(cap, 1), dtype=np.uint32) for _ in range(self.n_local)]
+            rc = self.L.niqki_group_query(self.g, self._ptrs(local_sketches), per, self._ptrs(off), self._ptrs(hc),
+                                          self._ptrs(hg), cap, MEM_HOST)
+            self._ck(rc, allow=(E_CAPACITY,))
+            if rc == 0:
+                return [(o, c[:int(o[per])], g_[:int(o[per])]) for o, c, g_ in zip(off, hc, hg)]
+            cap = max(int(o[per]) for o in off)

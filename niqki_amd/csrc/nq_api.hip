@@ -2,8 +2,7 @@
 // device memory, staging of host buffers, and the launch sequences.  No
 // compute happens on the host here and there is no CPU fallback: without a
 // gfx950 device niqki_create fails.
-#include "../../include/niqki_hip.h"
-#include "nq_kernels.h"
+#include "nq_handle.h"
 #include "nq_synth.h"
 
 #include <algorithm>
@@ -16,84 +15,15 @@
 #include <vector>
 
 namespace {
-
-struct Buf {
-  void *p = nullptr;
-  size_t n = 0;
-};
-
-struct ProfSpan {
-  int kc;
-  hipEvent_t a, b;
-};
-
+thread_local std::string g_create_err;  // why the last niqki_create / niqki_import_dump on this thread failed
 }  // namespace
 
-struct niqki_index {
-  niqki_params p{};
-  nq::Derived d{};
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  std::string err;
-
-  // sketch store, u16 [f_local][cap]
-  uint16_t *store = nullptr;
-  uint64_t cap = 0;
-  uint32_t n_genomes = 0;
-
-  // inverted index
-  uint32_t tile = 0, n_tiles = 0, built_n = 0, align_log2 = 0, padded = 0;
-  nq::Entry *entries = nullptr;
-  uint16_t *gids = nullptr;
-  uint64_t *tile_base = nullptr;   // n_tiles+1, device
-  uint32_t *slot_units = nullptr;  // n_tiles x (f_local+1), device
-  size_t entries_bytes = 0, gids_bytes = 0, tile_base_bytes = 0, slot_units_bytes = 0;
-  uint32_t stripe = 0;             // tiles are dealt round-robin
-  int stripe_opt = 1;              // option: 1 = stripe when there are several tiles
-  int bucket_align = -1;           // option: log2 ids per bucket alignment unit, -1 = choose
-  bool built = false;
-
-  int gather_variant = 0;
-  uint64_t record_len_hint = 0;  // avg bytes per sketch for device-side batches (0 = read it back)
-  uint32_t query_batch = 1024;
-  int query_order = 1;           // option: order the queries of a launch for cache locality
-  int lookup_prepass = -1;       // option: slot-major table look-up pre-pass: -1 = when it pays, 0 = never, 1 = whenever usable
-
-  Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
-      ws_misc, ws_stash;
-  // staged batch (niqki_stage_raw): framing results live in ws_seq / ws_recoff / ws_entry
-  Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk, ws_order, ws_pre;
-  struct {
-    bool valid = false, sketched = false;
-    uint32_t n_entry = 0, n_rec = 0;
-    uint64_t seq_bytes = 0;
-    const uint32_t *entry_rec = nullptr;  // device, n_entry+1
-  } staged;
-
-  bool prof = false;
-  double prof_ms[NIQKI_KC_COUNT] = {0};
-  uint64_t prof_n[NIQKI_KC_COUNT] = {0};
-  std::vector<ProfSpan> spans;
-  std::vector<hipEvent_t> ev_pool;
-};
-
-namespace {
-
-thread_local std::string g_create_err;  // why the last niqki_create / niqki_import_dump on this thread failed
+namespace nqi {
 
 int fail(niqki_index *ix, int code, const std::string &msg) {
   if (ix) ix->err = msg;
   return code;
 }
-
-#define NQ_HIP(ix, call)                                                                    \
-  do {                                                                                      \
-    hipError_t e_ = (call);                                                                 \
-    if (e_ != hipSuccess)                                                                   \
-      return fail(ix, e_ == hipErrorOutOfMemory ? NIQKI_E_NOMEM : NIQKI_E_HIP,              \
-                  std::string(#call) + ": " + hipGetErrorString(e_));                       \
-  } while (0)
 
 int ensure(niqki_index *ix, Buf &b, size_t bytes) {
   if (bytes <= b.n && b.p) return NIQKI_OK;
@@ -121,24 +51,19 @@ hipEvent_t get_event(niqki_index *ix) {
   return e;
 }
 
-struct Span {
-  niqki_index *ix;
-  int kc;
-  hipEvent_t a = nullptr, b = nullptr;
-  Span(niqki_index *ix_, int kc_) : ix(ix_), kc(kc_) {
-    if (ix->prof) {
-      a = get_event(ix);
-      b = get_event(ix);
-      (void)hipEventRecord(a, ix->stream);
-    }
+Span::Span(niqki_index *ix_, int kc_) : ix(ix_), kc(kc_) {
+  if (ix->prof) {
+    a = get_event(ix);
+    b = get_event(ix);
+    (void)hipEventRecord(a, ix->stream);
   }
-  ~Span() {
-    if (ix->prof && a && b) {
-      (void)hipEventRecord(b, ix->stream);
-      ix->spans.push_back({kc, a, b});
-    }
+}
+Span::~Span() {
+  if (ix->prof && a && b) {
+    (void)hipEventRecord(b, ix->stream);
+    ix->spans.push_back({kc, a, b});
   }
-};
+}
 
 int collect_spans(niqki_index *ix) {
   if (ix->spans.empty()) return NIQKI_OK;
@@ -187,6 +112,8 @@ nq::IndexView view(const niqki_index *ix) {
   v.stripe = ix->stripe;
   v.cap = ix->cap;
   v.store = ix->store;
+  v.q_stride = ix->d.F;
+  v.q_off = ix->d.slot_begin;
   v.entries = ix->entries;
   v.gids = ix->gids;
   v.tile_base = ix->tile_base;
@@ -262,7 +189,8 @@ int build_if_needed(niqki_index *ix) {
 }
 
 // counts for nq device-resident sketches into a device buffer
-int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *counts, uint64_t stride) {
+int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
+               uint16_t *counts, uint64_t stride) {
   int rc = build_if_needed(ix);
   if (rc) return rc;
   if (nq == 0) return NIQKI_OK;
@@ -272,10 +200,12 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *
   // launches of at most `chunk` queries bound the per-query stash (one Entry per
   // slot and extra tile) whatever the caller's batch size is
   const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
-  const nq::IndexView v = view(ix);
+  nq::IndexView v = view(ix);
+  v.q_stride = q_stride;
+  v.q_off = q_off;
   // Table look-ups: inside the gather kernel (one random table line per query and slot), or
   // by the slot-major pre-pass, which walks the table once per launch for all its queries.
-  bool pre = ix->lookup_prepass != 0 && nq::launch_lookup_usable(v) && (((uintptr_t)(sketches + ix->d.slot_begin)) & 15) == 0;
+  bool pre = ix->lookup_prepass != 0 && nq::launch_lookup_usable(v) && (((uintptr_t)(sketches + q_off)) & 15) == 0 && (q_stride & 3) == 0;
   // Measured at the north-star shape (profiles/r02_*): the pre-pass takes 19 % of the HBM traffic
   // off a launch but not its time -- both forms are bound by the number of random line requests a
   // CU keeps in flight, and inside the gather kernel the look-ups overlap with the bucket walk.
@@ -298,12 +228,12 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *
     const uint32_t *order = nullptr;
     if (ordered && n >= 64) {
       uint32_t *keys = (uint32_t *)ix->ws_order.p;
-      NQ_HIP(ix, nq::launch_order(view(ix), sketches + (size_t)q0 * ix->d.F, n, keys, keys + chunk, ix->stream));
+      NQ_HIP(ix, nq::launch_order(v, sketches + (size_t)q0 * q_stride, n, keys, keys + chunk, ix->stream));
       order = keys + chunk;
     }
     if (pre)
-      NQ_HIP(ix, nq::launch_lookup(v, sketches + (size_t)q0 * ix->d.F, n, (uint32_t *)ix->ws_pre.p, ix->stream));
-    NQ_HIP(ix, nq::launch_gather(v, sketches + (size_t)q0 * ix->d.F, n, counts + (size_t)q0 * stride, stride,
+      NQ_HIP(ix, nq::launch_lookup(v, sketches + (size_t)q0 * q_stride, n, (uint32_t *)ix->ws_pre.p, ix->stream));
+    NQ_HIP(ix, nq::launch_gather(v, sketches + (size_t)q0 * q_stride, n, counts + (size_t)q0 * stride, stride,
                                  pre ? (nq::Entry *)ix->ws_pre.p : (nq::Entry *)ix->ws_stash.p, order, ix->gather_variant,
                                  pre, ix->stream));
   }
@@ -376,7 +306,7 @@ int query_to_host(niqki_index *ix, const int32_t *sketches, bool sk_dev, uint32_
       NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, d_sk, (size_t)n * ix->d.F * 4, hipMemcpyHostToDevice, ix->stream));
       d_sk = (const int32_t *)ix->ws_sk.p;
     }
-    if ((rc = counts_dev(ix, d_sk, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+    if ((rc = counts_dev(ix, d_sk, ix->d.F, ix->d.slot_begin, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
     uint64_t total = 0;
     rc = hits_dev(ix, (const uint16_t *)ix->ws_counts.p, n, stride, 0, N, (unsigned long long *)ix->ws_hitoff.p,
                   (uint32_t *)ix->ws_hc.p, (uint32_t *)ix->ws_hg.p, room, true, &total);
@@ -394,7 +324,23 @@ int query_to_host(niqki_index *ix, const int32_t *sketches, bool sk_dev, uint32_
   return overflow ? NIQKI_E_CAPACITY : NIQKI_OK;
 }
 
-}  // namespace
+int insert_dev(niqki_index *ix, const int32_t *sketches, uint32_t sk_stride, uint32_t sk_off, uint32_t n) {
+  if (n == 0) return NIQKI_OK;
+  if ((uint64_t)ix->n_genomes + n > 0xFFFFFFFFull) return fail(ix, NIQKI_E_INVALID, "too many genomes");
+  int rc = reserve_store(ix, (uint64_t)ix->n_genomes + n);
+  if (rc) return rc;
+  {
+    Span sp(ix, NIQKI_KC_BUILD);
+    NQ_HIP(ix, nq::launch_store_insert(ix->d, sketches, sk_stride, sk_off, n, ix->store, ix->cap, ix->n_genomes, ix->stream));
+  }
+  ix->n_genomes += n;
+  ix->built = false;
+  return NIQKI_OK;
+}
+
+}  // namespace nqi
+
+using namespace nqi;
 
 extern "C" {
 
@@ -653,9 +599,7 @@ int niqki_insert(niqki_index *ix, const int32_t *sketches, uint32_t n, int mem) 
   if (!ix || (!sketches && n)) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
   if (n == 0) return NIQKI_OK;
-  if ((uint64_t)ix->n_genomes + n > 0xFFFFFFFFull) return fail(ix, NIQKI_E_INVALID, "too many genomes");
-  int rc = reserve_store(ix, (uint64_t)ix->n_genomes + n);
-  if (rc) return rc;
+  int rc;
   const int32_t *d_sk = sketches;
   if (mem == NIQKI_MEM_HOST) {
     const size_t bytes = (size_t)n * ix->d.F * 4;
@@ -663,13 +607,8 @@ int niqki_insert(niqki_index *ix, const int32_t *sketches, uint32_t n, int mem) 
     NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, sketches, bytes, hipMemcpyHostToDevice, ix->stream));
     d_sk = (const int32_t *)ix->ws_sk.p;
   }
-  {
-    Span sp(ix, NIQKI_KC_BUILD);
-    NQ_HIP(ix, nq::launch_store_insert(ix->d, d_sk, n, ix->store, ix->cap, ix->n_genomes, ix->stream));
-  }
+  if ((rc = insert_dev(ix, d_sk, ix->d.F, ix->d.slot_begin, n))) return rc;
   if (mem == NIQKI_MEM_HOST) NQ_HIP(ix, hipStreamSynchronize(ix->stream));
-  ix->n_genomes += n;
-  ix->built = false;
   return NIQKI_OK;
 }
 
@@ -747,7 +686,7 @@ int niqki_query_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq, ui
                        uint64_t stride, int mem) {
   if (!ix || (!sketches && nq) || (!counts && nq)) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
-  if (mem == NIQKI_MEM_DEVICE) return counts_dev(ix, sketches, nq, counts, stride);
+  if (mem == NIQKI_MEM_DEVICE) return counts_dev(ix, sketches, ix->d.F, ix->d.slot_begin, nq, counts, stride);
   if (stride < ix->n_genomes || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
   const uint32_t qb = ix->query_batch;
   for (uint32_t q0 = 0; q0 < nq; q0 += qb) {
@@ -757,7 +696,7 @@ int niqki_query_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq, ui
     if ((rc = ensure(ix, ix->ws_counts, (size_t)n * stride * 2))) return rc;
     NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, sketches + (size_t)q0 * ix->d.F, (size_t)n * ix->d.F * 4, hipMemcpyHostToDevice, ix->stream));
     NQ_HIP(ix, hipMemsetAsync(ix->ws_counts.p, 0, (size_t)n * stride * 2, ix->stream));
-    if ((rc = counts_dev(ix, (const int32_t *)ix->ws_sk.p, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+    if ((rc = counts_dev(ix, (const int32_t *)ix->ws_sk.p, ix->d.F, ix->d.slot_begin, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
     NQ_HIP(ix, hipMemcpyAsync(counts + (size_t)q0 * stride, ix->ws_counts.p, (size_t)n * stride * 2, hipMemcpyDeviceToHost, ix->stream));
     NQ_HIP(ix, hipStreamSynchronize(ix->stream));
   }
@@ -814,7 +753,7 @@ int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint64_t 
   const uint64_t stride = ((uint64_t)N + 1) & ~1ull;
   if (mem == NIQKI_MEM_DEVICE) {
     if ((rc = ensure(ix, ix->ws_counts, std::max<size_t>((size_t)nq * stride * 2, 2)))) return rc;
-    if ((rc = counts_dev(ix, sketches, nq, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+    if ((rc = counts_dev(ix, sketches, ix->d.F, ix->d.slot_begin, nq, (uint16_t *)ix->ws_counts.p, stride))) return rc;
     return hits_dev(ix, (const uint16_t *)ix->ws_counts.p, nq, stride, 0, N, (unsigned long long *)hit_off,
                     hit_counts, hit_gids, capacity, false, nullptr);
   }
@@ -1077,11 +1016,11 @@ int niqki_matrix_range(niqki_index *ix, uint32_t begin, uint32_t end, uint16_t *
     NQ_HIP(ix, nq::launch_store_read(ix->d, ix->store, ix->cap, t0, n, (int32_t *)ix->ws_misc.p, ix->stream));
     uint16_t *dst = counts + (size_t)(t0 - begin) * stride;
     if (mem == NIQKI_MEM_DEVICE) {
-      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, n, dst, stride))) return rc;
+      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, ix->d.F, ix->d.slot_begin, n, dst, stride))) return rc;
     } else {
       if ((rc = ensure(ix, ix->ws_counts, (size_t)n * stride * 2))) return rc;
       NQ_HIP(ix, hipMemsetAsync(ix->ws_counts.p, 0, (size_t)n * stride * 2, ix->stream));
-      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, ix->d.F, ix->d.slot_begin, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
       NQ_HIP(ix, hipMemcpyAsync(dst, ix->ws_counts.p, (size_t)n * stride * 2, hipMemcpyDeviceToHost, ix->stream));
       NQ_HIP(ix, hipStreamSynchronize(ix->stream));
     }

@@ -1,0 +1,107 @@
+// nq_handle.h -- the handle behind the C ABI (niqki_index) and the library-internal helpers
+// shared by nq_api.hip (single-GPU entry points) and nq_group.hip (slot-sharded groups).
+// Private to libniqki_hip.so.
+#pragma once
+#include "../../include/niqki_hip.h"
+#include "nq_kernels.h"
+
+#include <string>
+#include <vector>
+
+namespace nqi {
+
+struct Buf {
+  void *p = nullptr;
+  size_t n = 0;
+};
+
+struct ProfSpan {
+  int kc;
+  hipEvent_t a, b;
+};
+
+}  // namespace nqi
+
+struct niqki_index {
+  niqki_params p{};
+  nq::Derived d{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+
+  // sketch store, u16 [f_local][cap]
+  uint16_t *store = nullptr;
+  uint64_t cap = 0;
+  uint32_t n_genomes = 0;
+
+  // inverted index
+  uint32_t tile = 0, n_tiles = 0, built_n = 0, align_log2 = 0, padded = 0;
+  nq::Entry *entries = nullptr;
+  uint16_t *gids = nullptr;
+  uint64_t *tile_base = nullptr;   // n_tiles+1, device
+  uint32_t *slot_units = nullptr;  // n_tiles x (f_local+1), device
+  size_t entries_bytes = 0, gids_bytes = 0, tile_base_bytes = 0, slot_units_bytes = 0;
+  uint32_t stripe = 0;             // tiles are dealt round-robin
+  int stripe_opt = 1;              // option: 1 = stripe when there are several tiles
+  int bucket_align = -1;           // option: log2 ids per bucket alignment unit, -1 = choose
+  bool built = false;
+
+  int gather_variant = 0;
+  uint64_t record_len_hint = 0;  // avg bytes per sketch for device-side batches (0 = read it back)
+  uint32_t query_batch = 1024;
+  int query_order = 1;           // option: order the queries of a launch for cache locality
+  int lookup_prepass = -1;       // option: slot-major table look-up pre-pass: -1 = when it pays, 0 = never, 1 = whenever usable
+
+  nqi::Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
+      ws_misc, ws_stash;
+  // staged batch (niqki_stage_raw): framing results live in ws_seq / ws_recoff / ws_entry
+  nqi::Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk, ws_order, ws_pre;
+  struct {
+    bool valid = false, sketched = false;
+    uint32_t n_entry = 0, n_rec = 0;
+    uint64_t seq_bytes = 0;
+    const uint32_t *entry_rec = nullptr;  // device, n_entry+1
+  } staged;
+
+  bool prof = false;
+  double prof_ms[NIQKI_KC_COUNT] = {0};
+  uint64_t prof_n[NIQKI_KC_COUNT] = {0};
+  std::vector<nqi::ProfSpan> spans;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+
+namespace nqi {
+
+int fail(niqki_index *ix, int code, const std::string &msg);
+int ensure(niqki_index *ix, Buf &b, size_t bytes);   // device scratch of at least `bytes`
+nq::IndexView view(const niqki_index *ix);
+int build_if_needed(niqki_index *ix);
+// hit counters of nq device-resident sketches (rows q_stride apart, this shard's slots at q_off)
+int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
+               uint16_t *counts, uint64_t stride);
+int hits_dev(niqki_index *ix, const uint16_t *counts, uint32_t nq, uint64_t stride, uint32_t gid_begin,
+             uint32_t n_gids, unsigned long long *hit_off, uint32_t *hc, uint32_t *hg, uint64_t capacity,
+             bool check_capacity, uint64_t *total_out);
+// appends n device-resident sketches (same addressing as counts_dev) to the sketch store
+int insert_dev(niqki_index *ix, const int32_t *sketches, uint32_t sk_stride, uint32_t sk_off, uint32_t n);
+
+// HIP events around a kernel class while profiling is on (niqki_profile_*)
+struct Span {
+  niqki_index *ix;
+  int kc;
+  hipEvent_t a = nullptr, b = nullptr;
+  Span(niqki_index *ix_, int kc_);
+  ~Span();
+};
+
+}  // namespace nqi
+
+#define NQ_HIP(ix, call)                                                                    \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return nqi::fail(ix, e_ == hipErrorOutOfMemory ? NIQKI_E_NOMEM : NIQKI_E_HIP,         \
+                       std::string(#call) + ": " + hipGetErrorString(e_));                  \
+  } while (0)

@@ -26,9 +26,9 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, uint32_t lane) {
 }
 
 // ---- int32 [n][F] sketches -> u16 [F_local][cap] store (64x64 tiles via LDS) ----
-__global__ __launch_bounds__(256) void store_insert_kernel(Derived d, const int32_t *sk, uint32_t n,
-                                                          uint16_t *store, uint64_t cap,
-                                                          uint32_t first_gid) {
+__global__ __launch_bounds__(256) void store_insert_kernel(Derived d, const int32_t *sk, uint32_t sk_stride,
+                                                          uint32_t sk_off, uint32_t n, uint16_t *store,
+                                                          uint64_t cap, uint32_t first_gid) {
   __shared__ uint16_t tile[64][66];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t f_local = d.slot_end - d.slot_begin;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void store_insert_kernel(Derived d, const int3
     uint32_t i = i0 + r, s = s0 + lane;
     uint16_t v = kEmpty16;
     if (i < n && s < f_local) {
-      int32_t x = sk[(uint64_t)i * d.F + d.slot_begin + s];
+      int32_t x = sk[(uint64_t)i * sk_stride + sk_off + s];
       if (x >= 0 && (uint32_t)x < d.R) v = (uint16_t)x;  // src/niqki_index.cpp:364
     }
     tile[r][lane] = v;
@@ -49,14 +49,14 @@ __global__ __launch_bounds__(256) void store_insert_kernel(Derived d, const int3
   }
 }
 
-hipError_t launch_store_insert(const Derived &d, const int32_t *sketches, uint32_t n,
-                               uint16_t *store, uint64_t cap, uint32_t first_gid,
+hipError_t launch_store_insert(const Derived &d, const int32_t *sketches, uint32_t sk_stride, uint32_t sk_off,
+                               uint32_t n, uint16_t *store, uint64_t cap, uint32_t first_gid,
                                hipStream_t stream) {
   if (n == 0) return hipSuccess;
   uint32_t f_local = d.slot_end - d.slot_begin;
   dim3 grid((f_local + 63) / 64, (n + 63) / 64);
-  hipLaunchKernelGGL(store_insert_kernel, grid, dim3(256), 0, stream, d, sketches, n, store, cap,
-                     first_gid);
+  hipLaunchKernelGGL(store_insert_kernel, grid, dim3(256), 0, stream, d, sketches, sk_stride, sk_off, n, store,
+                     cap, first_gid);
   return hipGetLastError();
 }
 

@@ -53,6 +53,9 @@ struct IndexView {
                      // all tiles, which keeps their buckets short in every tile
   uint64_t cap;      // row stride of the sketch store (genomes)
   const uint16_t *store;
+  // query sketches handed to the query kernels: row q starts at sketches + q * q_stride, this
+  // shard's first slot at + q_off (whole sketches: F and slot_begin; slot slices: f_local and 0)
+  uint32_t q_stride, q_off;
   const Entry *entries;
   const uint16_t *gids;
   const uint64_t *tile_base;   // n_tiles+1 (in ids), device
@@ -69,8 +72,9 @@ NQ_HD uint32_t tile_gid(const IndexView &v, uint32_t t, uint32_t i) {
   return v.stripe ? i * v.n_tiles + t : t * v.tile + i;
 }
 
-hipError_t launch_store_insert(const Derived &d, const int32_t *sketches, uint32_t n,
-                               uint16_t *store, uint64_t cap, uint32_t first_gid,
+// sk_stride / sk_off: as q_stride / q_off of IndexView
+hipError_t launch_store_insert(const Derived &d, const int32_t *sketches, uint32_t sk_stride, uint32_t sk_off,
+                               uint32_t n, uint16_t *store, uint64_t cap, uint32_t first_gid,
                                hipStream_t stream);
 hipError_t launch_store_read(const Derived &d, const uint16_t *store, uint64_t cap,
                              uint32_t begin, uint32_t n, int32_t *sketches, hipStream_t stream);

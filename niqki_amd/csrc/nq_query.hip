@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const in
   // this thread's fingerprints (src/niqki_index.cpp:654: anything outside [0, R) has no bucket)
   int32_t fp[PS];
   {
-    const int4 *src = (const int4 *)(sketches + (uint64_t)q * v.d.F + v.d.slot_begin + (uint64_t)sb * PS);
+    const int4 *src = (const int4 *)(sketches + (uint64_t)q * v.q_stride + v.q_off + (uint64_t)sb * PS);
 #pragma unroll
     for (int u = 0; u < PS / 4; ++u) {
       const int4 a = src[u];
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(IndexView v, const int32_t
   extern __shared__ __align__(16) uint32_t cnt[];
   __shared__ uint32_t s_best;
   const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const int32_t *sk = sketches + (uint64_t)q * v.d.F + v.d.slot_begin;
+  const int32_t *sk = sketches + (uint64_t)q * v.q_stride + v.q_off;
   const uint32_t n_probe = v.f_local < kProbeSlots ? v.f_local : kProbeSlots;
   if (tid == 0) s_best = 0;
   for (uint32_t t = 0; t < v.n_tiles; ++t) {
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     q = order[i];
   }
   const uint32_t tid = threadIdx.x;
-  const int32_t *sk = NT < 0 ? nullptr : sketches + (uint64_t)q * v.d.F + v.d.slot_begin;
+  const int32_t *sk = NT < 0 ? nullptr : sketches + (uint64_t)q * v.q_stride + v.q_off;
   Item *queue = (Item *)(cnt + (v.tile + 1) / 2 + (PAD ? kPadWords : 0u));  // behind the counters: kQueue items per wave
   uint32_t sink = 0;
   for (uint32_t t = 0; t < v.n_tiles; ++t) {
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void gathered_kernel(IndexView v, const int32_
                                                       unsigned long long *per_query) {
   const uint32_t q = blockIdx.x;
   const uint32_t R = v.d.R;
-  const int32_t *sk = sketches + (uint64_t)q * v.d.F + v.d.slot_begin;
+  const int32_t *sk = sketches + (uint64_t)q * v.q_stride + v.q_off;
   unsigned long long sum = 0;
   for (uint32_t s = threadIdx.x; s < v.f_local; s += blockDim.x) {
     int32_t fp = sk[s];
