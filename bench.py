@@ -8,16 +8,24 @@ K=31 S=15 W=12 (H=4, J=0.1 -> min_score 3276), synthetic 5 Mbp genomes.
 One "step" = one pass of the hot path (k-mer rolling hash -> HyperMinHash
 sketch -> densification -> gather-histogram over the inverted index ->
 threshold + ordered hits) over one batch of query genomes whose bases are
-already resident in HBM (a ring of distinct batches, step i uses batch i mod ring).  N > 1 (torch.distributed.run, one rank per GPU over
-RCCL): the index is sharded by sketch-slot range, the per-genome hit vectors are
-summed across ranks by a reduce-scatter (niqki_amd/dist.py); total work is
-fixed, so scaling is "strong".
+already resident in HBM (a ring of distinct batches, step i uses batch i mod
+ring).  N > 1 (torch.distributed.run, one rank per GPU): the index is sharded by
+sketch-slot range, the exchange (RCCL all-to-all of sketch slices, sparse
+candidate exchange or reduce-scatter of the packed hit vectors) runs inside
+libniqki_hip.so (niqki_group_*); torch.distributed only carries the group id
+and the timing barrier.  Total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line (rank 0).  `roofline` is for the gather-histogram kernel
 (the HBM-bound kernel SURVEY.md 8d grades), timed live with HIP events on the
-engine's stream; `kernels` lists every kernel class so the ALU-bound sketch
-kernel's share is visible too.  `cpu_baseline` is the oracle (a port of the
-reference's CPU path, oracle/niqki_oracle.c) on this host's cores.
+engine's stream; `kernels` lists every kernel class; `sketch_kernel` holds the
+ALU-bound sketch kernel against integer-ALU ceilings measured in this run;
+`cpu_baseline` is the oracle (a port of the reference's CPU path) on this
+host's cores; `extra_workloads` (1 GPU) are BASELINE.json configs[1], configs[4]
+and the matrix path, each with its own in-run parity check.
+
+    python bench.py --shard-of 8      one GPU plays rank 0 of an 8-GPU slot shard
+                                      (slots [0, F/8), the full query batch): the
+                                      compute half of the 1 -> 8 scaling curve
 """
 import argparse
 import json
@@ -51,7 +59,7 @@ def query_spec(q, n_fam):
     """Query q: a fresh mutant (member id >= 2^20) of a pseudo-random indexed
     family; every 10th query comes from a family that is not indexed."""
     h = (q.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(33)
-    fam = (h % np.uint64(min(n_fam, int(os.environ.get("NIQKI_BENCH_QFAM") or n_fam)))).astype(np.uint32)
+    fam = (h % np.uint64(n_fam)).astype(np.uint32)
     fam = np.where(q % 10 == 9, n_fam + q, fam).astype(np.uint32)
     mem = ((1 << 20) + q).astype(np.uint32)
     rate = (16 + (h >> np.uint64(8)) % np.uint64(400)).astype(np.uint32)
@@ -71,8 +79,11 @@ def main():
     ap.add_argument("--family", type=int, default=100)
     ap.add_argument("--seed", type=int, default=20261003)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra workloads (configs[1], configs[4], matrix)")
     ap.add_argument("--exchange", default=os.environ.get("NIQKI_EXCHANGE", "auto"),
-                    help="cross-shard sum: auto | sparse | reduce_scatter | all_to_all (niqki_amd/dist.py)")
+                    help="cross-shard sum: auto | sparse | reduce_scatter (include/niqki_hip.h, niqki_group_set_option)")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="one GPU as rank 0 of a slot shard of this many GPUs (no exchange; see the module docstring)")
     args = ap.parse_args()
 
     # Only the JSON line may reach stdout: libraries (RCCL prints a version banner)
@@ -84,7 +95,7 @@ def main():
     import torch
     import torch.distributed as dist
     import niqki_amd
-    from niqki_amd.dist import ShardedQuery, slot_range
+    from niqki_amd.dist import ShardedQuery
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -95,6 +106,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     # NIQKI_FORCE_DIST=1 runs the sharded (collective) code path even on one rank
     use_dist = world > 1 or os.environ.get("NIQKI_FORCE_DIST") == "1"
+    emu = args.shard_of if (args.shard_of > 1 and not use_dist) else 0
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -106,7 +118,8 @@ def main():
     F = 1 << S
     N, L = args.genomes, args.len
     n_fam = max(1, N // args.family)
-    sb, se = slot_range(rank, world, F)
+    G = emu if emu else world                  # shards the index is cut into
+    sb, se = niqki_amd.group_slot_range(0 if emu else rank, G, S)
     eng = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_rank, slot_begin=sb, slot_end=se)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_option("record_len_hint", L)
@@ -118,51 +131,42 @@ def main():
     def rec_offsets(n):
         return torch.from_numpy((np.arange(n + 1, dtype=np.int64) * stride_b)).to(dev)
 
-    # ---- index build (not timed): synth -> sketch -> (all_gather) -> insert ----
+    sq = ShardedQuery(eng, N, F, dev, exchange=args.exchange, cand_cap=256) if use_dist else None
+
+    # ---- index build (not timed): synth -> sketch -> (slice exchange) -> insert ----
     t0 = time.time()
     eng.reserve(N)
     GB = 256
     seqbuf = torch.zeros(GB * stride_b + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
-    skbuf = torch.empty((GB, F), dtype=torch.int32, device=dev)
+    skbuf = torch.full((GB, F), -1, dtype=torch.int32, device=dev)
     ro_full = rec_offsets(GB)
-
-    def sketch_padded(n, out):
-        eng.sketch_dev(seqbuf, ro_full if n == GB else rec_offsets(n), n, out)
-
     n_rounds = ((N + GB - 1) // GB + world - 1) // world
-    gath = torch.empty((world, GB, F), dtype=torch.int32, device=dev) if use_dist else None
     for r in range(n_rounds):
-        b = r * world + rank
-        g0 = b * GB
+        g0 = (r * world + rank) * GB           # this rank's GB genomes of the round (rank major = id order)
         n = max(0, min(GB, N - g0))
         if n:
             fam, mem, rate = genome_spec(np.arange(g0, g0 + n), n_fam, args.family)
             eng.synth_dev(args.seed, dev_u32(fam), dev_u32(mem), dev_u32(rate), n, L, stride_b, seqbuf)
-            sketch_padded(n, skbuf)
+            eng.sketch_dev(seqbuf, ro_full if n == GB else rec_offsets(n), n, skbuf)
         if use_dist:
-            eng.synchronize()
-            dist.all_gather_into_tensor(gath.view(-1), skbuf.view(-1))
-            torch.cuda.synchronize()
-            for rr in range(world):
-                gg0 = (r * world + rr) * GB
-                nn = max(0, min(GB, N - gg0))
-                if nn:
-                    eng.insert_dev(gath[rr], nn)
+            sq.insert(skbuf, max(0, min(world * GB, N - r * world * GB)))
         elif n:
             eng.insert_dev(skbuf, n)
     eng.build()
     eng.synchronize()
     t_index = time.time() - t0
-    log("[rank %d] index: %d genomes, tile %d, built in %.1f s" % (rank, eng.n_genomes, eng.tile_genomes(), t_index))
+    log("[rank %d] index: %d genomes, slots [%d, %d), tile %d, built in %.1f s" % (rank, eng.n_genomes, sb, se, eng.tile_genomes(), t_index))
     del seqbuf
 
     # ---- query inputs resident in HBM: a ring of distinct batches, this rank's share ----
-    per = (args.batch + world - 1) // world
+    per = (args.batch + G - 1) // G            # queries this GPU sketches per step
+    nq_all = per * G                           # queries its gather kernel sees per step
+    nq_gather = nq_all if (use_dist or emu) else per
     n_steps_all = args.warmup + args.steps
     n_batches = max(1, min(n_steps_all, args.ring))
     qseq = torch.zeros(n_batches * per * stride_b + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
     for bi in range(n_batches):
-        q = bi * per * world + rank * per + np.arange(per)
+        q = bi * nq_all + (0 if emu else rank) * per + np.arange(per)
         fam, mem, rate = query_spec(q, n_fam)
         eng.synth_dev(args.seed, dev_u32(fam), dev_u32(mem), dev_u32(rate), per, L, stride_b,
                       qseq[bi * per * stride_b:])
@@ -173,18 +177,34 @@ def main():
     hc = torch.zeros(cap, dtype=torch.int32, device=dev)
     hg = torch.zeros(cap, dtype=torch.int32, device=dev)
     stride = (N + 1) & ~1
-    counts = torch.zeros((per * world, stride), dtype=torch.int16, device=dev)
-    # 256 candidates per query and shard (a family has 100 members); the calibration pass below
-    # switches to the dense exchange if any list overflows
-    sq = ShardedQuery(eng, N, F, dev, exchange=args.exchange, cand_cap=256, compact_sketches=True) if use_dist else None
+    counts = None if use_dist else torch.zeros((nq_gather, stride), dtype=torch.int16, device=dev)
+    allsk = None
+    if emu:
+        # the other ranks' sketches of every batch, made once outside the timed region: in the real
+        # job they arrive through the slice exchange
+        allsk = torch.empty((n_batches, nq_all, F), dtype=torch.int32, device=dev)
+        tmp = torch.zeros(per * stride_b + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
+        for bi in range(n_batches):
+            for r in range(G):
+                fam, mem, rate = query_spec(bi * nq_all + r * per + np.arange(per), n_fam)
+                eng.synth_dev(args.seed, dev_u32(fam), dev_u32(mem), dev_u32(rate), per, L, stride_b, tmp)
+                eng.sketch_dev(tmp, d_ro, per, allsk[bi, r * per:(r + 1) * per])
+        del tmp
+        cand = torch.zeros((nq_all, 256), dtype=torch.int32, device=dev)
+        ncand = torch.zeros(nq_all, dtype=torch.int32, device=dev)
     eng.synchronize()
 
     def step(si):
         bi = si % n_batches
-        base = qseq[bi * per * stride_b:]
-        eng.sketch_dev(base, d_ro, per, qsk[bi])
+        eng.sketch_dev(qseq[bi * per * stride_b:], d_ro, per, qsk[bi])
         if use_dist:
             sq.step(qsk[bi], hit_off[si], hc, hg, cap)
+        elif emu:
+            # rank 0's compute of one step: its share sketched above, partial hit vectors of ALL
+            # queries over its slots, its candidate lists, threshold + order of its own rows
+            eng.query_counts_dev(allsk[bi], nq_all, counts, stride)
+            eng.candidates_dev(counts, nq_all, stride, N, -(-eng.min_score // G), 256, cand, ncand)
+            eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[si], hc, hg, cap)
         else:
             eng.query_counts_dev(qsk[bi], per, counts, stride)
             eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[si], hc, hg, cap)
@@ -193,20 +213,10 @@ def main():
         if use_dist:
             dist.barrier()
 
-    if use_dist and sq.exchange == "sparse":
-        # exchange calibration (untimed, not a warm-up step): every resident batch once, so that
-        # a candidate list that does not fit is seen before anything is timed
-        for bi in range(n_batches):
-            step(bi)
     for bi in range(args.warmup):
         step(bi)
     eng.synchronize()
     torch.cuda.synchronize()
-    if use_dist and sq.exchange == "sparse" and int(sq.overflow.item()):
-        # a candidate list did not fit: this workload needs the dense exchange
-        log("[rank %d] sparse exchange overflowed its candidate capacity, using reduce_scatter" % rank)
-        sq.exchange = "reduce_scatter"
-        sq.overflow.zero_()
     eng.profile(True)
     eng.profile_reset()
     barrier()
@@ -224,7 +234,7 @@ def main():
         dt = float(tt.item())
     prof = {name: eng.profile_read(kc) for name, kc in (
         ("sketch", niqki_amd.KC_SKETCH), ("densify", niqki_amd.KC_DENSIFY), ("gather", niqki_amd.KC_GATHER),
-        ("hits", niqki_amd.KC_HITS))}
+        ("hits", niqki_amd.KC_HITS), ("exchange", niqki_amd.KC_EXCHANGE))}
     eng.profile(False)
 
     # ---- roofline of the gather kernel: algorithmic bytes 4T + 20F per query ----
@@ -232,14 +242,19 @@ def main():
     T = 0
     for si in range(args.warmup, n_steps_all):
         bi = si % n_batches
-        if use_dist:
-            allsk = sq.exchange_sketches(qsk[bi])
-            T += int(eng.gathered_dev(allsk, per * world).sum())
+        if use_dist:   # measurement only: whole sketches of every rank, this shard's slots are what counts
+            full = torch.empty((world * per, F), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(full.view(-1), qsk[bi].reshape(-1))
+            T += int(eng.gathered_dev(full, world * per).sum())
         else:
-            T += int(eng.gathered_dev(qsk[bi], per).sum())
-    n_q_local = args.steps * per * world  # queries this GPU's gather kernel saw
+            T += int(eng.gathered_dev(allsk[bi] if emu else qsk[bi], nq_gather).sum())
+    n_q_local = args.steps * nq_gather
     gather_ms, gather_launches = prof["gather"]
     alg_bytes = 4 * T + 20 * f_local * n_q_local
+    # the same quantities at the sizes the layout really stores: 2-byte ids, one 8-byte entry per slot and
+    # tile, 2-byte counters written back
+    n_tiles = -(-N // max(eng.tile_genomes(), 1))
+    layout_min = 2 * T + (8 * n_tiles + 4) * f_local * n_q_local + 2 * N * n_q_local
     achieved = alg_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
     total_hits = int(hit_off[args.warmup:, per].sum().item())
     overflow = bool((hit_off[:, per] > cap).any().item())
@@ -249,29 +264,44 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "gather_traffic.json")))
-        if (tj["index_genomes"], tj["query_batch"], tj["tile_genomes"]) == (N, per * world, eng.tile_genomes()) and world == 1:
+        if (tj["index_genomes"], tj["query_batch"], tj["tile_genomes"]) == (N, nq_gather, eng.tile_genomes()) and world == 1 and not emu:
             traffic = tj["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
 
+    # ---- sketch kernel against integer-ALU ceilings measured now, on this device ----
+    kmers = args.steps * per * max(L - K, 0)
+    sk_rate = kmers / (prof["sketch"][0] * 1e-3) if prof["sketch"][0] else 0.0
+    alu = None
+    if rank == 0:
+        adds, muls, arith = eng.measure_alu(0), eng.measure_alu(1), eng.measure_alu(2)
+        alu = {"add_lane_ops_per_s": adds, "mul_lane_ops_per_s": muls, "arithmetic_only_kmers_per_s": arith,
+               "alu_frac": sk_rate / arith if arith else None,
+               "note": "alu_frac = sketch kernel k-mers/s over the rate of its per-k-mer arithmetic alone (roll, canonical "
+                       "choice, filter hash; no LDS table, compaction, candidates or memory), both measured in this run"}
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, (K, S, W, H, J))
+    extra = None
+    if rank == 0 and world == 1 and not emu:
+        if not args.no_cpu:
+            cpu = cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, (K, S, W, H, J))
+        if not args.no_extra:
+            del counts
+            extra = extra_workloads(niqki_amd, torch, dev, args, no_cpu=args.no_cpu)
 
     # bytes a rank sends per step in the exchange (sketch slices, then the candidate lists or the
     # dense counters): with the step time this bounds the average xGMI rate per GPU
     xbytes = None
     if use_dist:
         g1 = (world - 1) / world
-        nq_all = per * world
-        xbytes = per * F * 2 * g1                                   # all_to_all of F/G-slot sketch slices (int16)
+        xbytes = nq_all * (F // world) * 2 * g1                          # all-to-all of F/G-slot sketch slices (int16)
         if sq.exchange == "sparse":
-            xbytes += nq_all * sq.cand_cap * 4 * g1 + nq_all * 4 * g1    # all_gather of candidates + their counts
-            xbytes += nq_all * world * sq.cand_cap * 4 * g1              # reduce_scatter of the candidates' partial counts
+            xbytes += nq_all * sq.cand_cap * 4 * g1 + nq_all * 4 * g1    # all-gather of candidates + their counts
+            xbytes += nq_all * world * sq.cand_cap * 4 * g1              # reduce-scatter of the candidates' partial counts
         else:
-            xbytes += nq_all * (stride // 2) * 4 * g1                    # dense u16 counters as int32 pairs
+            xbytes += nq_all * (stride // 2) * 4 * g1                    # dense u16 counters as u32 pairs
     if rank == 0:
-        n_queries = args.steps * per * world
+        n_queries = args.steps * nq_all
         out = {
             "metric": "query genomes/sec, %dk-genome index, K=31 S=15 W=12" % (N // 1000),
             "value": n_queries / dt,
@@ -288,35 +318,52 @@ def main():
             "config": {
                 "workload": "%d synthetic %d bp genomes indexed (families of %d, 0.1-5%% substitutions), "
                             "%d query genomes per step resident in HBM, K=31 S=15 W=12 H=4 J=0.1"
-                            % (N, L, args.family, per * world),
-                "index_genomes": N, "query_batch": per * world, "genome_len": L,
-                "parallelism": "slot-shard x%d (%s exchange)" % (world, sq.exchange) if use_dist else "1 GPU",
-                "exchange_overflow": bool(int(sq.overflow.item())) if use_dist else False,
+                            % (N, L, args.family, nq_all),
+                "index_genomes": N, "query_batch": nq_all, "genome_len": L,
+                "parallelism": ("slot-shard x%d (%s exchange, RCCL inside libniqki_hip.so)" % (world, sq.exchange)) if use_dist
+                else ("1 GPU as rank 0 of a %d-way slot shard" % emu if emu else "1 GPU"),
+                "exchange_redone_densely": sq.overflows if use_dist else 0,
                 "exchange_bytes_per_rank_per_step": xbytes,
                 "exchange_avg_gbs_per_rank": (xbytes / (dt / args.steps) / 1e9) if xbytes else None,
                 "tile_genomes": eng.tile_genomes(), "index_build_s": round(t_index, 2),
                 "hits_per_query": total_hits / max(1, args.steps * per), "hit_overflow": overflow,
             },
             "roofline": {
-                "kernel": "nq::gather_kernel (gather-histogram, rank 0's slot shard)",
+                "kernel": "nq::gather_kernel (gather-histogram, rank 0's slot shard) incl. its probe / order passes",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": alg_bytes / max(1, gather_launches),
+                "layout_min_bytes_per_launch": layout_min / max(1, gather_launches),
                 "launches": gather_launches, "avg_launch_ms": gather_ms / max(1, gather_launches),
                 "gathered_ids_per_query": T / max(1, n_q_local),
             },
             "kernels": {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items()},
             # the sketch kernel is integer-ALU bound (4 64-bit multiplies per k-mer):
-            # its rate in k-mers and the HBM bytes it needs (1 byte per base + the sketch)
+            # its rate in k-mers, the HBM bytes it needs (1 byte per base + the sketch) and the ALU ceilings
             "sketch_kernel": {
-                "gkmers_per_s": (args.steps * per * max(L - K, 0)) / (prof["sketch"][0] * 1e-3) / 1e9 if prof["sketch"][0] else 0.0,
+                "gkmers_per_s": sk_rate / 1e9,
                 "hbm_gbs": (args.steps * per * (L + 4 * F)) / (prof["sketch"][0] * 1e-3) / 1e9 if prof["sketch"][0] else 0.0,
-                "bound": "valu",
+                "bound": "valu", "alu": alu,
             },
             "cpu_baseline": cpu,
         }
+        if emu:
+            # what one shard of the real job computes per step; the exchange (nq * F/G * 2 bytes of slices out,
+            # candidate lists) is not part of it
+            out["metric"] += " (one GPU as rank 0 of %d slot shards, compute only)" % emu
+            out["shard_emulation"] = {
+                "shards": emu, "slots": [sb, se], "queries_sketched_per_step": per, "queries_gathered_per_step": nq_all,
+                "gather_ms_per_step": gather_ms / max(1, gather_launches), "roofline_frac": achieved / HBM_PEAK_GBS,
+                "counter_row_bytes_per_query": 2 * N, "counter_bytes_written_per_step": 2 * N * nq_all,
+                "sketch_ms_per_step": prof["sketch"][0] / max(1, args.steps), "hits_ms_per_step": prof["hits"][0] / max(1, args.steps),
+                "projected_genomes_per_s_if_exchange_is_free": nq_all / (dt / args.steps),
+            }
+        if extra is not None:
+            out["extra_workloads"] = extra
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if use_dist:
+        sq.close()
     eng.close()
     if use_dist:
         dist.destroy_process_group()
@@ -324,13 +371,15 @@ def main():
 
 def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, prm):
     """The oracle (port of the reference CPU path) on this host, on a bounded
-    sample of the same workload; also the in-run parity check."""
+    sample of the same workload; also the in-run parity check (sketches, dense counters and the
+    thresholded, ordered hit lists of the sample against what the timed steps produced)."""
     from oracle import pyoracle as po
     K, S, W, H, J = prm
     p = po.make_params(K, S, W, H, J)
     cores = po.lib().nqo_max_threads()
     n_s = int(min(per, max(8, 2 * cores)))
-    bi = args.warmup % qsk.shape[0]   # the batch the first timed step used
+    si = args.warmup + args.steps - 1  # the last timed step: its hits are what hc / hg still hold
+    bi = si % qsk.shape[0]
     seqs = qseq[bi * per * stride_b: bi * per * stride_b + n_s * stride_b].cpu().numpy()
     rec = np.stack([seqs[i * stride_b:i * stride_b + L] for i in range(n_s)])
     rec_off = (np.arange(n_s + 1) * L).astype(np.uint64)
@@ -346,26 +395,41 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
     cores = best_threads
     sk_gpu = qsk[bi, :n_s].cpu().numpy()
     parity_sketch = bool(np.array_equal(sk_cpu, sk_gpu))
-    # gather leg on sub-indexes of the first n genomes, extrapolated linearly in N
+    # gather leg timed on sub-indexes of the first 4096 / 16384 genomes and extrapolated linearly in N;
+    # parity over ALL columns: the oracle's counters from seven sub-indexes of <= 16384 genomes
     pts = []
-    parity_counts = True
-    for n_sub in (4096, 16384):
-        n_sub = min(n_sub, N)
-        sub = eng.get_sketches(0, n_sub)
+    n_par = min(n_s, 8)
+    exp_cols = np.zeros((n_par, N), np.uint32)
+    cnt = eng.query_counts(sk_gpu[:n_par])
+    for b0 in range(0, N, 16384):
+        n_sub = min(16384, N - b0)
+        sub = eng.get_sketches(b0, n_sub)
         ix = po.Index(p, sub)
-        best = None
-        for _ in range(3):  # first pass warms the pages, keep the fastest
-            t0 = time.perf_counter()
-            off, c, g = ix.query_batch(sk_cpu, threads=cores)
-            t = time.perf_counter() - t0
-            best = t if best is None else min(best, t)
-        pts.append((n_sub, best))
-        if n_sub == min(16384, N):
-            cnt = eng.query_counts(sk_gpu)[:, :n_sub]
-            for i in range(min(n_s, 4)):
-                parity_counts &= bool(np.array_equal(cnt[i].astype(np.uint32), ix.counts(sk_cpu[i])))
-        del ix
-    (n1, t1), (n2, t2) = pts
+        if b0 == 0:
+            for n_t in sorted({min(4096, n_sub), n_sub}):
+                ixt = ix if n_t == n_sub else po.Index(p, sub[:n_t])
+                best = None
+                for _ in range(3):        # first pass warms the pages, keep the fastest
+                    t0 = time.perf_counter()
+                    ixt.query_batch(sk_cpu, threads=cores)
+                    t = time.perf_counter() - t0
+                    best = t if best is None else min(best, t)
+                pts.append((n_t, best))
+        for i in range(n_par):
+            exp_cols[i, b0:b0 + n_sub] = ix.counts(sk_cpu[i])
+        del ix, sub
+    parity_counts = bool(np.array_equal(cnt.astype(np.uint32), exp_cols))
+    # hit lists of the timed step for these queries: threshold + order of the oracle's columns
+    off = hit_off[si].cpu().numpy()
+    g_hc, g_hg = hc.cpu().numpy(), hg.cpu().numpy()
+    parity_hits = True
+    for i in range(n_par):
+        gids = np.nonzero(exp_cols[i] >= p.min_score)[0]
+        order = np.lexsort((-gids.astype(np.int64), -exp_cols[i, gids].astype(np.int64)))
+        lo, hi = int(off[i]), int(off[i + 1])
+        parity_hits &= bool(np.array_equal(g_hc[lo:hi].astype(np.uint32), exp_cols[i, gids][order]) and
+                            np.array_equal(g_hg[lo:hi].astype(np.uint32), gids[order].astype(np.uint32)))
+    (n1, t1), (n2, t2) = pts[0], pts[-1]
     if n2 == n1:
         t_q = t2
     elif t2 > t1:
@@ -377,9 +441,222 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
         "value": val, "unit": "genomes/s", "cores": cores, "kind": "port",
         "sample": "%d query genomes of step %d: sketch leg timed in full (%.2f s); gather leg timed on "
                   "sub-indexes of %d and %d genomes (%.3f s, %.3f s) and extrapolated linearly to %d"
-                  % (n_s, bi, t_sk, n1, n2, t1, t2, N),
-        "parity": {"sketch_bit_exact": parity_sketch, "counts_bit_exact": parity_counts},
+                  % (n_s, si, t_sk, n1, n2, t1, t2, N),
+        "parity": {"sketch_bit_exact": parity_sketch, "counts_bit_exact_all_columns": parity_counts,
+                   "hit_lists_bit_exact": parity_hits, "queries_checked": n_par},
     }
+
+
+def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
+    """BASELINE.json configs[1] (1k genomes: index + self query), configs[4] (150-base reads against a
+    10k-genome index, S=12 W=10, lines-mode semantics) and the matrix path, each timed with inputs
+    resident in HBM and each with an in-run parity check against the oracle."""
+    from oracle import pyoracle as po
+    out = {}
+    seed, L = args.seed + 1, args.len
+    t32 = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).to(torch.int32).to(dev)  # noqa: E731
+    t64 = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).to(dev)  # noqa: E731
+
+    def timed(fn, eng, reps=1):
+        eng.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        eng.synchronize()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def hits_equal(off, hc_, hg_, i, cols, min_score):
+        gids = np.nonzero(cols >= min_score)[0]
+        order = np.lexsort((-gids.astype(np.int64), -cols[gids].astype(np.int64)))
+        lo, hi = int(off[i]), int(off[i + 1])
+        return bool(np.array_equal(hc_[lo:hi].astype(np.uint32), cols[gids][order]) and
+                    np.array_equal(hg_[lo:hi].astype(np.uint32), gids[order].astype(np.uint32)))
+
+    def engine(S, W):
+        e = niqki_amd.Engine(K=31, S=S, W=W, H=4, J=0.1, device=dev.index)
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        e.set_option("record_len_hint", L)
+        return e
+
+    # ---- configs[1]: 1k synthetic 5 Mbp genomes, index + self query, K=31 S=15 W=12 ----
+    K, S, W, H, J = 31, 15, 12, 4, 0.1
+    F, N1 = 1 << S, 1000
+    fam, mem, rate = genome_spec(np.arange(N1), N1 // 10, 10)
+    seq = torch.zeros(N1 * L + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
+    ro = t64(np.arange(N1 + 1, dtype=np.int64) * L)
+    sk = torch.empty((N1, F), dtype=torch.int32, device=dev)
+    cap = N1 * 64
+    ho = torch.zeros(N1 + 1, dtype=torch.int64, device=dev)
+    hc = torch.zeros(cap, dtype=torch.int32, device=dev)
+    hg = torch.zeros(cap, dtype=torch.int32, device=dev)
+    t_index = None
+    for attempt in range(2):                     # first pass warms kernels and allocations; the second is timed
+        e = engine(S, W)
+        if attempt == 0:
+            e.synth_dev(seed, t32(fam), t32(mem), t32(rate), N1, L, L, seq)
+
+        def index_1k():
+            e.sketch_dev(seq, ro, N1, sk)
+            e.insert_dev(sk, N1)
+            e.build()
+        t_index = timed(index_1k, e)
+        if attempt == 0:
+            e.close()
+    e.query_sequences_dev(seq, ro, N1, ho, hc, hg, cap)
+    t_query = timed(lambda: e.query_sequences_dev(seq, ro, N1, ho, hc, hg, cap), e, reps=3)
+    p = po.make_params(K, S, W, H, J)
+    skh = sk.cpu().numpy()
+    n_par = 4
+    par_sk = all(np.array_equal(skh[i], po.compute_sketch(p, seq[i * L:(i + 1) * L].cpu().numpy())) for i in range(n_par))
+    ix = po.Index(p, skh)
+    off, c_, g_ = ho.cpu().numpy(), hc.cpu().numpy(), hg.cpu().numpy()
+    par_hits = all(hits_equal(off, c_, g_, i, ix.counts(skh[i]), p.min_score) for i in range(0, N1, 16))
+    cpu1 = None
+    if not no_cpu:
+        th = po.lib().nqo_max_threads()
+        t0 = time.perf_counter()
+        ix.query_batch(skh[:256], threads=th)
+        cpu1 = {"gather_genomes_per_s": 256 / (time.perf_counter() - t0), "threads": th, "sample": "256 self queries, gather leg only"}
+    out["configs1_1k_index_self_query"] = {
+        "workload": "1000 synthetic %d bp genomes (100 families of 10), K=31 S=15 W=12 J=0.1, bases resident in HBM" % L,
+        "index_genomes_per_s": N1 / t_index, "index_s": t_index,
+        "query_genomes_per_s": N1 / t_query, "query_s": t_query, "hits": int(off[N1]),
+        "parity": {"sketch_bit_exact": bool(par_sk), "sketches_checked": n_par, "hit_lists_bit_exact": bool(par_hits),
+                   "queries_checked": len(range(0, N1, 16))},
+        "cpu_oracle": cpu1,
+    }
+    del ix, seq, sk
+    e.close()
+
+    # ---- matrix path: all-vs-all of a 10k-genome index (query_range / query_matrix) ----
+    NM, GB = 10_000, 250
+    e = engine(S, W)
+    seq = torch.zeros(GB * L + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
+    skb = torch.empty((GB, F), dtype=torch.int32, device=dev)
+    rob = t64(np.arange(GB + 1, dtype=np.int64) * L)
+    for g0 in range(0, NM, GB):
+        fam, mem, rate = genome_spec(np.arange(g0, g0 + GB), NM // 100, 100)
+        e.synth_dev(seed + 1, t32(fam), t32(mem), t32(rate), GB, L, L, seq)
+        e.sketch_dev(seq, rob, GB, skb)
+        e.insert_dev(skb, GB)
+    e.build()
+    del skb
+    rows = 1024
+    mstride = (NM + 1) & ~1
+    mat = torch.zeros((rows, mstride), dtype=torch.int16, device=dev)
+
+    def matrix_all():
+        for t0_ in range(0, NM, rows):
+            e._ck(e.L.niqki_matrix_range(e.h, t0_, min(NM, t0_ + rows), mat.data_ptr(), mstride, niqki_amd.MEM_DEVICE))
+    matrix_all()
+    t_mat = timed(matrix_all, e)
+    e._ck(e.L.niqki_matrix_range(e.h, 5000, 5000 + rows, mat.data_ptr(), mstride, niqki_amd.MEM_DEVICE))
+    e.synchronize()
+    mh = mat.cpu().numpy().view(np.uint16)[:, :NM]
+    ixm = po.Index(p, e.get_sketches(0, NM))
+    exp = ixm.matrix_range(5000, 5008)            # [a][t - begin]
+    par_mat = bool(np.array_equal(mh[:8], exp.T))
+    out["matrix_10k"] = {
+        "workload": "all-vs-all hit matrix of a 10000-genome index (100 families of 100), K=31 S=15 W=12, counters left on the device",
+        "rows_per_s": NM / t_mat, "seconds": t_mat,
+        "algorithmic_bytes": 4 * NM * F + 2 * NM * NM, "algorithmic_gbs": (4 * NM * F + 2 * NM * NM) / t_mat / 1e9,
+        "parity": {"rows_bit_exact_vs_bucket_cooccurrence": par_mat, "rows_checked": 8},
+    }
+    del ixm, mat
+    e.close()
+
+    # ---- configs[4]: 150-base reads vs a 10k-genome index, K=31 S=12 W=10 (lines mode: one sketch per read) ----
+    S4, W4 = 12, 10
+    F4, N4, NR, RL, RB = 1 << S4, 10_000, 10_485_760, 150, 65536
+    e = engine(S4, W4)
+    skb = torch.empty((GB, F4), dtype=torch.int32, device=dev)
+    for g0 in range(0, N4, GB):
+        fam, mem, rate = genome_spec(np.arange(g0, g0 + GB), N4 // 100, 100)
+        e.synth_dev(seed + 2, t32(fam), t32(mem), t32(rate), GB, L, L, seq)
+        e.sketch_dev(seq, rob, GB, skb)
+        e.insert_dev(skb, GB)
+    e.build()
+    del seq, skb
+    # 10 M distinct reads generated on the device: read i = 150 bases at a pseudo-random offset of a
+    # pseudo-random indexed genome, 1 % substitutions of its own (164/16384)
+    rng = np.random.default_rng(args.seed)
+    reads = torch.zeros(NR * RL + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
+    src_g = rng.integers(0, N4, NR)
+    src_off = rng.integers(0, L - RL, NR).astype(np.uint64)
+    CH = 1 << 20
+    for a in range(0, NR, CH):
+        gch = src_g[a:a + CH]
+        fam, mem, rate = genome_spec(gch, N4 // 100, 100)
+        e.synth_reads_dev(seed + 2, t32(fam), t32(mem), t32(rate), t64(src_off[a:a + CH]), t32(np.arange(a, a + len(gch))),
+                          164, len(gch), RL, RL, reads[a * RL:])
+    e.set_option("record_len_hint", RL)
+    rro = t64(np.arange(RB + 1, dtype=np.int64) * RL)
+    rsk = torch.empty((RB, F4), dtype=torch.int32, device=dev)
+    rstride = (N4 + 1) & ~1
+    rcnt = torch.zeros((RB, rstride), dtype=torch.int16, device=dev)
+    # the threshold: reads share few slots with 5 Mbp genomes, so J is set where hits exist -- the count
+    # the source genome of a read typically reaches (calibrated on the first batch, then fixed)
+    e.sketch_dev(reads, rro, RB, rsk)
+    e.query_counts_dev(rsk, RB, rcnt, rstride)
+    e.synchronize()
+    c0 = rcnt[:4096].cpu().numpy().view(np.uint16)[:, :N4]
+    own = c0[np.arange(4096), src_g[:4096]]
+    min_score = max(2, int(np.percentile(own, 25)))
+    del rcnt
+    e.set_option("min_score", min_score)
+    rcap = RB * 256
+    rho = torch.zeros(RB + 1, dtype=torch.int64, device=dev)
+    rhc = torch.zeros(rcap, dtype=torch.int32, device=dev)
+    rhg = torch.zeros(rcap, dtype=torch.int32, device=dev)
+    tots = torch.zeros(NR // RB, dtype=torch.int64, device=dev)
+
+    def all_reads():
+        for k, a in enumerate(range(0, NR, RB)):
+            e.sketch_dev(reads[a * RL:], rro, RB, rsk)
+            e.query_dev(rsk, RB, rho, rhc, rhg, rcap)
+            tots[k] = rho[RB]                     # device-side copy: no host sync inside the timed loop
+    all_reads()
+    e.profile(True)
+    e.profile_reset()
+    t_reads = timed(all_reads, e)
+    kprof = {n_: e.profile_read(kc)[0] for n_, kc in (("sketch", niqki_amd.KC_SKETCH), ("gather", niqki_amd.KC_GATHER), ("hits", niqki_amd.KC_HITS))}
+    e.profile(False)
+    th_ = tots.cpu().numpy()
+    # parity on the last batch: oracle sketches of 64 reads, dense counters and hit lists against an oracle index
+    a = NR - RB
+    rd = reads[a * RL:(a + 64) * RL].cpu().numpy().reshape(64, RL)
+    host_rd = e.synth_reads_host(seed + 2, *genome_spec(src_g[a:a + 64], N4 // 100, 100), src_off[a:a + 64], np.arange(a, a + 64), 164, RL)
+    p4 = po.make_params(K, S4, W4, H, J)
+    p4.min_score = min_score
+    rskh = rsk[:64].cpu().numpy()
+    par_sk = all(np.array_equal(rskh[i], po.compute_sketch(p4, rd[i])) for i in range(64))
+    ix4 = po.Index(p4, e.get_sketches(0, N4))
+    off, c_, g_ = rho.cpu().numpy(), rhc.cpu().numpy(), rhg.cpu().numpy()
+    par_hits = all(hits_equal(off, c_, g_, i, ix4.counts(rskh[i]), min_score) for i in range(64))
+    cpu4 = None
+    if not no_cpu:
+        th = po.lib().nqo_max_threads()
+        n_c = 2048
+        rdc = reads[:n_c * RL].cpu().numpy()
+        t0 = time.perf_counter()
+        skc = po.sketch_batch(p4, rdc, (np.arange(n_c + 1) * RL).astype(np.uint64), threads=th)
+        ix4.query_batch(skc, threads=th)
+        cpu4 = {"reads_per_s": n_c / (time.perf_counter() - t0), "threads": th, "kind": "port",
+                "sample": "%d reads: sketch (densification dominated, src/niqki_index.cpp:313-331) + query" % n_c}
+    out["configs4_reads_vs_10k_index"] = {
+        "workload": "%d distinct 150-base reads (1 %% substitutions, generated on the device) against a 10000-genome index, "
+                    "K=31 S=12 W=10, one sketch per read, batches of %d resident in HBM" % (NR, RB),
+        "reads_per_s": NR / t_reads, "seconds": t_reads, "min_score": min_score, "J_equivalent": min_score / F4,
+        "hits_total": int(th_.sum()), "hits_per_read": float(th_.sum()) / NR, "hit_overflow": bool((th_ > rcap).any()),
+        "kernel_ms": {k_: round(v, 1) for k_, v in kprof.items()},
+        "parity": {"device_reads_equal_host_generator": bool(np.array_equal(rd, host_rd)), "sketch_bit_exact": bool(par_sk),
+                   "hit_lists_bit_exact": bool(par_hits), "reads_checked": 64},
+        "cpu_oracle": cpu4,
+    }
+    e.close()
+    return out
 
 
 if __name__ == "__main__":

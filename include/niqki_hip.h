@@ -393,6 +393,19 @@ int niqki_synth_genomes(niqki_index *ix, uint64_t seed, const uint32_t *family,
                         int mem);
 void niqki_synth_genome_host(uint64_t seed, uint32_t family, uint32_t member,
                              uint32_t rate14, uint64_t len, uint8_t *out);
+/* Deterministic synthetic reads (BASELINE.json's short-sequence config): read i is bases
+ * [offset[i], offset[i]+len) of the genome (family[i], member[i], rate14[i]) above, with the
+ * read's own substitutions at rate read_rate14/16384 keyed by read_id[i] on top.  Record i at
+ * out + i*stride.  Host and device produce identical bytes. */
+int niqki_synth_reads(niqki_index *ix, uint64_t seed, const uint32_t *family, const uint32_t *member,
+                      const uint32_t *rate14, const uint64_t *offset, const uint32_t *read_id,
+                      uint32_t read_rate14, uint32_t n, uint32_t len, uint64_t stride, uint8_t *out,
+                      int mem);
+/* Integer-ALU ceilings of the device, measured live (SURVEY.md 8d asks for the sketch kernel as a
+ * fraction of one): what = 0 independent 32-bit adds, 1 = 32-bit multiplies, 2 = the sketch
+ * kernel's per-k-mer arithmetic alone (K = 31 roll + canonical choice + filter hash; no LDS,
+ * memory or compaction).  *rate = adds / multiplies / k-mers per second over ~ms milliseconds. */
+int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,8 @@ ABI = [
     ("niqki_profile_read", _int, [_vp, _int, C.POINTER(_dbl), C.POINTER(_u64)]),
     ("niqki_synth_genomes", _int, [_vp, _u64, _vp, _vp, _vp, _u32, _u64, _u64, _vp, _int]),
     ("niqki_synth_genome_host", None, [_u64, _u32, _u32, _u32, _u64, _vp]),
+    ("niqki_synth_reads", _int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _vp, _int]),
+    ("niqki_measure_alu", _int, [_vp, _int, _dbl, C.POINTER(_dbl)]),
 ]
 
 _lib = None
@@ -421,6 +423,23 @@ class Engine:
     def synth_dev(self, seed, family, member, rate14, n, length, stride, out):
         self._ck(self.L.niqki_synth_genomes(self.h, seed, _p(family), _p(member), _p(rate14), n,
                                             length, stride, _p(out), MEM_DEVICE))
+
+    def synth_reads_dev(self, seed, family, member, rate14, offset, read_id, read_rate14, n, length, stride, out):
+        self._ck(self.L.niqki_synth_reads(self.h, seed, _p(family), _p(member), _p(rate14), _p(offset), _p(read_id),
+                                          read_rate14, n, length, stride, _p(out), MEM_DEVICE))
+
+    def synth_reads_host(self, seed, family, member, rate14, offset, read_id, read_rate14, length):
+        a = [np.ascontiguousarray(x, dtype=np.uint32) for x in (family, member, rate14, read_id)]
+        off = np.ascontiguousarray(offset, dtype=np.uint64)
+        out = np.empty((a[0].size, length), dtype=np.uint8)
+        self._ck(self.L.niqki_synth_reads(self.h, seed, _p(a[0]), _p(a[1]), _p(a[2]), _p(off), _p(a[3]), read_rate14,
+                                          a[0].size, length, length, _p(out), MEM_HOST))
+        return out
+
+    def measure_alu(self, what, ms=20.0):
+        r = _dbl(0)
+        self._ck(self.L.niqki_measure_alu(self.h, what, ms, C.byref(r)))
+        return r.value
 
     def stage_raw_dev(self, raw, file_off, types, lines=False, final=True, max_entries=16384):
         """raw: device bytes (torch tensor / address); file_off, types: host numpy arrays."""

@@ -1279,6 +1279,58 @@ void niqki_synth_genome_host(uint64_t seed, uint32_t family, uint32_t member, ui
   }
 }
 
+int niqki_synth_reads(niqki_index *ix, uint64_t seed, const uint32_t *family, const uint32_t *member, const uint32_t *rate14,
+                      const uint64_t *offset, const uint32_t *read_id, uint32_t read_rate14, uint32_t n, uint32_t len,
+                      uint64_t stride, uint8_t *out, int mem) {
+  if (!ix || (n && (!family || !member || !rate14 || !offset || !read_id || !out)) || stride < len) return NIQKI_E_INVALID;
+  if (mem == NIQKI_MEM_HOST) {
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint64_t ka = nq::synth_key_anc(seed, family[i]), km = nq::synth_key_mut(seed, family[i], member[i]);
+      const uint64_t kr = nq::synth_key_read(seed, family[i], read_id[i]);
+      uint64_t blk = ~0ull, codes = 0;
+      for (uint32_t j = 0; j < len; ++j) {
+        const uint64_t p = offset[i] + j;
+        if ((p >> 5) != blk) { blk = p >> 5; codes = nq::synth_block2(ka, km, rate14[i], kr, read_rate14, blk); }
+        out[(uint64_t)i * stride + j] = nq::synth_ascii((uint32_t)(codes >> (2 * (p & 31))) & 3u);
+      }
+    }
+    return NIQKI_OK;
+  }
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  NQ_HIP(ix, nq::launch_synth_reads(seed, family, member, rate14, offset, read_id, read_rate14, n, len, stride, out, ix->stream));
+  return NIQKI_OK;
+}
+
+int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate) {
+  if (!ix || !rate || what < 0 || what > 2 || !(ms > 0)) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = ensure(ix, ix->ws_misc, 256);
+  if (rc) return rc;
+  hipEvent_t a, b;
+  NQ_HIP(ix, hipEventCreate(&a));
+  NQ_HIP(ix, hipEventCreate(&b));
+  auto run = [&](uint32_t iters, double &t_ms, uint64_t &units) -> hipError_t {
+    hipError_t e = hipEventRecord(a, ix->stream);
+    if (e == hipSuccess) e = nq::launch_alu_probe(what, iters, (uint32_t *)ix->ws_misc.p, &units, ix->stream);
+    if (e == hipSuccess) e = hipEventRecord(b, ix->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(b);
+    float f = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&f, a, b);
+    t_ms = f;
+    return e;
+  };
+  double t = 0;
+  uint64_t units = 0;
+  uint32_t iters = 256;
+  NQ_HIP(ix, run(iters, t, units));                       // warm-up + calibration
+  iters = (uint32_t)std::min<double>(1e7, std::max<double>(256, iters * ms / std::max(t, 1e-3)));
+  NQ_HIP(ix, run(iters, t, units));
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  *rate = t > 0 ? (double)units / (t * 1e-3) : 0.0;
+  return NIQKI_OK;
+}
+
 int niqki_synth_genomes(niqki_index *ix, uint64_t seed, const uint32_t *family, const uint32_t *member,
                         const uint32_t *rate14, uint32_t n, uint64_t len, uint64_t stride, uint8_t *out,
                         int mem) {

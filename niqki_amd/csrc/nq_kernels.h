@@ -177,4 +177,14 @@ hipError_t launch_synth(uint64_t seed, const uint32_t *family, const uint32_t *m
                         const uint32_t *rate14, uint32_t n, uint64_t len, uint64_t stride,
                         uint8_t *out, hipStream_t stream);
 
+hipError_t launch_synth_reads(uint64_t seed, const uint32_t *family, const uint32_t *member, const uint32_t *rate14,
+                              const uint64_t *offset, const uint32_t *read_id, uint32_t read_rate14, uint32_t n,
+                              uint32_t len, uint64_t stride, uint8_t *out, hipStream_t stream);
+
+// ---- integer-ALU ceiling probes (nq_sketch.hip; measurement support) ----------------------------
+// what = 0: independent 32-bit adds; 1: 32-bit multiplies (v_mul_lo_u32); 2: the sketch kernel's
+// per-k-mer arithmetic alone (roll, canonical choice, high word of the filter hash, K = 31) with no
+// LDS, memory or compaction.  *units = adds / multiplies / k-mers executed; timed by the caller.
+hipError_t launch_alu_probe(int what, uint32_t iters, uint32_t *sink, uint64_t *units, hipStream_t stream);
+
 }  // namespace nq

@@ -719,6 +719,50 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   return hipGetLastError();
 }
 
+// ---- integer-ALU ceiling probes ---------------------------------------------------------------
+template <int WHAT>
+__global__ __launch_bounds__(1024) void alu_probe_kernel(uint32_t iters, uint32_t *sink) {
+  const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
+  if (WHAT == 2) {
+    // the long-record path's arithmetic per k-mer: rolling update of both words, canonical choice,
+    // high word of revhash64 and the filter compare (roll_step<31> + rev64_hi), 16 k-mers per round
+    Derived d{};
+    uint64_t fw = t * 0x9E3779B97F4A7C15ULL, rc = ~fw;
+    fw &= (1ULL << 62) - 1; rc &= (1ULL << 62) - 1;
+    uint32_t e = t * 2654435761u, pass = 0;
+    for (uint32_t i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const uint64_t canon = roll_step<31>((e >> (2 * j)) & 15u, fw, rc, d, 60);
+        pass += rev64_hi(canon) < (1u << 29);
+      }
+      e = e * 1664525u + 1013904223u;
+    }
+    if (pass == 0xFFFFFFFFu) sink[0] = pass;
+  } else {
+    uint32_t a0 = t, a1 = t * 3 + 1, a2 = t ^ 0x1234567, a3 = t + 77, a4 = t * 5, a5 = ~t, a6 = t + 9, a7 = t * 7;
+    for (uint32_t i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (WHAT == 0) { a0 += a1; a1 += a2; a2 += a3; a3 += a4; a4 += a5; a5 += a6; a6 += a7; a7 += a0; }
+        else { a0 *= a1; a1 *= a2; a2 *= a3; a3 *= a4; a4 *= a5; a5 *= a6; a6 *= a7; a7 *= (a0 | 1u); }  // data dependent: nothing folds
+      }
+    }
+    const uint32_t x = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    if (x == 0x12345u) sink[0] = x;
+  }
+}
+
+hipError_t launch_alu_probe(int what, uint32_t iters, uint32_t *sink, uint64_t *units, hipStream_t stream) {
+  const uint32_t blocks = 256 * 4;  // four 1024-thread workgroups per CU: 16 waves per SIMD-quartet, as the sketch kernel
+  const uint64_t threads = (uint64_t)blocks * 1024;
+  if (what == 0) { hipLaunchKernelGGL(alu_probe_kernel<0>, dim3(blocks), dim3(1024), 0, stream, iters, sink); *units = threads * iters * 64; }
+  else if (what == 1) { hipLaunchKernelGGL(alu_probe_kernel<1>, dim3(blocks), dim3(1024), 0, stream, iters, sink); *units = threads * iters * 64; }
+  else if (what == 2) { hipLaunchKernelGGL(alu_probe_kernel<2>, dim3(blocks), dim3(1024), 0, stream, iters, sink); *units = threads * iters * 16; }
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 __global__ void fill_u32_kernel(uint32_t *p, uint64_t n, uint32_t v) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t stride = (uint64_t)gridDim.x * blockDim.x;

@@ -49,6 +49,31 @@ NQ_HD uint64_t synth_block(uint64_t key_anc, uint64_t key_mut, uint32_t rate14, 
   return codes;
 }
 
+// second layer of substitutions on a block (a read sampled from a genome: the genome's own
+// substitutions first, then the read's, keyed by key_mut2)
+NQ_HD uint64_t synth_block2(uint64_t key_anc, uint64_t key_mut, uint32_t rate14, uint64_t key_mut2, uint32_t rate14_2,
+                            uint64_t block) {
+  uint64_t codes = synth_block(key_anc, key_mut, rate14, block);
+  if (rate14_2) {
+    for (uint32_t q = 0; q < 8; ++q) {
+      uint64_t r = smix(key_mut2 + block * 8 + q);
+      for (uint32_t j = 0; j < 4; ++j) {
+        uint32_t u = (uint32_t)(r >> (16 * j)) & 0xFFFFu;
+        if ((u & 0x3FFFu) < rate14_2) {
+          uint32_t pos = q * 4 + j;
+          uint64_t b = (codes >> (2 * pos)) & 3u;
+          b = (b + 1 + ((u >> 14) % 3u)) & 3u;
+          codes = (codes & ~(3ULL << (2 * pos))) | (b << (2 * pos));
+        }
+      }
+    }
+  }
+  return codes;
+}
+NQ_HD uint64_t synth_key_read(uint64_t seed, uint32_t family, uint32_t read_id) {
+  return smix(smix(seed + 2) ^ (((uint64_t)family << 32) | read_id));
+}
+
 NQ_HD uint8_t synth_ascii(uint32_t code) {
   // A C G T = 0x41 0x43 0x47 0x54
   return (uint8_t)((0x54474341u >> (8 * code)) & 0xFFu);

@@ -40,6 +40,36 @@ __global__ __launch_bounds__(256) void synth_kernel(uint64_t seed, const uint32_
   }
 }
 
+// one thread per read: bases [offset, offset + len) of genome (family, member, rate14) with the
+// read's own substitutions (read_id, read_rate14) on top
+__global__ __launch_bounds__(256) void synth_reads_kernel(uint64_t seed, const uint32_t *family, const uint32_t *member,
+                                                         const uint32_t *rate14, const uint64_t *offset,
+                                                         const uint32_t *read_id, uint32_t read_rate14, uint32_t n,
+                                                         uint32_t len, uint64_t stride, uint8_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t ka = synth_key_anc(seed, family[i]);
+  const uint64_t km = synth_key_mut(seed, family[i], member[i]);
+  const uint64_t kr = synth_key_read(seed, family[i], read_id[i]);
+  const uint64_t p0 = offset[i];
+  uint8_t *dst = out + (uint64_t)i * stride;
+  uint64_t blk = ~0ull, codes = 0;
+  for (uint32_t j = 0; j < len; ++j) {
+    const uint64_t p = p0 + j;
+    if ((p >> 5) != blk) { blk = p >> 5; codes = synth_block2(ka, km, rate14[i], kr, read_rate14, blk); }
+    dst[j] = synth_ascii((uint32_t)(codes >> (2 * (p & 31))) & 3u);
+  }
+}
+
+hipError_t launch_synth_reads(uint64_t seed, const uint32_t *family, const uint32_t *member, const uint32_t *rate14,
+                              const uint64_t *offset, const uint32_t *read_id, uint32_t read_rate14, uint32_t n,
+                              uint32_t len, uint64_t stride, uint8_t *out, hipStream_t stream) {
+  if (n == 0 || len == 0) return hipSuccess;
+  hipLaunchKernelGGL(synth_reads_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, seed, family, member, rate14, offset,
+                     read_id, read_rate14, n, len, stride, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_synth(uint64_t seed, const uint32_t *family, const uint32_t *member,
                         const uint32_t *rate14, uint32_t n, uint64_t len, uint64_t stride,
                         uint8_t *out, hipStream_t stream) {

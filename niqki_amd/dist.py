@@ -1,14 +1,22 @@
-"""Slot-range sharding of one index over the GPUs of a node (one process per
-GPU, torch.distributed; backend "nccl" is RCCL over xGMI, "gloo" on CPU).
+"""Slot-range sharding of one index over the GPUs of a node, one process per GPU
+(torch.distributed.run).
 
-Rank r of G owns sketch slots [r*F/G, (r+1)*F/G) of EVERY indexed genome
-(SURVEY.md 8e).  The hit count of a genome is a sum over slots, so a query step
-has exactly one exchange of partial results:
+The exchange itself lives behind the C ABI (niqki_group_*, niqki_amd/csrc/nq_group.hip): RCCL
+all-to-all of int16 sketch slices, slot-shard gather, sparse candidate exchange or dense
+reduce-scatter of packed u16 hit vectors, per-rank threshold.  On a GPU, ShardedQuery is a thin
+caller of it: torch.distributed only carries the 128-byte group id from rank 0 to the others.
+
+The same protocol written with torch collectives (class TorchExchange below) is what the CPU
+tests run over gloo with a stand-in engine: it documents the protocol and lets the N > 1 logic
+be checked without GPUs.
+
+Rank r of G owns sketch slots [r*F/G, (r+1)*F/G) of EVERY indexed genome.  The hit
+count of a genome is a sum over slots, so a query step has exactly one exchange of partial results:
 
   1. every rank sketches its share of the query batch                 (no comm)
   2. sketch exchange: each rank needs only ITS slot range of every query, so the
-     int32 sketches go through one all_to_all of F/G-slot slices (4F/G bytes per
-     query and peer) instead of an all_gather of whole sketches
+     sketches go through one all_to_all of F/G-slot slices (2F/G bytes per
+     query and peer as int16) instead of an all_gather of whole sketches
   3. gather-histogram on the local slot range for ALL queries          (no comm)
   4. cross-shard sum of the per-genome hit vectors, scattered by query:
        "dense"   reduce_scatter of the u16 counters viewed as int32 pairs -- a
@@ -20,13 +28,9 @@ has exactly one exchange of partial results:
                  rank, so ranks all_gather those (few) candidate ids, look their
                  own partial counts up for the union, and reduce_scatter just
                  these values; exact, a few KB per query.  Needs
-                 min_score >= 4*G; a candidate list overflowing its capacity is
-                 reported (`overflow`) and that step must be redone densely.
-       "all_to_all" / "reduce_scatter" are the two transports of the dense form.
+                 min_score >= 4*G; a step whose candidate lists overflow their
+                 capacity is redone densely.
   5. every rank thresholds + orders the hits of its share of the queries
-
-The engine argument is anything with the *_dev methods of niqki_amd.Engine (the
-tests drive this module on CPU tensors over gloo with a stand-in engine).
 """
 import torch
 import torch.distributed as dist
@@ -43,6 +47,57 @@ def padded_batch(nq, world):
 
 
 class ShardedQuery:
+    """One rank's end of a slot-sharded query.  With a real engine on a GPU: the C ABI group
+    (RCCL inside libniqki_hip.so).  Otherwise (CPU tensors, stand-in engine): TorchExchange."""
+
+    def __new__(cls, engine, n_genomes, F, device, group=None, **kw):
+        if cls is ShardedQuery and not (getattr(engine, "h", None) is not None and torch.device(device).type == "cuda"):
+            return TorchExchange(engine, n_genomes, F, device, group=group, **kw)
+        return super().__new__(cls)
+
+    def __init__(self, engine, n_genomes, F, device, group=None, exchange="auto", min_score=None,
+                 cand_cap=1024, compact_sketches=True):
+        import numpy as np
+        from . import capi
+        self.e = engine
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = torch.device(device)
+        ident = torch.zeros(capi.GROUP_ID_BYTES, dtype=torch.uint8, device=self.device)
+        if self.rank == 0:
+            ident.copy_(torch.from_numpy(capi.group_new_id()))
+        dist.broadcast(ident, src=0, group=group)           # the only torch collective on this path
+        self.g = capi.Group([engine], first_rank=self.rank, world=self.world, group_id=ident.cpu().numpy().astype(np.uint8))
+        self.g.set_option("exchange", {"auto": 0, "sparse": 1, "reduce_scatter": 2, "dense": 2}[exchange])
+        self.g.set_option("cand_cap", cand_cap)
+        self.cand_cap = cand_cap
+        self.exchange = "sparse" if self.g.stat("sparse") else "reduce_scatter"
+
+    @property
+    def overflows(self):
+        return self.g.stat("overflows")
+
+    def step(self, local_sketches, hit_off, hit_counts, hit_gids, capacity):
+        """One query batch.  local_sketches: [per, F] int32 of this rank's share (device).
+        Fills hit_off[per+1] (int64), hit_counts / hit_gids (int32, capacity).  The engine's
+        stream is (re)bound to torch's current stream so that the library's kernels and RCCL
+        calls order against the caller's torch work."""
+        self.e.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.g.query_dev([local_sketches], local_sketches.shape[0], [hit_off], [hit_counts], [hit_gids], capacity)
+
+    def insert(self, local_sketches, n_total):
+        """Batch of world * per sketches, this rank holding rows [rank*per, (rank+1)*per); the
+        first n_total rows (rank major) are inserted."""
+        self.e.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.g.insert_dev([local_sketches], local_sketches.shape[0], n_total)
+
+    def close(self):
+        self.g.close()
+
+
+class TorchExchange:
+    """The protocol with torch collectives (gloo on CPU, or nccl): reference for the tests."""
+
     def __init__(self, engine, n_genomes, F, device, group=None, exchange="auto", min_score=None,
                  cand_cap=1024, compact_sketches=False):
         self.e = engine
@@ -52,7 +107,7 @@ class ShardedQuery:
         self.N = n_genomes
         self.F = F
         self.stride = (n_genomes + 1) & ~1
-        self.device = device
+        self.device = torch.device(device)
         self.min_score = engine.min_score if min_score is None else min_score
         self.cand_cap = cand_cap
         # sketch cells are -1 or a fingerprint below 2^W <= 2^15: they travel as int16 when the
