@@ -286,6 +286,9 @@ int niqki_import_dump(const niqki_params *params, const uint8_t *buf,
  * buffer (13.6 GB at 100k genomes): the 24-byte header, the byte position of
  * every slot's first bucket in the payload (2^S + 1 entries, header excluded),
  * and the payload of a range of whole slots. */
+/* On a slot-range handle (one shard of a multi-GPU index) the layout and the slot numbers of
+ * niqki_export_dump_slots are relative to the shard's first slot (2^S -> slot_end - slot_begin):
+ * the shards' payloads in rank order are the dump of the whole index. */
 int niqki_export_dump_header(niqki_index *ix, uint8_t header[24]);
 int niqki_export_dump_layout(niqki_index *ix, uint64_t *slot_bytes);
 int niqki_export_dump_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end,
@@ -360,6 +363,17 @@ int niqki_group_insert(niqki_group *g, const int32_t *const *local_sketches, uin
 int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint32_t per,
                       uint64_t *const *hit_off, uint32_t *const *hit_counts,
                       uint32_t *const *hit_gids, uint64_t capacity, int mem);
+
+/* The two calls above on the shards' STAGED batches (niqki_stage_raw on each shard handle --
+ * how the `niqki` host program feeds a multi-GPU index from files; all ranks in one process):
+ * rank r contributes the first n_entry[r] sketches of its staged batch (0: none) as rows
+ * [r*per, r*per + n_entry[r]) of the batch, the rest of its rows is padding.  An insert gives
+ * the entries their ids rank after rank (rank 0's entries first), like the id counter of
+ * src/niqki_index.cpp:396-401 does in file order. */
+int niqki_group_staged_insert(niqki_group *g, uint32_t per, const uint32_t *n_entry);
+int niqki_group_staged_query(niqki_group *g, uint32_t per, const uint32_t *n_entry, uint64_t *const *hit_off,
+                             uint32_t *const *hit_counts, uint32_t *const *hit_gids, uint64_t capacity,
+                             int mem);
 
 /* ---- measurement support -------------------------------------------------- */
 

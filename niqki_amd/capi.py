@@ -108,6 +108,8 @@ ABI = [
     ("niqki_group_get_stat", _int, [_vp, C.c_char_p, C.POINTER(_u64)]),
     ("niqki_group_insert", _int, [_vp, _vp, _u32, _u32]),
     ("niqki_group_query", _int, [_vp, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_group_staged_insert", _int, [_vp, _u32, _vp]),
+    ("niqki_group_staged_query", _int, [_vp, _u32, _vp, _vp, _vp, _vp, _u64, _int]),
     ("niqki_profile_enable", _int, [_vp, _int]),
     ("niqki_profile_reset", _int, [_vp]),
     ("niqki_profile_read", _int, [_vp, _int, C.POINTER(_dbl), C.POINTER(_u64)]),

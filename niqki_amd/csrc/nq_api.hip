@@ -921,7 +921,8 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   return NIQKI_OK;
 }
 
-namespace {
+extern "C++" {
+namespace nqi {
 // sketches of the staged entries into their own buffer (once per staged batch; the other
 // entry points keep using ws_sk, so they cannot disturb a staged batch)
 int staged_sketch_ws(niqki_index *ix) {
@@ -936,7 +937,8 @@ int staged_sketch_ws(niqki_index *ix) {
   ix->staged.sketched = true;
   return NIQKI_OK;
 }
-}  // namespace
+}  // namespace nqi
+}  // extern "C++"
 
 int niqki_staged_sketch(niqki_index *ix, int32_t *sketches, int mem) {
   if (!ix) return NIQKI_E_INVALID;
@@ -1074,7 +1076,6 @@ int niqki_export_dump_header(niqki_index *ix, uint8_t header[24]) {
 
 int niqki_export_dump_layout(niqki_index *ix, uint64_t *slot_bytes) {
   if (!ix || !slot_bytes) return NIQKI_E_INVALID;
-  if (ix->d.slot_begin != 0 || ix->d.slot_end != ix->d.F) return fail(ix, NIQKI_E_STATE, "export needs a whole-range handle");
   NQ_HIP(ix, hipSetDevice(ix->device));
   std::vector<uint64_t> sw;
   int rc = export_layout(ix, sw);
@@ -1085,8 +1086,7 @@ int niqki_export_dump_layout(niqki_index *ix, uint64_t *slot_bytes) {
 
 int niqki_export_dump_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end, uint8_t *buf,
                             uint64_t capacity, uint64_t *size) {
-  if (!ix || !size || slot_begin > slot_end || slot_end > ix->d.F) return NIQKI_E_INVALID;
-  if (ix->d.slot_begin != 0 || ix->d.slot_end != ix->d.F) return fail(ix, NIQKI_E_STATE, "export needs a whole-range handle");
+  if (!ix || !size || slot_begin > slot_end || slot_end > ix->d.slot_end - ix->d.slot_begin) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
   std::vector<uint64_t> sw;
   int rc = export_layout(ix, sw);

@@ -162,7 +162,7 @@ struct niqki_group {
   uint64_t overflows = 0;            // sparse steps redone densely
   std::string err;
   struct Ws {
-    Buf send, recv, allsk, counts, cand, ncand, cand_all, ncand_all, mine, tot, red, flag, hitoff, hc, hg;
+    Buf send, recv, allsk, counts, cand, ncand, cand_all, ncand_all, mine, tot, red, flag, hitoff, hc, hg, stpad;
     hipEvent_t ev = nullptr;
   };
   std::vector<Ws> ws;
@@ -391,7 +391,7 @@ void niqki_group_destroy(niqki_group *g) {
     }
     auto &w = g->ws[l];
     for (Buf *b : {&w.send, &w.recv, &w.allsk, &w.counts, &w.cand, &w.ncand, &w.cand_all, &w.ncand_all, &w.mine, &w.tot, &w.red,
-                   &w.flag, &w.hitoff, &w.hc, &w.hg})
+                   &w.flag, &w.hitoff, &w.hc, &w.hg, &w.stpad})
       if (b->p) (void)hipFree(b->p);
     if (w.ev) (void)hipEventDestroy(w.ev);
     if (l < g->comm.size() && g->comm[l]) (void)rccl().CommDestroy(g->comm[l]);
@@ -556,6 +556,59 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
     if (rc == NIQKI_E_CAPACITY) return gfail(g, rc, "hit capacity too small; hit_off holds the sizes needed");
   }
   return NIQKI_OK;
+}
+
+namespace {
+// per local rank: `per` sketch rows = the first n_entry[l] sketches of the shard's staged batch
+// (niqki_stage_raw on that shard), the rest empty sketches (-1)
+int staged_rows(niqki_group *g, uint32_t per, const uint32_t *n_entry, std::vector<const int32_t *> &rows) {
+  rows.assign(g->n_local, nullptr);
+  for (uint32_t l = 0; l < g->n_local; ++l) {
+    niqki_index *ix = g->sh[l];
+    NQ_GH(g, hipSetDevice(ix->device));
+    const uint32_t n = n_entry ? n_entry[l] : 0;
+    if (n > per) return gfail(g, NIQKI_E_INVALID, "a rank's staged entries exceed `per`");
+    const size_t row = (size_t)ix->d.F * 4;
+    NQ_G(g, l, nqi::ensure(ix, g->ws[l].stpad, std::max<size_t>((size_t)per * row, 4)));
+    if (n) {
+      if (!ix->staged.valid || ix->staged.n_entry < n) return gfail(g, NIQKI_E_STATE, "rank " + std::to_string(g->first + l) + " has no staged batch of that size");
+      NQ_G(g, l, nqi::staged_sketch_ws(ix));
+      NQ_GH(g, hipMemcpyAsync(g->ws[l].stpad.p, ix->ws_stsk.p, (size_t)n * row, hipMemcpyDeviceToDevice, ix->stream));
+    }
+    if (n < per) NQ_GH(g, hipMemsetAsync((char *)g->ws[l].stpad.p + (size_t)n * row, 0xFF, (size_t)(per - n) * row, ix->stream));
+    rows[l] = (const int32_t *)g->ws[l].stpad.p;
+  }
+  return NIQKI_OK;
+}
+}  // namespace
+
+int niqki_group_staged_insert(niqki_group *g, uint32_t per, const uint32_t *n_entry) {
+  if (!g || !n_entry) return NIQKI_E_INVALID;
+  if (g->n_local != g->world) return gfail(g, NIQKI_E_STATE, "staged group calls need all ranks in one process");
+  std::vector<const int32_t *> rows;
+  int rc = staged_rows(g, per, n_entry, rows);
+  if (rc) return rc;
+  if (per == 0) return NIQKI_OK;
+  if ((rc = exchange_slices(g, rows.data(), per))) return rc;
+  for (uint32_t l = 0; l < g->n_local; ++l) {
+    niqki_index *ix = g->sh[l];
+    NQ_GH(g, hipSetDevice(ix->device));
+    const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
+    // ids follow the entries: rank after rank, each rank's valid rows
+    for (uint32_t s = 0; s < g->world; ++s)
+      NQ_G(g, l, nqi::insert_dev(ix, (const int32_t *)g->ws[l].allsk.p + (size_t)s * per * f_local, f_local, 0, n_entry[s]));
+  }
+  return NIQKI_OK;
+}
+
+int niqki_group_staged_query(niqki_group *g, uint32_t per, const uint32_t *n_entry, uint64_t *const *hit_off,
+                             uint32_t *const *hit_counts, uint32_t *const *hit_gids, uint64_t capacity, int mem) {
+  if (!g || !n_entry) return NIQKI_E_INVALID;
+  if (g->n_local != g->world) return gfail(g, NIQKI_E_STATE, "staged group calls need all ranks in one process");
+  std::vector<const int32_t *> rows;
+  int rc = staged_rows(g, per, n_entry, rows);
+  if (rc) return rc;
+  return niqki_group_query(g, rows.data(), per, hit_off, hit_counts, hit_gids, capacity, mem);
 }
 
 }  // extern "C"

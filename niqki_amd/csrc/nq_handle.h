@@ -84,6 +84,8 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint
 int hits_dev(niqki_index *ix, const uint16_t *counts, uint32_t nq, uint64_t stride, uint32_t gid_begin,
              uint32_t n_gids, unsigned long long *hit_off, uint32_t *hc, uint32_t *hg, uint64_t capacity,
              bool check_capacity, uint64_t *total_out);
+// sketches of the handle's staged batch (niqki_stage_raw) into ix->ws_stsk, once per batch
+int staged_sketch_ws(niqki_index *ix);
 // appends n device-resident sketches (same addressing as counts_dev) to the sketch store
 int insert_dev(niqki_index *ix, const int32_t *sketches, uint32_t sk_stride, uint32_t sk_off, uint32_t n);
 

@@ -222,19 +222,45 @@ void Index::check(int rc, const char *what) const {
   throw std::runtime_error(std::string(what) + ": " + niqki_status_string(rc) + " (" + niqki_last_error(h_) + ")");
 }
 
+void Index::check_group(int rc, const char *what) const {
+  if (rc == NIQKI_OK) return;
+  throw std::runtime_error(std::string(what) + ": " + niqki_status_string(rc) + " (" + niqki_group_last_error(grp_) + ")");
+}
+
+// One handle per GPU: with n_gpus > 1 shard r owns the slots of rank r (niqki_group_slot_range) on device
+// device + r.  dump_header != nullptr: the handles are made for a streamed dump import.
+void Index::make_shards(const niqki_params &p0, int device, int n_gpus, const uint8_t *dump_header) {
+  if (n_gpus < 1 || n_gpus > 64) throw std::runtime_error("--gpus must be in 1..64");
+  for (int r = 0; r < n_gpus; ++r) {
+    niqki_params p = p0;
+    p.device = n_gpus > 1 ? (device < 0 ? 0 : device) + r : device;
+    // test hook: all shards on one device (a 1-GPU box emulating N; the library then moves the
+    // exchanged data with device-to-device copies instead of RCCL)
+    if (n_gpus > 1 && std::getenv("NIQKI_SHARDS_ON_ONE_DEVICE")) p.device = device;
+    if (n_gpus > 1) niqki_group_slot_range((uint32_t)r, (uint32_t)n_gpus, dump_header ? ((const uint32_t *)dump_header)[0] : p.S, &p.slot_begin, &p.slot_end);
+    niqki_index *h = nullptr;
+    const int rc = dump_header ? niqki_import_begin(&p, dump_header, &h) : niqki_create(&p, &h);
+    if (rc) throw std::runtime_error(std::string(dump_header ? "niqki_import_begin: " : "niqki_create: ") + niqki_status_string(rc) + " (" + niqki_last_error(nullptr) + ")");
+    sh_.push_back(h);
+  }
+  h_ = sh_[0];
+}
+
 Index::Index(uint32_t ilF, uint32_t iK, uint32_t iW, uint32_t iH, const std::string &out_filename,
-             double min_fract, int device) {
+             double min_fract, int device, int n_gpus) {
   niqki_params p{};
   p.K = iK; p.S = ilF; p.W = iW; p.H = iH;
   p.min_score = niqki_min_score(min_fract, ilF);
-  p.device = device;
-  int rc = niqki_create(&p, &h_);
-  if (rc) throw std::runtime_error(std::string("niqki_create: ") + niqki_status_string(rc) + " (" + niqki_last_error(nullptr) + ")");
+  make_shards(p, device, n_gpus, nullptr);
+  if (n_gpus > 1) {
+    const int rc = niqki_group_create(sh_.data(), (uint32_t)sh_.size(), 0, (uint32_t)sh_.size(), nullptr, &grp_);
+    if (rc) throw std::runtime_error(std::string("niqki_group_create: ") + niqki_status_string(rc) + " (" + niqki_last_error(h_) + ")");
+  }
   K = iK; W = iW; H = iH; lF = ilF; F = 1u << ilF; min_score = p.min_score;
   outfile.reset(new GzWriter(out_filename));
 }
 
-Index::Index(const std::string &dump_file, bool pretty, const std::string &out_filename, int device) {
+Index::Index(const std::string &dump_file, bool pretty, const std::string &out_filename, int device, int n_gpus) {
   pretty_printing = pretty;
   // The dump is streamed: header, then the buckets in groups of whole slots (the
   // payload of a 100k-genome index is 13.6 GB), then the names.
@@ -242,9 +268,7 @@ Index::Index(const std::string &dump_file, bool pretty, const std::string &out_f
   uint8_t hdr[24];
   if (in.read(hdr, 24) != 24) throw std::runtime_error("'" + dump_file + "' is not a niqki dump");
   niqki_params p{};
-  p.device = device;
-  int rc = niqki_import_begin(&p, hdr, &h_);
-  if (rc) throw std::runtime_error(std::string("niqki_import_begin: ") + niqki_status_string(rc) + " (" + niqki_last_error(nullptr) + ")");
+  make_shards(p, device, n_gpus, hdr);   // every shard keeps its own slots of the stream
   niqki_params q{};
   niqki_get_params(h_, &q);
   K = q.K; W = q.W; H = q.H; lF = q.S; F = 1u << q.S; min_score = q.min_score;
@@ -253,7 +277,7 @@ Index::Index(const std::string &dump_file, bool pretty, const std::string &out_f
   uint32_t s0 = 0;
   auto flush = [&](uint32_t s1) {
     uint64_t used = 0;
-    check(niqki_import_slots(h_, s0, s1, chunk.data(), chunk.size(), &used), "niqki_import_slots");
+    for (auto *h : sh_) check(niqki_import_slots(h, s0, s1, chunk.data(), chunk.size(), &used), "niqki_import_slots");
     chunk.clear();
     s0 = s1;
   };
@@ -277,18 +301,23 @@ Index::Index(const std::string &dump_file, bool pretty, const std::string &out_f
     in.getline(name);
     filenames.push_back(name);
   }
+  if (n_gpus > 1) {
+    const int rc = niqki_group_create(sh_.data(), (uint32_t)sh_.size(), 0, (uint32_t)sh_.size(), nullptr, &grp_);
+    if (rc) throw std::runtime_error(std::string("niqki_group_create: ") + niqki_status_string(rc) + " (" + niqki_last_error(h_) + ")");
+  }
   outfile.reset(new GzWriter(out_filename));
 }
 
 Index::~Index() {
   if (outfile) outfile->close();
-  if (h_) niqki_destroy(h_);
+  if (grp_) niqki_group_destroy(grp_);
+  for (auto *h : sh_) niqki_destroy(h);
 }
 
 // src/niqki_index.cpp:126-138, including its message
 void Index::select_best_H(double genome_size) {
   uint32_t chosen = H;
-  check(niqki_select_best_H(h_, genome_size, &chosen), "select_best_H");
+  for (auto *h : sh_) check(niqki_select_best_H(h, genome_size, &chosen), "select_best_H");
   H = chosen;
   std::cout << "I chosed H=" << H << std::endl;
 }
@@ -301,13 +330,22 @@ void Index::compute_sketch(const std::string &reference, std::vector<int32_t> &s
 
 void Index::insert_sketch(const std::vector<int32_t> &sketch, uint32_t genome_id) {
   if (genome_id != niqki_genome_count(h_)) throw std::runtime_error("insert_sketch: ids must be consecutive");
-  check(niqki_insert(h_, sketch.data(), 1, NIQKI_MEM_HOST), "niqki_insert");
+  for (auto *h : sh_) check(niqki_insert(h, sketch.data(), 1, NIQKI_MEM_HOST), "niqki_insert");  // each shard keeps its slots
 }
 
 query_output Index::query_sketch(const std::vector<int32_t> &sketch) const {
   const uint32_t n = niqki_genome_count(h_);
   std::vector<uint32_t> hc(n ? n : 1), hg(n ? n : 1);
   uint64_t off[2] = {0, 0};
+  if (grp_) {  // the shards' partial hit vectors summed on the host (a single sketch: API parity, not a fast path)
+    const uint64_t stride = ((uint64_t)n + 1) & ~1ull;
+    std::vector<uint16_t> sum(std::max<uint64_t>(stride, 2), 0), part(std::max<uint64_t>(stride, 2));
+    for (auto *h : sh_) {
+      check(niqki_query_counts(h, sketch.data(), 1, part.data(), stride, NIQKI_MEM_HOST), "niqki_query_counts");
+      for (uint32_t i = 0; i < n; ++i) sum[i] = (uint16_t)(sum[i] + part[i]);
+    }
+    check(niqki_hits_from_counts(h_, sum.data(), 1, stride, 0, n, off, hc.data(), hg.data(), n, NIQKI_MEM_HOST), "niqki_hits_from_counts");
+  } else
   check(niqki_query(h_, sketch.data(), 1, off, hc.data(), hg.data(), n, NIQKI_MEM_HOST), "niqki_query");
   query_output r;
   for (uint64_t i = 0; i < off[1]; ++i) r.push_back({hc[i], hg[i]});
@@ -318,7 +356,38 @@ query_output Index::query_sketch(const std::vector<int32_t> &sketch) const {
 
 // stage the files of a batch: one entry per file (insert_file_whole / query_file_whole,
 // src/niqki_index.cpp:442-456, :505-519)
+// multi-GPU: the batch's files are dealt to the shards in list order, `per` to each
+static void rank_share(size_t n, size_t per, size_t r, size_t &lo, size_t &hi) {
+  lo = std::min(n, r * per);
+  hi = std::min(n, lo + per);
+}
+
 void Index::stage_batch(Batch &b) {
+  if (grp_) {
+    const size_t n = b.files.size(), per = per_rank(n);
+    for (size_t r = 0; r < sh_.size(); ++r) {
+      size_t lo, hi;
+      rank_share(n, per, r, lo, hi);
+      if (lo == hi) continue;
+      std::vector<const uint8_t *> ptr(hi - lo);
+      std::vector<uint64_t> off(hi - lo + 1, 0);
+      std::vector<uint8_t> type(hi - lo);
+      for (size_t i = lo; i < hi; ++i) {
+        ptr[i - lo] = b.files[i]->buf.p;
+        off[i - lo + 1] = off[i - lo] + b.files[i]->buf.size;
+        type[i - lo] = (uint8_t)data_type(b.names[i]);
+      }
+      niqki_raw_batch rb{};
+      rb.file_ptr = ptr.data();
+      rb.file_off = off.data();
+      rb.file_type = type.data();
+      rb.n_files = (uint32_t)(hi - lo);
+      niqki_stage_info info{};
+      const int rc = niqki_stage_raw(sh_[r], &rb, NIQKI_MEM_HOST, &info, nullptr);
+      if (rc) throw std::runtime_error(std::string("niqki_stage_raw: ") + niqki_status_string(rc) + " (" + niqki_last_error(sh_[r]) + ")");
+    }
+    return;
+  }
   const size_t n = b.files.size();
   std::vector<const uint8_t *> ptr(n);
   std::vector<uint64_t> off(n + 1, 0);
@@ -340,8 +409,54 @@ void Index::stage_batch(Batch &b) {
 void Index::flush_insert(Batch &b) {
   if (b.files.empty()) return;
   stage_batch(b);
-  check(niqki_staged_insert(h_), "niqki_staged_insert");
+  if (grp_) {
+    const size_t n = b.files.size(), per = per_rank(n);
+    std::vector<uint32_t> n_entry(sh_.size());
+    for (size_t r = 0; r < sh_.size(); ++r) {
+      size_t lo, hi;
+      rank_share(n, per, r, lo, hi);
+      n_entry[r] = (uint32_t)(hi - lo);
+    }
+    check_group(niqki_group_staged_insert(grp_, (uint32_t)per, n_entry.data()), "niqki_group_staged_insert");
+  } else {
+    check(niqki_staged_insert(h_), "niqki_staged_insert");
+  }
   for (auto &nm : b.names) filenames.push_back(nm);
+}
+
+// hits of the entries staged on the shards, rank after rank = entry order
+void Index::group_query_staged(uint32_t per, const std::vector<uint32_t> &n_entry, Hits &h) {
+  const size_t G = sh_.size();
+  const uint64_t N = niqki_genome_count(h_);
+  uint64_t cap = std::max<uint64_t>(uint64_t(1) << 20, (uint64_t)per * 64);
+  std::vector<std::vector<uint64_t>> off(G, std::vector<uint64_t>(per + 1));
+  std::vector<std::vector<uint32_t>> hc(G), hg(G);
+  for (;;) {
+    std::vector<uint64_t *> p_off(G);
+    std::vector<uint32_t *> p_hc(G), p_hg(G);
+    for (size_t r = 0; r < G; ++r) {
+      hc[r].resize(cap);
+      hg[r].resize(cap);
+      p_off[r] = off[r].data(); p_hc[r] = hc[r].data(); p_hg[r] = hg[r].data();
+    }
+    const int rc = niqki_group_staged_query(grp_, per, n_entry.data(), p_off.data(), p_hc.data(), p_hg.data(), cap, NIQKI_MEM_HOST);
+    if (rc == NIQKI_E_CAPACITY && cap < (uint64_t)per * N) {
+      for (size_t r = 0; r < G; ++r) cap = std::max(cap, off[r][per]);
+      cap *= 2;
+      continue;
+    }
+    check_group(rc, "niqki_group_staged_query");
+    break;
+  }
+  h.off.assign(1, 0);
+  h.hc.clear();
+  h.hg.clear();
+  for (size_t r = 0; r < G; ++r)
+    for (uint32_t i = 0; i < n_entry[r]; ++i) {
+      h.hc.insert(h.hc.end(), hc[r].begin() + off[r][i], hc[r].begin() + off[r][i + 1]);
+      h.hg.insert(h.hg.end(), hg[r].begin() + off[r][i], hg[r].begin() + off[r][i + 1]);
+      h.off.push_back(h.hc.size());
+    }
 }
 
 // hits of the staged entries, written in entry order
@@ -380,6 +495,20 @@ void Index::output_staged(const std::vector<std::string> &names) {
 void Index::flush_query(Batch &b) {
   if (b.files.empty()) return;
   stage_batch(b);
+  if (grp_) {
+    const size_t n = b.files.size(), per = per_rank(n);
+    std::vector<uint32_t> n_entry(sh_.size());
+    for (size_t r = 0; r < sh_.size(); ++r) {
+      size_t lo, hi;
+      rank_share(n, per, r, lo, hi);
+      n_entry[r] = (uint32_t)(hi - lo);
+    }
+    Hits h;
+    h.names = b.names;
+    group_query_staged((uint32_t)per, n_entry, h);
+    write_hits(h);
+    return;
+  }
   output_staged(b.names);
 }
 
@@ -588,7 +717,64 @@ void Index::stream_lines(const std::string &filestr, bool insert) {
       last = pc->last;
       if (!pc->err.empty()) throw std::runtime_error(pc->err);
       size_t at = 0;
-      do {
+      while (grp_ && at < pc->buf.size) {
+        // multi-GPU: the rest of the piece is cut into one run of whole records per GPU; every GPU
+        // frames and sketches its run, the entries keep the order of the file
+        const size_t G = sh_.size(), left = pc->buf.size - at;
+        const uint8_t *base = pc->buf.p + at;
+        std::vector<size_t> cutp(G + 1, 0);
+        cutp[G] = left;
+        for (size_t r = 1; r < G; ++r) cutp[r] = std::max(cutp[r - 1], record_cut(base, left * r / G, type));
+        std::vector<niqki_stage_info> info(G);
+        std::vector<std::vector<uint64_t>> hdrs(G, std::vector<uint64_t>(max_entries));
+        std::vector<uint32_t> n_entry(G, 0);
+        size_t done = left;       // bytes of the piece this round covers
+        for (size_t r = 0; r < G; ++r) {
+          if (cutp[r + 1] == cutp[r]) continue;
+          const uint64_t off[2] = {0, cutp[r + 1] - cutp[r]};
+          niqki_raw_batch rb{};
+          rb.raw = base + cutp[r];
+          rb.file_off = off;
+          rb.file_type = &type_u8;
+          rb.n_files = 1;
+          rb.lines = 1;
+          rb.final = 1;
+          rb.max_entries = max_entries;
+          const int rc = niqki_stage_raw(sh_[r], &rb, NIQKI_MEM_HOST, &info[r], hdrs[r].data());
+          if (rc) throw std::runtime_error(std::string("niqki_stage_raw: ") + niqki_status_string(rc) + " (" + niqki_last_error(sh_[r]) + ")");
+          n_entry[r] = info[r].n_entry;
+          if (info[r].consumed < off[1]) {   // more entries than one call takes: the round ends inside this run
+            done = cutp[r] + info[r].consumed;
+            break;
+          }
+        }
+        uint32_t per = 0, total = 0;
+        for (size_t r = 0; r < G; ++r) { per = std::max(per, n_entry[r]); total += n_entry[r]; }
+        n_entries_total += total;
+        if (total) {
+          Hits *h = insert ? nullptr : out_free.pop();
+          std::vector<std::string> local;
+          std::vector<std::string> &names = h ? h->names : local;
+          names.clear();
+          for (size_t r = 0; r < G; ++r)
+            for (uint32_t e = 0; e < n_entry[r]; ++e) {
+              const uint8_t *b = base + cutp[r] + hdrs[r][e];
+              const size_t room = left - cutp[r] - hdrs[r][e];
+              const uint8_t *nl = (const uint8_t *)memchr(b, '\n', room);
+              names.emplace_back((const char *)b, nl ? (size_t)(nl - b) : room);
+            }
+          if (insert) {
+            check_group(niqki_group_staged_insert(grp_, per, n_entry.data()), "niqki_group_staged_insert");
+            for (auto &nm : names) filenames.push_back(nm);
+          } else {
+            try { group_query_staged(per, n_entry, *h); } catch (...) { out_free.push(h); throw; }
+            out_q.push(h);
+          }
+        }
+        if (done == 0 && total == 0) break;   // nothing but a header without end
+        at += done;
+      }
+      if (!grp_) do {
         const uint64_t off[2] = {0, pc->buf.size - at};
         niqki_raw_batch rb{};
         rb.raw = pc->buf.p + at;
@@ -690,9 +876,15 @@ void Index::query_matrix() {
   const uint64_t stride = ((uint64_t)n + 1) & ~1ull;
   const uint32_t rows = 256;
   std::vector<uint16_t> counts((size_t)rows * std::max<uint64_t>(stride, 2));
+  std::vector<uint16_t> part(grp_ ? counts.size() : 0);
   for (uint32_t t0 = 0; t0 < n; t0 += rows) {
     const uint32_t t1 = std::min(n, t0 + rows);
     check(niqki_matrix_range(h_, t0, t1, counts.data(), stride, NIQKI_MEM_HOST), "niqki_matrix_range");
+    for (size_t r = 1; r < sh_.size(); ++r) {   // slot shards: co-occurrence counts add up over the slots
+      check(niqki_matrix_range(sh_[r], t0, t1, part.data(), stride, NIQKI_MEM_HOST), "niqki_matrix_range");
+      const size_t m = (size_t)(t1 - t0) * stride;
+      for (size_t i = 0; i < m; ++i) counts[i] = (uint16_t)(counts[i] + part[i]);
+    }
     for (uint32_t t = t0; t < t1; ++t) output_matrix_row(counts.data() + (size_t)(t - t0) * stride, filenames[t]);
   }
 }
@@ -707,21 +899,26 @@ void Index::dump_index_disk(const std::string &filestr) {
   ParallelGzWriter out(filestr, threads);
   std::vector<uint8_t> block(24);
   check(niqki_export_dump_header(h_, block.data()), "niqki_export_dump_header");
-  std::vector<uint64_t> slot_bytes((size_t)F + 1);
-  check(niqki_export_dump_layout(h_, slot_bytes.data()), "niqki_export_dump_layout");
   const uint64_t target = uint64_t(32) << 20;
-  uint32_t s0 = 0;
-  while (s0 < F) {
-    uint32_t s1 = s0 + 1;
-    while (s1 < F && slot_bytes[s1 + 1] - slot_bytes[s0] <= target) ++s1;
-    const size_t at = block.size();
-    const uint64_t want = slot_bytes[s1] - slot_bytes[s0];
-    block.resize(at + want);
-    uint64_t size = 0;
-    check(niqki_export_dump_slots(h_, s0, s1, block.data() + at, want, &size), "niqki_export_dump_slots");
-    out.add(std::move(block));
-    block.clear();
-    s0 = s1;
+  for (size_t r = 0; r < sh_.size(); ++r) {   // the shards' slots in rank order are the whole payload
+    uint32_t sb = 0, se = F;
+    if (grp_) niqki_group_slot_range((uint32_t)r, (uint32_t)sh_.size(), lF, &sb, &se);
+    const uint32_t f_local = se - sb;
+    std::vector<uint64_t> slot_bytes((size_t)f_local + 1);
+    check(niqki_export_dump_layout(sh_[r], slot_bytes.data()), "niqki_export_dump_layout");
+    uint32_t s0 = 0;
+    while (s0 < f_local) {
+      uint32_t s1 = s0 + 1;
+      while (s1 < f_local && slot_bytes[s1 + 1] - slot_bytes[s0] <= target) ++s1;
+      const size_t at = block.size();
+      const uint64_t want = slot_bytes[s1] - slot_bytes[s0];
+      block.resize(at + want);
+      uint64_t size = 0;
+      check(niqki_export_dump_slots(sh_[r], s0, s1, block.data() + at, want, &size), "niqki_export_dump_slots");
+      out.add(std::move(block));
+      block.clear();
+      s0 = s1;
+    }
   }
   for (const auto &nm : filenames) {
     block.insert(block.end(), nm.begin(), nm.end());

@@ -19,10 +19,14 @@ using query_output = std::vector<std::pair<uint32_t, uint32_t>>;  // (count, gid
 class Index {
  public:
   // Index(lF,K,W,H,filename,min_fract): src/niqki_index.cpp:13-38
+  // n_gpus > 1 (the program's --gpus): the index is cut by sketch-slot range over devices
+  // device .. device + n_gpus - 1 (niqki_group_*, RCCL inside libniqki_hip.so); the files of a
+  // batch are dealt to the GPUs in order, every GPU frames and sketches its share
   Index(uint32_t lF, uint32_t K, uint32_t W, uint32_t H, const std::string &out_filename, double min_fract,
-        int device = -1);
+        int device = -1, int n_gpus = 1);
   // Index(dump file, pretty, filename): src/niqki_index.cpp:63-102
-  Index(const std::string &dump_file, bool pretty_printing, const std::string &out_filename, int device = -1);
+  Index(const std::string &dump_file, bool pretty_printing, const std::string &out_filename, int device = -1,
+        int n_gpus = 1);
   ~Index();
   Index(const Index &) = delete;
   Index &operator=(const Index &) = delete;
@@ -68,7 +72,14 @@ class Index {
   void output_staged(const std::vector<std::string> &names);
   void stream_lines(const std::string &filestr, bool insert);
   void check(int rc, const char *what) const;
-  niqki_index *h_ = nullptr;
+  void check_group(int rc, const char *what) const;
+  void make_shards(const niqki_params &p, int device, int n_gpus, const uint8_t *dump_header);
+  uint32_t per_rank(size_t n) const { return (uint32_t)((n + sh_.size() - 1) / sh_.size()); }
+  // multi-GPU: hits of a batch whose entries sit in the shards' staged batches (n_entry[r] of rank r)
+  void group_query_staged(uint32_t per, const std::vector<uint32_t> &n_entry, Hits &h);
+  niqki_index *h_ = nullptr;            // shard 0 (the only one with one GPU)
+  std::vector<niqki_index *> sh_;       // all shards, rank order
+  niqki_group *grp_ = nullptr;          // null with one GPU
 };
 
 }  // namespace nqhost

@@ -3,6 +3,7 @@
 // (src/niqki.cpp:229-456, option table :102-185); the work is done by
 // nqhost::Index -> libniqki_hip.so.  Extensions (long options only):
 //   --device <n>   HIP device ordinal (default: current device)
+//   --gpus <n>     cut the index by sketch-slot range over n GPUs (devices --device .. +n-1)
 #include <libgen.h>
 #include <limits.h>
 #include <unistd.h>
@@ -28,7 +29,7 @@ using namespace std::chrono;
 namespace {
 
 enum Opt { LIST, QUERY, LISTLINES, QUERYLINES, KMER, FETCH, OUTPUT, MIN, PRETTY, MATRIX, WORD, GENOME_SIZE, HHL,
-           DUMP, LOAD, DOWNLAD, LOGO, HELP, DEVICE, N_OPT };
+           DUMP, LOAD, DOWNLAD, LOGO, HELP, DEVICE, GPUS, N_OPT };
 enum ArgKind { NONE, NONEMPTY, NUMERIC };
 
 // Same order as the reference's descriptor table: a short option character
@@ -55,6 +56,7 @@ const Desc kDesc[] = {
     {LOGO, "", "logo", NONE, "  --logo                        Print ASCII art logo, then exit."},
     {HELP, "h", "help", NONE, "  --help, -h                    Print usage and exit."},
     {DEVICE, "", "device", NUMERIC, "  --device <int>                HIP device ordinal."},
+    {GPUS, "", "gpus", NUMERIC, "  --gpus <int>                  Number of GPUs the index is sharded over (1)."},
 };
 
 struct Parsed {
@@ -173,6 +175,7 @@ int main(int argc, char *argv[]) {
   const double min_fract = o.has(MIN) ? atof(o.last(MIN).c_str()) : 0;
   const unsigned genomes_sizes = o.has(GENOME_SIZE) ? (unsigned)atoi(o.last(GENOME_SIZE).c_str()) : 0;
   const int device = o.has(DEVICE) ? atoi(o.last(DEVICE).c_str()) : -1;
+  const int n_gpus = o.has(GPUS) ? atoi(o.last(GPUS).c_str()) : 1;
 
   for (size_t i = 0; i < o.non_options.size(); ++i) {
     cout << "Non-option argument #" << i << " is " << o.non_options[i] << endl;
@@ -188,8 +191,8 @@ int main(int argc, char *argv[]) {
   cout << "+-----------------------------------+-------------------------------+" << endl;
   nqhost::Index *monindex = nullptr;
   try {
-    if (o.has(LOAD)) monindex = new nqhost::Index(o.last(LOAD), true, out_file, device);
-    else monindex = new nqhost::Index(F, K, W, H, out_file, min_fract, device);
+    if (o.has(LOAD)) monindex = new nqhost::Index(o.last(LOAD), true, out_file, device, n_gpus);
+    else monindex = new nqhost::Index(F, K, W, H, out_file, min_fract, device, n_gpus);
   } catch (const std::exception &e) {
     cerr << "niqki: " << e.what() << endl;
     return EXIT_FAILURE;

@@ -214,3 +214,32 @@ def test_dump_file_equals_the_committed_fixture(workdir, gold):
     assert os.path.exists(fixture), "run tools/make_dump_fixture.py on a GPU box and commit its output"
     assert gunzip(workdir / "ours.dump") == gunzip(fixture)
     assert (workdir / "ours.dump").read_bytes().count(b"\x1f\x8b\x08") >= 2   # really several gzip members
+
+
+@pytest.mark.parametrize("gpus", [3, 8])
+def test_host_program_sharded_over_gpus(workdir, gold, gpus, monkeypatch):
+    """`niqki --gpus N`: the index cut by sketch-slot range over N shards (here all on the one GPU
+    of the box: NIQKI_SHARDS_ON_ONE_DEVICE, the exchange then runs on device copies instead of RCCL),
+    every shard framing and sketching its share of each batch.  Same hits, matrix, lines-mode text and
+    dump bytes as the reference CLI's goldens, i.e. as one GPU."""
+    monkeypatch.setenv("NIQKI_SHARDS_ON_ONE_DEVICE", "1")
+    _, meta = gold
+    g = ["--gpus", str(gpus)]
+    run(workdir, g + ["-I", "fof.txt", "-Q", "fof.txt", "-S", "10", "-J", "0.1", "-O", "mg_hits.gz", "-D", "mg.dump"])
+    assert_same_text(gunzip(workdir / "mg_hits.gz").decode(), meta["cli"]["hits"])
+    raw = gunzip(workdir / "mg.dump")
+    assert len(raw) == meta["cli"]["dump_len"] and hashlib.md5(raw).hexdigest() == meta["cli"]["dump_md5"]
+    run(workdir, g + ["-L", "mg.dump", "-Q", "fof.txt", "-O", "mg_loaded.gz"])
+    assert_same_text(gunzip(workdir / "mg_loaded.gz").decode(), meta["cli"]["hits_loaded"])
+    run(workdir, g + ["-M", "fof.txt", "-S", "10", "-O", "mg_matrix.gz"])
+    assert_same_text(gunzip(workdir / "mg_matrix.gz").decode(), meta["cli"]["matrix"])
+    run(workdir, g + ["-i", "reads.fa", "-l", "reads.fa", "-S", "10", "-W", "10", "-J", "0.2", "-O", "mg_lines.gz"])
+    assert_same_text(gunzip(workdir / "mg_lines.gz").decode(), meta["cli"]["lines"])
+    (workdir / "nasty.fa").write_bytes(meta["cli"]["nasty_fa_input"].encode("latin1"))
+    run(workdir, g + ["-I", "fof.txt", "-l", "nasty.fa", "-S", "10", "-J", "0", "-O", "mg_nasty.gz"])
+    assert_same_text(gunzip(workdir / "mg_nasty.gz").decode("latin1"), meta["cli"]["nasty_fa"])
+    if (workdir / "many.fa").exists():   # 150 000 reads in several pieces (written by the streaming test above)
+        run(workdir, ["-I", "fof.txt", "-l", "many.fa", "-S", "10", "-W", "10", "-J", "0.002", "-O", "sg_many.gz"])
+        run(workdir, g + ["-I", "fof.txt", "-l", "many.fa", "-S", "10", "-W", "10", "-J", "0.002", "-O", "mg_many.gz"])
+        one = gunzip(workdir / "sg_many.gz")
+        assert gunzip(workdir / "mg_many.gz") == one and one.count(b":") > 1000
