@@ -70,7 +70,9 @@ typedef struct niqki_params {
   uint32_t slot_end;   /*   0,0 means the whole range [0, 2^S)                 */
   int32_t device;      /* HIP device ordinal; -1 = current device */
   uint32_t tile_genomes; /* genomes per counter tile (0 = choose); see DESIGN.md */
-  uint32_t reserved[3];
+  uint32_t resident_mib; /* > 0: paged index, as option "resident_bytes" (in MiB) from the start --
+                            the way to load a dump into a paged handle */
+  uint32_t reserved[2];
 } niqki_params;
 
 int niqki_abi_version(void);
@@ -117,7 +119,15 @@ int niqki_synchronize(niqki_index *ix);
  * unaffected; 0 = input order), "lookup_prepass" (1 = the index table is walked
  * once per launch, slot block by slot block, for all its queries instead of one random
  * table line per query and slot inside the gather kernel, wherever the index shape
- * allows: less HBM traffic, no faster on MI355X, so the default (-1, like 0) is off). */
+ * allows: less HBM traffic, no faster on MI355X, so the default (-1, like 0) is off),
+ * "resident_bytes" (indexes beyond the memory one wants to give them -- or beyond HBM: with a
+ * value > 0, set before the first insert, the sketch store (2 bytes per genome and slot) lives
+ * in page-locked host memory and the inverted index is built for one PAGE of slots at a time,
+ * sized so that the page's store rows + index stay within the value; a query batch walks the
+ * pages and the gather kernel accumulates the hit counters, which are sums over slots.  Same
+ * answers as a resident index.  Insert, the dump import (niqki_params.resident_mib), every query
+ * call and niqki_get_sketches work on a paged handle; dump export, niqki_matrix_range,
+ * niqki_query_gathered and groups do not (NIQKI_E_STATE)). */
 int niqki_set_option(niqki_index *ix, const char *key, int64_t value);
 
 /* Pre-sizes the sketch store for n_genomes (optional; the store grows). */
@@ -391,6 +401,10 @@ enum niqki_kernel_class {
 /* When enabled, every launch of the classes above is bracketed by HIP events
  * on the handle's stream; niqki_profile_read synchronises and returns the
  * accumulated device time and launch count since the last reset. */
+/* Sizes of the handle's state: "store_bytes" (sketch store), "index_bytes" (table + id lists of
+ * the built index or resident page), "tiles", "pages" / "page_slots" (pages a query walks and
+ * slots per page; 1 / all slots unless the index is paged). */
+int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value);
 int niqki_profile_enable(niqki_index *ix, int on);
 int niqki_profile_reset(niqki_index *ix);
 int niqki_profile_read(niqki_index *ix, int kernel_class, double *ms,

@@ -28,7 +28,8 @@ class NiqkiError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [("K", C.c_uint32), ("S", C.c_uint32), ("W", C.c_uint32), ("H", C.c_uint32),
                 ("min_score", C.c_uint32), ("slot_begin", C.c_uint32), ("slot_end", C.c_uint32),
-                ("device", C.c_int32), ("tile_genomes", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("device", C.c_int32), ("tile_genomes", C.c_uint32), ("resident_mib", C.c_uint32),
+                ("reserved", C.c_uint32 * 2)]
 
 
 class RawBatch(C.Structure):
@@ -110,6 +111,7 @@ ABI = [
     ("niqki_group_query", _int, [_vp, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_group_staged_insert", _int, [_vp, _u32, _vp]),
     ("niqki_group_staged_query", _int, [_vp, _u32, _vp, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_get_stat", _int, [_vp, C.c_char_p, C.POINTER(_u64)]),
     ("niqki_profile_enable", _int, [_vp, _int]),
     ("niqki_profile_reset", _int, [_vp]),
     ("niqki_profile_read", _int, [_vp, _int, C.POINTER(_dbl), C.POINTER(_u64)]),
@@ -171,13 +173,13 @@ class Engine:
     """One handle = one GPU (or one slot shard of an index)."""
 
     def __init__(self, K=31, S=15, W=12, H=4, J=0.0, min_score_value=None, device=-1,
-                 slot_begin=0, slot_end=0, tile_genomes=0, _handle=None):
+                 slot_begin=0, slot_end=0, tile_genomes=0, resident_mib=0, _handle=None):
         self.L = lib()
         if _handle is not None:
             self.h = _handle
         else:
             ms = self.L.niqki_min_score(J, S) if min_score_value is None else min_score_value
-            p = Params(K, S, W, H, ms, slot_begin, slot_end, device, tile_genomes)
+            p = Params(K, S, W, H, ms, slot_begin, slot_end, device, tile_genomes, resident_mib)
             h = _vp()
             rc = self.L.niqki_create(C.byref(p), C.byref(h))
             if rc:
@@ -230,6 +232,11 @@ class Engine:
     @property
     def n_genomes(self):
         return self.L.niqki_genome_count(self.h)
+
+    def stat(self, key):
+        v = _u64(0)
+        self._ck(self.L.niqki_get_stat(self.h, key.encode(), C.byref(v)))
+        return v.value
 
     def tile_genomes(self):
         q = Params()
@@ -396,10 +403,10 @@ class Engine:
         return buf.tobytes()
 
     @classmethod
-    def import_dump(cls, data, device=-1, tile_genomes=0):
+    def import_dump(cls, data, device=-1, tile_genomes=0, resident_mib=0):
         L = lib()
         buf = np.frombuffer(data, dtype=np.uint8)
-        p = Params(31, 15, 12, 4, 0, 0, 0, device, tile_genomes)
+        p = Params(31, 15, 12, 4, 0, 0, 0, device, tile_genomes, resident_mib)
         h = _vp()
         consumed = _u64(0)
         rc = L.niqki_import_dump(C.byref(p), _p(buf), buf.size, C.byref(consumed), C.byref(h))

@@ -114,6 +114,7 @@ nq::IndexView view(const niqki_index *ix) {
   v.store = ix->store;
   v.q_stride = ix->d.F;
   v.q_off = ix->d.slot_begin;
+  v.accumulate = 0;
   v.entries = ix->entries;
   v.gids = ix->gids;
   v.tile_base = ix->tile_base;
@@ -121,7 +122,28 @@ nq::IndexView view(const niqki_index *ix) {
   return v;
 }
 
+// paged index: the store is page-locked host memory
+int reserve_host_store(niqki_index *ix, uint64_t want) {
+  if (want <= ix->host_cap) return NIQKI_OK;
+  uint64_t cap = std::max<uint64_t>(want, ix->host_cap * 2);
+  cap = (cap + 63) / 64 * 64;
+  const uint32_t f_all = ix->full_end - ix->full_begin;
+  uint16_t *ns = nullptr;
+  if (hipHostMalloc((void **)&ns, (size_t)f_all * cap * 2, hipHostMallocDefault) != hipSuccess)
+    return fail(ix, NIQKI_E_NOMEM, "page-locked sketch store allocation failed");
+  if (ix->host_store && ix->n_genomes) {
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    for (uint32_t s = 0; s < f_all; ++s)
+      std::memcpy(ns + (size_t)s * cap, ix->host_store + (size_t)s * ix->host_cap, (size_t)ix->n_genomes * 2);
+  }
+  if (ix->host_store) (void)hipHostFree(ix->host_store);
+  ix->host_store = ns;
+  ix->host_cap = cap;
+  return NIQKI_OK;
+}
+
 int reserve_store(niqki_index *ix, uint64_t want) {
+  if (ix->resident_bytes) return reserve_host_store(ix, want);
   if (want <= ix->cap) return NIQKI_OK;
   uint64_t cap = std::max<uint64_t>(want, ix->cap * 2);
   cap = (cap + 63) / 64 * 64;
@@ -183,15 +205,84 @@ int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, ui
   return NIQKI_OK;
 }
 
+// first slot of the handle in a whole sketch row (while a page is resident d.slot_begin is the page's)
+uint32_t first_slot(const niqki_index *ix) { return ix->resident_bytes ? ix->full_begin : ix->d.slot_begin; }
+
 int build_if_needed(niqki_index *ix) {
+  if (ix->resident_bytes) {   // paged: pages are built while a query walks them
+    ix->built_n = ix->n_genomes;
+    return NIQKI_OK;
+  }
   if (ix->built && ix->built_n == ix->n_genomes) return NIQKI_OK;
   return niqki_build(ix);
+}
+
+// ---- paged index ---------------------------------------------------------------------------
+// slots per page so that a page's sketch-store rows and its inverted index stay within the budget
+uint32_t page_slots(const niqki_index *ix) {
+  const uint64_t N = std::max<uint64_t>(ix->n_genomes, 1), R = ix->d.R;
+  const uint64_t nt = (N + nq::kPadMaxTile - 1) / nq::kPadMaxTile;
+  const uint64_t per_slot = (N + 63) / 64 * 64 * 2      // store row
+                            + R * nt * sizeof(nq::Entry)  // table row
+                            + (N + R * nt * 32) * 2;      // id lists with their alignment padding (estimate)
+  uint64_t f = ix->resident_bytes / per_slot / 32 * 32;
+  const uint32_t f_all = ix->full_end - ix->full_begin;
+  if (f < 32) f = 32;
+  return (uint32_t)std::min<uint64_t>(f, f_all);
+}
+
+// Makes slots [s0, s1) (relative to the handle's first slot) the resident page: store rows from host
+// memory, then the normal index build on them.
+int load_page(niqki_index *ix, uint32_t s0, uint32_t s1) {
+  if (ix->page_begin == s0 && ix->page_end == s1 && ix->page_n == ix->n_genomes && ix->built) return NIQKI_OK;
+  const uint32_t N = ix->n_genomes;
+  const uint64_t cap = ((uint64_t)N + 63) / 64 * 64;
+  int rc = ensure(ix, ix->pg_store, std::max<size_t>((size_t)(s1 - s0) * cap * 2, 4));
+  if (rc) return rc;
+  if (N)
+    NQ_HIP(ix, hipMemcpy2DAsync(ix->pg_store.p, cap * 2, ix->host_store + (size_t)s0 * ix->host_cap, ix->host_cap * 2,
+                                (size_t)N * 2, s1 - s0, hipMemcpyHostToDevice, ix->stream));
+  ix->d.slot_begin = ix->full_begin + s0;
+  ix->d.slot_end = ix->full_begin + s1;
+  ix->store = (uint16_t *)ix->pg_store.p;
+  ix->cap = cap;
+  ix->page_begin = s0;
+  ix->page_end = s1;
+  ix->page_n = N;
+  ix->built = false;
+  return niqki_build(ix);
+}
+
+int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
+                    uint16_t *counts, uint64_t stride, bool accumulate);
+
+// counts over a paged index: page after page, the gather kernel adding to the rows from the second on
+int counts_paged(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq, uint16_t *counts,
+                 uint64_t stride) {
+  const uint32_t f_all = ix->full_end - ix->full_begin, f_page = page_slots(ix);
+  if (stride < ix->n_genomes || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
+  ix->built_n = ix->n_genomes;
+  if (nq == 0 || ix->n_genomes == 0) return NIQKI_OK;
+  for (uint32_t s0 = 0; s0 < f_all; s0 += f_page) {
+    const uint32_t s1 = std::min(f_all, s0 + f_page);
+    int rc = load_page(ix, s0, s1);
+    if (rc) return rc;
+    // q_off addresses the handle's first slot in a sketch row; the page starts s0 slots further
+    if ((rc = counts_resident(ix, sketches, q_stride, q_off + s0, nq, counts, stride, s0 != 0))) return rc;
+  }
+  return NIQKI_OK;
 }
 
 // counts for nq device-resident sketches into a device buffer
 int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
                uint16_t *counts, uint64_t stride) {
-  int rc = build_if_needed(ix);
+  if (ix->resident_bytes) return counts_paged(ix, sketches, q_stride, q_off, nq, counts, stride);
+  return counts_resident(ix, sketches, q_stride, q_off, nq, counts, stride, false);
+}
+
+int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
+                    uint16_t *counts, uint64_t stride, bool accumulate) {
+  int rc = ix->resident_bytes ? NIQKI_OK : build_if_needed(ix);
   if (rc) return rc;
   if (nq == 0) return NIQKI_OK;
   if (stride < ix->built_n || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
@@ -203,6 +294,7 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint
   nq::IndexView v = view(ix);
   v.q_stride = q_stride;
   v.q_off = q_off;
+  v.accumulate = accumulate ? 1u : 0u;
   // Table look-ups: inside the gather kernel (one random table line per query and slot), or
   // by the slot-major pre-pass, which walks the table once per launch for all its queries.
   bool pre = ix->lookup_prepass != 0 && nq::launch_lookup_usable(v) && (((uintptr_t)(sketches + q_off)) & 15) == 0 && (q_stride & 3) == 0;
@@ -306,7 +398,7 @@ int query_to_host(niqki_index *ix, const int32_t *sketches, bool sk_dev, uint32_
       NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, d_sk, (size_t)n * ix->d.F * 4, hipMemcpyHostToDevice, ix->stream));
       d_sk = (const int32_t *)ix->ws_sk.p;
     }
-    if ((rc = counts_dev(ix, d_sk, ix->d.F, ix->d.slot_begin, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+    if ((rc = counts_dev(ix, d_sk, ix->d.F, first_slot(ix), n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
     uint64_t total = 0;
     rc = hits_dev(ix, (const uint16_t *)ix->ws_counts.p, n, stride, 0, N, (unsigned long long *)ix->ws_hitoff.p,
                   (uint32_t *)ix->ws_hc.p, (uint32_t *)ix->ws_hg.p, room, true, &total);
@@ -329,6 +421,25 @@ int insert_dev(niqki_index *ix, const int32_t *sketches, uint32_t sk_stride, uin
   if ((uint64_t)ix->n_genomes + n > 0xFFFFFFFFull) return fail(ix, NIQKI_E_INVALID, "too many genomes");
   int rc = reserve_store(ix, (uint64_t)ix->n_genomes + n);
   if (rc) return rc;
+  if (ix->resident_bytes) {
+    // paged: transpose into a device staging block of all the handle's slots, then rows to the host store
+    const uint32_t f_all = ix->full_end - ix->full_begin;
+    const uint64_t n_pad = ((uint64_t)n + 63) / 64 * 64;
+    if ((rc = ensure(ix, ix->pg_stage, (size_t)f_all * n_pad * 2))) return rc;
+    nq::Derived d = ix->d;
+    d.slot_begin = ix->full_begin;
+    d.slot_end = ix->full_end;
+    {
+      Span sp(ix, NIQKI_KC_BUILD);
+      NQ_HIP(ix, nq::launch_store_insert(d, sketches, sk_stride, sk_off, n, (uint16_t *)ix->pg_stage.p, n_pad, 0, ix->stream));
+    }
+    NQ_HIP(ix, hipMemcpy2DAsync(ix->host_store + ix->n_genomes, ix->host_cap * 2, ix->pg_stage.p, n_pad * 2, (size_t)n * 2, f_all,
+                                hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    ix->n_genomes += n;
+    ix->built = false;
+    return NIQKI_OK;
+  }
   {
     Span sp(ix, NIQKI_KC_BUILD);
     NQ_HIP(ix, nq::launch_store_insert(ix->d, sketches, sk_stride, sk_off, n, ix->store, ix->cap, ix->n_genomes, ix->stream));
@@ -426,6 +537,9 @@ int niqki_create(const niqki_params *params, niqki_index **out) {
   if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return bail(NIQKI_E_NODEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return bail(NIQKI_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is gfx950 only");
   ix->device = dev;
+  ix->resident_bytes = (uint64_t)params->resident_mib << 20;
+  ix->full_begin = ix->d.slot_begin;
+  ix->full_end = ix->d.slot_end;
   if ((e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking)) != hipSuccess) return bail(NIQKI_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   ix->own_stream = true;
   if (const char *v = std::getenv("NIQKI_GATHER_VARIANT"))
@@ -445,7 +559,10 @@ void niqki_destroy(niqki_index *ix) {
                  &ix->ws_raw, &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
                  &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order, &ix->ws_pre})
     if (b->p) (void)hipFree(b->p);
-  if (ix->store) (void)hipFree(ix->store);
+  for (Buf *b : {&ix->pg_store, &ix->pg_stage})
+    if (b->p) (void)hipFree(b->p);
+  if (ix->store && !ix->resident_bytes) (void)hipFree(ix->store);
+  if (ix->host_store) (void)hipHostFree(ix->host_store);
   if (ix->entries) (void)hipFree(ix->entries);
   if (ix->gids) (void)hipFree(ix->gids);
   if (ix->tile_base) (void)hipFree(ix->tile_base);
@@ -461,8 +578,8 @@ const char *niqki_last_error(const niqki_index *ix) { return ix ? ix->err.c_str(
 int niqki_get_params(const niqki_index *ix, niqki_params *out) {
   if (!ix || !out) return NIQKI_E_INVALID;
   *out = ix->p;
-  out->slot_begin = ix->d.slot_begin;
-  out->slot_end = ix->d.slot_end;
+  out->slot_begin = ix->resident_bytes ? ix->full_begin : ix->d.slot_begin;
+  out->slot_end = ix->resident_bytes ? ix->full_end : ix->d.slot_end;
   out->device = ix->device;
   out->tile_genomes = ix->tile ? ix->tile : ix->p.tile_genomes;
   return NIQKI_OK;
@@ -511,6 +628,12 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
     if (value < -1 || value > 6) return fail(ix, NIQKI_E_INVALID, "bucket_align_log2 must be -1 (choose) .. 6");
     ix->bucket_align = (int)value;
     ix->built = false;
+    return NIQKI_OK;
+  }
+  if (!std::strcmp(key, "resident_bytes")) {
+    if (value < 0) return fail(ix, NIQKI_E_INVALID, "resident_bytes must be >= 0");
+    if (ix->n_genomes || ix->store) return fail(ix, NIQKI_E_STATE, "resident_bytes must be set before the first insert");
+    ix->resident_bytes = (uint64_t)value;
     return NIQKI_OK;
   }
   if (!std::strcmp(key, "record_len_hint")) { ix->record_len_hint = (uint64_t)value; return NIQKI_OK; }
@@ -607,7 +730,7 @@ int niqki_insert(niqki_index *ix, const int32_t *sketches, uint32_t n, int mem) 
     NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, sketches, bytes, hipMemcpyHostToDevice, ix->stream));
     d_sk = (const int32_t *)ix->ws_sk.p;
   }
-  if ((rc = insert_dev(ix, d_sk, ix->d.F, ix->d.slot_begin, n))) return rc;
+  if ((rc = insert_dev(ix, d_sk, ix->d.F, first_slot(ix), n))) return rc;
   if (mem == NIQKI_MEM_HOST) NQ_HIP(ix, hipStreamSynchronize(ix->stream));
   return NIQKI_OK;
 }
@@ -617,6 +740,10 @@ uint32_t niqki_genome_count(const niqki_index *ix) { return ix ? ix->n_genomes :
 int niqki_build(niqki_index *ix) {
   if (!ix) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
+  if (ix->resident_bytes && ix->page_begin == ix->page_end) {  // paged, no page chosen: queries build their pages
+    ix->built_n = ix->n_genomes;
+    return NIQKI_OK;
+  }
   const uint32_t N = ix->n_genomes;
   const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
   uint32_t tile = ix->p.tile_genomes;
@@ -686,7 +813,7 @@ int niqki_query_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq, ui
                        uint64_t stride, int mem) {
   if (!ix || (!sketches && nq) || (!counts && nq)) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
-  if (mem == NIQKI_MEM_DEVICE) return counts_dev(ix, sketches, ix->d.F, ix->d.slot_begin, nq, counts, stride);
+  if (mem == NIQKI_MEM_DEVICE) return counts_dev(ix, sketches, ix->d.F, first_slot(ix), nq, counts, stride);
   if (stride < ix->n_genomes || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
   const uint32_t qb = ix->query_batch;
   for (uint32_t q0 = 0; q0 < nq; q0 += qb) {
@@ -696,7 +823,7 @@ int niqki_query_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq, ui
     if ((rc = ensure(ix, ix->ws_counts, (size_t)n * stride * 2))) return rc;
     NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, sketches + (size_t)q0 * ix->d.F, (size_t)n * ix->d.F * 4, hipMemcpyHostToDevice, ix->stream));
     NQ_HIP(ix, hipMemsetAsync(ix->ws_counts.p, 0, (size_t)n * stride * 2, ix->stream));
-    if ((rc = counts_dev(ix, (const int32_t *)ix->ws_sk.p, ix->d.F, ix->d.slot_begin, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+    if ((rc = counts_dev(ix, (const int32_t *)ix->ws_sk.p, ix->d.F, first_slot(ix), n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
     NQ_HIP(ix, hipMemcpyAsync(counts + (size_t)q0 * stride, ix->ws_counts.p, (size_t)n * stride * 2, hipMemcpyDeviceToHost, ix->stream));
     NQ_HIP(ix, hipStreamSynchronize(ix->stream));
   }
@@ -753,7 +880,7 @@ int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint64_t 
   const uint64_t stride = ((uint64_t)N + 1) & ~1ull;
   if (mem == NIQKI_MEM_DEVICE) {
     if ((rc = ensure(ix, ix->ws_counts, std::max<size_t>((size_t)nq * stride * 2, 2)))) return rc;
-    if ((rc = counts_dev(ix, sketches, ix->d.F, ix->d.slot_begin, nq, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+    if ((rc = counts_dev(ix, sketches, ix->d.F, first_slot(ix), nq, (uint16_t *)ix->ws_counts.p, stride))) return rc;
     return hits_dev(ix, (const uint16_t *)ix->ws_counts.p, nq, stride, 0, N, (unsigned long long *)hit_off,
                     hit_counts, hit_gids, capacity, false, nullptr);
   }
@@ -789,6 +916,19 @@ int niqki_get_sketches(niqki_index *ix, uint32_t begin, uint32_t n, int32_t *ske
     if (rc) return rc;
     d_sk = (int32_t *)ix->ws_sk.p;
   }
+  if (ix->resident_bytes) {
+    // paged: the genomes' columns of every slot row, host -> device, then the usual transpose
+    const uint32_t f_all = ix->full_end - ix->full_begin;
+    const uint64_t n_pad = ((uint64_t)n + 63) / 64 * 64;
+    int rc = ensure(ix, ix->pg_stage, (size_t)f_all * n_pad * 2);
+    if (rc) return rc;
+    NQ_HIP(ix, hipMemcpy2DAsync(ix->pg_stage.p, n_pad * 2, ix->host_store + begin, ix->host_cap * 2, (size_t)n * 2, f_all,
+                                hipMemcpyHostToDevice, ix->stream));
+    nq::Derived d = ix->d;
+    d.slot_begin = ix->full_begin;
+    d.slot_end = ix->full_end;
+    NQ_HIP(ix, nq::launch_store_read(d, (const uint16_t *)ix->pg_stage.p, n_pad, 0, n, d_sk, ix->stream));
+  } else
   NQ_HIP(ix, nq::launch_store_read(ix->d, ix->store, ix->cap, begin, n, d_sk, ix->stream));
   if (mem == NIQKI_MEM_HOST) {
     NQ_HIP(ix, hipMemcpyAsync(sketches, d_sk, bytes, hipMemcpyDeviceToHost, ix->stream));
@@ -1004,6 +1144,7 @@ int niqki_matrix_range(niqki_index *ix, uint32_t begin, uint32_t end, uint16_t *
                        int mem) {
   if (!ix || begin > end || end > ix->n_genomes || (!counts && end > begin)) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
+  if (ix->resident_bytes) return fail(ix, NIQKI_E_STATE, "niqki_matrix_range is not available on a paged index (resident_bytes)");
   int rc = build_if_needed(ix);
   if (rc) return rc;
   if (stride < ix->built_n || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
@@ -1018,11 +1159,11 @@ int niqki_matrix_range(niqki_index *ix, uint32_t begin, uint32_t end, uint16_t *
     NQ_HIP(ix, nq::launch_store_read(ix->d, ix->store, ix->cap, t0, n, (int32_t *)ix->ws_misc.p, ix->stream));
     uint16_t *dst = counts + (size_t)(t0 - begin) * stride;
     if (mem == NIQKI_MEM_DEVICE) {
-      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, ix->d.F, ix->d.slot_begin, n, dst, stride))) return rc;
+      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, ix->d.F, first_slot(ix), n, dst, stride))) return rc;
     } else {
       if ((rc = ensure(ix, ix->ws_counts, (size_t)n * stride * 2))) return rc;
       NQ_HIP(ix, hipMemsetAsync(ix->ws_counts.p, 0, (size_t)n * stride * 2, ix->stream));
-      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, ix->d.F, ix->d.slot_begin, n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, ix->d.F, first_slot(ix), n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
       NQ_HIP(ix, hipMemcpyAsync(dst, ix->ws_counts.p, (size_t)n * stride * 2, hipMemcpyDeviceToHost, ix->stream));
       NQ_HIP(ix, hipStreamSynchronize(ix->stream));
     }
@@ -1036,6 +1177,7 @@ namespace {
 
 // slot_word (F+1 word positions, header excluded) computed on the device, copied to the host
 int export_layout(niqki_index *ix, std::vector<uint64_t> &slot_word) {
+  if (ix->resident_bytes) return fail(ix, NIQKI_E_STATE, "dump export is not available on a paged index (resident_bytes)");
   int rc = build_if_needed(ix);
   if (rc) return rc;
   nq::IndexView v = view(ix);
@@ -1133,7 +1275,8 @@ int niqki_import_begin(const niqki_params *params, const uint8_t header[24], niq
   const uint32_t N = hdr[5];
   rc = reserve_store(ix, std::max<uint32_t>(N, 1));
   hipError_t e = hipSuccess;
-  if (!rc) e = hipMemsetAsync(ix->store, 0xFF, (size_t)(ix->d.slot_end - ix->d.slot_begin) * ix->cap * 2, ix->stream);
+  if (!rc && ix->resident_bytes) std::memset(ix->host_store, 0xFF, (size_t)(ix->full_end - ix->full_begin) * ix->host_cap * 2);
+  else if (!rc) e = hipMemsetAsync(ix->store, 0xFF, (size_t)(ix->d.slot_end - ix->d.slot_begin) * ix->cap * 2, ix->stream);
   if (rc || e != hipSuccess) {
     g_create_err = rc ? ix->err : std::string(hipGetErrorString(e));
     niqki_destroy(ix);
@@ -1167,7 +1310,8 @@ int niqki_import_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end, 
   slot_word[n_slots] = w;
   if (consumed) *consumed = w * 4;
   // the part of [slot_begin, slot_end) this shard owns (all of it for a whole-range handle)
-  const uint32_t own0 = std::max(slot_begin, ix->d.slot_begin), own1 = std::min(slot_end, ix->d.slot_end);
+  const uint32_t my0 = ix->resident_bytes ? ix->full_begin : ix->d.slot_begin, my1 = ix->resident_bytes ? ix->full_end : ix->d.slot_end;
+  const uint32_t own0 = std::max(slot_begin, my0), own1 = std::min(slot_end, my1);
   if (own0 >= own1) return NIQKI_OK;
   const uint32_t n_own = own1 - own0;
   const uint64_t w0 = slot_word[own0 - slot_begin], w1 = slot_word[own1 - slot_begin];
@@ -1181,6 +1325,17 @@ int niqki_import_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end, 
   NQ_HIP(ix, hipMemcpyAsync(ix->ws_counts.p, buf + w0 * 4, (w1 - w0) * 4, hipMemcpyHostToDevice, ix->stream));
   NQ_HIP(ix, hipMemcpyAsync(d_slot, own_word.data(), (size_t)(n_own + 1) * 8, hipMemcpyHostToDevice, ix->stream));
   NQ_HIP(ix, hipMemsetAsync(d_bad, 0, 4, ix->stream));
+  if (ix->resident_bytes) {
+    // paged: the slots' rows are made in a device block and copied to the host store
+    const uint64_t cap2 = ((uint64_t)std::max<uint32_t>(ix->n_genomes, 1) + 63) / 64 * 64;
+    if ((rc = ensure(ix, ix->pg_stage, (size_t)n_own * cap2 * 2))) return rc;
+    NQ_HIP(ix, hipMemsetAsync(ix->pg_stage.p, 0xFF, (size_t)n_own * cap2 * 2, ix->stream));
+    NQ_HIP(ix, nq::launch_import(ix->d, (const uint32_t *)ix->ws_counts.p, (const uint64_t *)d_slot, (uint16_t *)ix->pg_stage.p, cap2,
+                                 ix->n_genomes, d_bad, 0, n_own, ix->stream));
+    if (ix->n_genomes)
+      NQ_HIP(ix, hipMemcpy2DAsync(ix->host_store + (size_t)(own0 - my0) * ix->host_cap, ix->host_cap * 2, ix->pg_stage.p, cap2 * 2,
+                                  (size_t)ix->n_genomes * 2, n_own, hipMemcpyDeviceToHost, ix->stream));
+  } else
   // rows of the store are shard-local slots
   NQ_HIP(ix, nq::launch_import(ix->d, (const uint32_t *)ix->ws_counts.p, (const uint64_t *)d_slot, ix->store, ix->cap,
                                ix->n_genomes, d_bad, own0 - ix->d.slot_begin, n_own, ix->stream));
@@ -1230,6 +1385,7 @@ int niqki_import_dump(const niqki_params *params, const uint8_t *buf, uint64_t l
 int niqki_query_gathered(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint64_t *gathered, int mem) {
   if (!ix || (!sketches && nq) || (!gathered && nq)) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
+  if (ix->resident_bytes) return fail(ix, NIQKI_E_STATE, "niqki_query_gathered is not available on a paged index (resident_bytes)");
   int rc = build_if_needed(ix);
   if (rc) return rc;
   if (nq == 0) return NIQKI_OK;
@@ -1245,6 +1401,21 @@ int niqki_query_gathered(niqki_index *ix, const int32_t *sketches, uint32_t nq, 
   NQ_HIP(ix, hipMemcpyAsync(gathered, ix->ws_misc.p, (size_t)nq * 8, hipMemcpyDeviceToHost, ix->stream));
   NQ_HIP(ix, hipStreamSynchronize(ix->stream));
   return NIQKI_OK;
+}
+
+int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value) {
+  if (!ix || !key || !value) return NIQKI_E_INVALID;
+  const uint32_t f_all = ix->resident_bytes ? ix->full_end - ix->full_begin : ix->d.slot_end - ix->d.slot_begin;
+  if (!std::strcmp(key, "store_bytes")) { *value = (uint64_t)f_all * (ix->resident_bytes ? ix->host_cap : ix->cap) * 2; return NIQKI_OK; }
+  if (!std::strcmp(key, "index_bytes")) { *value = ix->built ? (uint64_t)ix->entries_bytes + ix->gids_bytes : 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "tiles")) { *value = ix->n_tiles; return NIQKI_OK; }
+  if (!std::strcmp(key, "page_slots")) { *value = ix->resident_bytes ? page_slots(ix) : f_all; return NIQKI_OK; }
+  if (!std::strcmp(key, "pages")) {
+    const uint32_t ps = ix->resident_bytes ? page_slots(ix) : f_all;
+    *value = ps ? (f_all + ps - 1) / ps : 0;
+    return NIQKI_OK;
+  }
+  return NIQKI_E_INVALID;
 }
 
 int niqki_profile_enable(niqki_index *ix, int on) {

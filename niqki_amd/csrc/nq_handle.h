@@ -35,6 +35,19 @@ struct niqki_index {
   uint64_t cap = 0;
   uint32_t n_genomes = 0;
 
+  // Paged index (option "resident_bytes"): the sketch store lives in page-locked host memory and
+  // the inverted index exists for one page of slots at a time; a query batch walks the pages and
+  // the gather kernel accumulates the counters (hit counts are sums over slots).  While a page is
+  // resident, d.slot_begin/slot_end, store and cap describe THAT page, so every kernel and launch
+  // sequence of the resident case is reused unchanged.
+  uint64_t resident_bytes = 0;          // 0 = everything resident (default)
+  uint16_t *host_store = nullptr;       // u16 [full_end - full_begin][host_cap], page-locked
+  uint64_t host_cap = 0;
+  uint32_t full_begin = 0, full_end = 0;   // the handle's real slot range
+  uint32_t page_begin = 0, page_end = 0;   // slots (relative to full_begin) of the resident page; equal = none
+  uint32_t page_n = 0;                     // genomes the resident page was built for
+  nqi::Buf pg_store, pg_stage;
+
   // inverted index
   uint32_t tile = 0, n_tiles = 0, built_n = 0, align_log2 = 0, padded = 0;
   nq::Entry *entries = nullptr;

@@ -56,6 +56,7 @@ struct IndexView {
   // query sketches handed to the query kernels: row q starts at sketches + q * q_stride, this
   // shard's first slot at + q_off (whole sketches: F and slot_begin; slot slices: f_local and 0)
   uint32_t q_stride, q_off;
+  uint32_t accumulate;   // gather: add to the counter rows instead of overwriting them (slot pages after the first)
   const Entry *entries;
   const uint16_t *gids;
   const uint64_t *tile_base;   // n_tiles+1 (in ids), device

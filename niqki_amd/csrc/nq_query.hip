@@ -433,15 +433,22 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     uint16_t *row = counts + (uint64_t)q * stride;
     if (v.stripe && v.n_tiles > 1) {
       // striped tiles: the tile's i-th counter belongs to genome i * n_tiles + t
-      for (uint32_t i = tid; i < n_t; i += BLOCK)
-        row[tile_gid(v, t, i)] = (uint16_t)(cnt[i >> 1] >> ((i & 1u) * 16u));
+      for (uint32_t i = tid; i < n_t; i += BLOCK) {
+        const uint16_t c = (uint16_t)(cnt[i >> 1] >> ((i & 1u) * 16u));
+        uint16_t *dst = row + tile_gid(v, t, i);
+        *dst = v.accumulate ? (uint16_t)(*dst + c) : c;
+      }
     } else {
       // dense counter row of this tile: u16 counts[q*stride + g0 + i], written as the packed words
       const uint32_t g0 = t * v.tile;
       uint32_t *out = (uint32_t *)(row + g0);
       const uint32_t full = n_t / 2;
-      for (uint32_t i = tid; i < full; i += BLOCK) out[i] = cnt[i];
-      if ((n_t & 1u) && tid == 0) row[g0 + n_t - 1] = (uint16_t)(cnt[full] & 0xFFFFu);
+      // (accumulating: sums stay <= F <= 2^15 per half, so the packed add cannot carry)
+      for (uint32_t i = tid; i < full; i += BLOCK) out[i] = v.accumulate ? out[i] + cnt[i] : cnt[i];
+      if ((n_t & 1u) && tid == 0) {
+        const uint16_t c = (uint16_t)(cnt[full] & 0xFFFFu);
+        row[g0 + n_t - 1] = v.accumulate ? (uint16_t)(row[g0 + n_t - 1] + c) : c;
+      }
     }
     __syncthreads();
   }
