@@ -147,3 +147,47 @@ def test_candidates_from_counts_vs_numpy(native):
             if len(want) <= cap:
                 assert sorted(got.tolist()) == want.tolist()
     e.close()
+
+
+def test_config4_eight_slot_shards_at_full_size(native, big):
+    """BASELINE.json configs[3] on the one GPU a test box has: the 100 000-genome index cut into 8
+    slot shards (niqki_group_*, all ranks in this process, device copies standing in for RCCL), the
+    bench's queries through the sparse exchange and through the dense one: the hit lists of the
+    whole-range index (checked against the oracle above)."""
+    import torch
+    dev = torch.device("cuda")
+    e, qsk, _, _ = big
+    G, per = 8, NQ // 8
+    shards = []
+    for r in range(G):
+        b, s_end = native.group_slot_range(r, G, S)
+        sh = native.Engine(K=K, S=S, W=W, H=H, J=J, slot_begin=b, slot_end=s_end)
+        sh.set_stream(torch.cuda.current_stream().cuda_stream)
+        sh.reserve(N)
+        shards.append(sh)
+    grp = native.Group(shards)
+    # the stored sketches of the whole-range index, through the group's slice exchange
+    INS = 512
+    for g0 in range(0, N, G * INS):
+        n = min(G * INS, N - g0)
+        blk = torch.full((G * INS, F), -1, dtype=torch.int32, device=dev)
+        blk[:n] = torch.from_numpy(e.get_sketches(g0, n)).to(dev)
+        grp.insert_dev([blk[r * INS:(r + 1) * INS] for r in range(G)], INS, n)
+    del blk
+    assert all(sh.n_genomes == N for sh in shards)
+    off, hc, hg = e.query(qsk)
+    dq = torch.from_numpy(qsk).to(dev)
+    loc = [dq[r * per:(r + 1) * per].contiguous() for r in range(G)]
+    for mode in (1, 2):                       # sparse, dense
+        grp.set_option("exchange", mode)
+        res = grp.query(loc, per)
+        for r in range(G):
+            o, c, g_ = res[r]
+            for i in range(per):
+                q = r * per + i
+                lo, hi = int(off[q]), int(off[q + 1])
+                assert np.array_equal(c[int(o[i]):int(o[i + 1])], hc[lo:hi]) and np.array_equal(g_[int(o[i]):int(o[i + 1])], hg[lo:hi]), (mode, q)
+    assert grp.stat("overflows") == 0
+    grp.close()
+    for sh in shards:
+        sh.close()
