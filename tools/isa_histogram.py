@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-basic-block instruction histogram of one kernel in a hipcc --save-temps .s file.
 
-    python tools/isa_histogram.py file.s 'sketch_kernelILi1024ELi32ELi31' [--per N] [--min 200]
+    python tools/isa_histogram.py file.s 'sketch_kernelILi1024ELi32ELi31' [--per N] [--min 200] [--grep OPCODE] [--limit N]
 
 Prints, for every basic block with at least --min instructions, the instruction count by class
 (VALU multiply / other VALU / SALU / LDS / VMEM / wait / branch) and the top opcodes; --per N
@@ -33,6 +33,8 @@ def main():
     path, pat = sys.argv[1], sys.argv[2]
     per = float(sys.argv[sys.argv.index("--per") + 1]) if "--per" in sys.argv else 1.0
     mn = int(sys.argv[sys.argv.index("--min") + 1]) if "--min" in sys.argv else 200
+    want = sys.argv[sys.argv.index("--grep") + 1] if "--grep" in sys.argv else None   # only blocks holding this opcode
+    limit = int(sys.argv[sys.argv.index("--limit") + 1]) if "--limit" in sys.argv else 1 << 30
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\S*" + re.escape(pat) + r"\S*:", l))
     blocks, cur, name = [], [], "entry"
@@ -51,9 +53,11 @@ def main():
     blocks.append((name, cur))
     total = sum(len(b) for _, b in blocks)
     print("kernel %s: %d instructions in %d blocks" % (pat, total, len(blocks)))
+    shown = 0
     for name, b in blocks:
-        if len(b) < mn:
+        if len(b) < mn or (want and not any(o.startswith(want) for o in b)) or shown >= limit:
             continue
+        shown += 1
         cls = collections.Counter(classify(o) for o in b)
         ops = collections.Counter(b)
         print("\n%s: %d instructions (%.1f per unit)" % (name, len(b), len(b) / per))

@@ -1,22 +1,38 @@
 #!/bin/bash
-# Round profile (run on the GPU box from the repo root):  tools/profile_round.sh r01
-# 1) rocprofv3 --kernel-trace --stats of the default bench command
-# 2) separate --pmc passes (no tracing flags) for the gather kernel's HBM traffic:
-#    FETCH_SIZE, WRITE_SIZE, TCC_EA0_RDREQ_128B (MI355X_MICROARCH.md: on gfx950
-#    FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled)
+# Round profile (run on the GPU box from the repo root):  tools/profile_round.sh r02
+# 1) the default bench line (with cpu_baseline and extra workloads)
+# 2) rocprofv3 --kernel-trace --stats of the same command (without the CPU legs)
+# 3) separate --pmc passes (no tracing flags) for HBM traffic and the SQ counters of the query
+#    path's kernels (tools/pmc_bench.sh: FETCH_SIZE, WRITE_SIZE, TCC_EA0_RDREQ[_128B], SQ_*;
+#    MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled)
+# 4) the same with the look-up pre-pass on, the 8-way shard emulation, the world-1 RCCL run
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r01}
-OUT=$R/gpurun_out/prof_$TAG
-rm -rf $OUT; mkdir -p $OUT
+TAG=${1:-r02}
+cd $R; mkdir -p gpurun_out
+timeout -k 10 900 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err || { tail -5 gpurun_out/${TAG}_bench_n1.err; exit 1; }
 cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --no-cpu > $OUT/kt.json 2> $OUT/kt.log
-for c in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_128B; do
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --no-cpu --steps 2 > $OUT/$c.json 2> $OUT/$c.log
-done
+rm -rf /tmp/kt; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-cpu --no-extra > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> /tmp/kt.log || { tail -5 /tmp/kt.log; exit 1; }
 cd $R
-python tools/prof_summary.py $OUT/kt > gpurun_out/${TAG}_kernel_trace_summary.txt
-cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_rocprofv3_kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE TCC_EA0_RDREQ_128B; do python tools/prof_summary.py $OUT/$c | grep -E "^==|gather_kernel|probe_kernel|order_kernel|sketch_kernel|hits_|build_kernel"; done > gpurun_out/${TAG}_pmc_summary.txt
-cp $OUT/kt.json gpurun_out/${TAG}_bench_under_rocprof.json
-rm -rf $OUT
-cat gpurun_out/${TAG}_pmc_summary.txt | cut -c1-200; head -12 gpurun_out/${TAG}_kernel_trace_summary.txt | cut -c1-170
+python3 tools/prof_summary.py /tmp/kt > gpurun_out/${TAG}_bench_kernel_trace_summary.txt
+cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_bench_rocprofv3_kernel_stats.csv
+bash tools/pmc_bench.sh ${TAG}_default --no-extra || exit 1
+NIQKI_LOOKUP_PREPASS=1 bash tools/pmc_bench.sh ${TAG}_prepass --no-extra || exit 1
+cd /tmp
+rm -rf /tmp/kt2; NIQKI_LOOKUP_PREPASS=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python3 $R/bench.py --no-cpu --no-extra > $R/gpurun_out/${TAG}_prepass_bench_under_rocprof.json 2> /tmp/kt2.log || exit 1
+cd $R
+python3 tools/prof_summary.py /tmp/kt2 | grep -E "gather_kernel|lookup_kernel|probe_kernel|order_kernel|^==|kernel " > gpurun_out/${TAG}_prepass_kernel_trace_summary.txt
+timeout -k 10 600 python3 bench.py --shard-of 8 --no-cpu > gpurun_out/${TAG}_shard_of_8.json 2> gpurun_out/${TAG}_shard_of_8.err || exit 1
+NIQKI_FORCE_DIST=1 timeout -k 10 600 python3 bench.py --no-cpu --no-extra > gpurun_out/${TAG}_force_dist_world1.json 2> gpurun_out/${TAG}_force_dist_world1.err || exit 1
+hipcc -O3 --offload-arch=gfx950 tools/ubench_sector.hip -o /tmp/ubench_sector 2>/dev/null && /tmp/ubench_sector > gpurun_out/${TAG}_ubench_sector.txt
+cd /tmp
+for c in TCC_EA0_RDREQ TCC_EA0_RDREQ_128B; do
+  rm -rf /tmp/pmc_$c; timeout -k 10 120 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- /tmp/ubench_sector > /dev/null 2>&1
+  python3 $R/tools/prof_summary.py /tmp/pmc_$c | grep -E "sector_kernel" | sed 's/  */ /g' >> $R/gpurun_out/${TAG}_ubench_sector.txt
+done
+cd $R; head -14 gpurun_out/${TAG}_bench_kernel_trace_summary.txt | cut -c1-170
+python3 -c "
+import json
+j=json.load(open('gpurun_out/${TAG}_bench_n1.json'))
+print('value %.0f ms/step %.2f gather %.3f frac %.3f' % (j['value'], j['ms_per_step'], j['roofline']['avg_launch_ms'], j['roofline']['frac']))
+print(json.dumps(j['cpu_baseline']))
+print(json.dumps(j['sketch_kernel']))"
