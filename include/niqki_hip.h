@@ -58,8 +58,11 @@ typedef struct niqki_index niqki_index; /* opaque */
 
 /* Constructor arguments: Index(lF,K,W,H,filename,min_fract),
  * src/niqki_index.cpp:13-38 (output-file handling stays in the host program).
- * Supported: 1<=K<=31 (K=32 is UB in the reference, :28-29), 1<=S<=15,
- * H<=W<=15, S+W<=30. */
+ * Supported: 1<=K<=31 (K=32 is UB in the reference, :28-29), 1<=S<=16,
+ * H<=W<=15, S+W<=30.  S = 16 is the reference's lF>15 branch (uint32 counters, :668-682): a
+ * count can reach 2^16, so the u16 counter calls (niqki_query_counts, niqki_hits_from_counts),
+ * groups and paging refuse it; niqki_query* / niqki_staged_query / niqki_query_counts32 are exact
+ * and niqki_matrix_range wraps like the reference's uint16 matrix counters (:572). */
 typedef struct niqki_params {
   uint32_t K;          /* k-mer length */
   uint32_t S;          /* lF: log2 of the number of sketch slots */
@@ -175,6 +178,11 @@ int niqki_build(niqki_index *ix);
  * hit vector the multi-GPU path sums across slot shards. */
 int niqki_query_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq,
                        uint16_t *counts, uint64_t stride, int mem);
+
+/* The same with uint32 counters, exact for every S (the reference's lF>15 branch,
+ * src/niqki_index.cpp:668-677). */
+int niqki_query_counts32(niqki_index *ix, const int32_t *sketches, uint32_t nq,
+                         uint32_t *counts, uint64_t stride, int mem);
 
 /* Threshold + order half of Index::query_sketch (src/niqki_index.cpp:662-666,
  * :685): from (possibly cross-shard summed) counters of genomes

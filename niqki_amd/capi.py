@@ -79,6 +79,7 @@ ABI = [
     ("niqki_genome_count", _u32, [_vp]),
     ("niqki_build", _int, [_vp]),
     ("niqki_query_counts", _int, [_vp, _vp, _u32, _vp, _u64, _int]),
+    ("niqki_query_counts32", _int, [_vp, _vp, _u32, _vp, _u64, _int]),
     ("niqki_hits_from_counts", _int, [_vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_candidates_from_counts", _int, [_vp, _vp, _u32, _u64, _u32, _u32, _u32, _vp, _vp, _int]),
     ("niqki_query", _int, [_vp, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
@@ -292,6 +293,14 @@ class Engine:
         stride = (n + 1) & ~1
         out = np.zeros((sk.shape[0], max(stride, 2)), dtype=np.uint16)
         self._ck(self.L.niqki_query_counts(self.h, _p(sk), sk.shape[0], _p(out), out.shape[1], MEM_HOST))
+        return out[:, :n]
+
+    def query_counts32(self, sketches):
+        sk = np.ascontiguousarray(sketches, dtype=np.int32).reshape(-1, self.F)
+        n = self.n_genomes
+        stride = (n + 1) & ~1
+        out = np.zeros((sk.shape[0], max(stride, 2)), dtype=np.uint32)
+        self._ck(self.L.niqki_query_counts32(self.h, _p(sk), sk.shape[0], _p(out), out.shape[1], MEM_HOST))
         return out[:, :n]
 
     def _hits(self, call, nq, capacity):

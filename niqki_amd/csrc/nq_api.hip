@@ -83,7 +83,7 @@ int collect_spans(niqki_index *ix) {
 
 int derive(const niqki_params &p, nq::Derived &d, std::string &why) {
   if (p.K < 1 || p.K > 31) { why = "K must be in 1..31"; return NIQKI_E_INVALID; }
-  if (p.S < 1 || p.S > 15) { why = "S must be in 1..15"; return NIQKI_E_INVALID; }
+  if (p.S < 1 || p.S > 16) { why = "S must be in 1..16"; return NIQKI_E_INVALID; }
   if (p.W < 1 || p.W > 15 || p.H > p.W) { why = "need H <= W <= 15"; return NIQKI_E_INVALID; }
   if (p.S + p.W > 30) { why = "S+W must be <= 30"; return NIQKI_E_INVALID; }
   d.K = p.K; d.S = p.S; d.W = p.W; d.H = p.H; d.M = p.W - p.H;
@@ -182,7 +182,7 @@ int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, ui
   const uint64_t avg = total_bytes / n_entry;
   if (avg >= 16384 && !entry_rec && n_entry < 128 && avg >= (1u << 20))
     a.splits = std::min<uint32_t>(32, 512 / n_entry);
-  if (a.splits > 1) {
+  if (a.splits > 1 || nq::sketch_needs_merge(ix->d)) {  // partial sketches merged in global memory, then densified
     {
       Span sp(ix, NIQKI_KC_SKETCH);
       NQ_HIP(ix, nq::launch_fill_u32((uint32_t *)sketches, (uint64_t)n_entry * ix->d.F, nq::kEmpty32,
@@ -204,6 +204,9 @@ int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, ui
   (void)n_rec;
   return NIQKI_OK;
 }
+
+// a whole-range S = 16 handle counts in two planes of <= 2^15 slots each (nq_kernels.h, kPassSlots)
+bool two_planes(const niqki_index *ix) { return !ix->resident_bytes && ix->d.slot_end - ix->d.slot_begin > nq::kPassSlots; }
 
 // first slot of the handle in a whole sketch row (while a page is resident d.slot_begin is the page's)
 uint32_t first_slot(const niqki_index *ix) { return ix->resident_bytes ? ix->full_begin : ix->d.slot_begin; }
@@ -254,7 +257,7 @@ int load_page(niqki_index *ix, uint32_t s0, uint32_t s1) {
 }
 
 int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
-                    uint16_t *counts, uint64_t stride, bool accumulate);
+                    uint16_t *counts, uint64_t stride, bool accumulate, uint16_t *counts2 = nullptr);
 
 // counts over a paged index: page after page, the gather kernel adding to the rows from the second on
 int counts_paged(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq, uint16_t *counts,
@@ -275,13 +278,14 @@ int counts_paged(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, ui
 
 // counts for nq device-resident sketches into a device buffer
 int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
-               uint16_t *counts, uint64_t stride) {
+               uint16_t *counts, uint64_t stride, uint16_t *counts2) {
   if (ix->resident_bytes) return counts_paged(ix, sketches, q_stride, q_off, nq, counts, stride);
-  return counts_resident(ix, sketches, q_stride, q_off, nq, counts, stride, false);
+  if (two_planes(ix) && !counts2) return fail(ix, NIQKI_E_INVALID, "S = 16: counts reach 2^16, use niqki_query_counts32 (or the hit calls)");
+  return counts_resident(ix, sketches, q_stride, q_off, nq, counts, stride, false, counts2);
 }
 
 int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
-                    uint16_t *counts, uint64_t stride, bool accumulate) {
+                    uint16_t *counts, uint64_t stride, bool accumulate, uint16_t *counts2) {
   int rc = ix->resident_bytes ? NIQKI_OK : build_if_needed(ix);
   if (rc) return rc;
   if (nq == 0) return NIQKI_OK;
@@ -325,7 +329,8 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
     }
     if (pre)
       NQ_HIP(ix, nq::launch_lookup(v, sketches + (size_t)q0 * q_stride, n, (uint32_t *)ix->ws_pre.p, ix->stream));
-    NQ_HIP(ix, nq::launch_gather(v, sketches + (size_t)q0 * q_stride, n, counts + (size_t)q0 * stride, stride,
+    NQ_HIP(ix, nq::launch_gather(v, sketches + (size_t)q0 * q_stride, n, counts + (size_t)q0 * stride,
+                                 counts2 ? counts2 + (size_t)q0 * stride : nullptr, stride,
                                  pre ? (nq::Entry *)ix->ws_pre.p : (nq::Entry *)ix->ws_stash.p, order, ix->gather_variant,
                                  pre, ix->stream));
   }
@@ -335,9 +340,10 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
 // hits from device-resident counters into device buffers; hit_off device (nq+1)
 int hits_dev(niqki_index *ix, const uint16_t *counts, uint32_t nq, uint64_t stride, uint32_t gid_begin,
              uint32_t n_gids, unsigned long long *hit_off, uint32_t *hc, uint32_t *hg, uint64_t capacity,
-             bool check_capacity, uint64_t *total_out) {
+             bool check_capacity, uint64_t *total_out, const uint16_t *counts2) {
   nq::HitsArgs a;
   a.counts = counts;
+  a.counts2 = counts2;
   a.stride = stride;
   a.nq = nq;
   a.gid_begin = gid_begin;
@@ -384,11 +390,14 @@ int query_to_host(niqki_index *ix, const int32_t *sketches, bool sk_dev, uint32_
   bool overflow = false;
   hit_off[0] = 0;
   const uint32_t qb = ix->query_batch;
+  const size_t planes = two_planes(ix) ? 2 : 1;
   std::vector<unsigned long long> off(qb + 1);
   for (uint32_t q0 = 0; q0 < nq; q0 += qb) {
     const uint32_t n = std::min(qb, nq - q0);
     if (!sk_dev && (rc = ensure(ix, ix->ws_sk, (size_t)n * ix->d.F * 4))) return rc;
-    if ((rc = ensure(ix, ix->ws_counts, std::max<size_t>((size_t)n * stride * 2, 2)))) return rc;
+    const size_t plane = std::max<size_t>((size_t)n * stride * 2, 2);
+    if ((rc = ensure(ix, ix->ws_counts, plane * planes))) return rc;
+    uint16_t *c1 = (uint16_t *)ix->ws_counts.p, *c2 = planes == 2 ? (uint16_t *)((char *)ix->ws_counts.p + plane) : nullptr;
     if ((rc = ensure(ix, ix->ws_hitoff, (size_t)(n + 1) * 8))) return rc;
     const uint64_t room = overflow || base > capacity ? 0 : capacity - base;
     if ((rc = ensure(ix, ix->ws_hc, (size_t)std::max<uint64_t>(room, 1) * 4))) return rc;
@@ -398,10 +407,10 @@ int query_to_host(niqki_index *ix, const int32_t *sketches, bool sk_dev, uint32_
       NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, d_sk, (size_t)n * ix->d.F * 4, hipMemcpyHostToDevice, ix->stream));
       d_sk = (const int32_t *)ix->ws_sk.p;
     }
-    if ((rc = counts_dev(ix, d_sk, ix->d.F, first_slot(ix), n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+    if ((rc = counts_dev(ix, d_sk, ix->d.F, first_slot(ix), n, c1, stride, c2))) return rc;
     uint64_t total = 0;
-    rc = hits_dev(ix, (const uint16_t *)ix->ws_counts.p, n, stride, 0, N, (unsigned long long *)ix->ws_hitoff.p,
-                  (uint32_t *)ix->ws_hc.p, (uint32_t *)ix->ws_hg.p, room, true, &total);
+    rc = hits_dev(ix, c1, n, stride, 0, N, (unsigned long long *)ix->ws_hitoff.p,
+                  (uint32_t *)ix->ws_hc.p, (uint32_t *)ix->ws_hg.p, room, true, &total, c2);
     if (rc && rc != NIQKI_E_CAPACITY) return rc;
     NQ_HIP(ix, hipMemcpyAsync(off.data(), ix->ws_hitoff.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
     if (rc == NIQKI_OK && total) {
@@ -538,6 +547,7 @@ int niqki_create(const niqki_params *params, niqki_index **out) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return bail(NIQKI_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is gfx950 only");
   ix->device = dev;
   ix->resident_bytes = (uint64_t)params->resident_mib << 20;
+  if (ix->resident_bytes && ix->d.S > 15) return bail(NIQKI_E_INVALID, "paged indexes need S <= 15 (pages accumulate u16 counters)");
   ix->full_begin = ix->d.slot_begin;
   ix->full_end = ix->d.slot_end;
   if ((e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking)) != hipSuccess) return bail(NIQKI_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -633,6 +643,7 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
   if (!std::strcmp(key, "resident_bytes")) {
     if (value < 0) return fail(ix, NIQKI_E_INVALID, "resident_bytes must be >= 0");
     if (ix->n_genomes || ix->store) return fail(ix, NIQKI_E_STATE, "resident_bytes must be set before the first insert");
+    if (value && ix->d.S > 15) return fail(ix, NIQKI_E_INVALID, "paged indexes need S <= 15 (pages accumulate u16 counters)");
     ix->resident_bytes = (uint64_t)value;
     return NIQKI_OK;
   }
@@ -830,11 +841,45 @@ int niqki_query_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq, ui
   return NIQKI_OK;
 }
 
+int niqki_query_counts32(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint32_t *counts, uint64_t stride, int mem) {
+  if (!ix || (!sketches && nq) || (!counts && nq)) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = build_if_needed(ix);
+  if (rc) return rc;
+  if (stride < ix->n_genomes || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
+  const uint32_t qb = mem == NIQKI_MEM_DEVICE ? std::min<uint32_t>(nq, 4096) : ix->query_batch;
+  const size_t planes = two_planes(ix) ? 2 : 1;
+  for (uint32_t q0 = 0; q0 < nq; q0 += qb) {
+    const uint32_t n = std::min(qb, nq - q0);
+    const size_t plane = (size_t)n * stride * 2;
+    if ((rc = ensure(ix, ix->ws_counts, std::max<size_t>(plane * planes, 4)))) return rc;
+    uint16_t *c1 = (uint16_t *)ix->ws_counts.p, *c2 = planes == 2 ? (uint16_t *)((char *)ix->ws_counts.p + plane) : nullptr;
+    NQ_HIP(ix, hipMemsetAsync(ix->ws_counts.p, 0, std::max<size_t>(plane * planes, 4), ix->stream));
+    const int32_t *d_sk = sketches + (size_t)q0 * ix->d.F;
+    uint32_t *d_out = counts + (size_t)q0 * stride;
+    if (mem == NIQKI_MEM_HOST) {
+      if ((rc = ensure(ix, ix->ws_sk, (size_t)n * ix->d.F * 4))) return rc;
+      if ((rc = ensure(ix, ix->ws_misc, (size_t)n * stride * 4))) return rc;
+      NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, d_sk, (size_t)n * ix->d.F * 4, hipMemcpyHostToDevice, ix->stream));
+      d_sk = (const int32_t *)ix->ws_sk.p;
+      d_out = (uint32_t *)ix->ws_misc.p;
+    }
+    if ((rc = counts_dev(ix, d_sk, ix->d.F, first_slot(ix), n, c1, stride, c2))) return rc;
+    NQ_HIP(ix, nq::launch_plane_sum32(c1, c2, d_out, (uint64_t)n * stride, ix->stream));
+    if (mem == NIQKI_MEM_HOST) {
+      NQ_HIP(ix, hipMemcpyAsync(counts + (size_t)q0 * stride, d_out, (size_t)n * stride * 4, hipMemcpyDeviceToHost, ix->stream));
+      NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    }
+  }
+  return NIQKI_OK;
+}
+
 int niqki_hits_from_counts(niqki_index *ix, const uint16_t *counts, uint32_t nq, uint64_t stride,
                            uint32_t gid_begin, uint32_t n_gids, uint64_t *hit_off, uint32_t *hit_counts,
                            uint32_t *hit_gids, uint64_t capacity, int mem) {
   if (!ix || !hit_off || (!counts && nq)) return NIQKI_E_INVALID;
   if ((uint64_t)gid_begin + n_gids > stride) return fail(ix, NIQKI_E_INVALID, "gid range exceeds stride");
+  if (ix->d.S > 15) return fail(ix, NIQKI_E_INVALID, "S = 16: u16 counters cannot hold a count of 2^16; use niqki_query");
   NQ_HIP(ix, hipSetDevice(ix->device));
   if (mem == NIQKI_MEM_DEVICE)
     return hits_dev(ix, counts, nq, stride, gid_begin, n_gids, (unsigned long long *)hit_off, hit_counts,
@@ -879,10 +924,11 @@ int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint64_t 
   const uint32_t N = ix->built_n;
   const uint64_t stride = ((uint64_t)N + 1) & ~1ull;
   if (mem == NIQKI_MEM_DEVICE) {
-    if ((rc = ensure(ix, ix->ws_counts, std::max<size_t>((size_t)nq * stride * 2, 2)))) return rc;
-    if ((rc = counts_dev(ix, sketches, ix->d.F, first_slot(ix), nq, (uint16_t *)ix->ws_counts.p, stride))) return rc;
-    return hits_dev(ix, (const uint16_t *)ix->ws_counts.p, nq, stride, 0, N, (unsigned long long *)hit_off,
-                    hit_counts, hit_gids, capacity, false, nullptr);
+    const size_t plane = std::max<size_t>((size_t)nq * stride * 2, 2);
+    if ((rc = ensure(ix, ix->ws_counts, plane * (two_planes(ix) ? 2 : 1)))) return rc;
+    uint16_t *c1 = (uint16_t *)ix->ws_counts.p, *c2 = two_planes(ix) ? (uint16_t *)((char *)ix->ws_counts.p + plane) : nullptr;
+    if ((rc = counts_dev(ix, sketches, ix->d.F, first_slot(ix), nq, c1, stride, c2))) return rc;
+    return hits_dev(ix, c1, nq, stride, 0, N, (unsigned long long *)hit_off, hit_counts, hit_gids, capacity, false, nullptr, c2);
   }
   return query_to_host(ix, sketches, false, nq, hit_off, hit_counts, hit_gids, capacity);
 }
@@ -1159,11 +1205,21 @@ int niqki_matrix_range(niqki_index *ix, uint32_t begin, uint32_t end, uint16_t *
     NQ_HIP(ix, nq::launch_store_read(ix->d, ix->store, ix->cap, t0, n, (int32_t *)ix->ws_misc.p, ix->stream));
     uint16_t *dst = counts + (size_t)(t0 - begin) * stride;
     if (mem == NIQKI_MEM_DEVICE) {
-      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, ix->d.F, first_slot(ix), n, dst, stride))) return rc;
+      uint16_t *c2 = nullptr;
+      if (two_planes(ix)) {
+        if ((rc = ensure(ix, ix->ws_counts, (size_t)n * stride * 2))) return rc;
+        c2 = (uint16_t *)ix->ws_counts.p;
+      }
+      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, ix->d.F, first_slot(ix), n, dst, stride, c2))) return rc;
+      // uint16 counters whatever S (src/niqki_index.cpp:572): at S = 16 a count of 2^16 reads 0, as in the reference
+      if (c2) NQ_HIP(ix, nq::launch_plane_add16(dst, c2, (uint64_t)n * stride, ix->stream));
     } else {
-      if ((rc = ensure(ix, ix->ws_counts, (size_t)n * stride * 2))) return rc;
-      NQ_HIP(ix, hipMemsetAsync(ix->ws_counts.p, 0, (size_t)n * stride * 2, ix->stream));
-      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, ix->d.F, first_slot(ix), n, (uint16_t *)ix->ws_counts.p, stride))) return rc;
+      const size_t plane = (size_t)n * stride * 2;
+      if ((rc = ensure(ix, ix->ws_counts, plane * (two_planes(ix) ? 2 : 1)))) return rc;
+      NQ_HIP(ix, hipMemsetAsync(ix->ws_counts.p, 0, plane * (two_planes(ix) ? 2 : 1), ix->stream));
+      uint16_t *c2 = two_planes(ix) ? (uint16_t *)((char *)ix->ws_counts.p + plane) : nullptr;
+      if ((rc = counts_dev(ix, (const int32_t *)ix->ws_misc.p, ix->d.F, first_slot(ix), n, (uint16_t *)ix->ws_counts.p, stride, c2))) return rc;
+      if (c2) NQ_HIP(ix, nq::launch_plane_add16((uint16_t *)ix->ws_counts.p, c2, (uint64_t)n * stride, ix->stream));
       NQ_HIP(ix, hipMemcpyAsync(dst, ix->ws_counts.p, (size_t)n * stride * 2, hipMemcpyDeviceToHost, ix->stream));
       NQ_HIP(ix, hipStreamSynchronize(ix->stream));
     }

@@ -351,6 +351,7 @@ int niqki_group_create(niqki_index *const *shards, uint32_t n_local, uint32_t fi
       return bail(NIQKI_E_INVALID, "shard " + std::to_string(first_rank + l) + " must own slots [" + std::to_string(b) + ", " +
                                        std::to_string(e) + ") (niqki_group_slot_range)");
     if (ix->resident_bytes) return bail(NIQKI_E_INVALID, "a paged index (resident_bytes) cannot be a shard of a group");
+    if (ix->d.S > 15) return bail(NIQKI_E_INVALID, "groups need S <= 15 (the exchange sums u16 counters)");
     if (ix->d.K != shards[0]->d.K || ix->d.W != shards[0]->d.W || ix->d.min_score != shards[0]->d.min_score ||
         ix->n_genomes != shards[0]->n_genomes)
       return bail(NIQKI_E_INVALID, "the shards of a group must agree in K, W, min_score and genome count");

@@ -92,11 +92,12 @@ int ensure(niqki_index *ix, Buf &b, size_t bytes);   // device scratch of at lea
 nq::IndexView view(const niqki_index *ix);
 int build_if_needed(niqki_index *ix);
 // hit counters of nq device-resident sketches (rows q_stride apart, this shard's slots at q_off)
+// counts2: the second counter plane of a whole-range S = 16 handle (nq_kernels.h, kPassSlots), else nullptr
 int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
-               uint16_t *counts, uint64_t stride);
+               uint16_t *counts, uint64_t stride, uint16_t *counts2 = nullptr);
 int hits_dev(niqki_index *ix, const uint16_t *counts, uint32_t nq, uint64_t stride, uint32_t gid_begin,
              uint32_t n_gids, unsigned long long *hit_off, uint32_t *hc, uint32_t *hg, uint64_t capacity,
-             bool check_capacity, uint64_t *total_out);
+             bool check_capacity, uint64_t *total_out, const uint16_t *counts2 = nullptr);
 // sketches of the handle's staged batch (niqki_stage_raw) into ix->ws_stsk, once per batch
 int staged_sketch_ws(niqki_index *ix);
 // appends n device-resident sketches (same addressing as counts_dev) to the sketch store

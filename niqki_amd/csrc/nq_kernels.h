@@ -13,6 +13,8 @@ struct SketchArgs {
   const uint32_t *entry_rec;  // n_entry+1 or nullptr (one record per sketch)
   int32_t *sketches;          // n_entry x F
   uint32_t splits;            // workgroups per sketch (>1: partial mins merged in global memory)
+  uint32_t halves;            // set by launch_sketch: 2 when the F cells do not fit LDS (S = 16): every workgroup
+                              // keeps one half of the slots and sees all k-mers; results merge in global memory
   uint32_t accumulate;        // start from the sketches already in `sketches`
   uint32_t densify;           // run densification before the store (splits == 1 only)
   uint32_t distinct;          // set by launch_sketch: densify over distinct values (short-read path)
@@ -22,6 +24,9 @@ struct SketchArgs {
 hipError_t launch_sketch(const SketchArgs &a, uint32_t n_entry, uint64_t avg_len,
                          hipStream_t stream);
 hipError_t launch_fill_u32(uint32_t *p, uint64_t n, uint32_t v, hipStream_t stream);
+// true: launch_sketch cannot densify inside the kernel for these parameters -- the caller fills the
+// output with "empty" first, launches with densify = 0, then a densify-only launch (seqs = nullptr)
+bool sketch_needs_merge(const Derived &d);
 
 // ---- sketch store + inverted index (nq_index.hip) ---------------------------
 // Sketch store: u16 [F_local][cap], slot major; 0xFFFF = empty/invalid cell.
@@ -108,9 +113,17 @@ hipError_t launch_import(const Derived &d, const uint32_t *words, const uint64_t
 // stash: nq x (n_tiles-1) x f_local Entry scratch (unused for n_tiles == 1)
 // order: nullptr, or the locality order of the batch from launch_order (nq <= 4096)
 // pre: `stash` holds the packed words of launch_lookup for ALL tiles (sketches are then unused)
+// counts2: second counter plane, needed (and used) when the view has more than kPassSlots slots
+// (S = 16 on a whole-range handle): a count can then reach 2^16, so the slots are walked in two
+// passes of <= 2^15 and plane p holds pass p's counters; the true count is the 32-bit sum.
+constexpr uint32_t kPassSlots = 32768;
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq,
-                         uint16_t *counts, uint64_t stride, Entry *stash, const uint32_t *order,
+                         uint16_t *counts, uint16_t *counts2, uint64_t stride, Entry *stash, const uint32_t *order,
                          int variant, bool pre, hipStream_t stream);
+// out[i] = a[i] + b[i]: as u16 with wrap-around (the reference's uint16 matrix counters, src/niqki_index.cpp:572)
+// or as u32
+hipError_t launch_plane_add16(uint16_t *a, const uint16_t *b, uint64_t n, hipStream_t stream);
+hipError_t launch_plane_sum32(const uint16_t *a, const uint16_t *b, uint32_t *out, uint64_t n, hipStream_t stream);
 // Slot-major look-up pre-pass for the queries of a launch (nq_query.hip): fills
 // pre[q][tile][slot] (lookup_pre_bytes of scratch) from the table streamed once.
 bool launch_lookup_usable(const IndexView &v);
@@ -128,6 +141,7 @@ hipError_t launch_gathered(const IndexView &v, const int32_t *sketches, uint32_t
 // hit_off nq+1 (u64); tmp_*: capacity-sized scratch for the sort.
 struct HitsArgs {
   const uint16_t *counts;
+  const uint16_t *counts2;   // second counter plane (S = 16) or nullptr: the count is the 32-bit sum
   uint64_t stride;
   uint32_t nq;
   uint32_t gid_begin, n_gids;

@@ -19,6 +19,8 @@
 // share their table and bucket lines through its L2.
 #include "nq_kernels.h"
 
+#include <algorithm>
+
 namespace nq {
 
 __device__ __forceinline__ void bump(uint32_t *cnt, uint32_t g) {
@@ -98,12 +100,12 @@ __device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t 
 template <int BLOCK, int UNROLL, int NT, bool STASH_OUT, bool STASH_IN, int MODE, bool PRE = false, bool PAD = false>
 __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk, uint32_t q, uint32_t t,
                                           uint32_t *cnt, Item *queue, Entry *stash, uint32_t &sink,
-                                          const uint32_t *pre = nullptr) {
+                                          uint32_t it_lo, uint32_t n_it, const uint32_t *pre = nullptr) {
+  // slots [64 * it_lo, min(64 * n_it, f_local)): one pass of the kernel
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   constexpr uint32_t NW = BLOCK / 64;
   constexpr int NE = STASH_OUT ? NT : 1;  // entries fetched per lookup
   const uint32_t R = v.d.R, a = v.align_log2;
-  const uint32_t n_it = (v.f_local + 63) / 64;
   const uint16_t *gl = v.gids + v.tile_base[t];
   Entry *my_stash = PRE ? nullptr : stash + (uint64_t)q * (v.n_tiles - 1) * v.f_local;
   const uint32_t *my_pre = PRE ? pre + ((uint64_t)q * v.n_tiles + t) * v.f_local : nullptr;
@@ -151,7 +153,7 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
 
   // software pipeline: table look-ups run two iterations ahead of the walk, fingerprints
   // three (a pass over short buckets has little walk work to hide a look-up behind)
-  uint32_t it = wave;
+  uint32_t it = it_lo + wave;
   int32_t fp0 = load_fp(it);
   int32_t fp1 = load_fp(it + NW);
   int32_t fp2 = load_fp(it + 2 * NW);
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *keys, uint3
 // NT = -1: every tile's entries come from the look-up pre-pass (`stash` then holds its packed words)
 template <int BLOCK, int UNROLL, int NT, int MODE = 0, bool PAD = false>
 __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_t *sketches,
-                                                       uint16_t *counts, uint64_t stride, Entry *stash,
+                                                       uint16_t *counts, uint16_t *counts2, uint64_t stride, Entry *stash,
                                                        const uint32_t *order, uint32_t nq) {
   extern __shared__ __align__(16) uint32_t cnt[];
   uint32_t q = blockIdx.x;
@@ -415,22 +417,26 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
   const int32_t *sk = NT < 0 ? nullptr : sketches + (uint64_t)q * v.q_stride + v.q_off;
   Item *queue = (Item *)(cnt + (v.tile + 1) / 2 + (PAD ? kPadWords : 0u));  // behind the counters: kQueue items per wave
   uint32_t sink = 0;
+  const uint32_t n_it_all = (v.f_local + 63) / 64, it_pass = kPassSlots / 64;
+  for (uint32_t it_lo = 0; it_lo < n_it_all; it_lo += it_pass) {   // one pass unless f_local > 2^15 (S = 16)
+  const uint32_t n_it = it_lo + it_pass < n_it_all ? it_lo + it_pass : n_it_all;
+  uint16_t *plane = it_lo ? counts2 : counts;
   for (uint32_t t = 0; t < v.n_tiles; ++t) {
     const uint32_t n_t = tile_count(v, t);
     const uint32_t n_words = (n_t + 1) / 2;
     for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
     __syncthreads();
     if constexpr (NT < 0) {
-      walk_tile<BLOCK, UNROLL, 1, false, false, MODE, true, PAD>(v, sk, q, t, cnt, queue, nullptr, sink, (const uint32_t *)stash);
+      walk_tile<BLOCK, UNROLL, 1, false, false, MODE, true, PAD>(v, sk, q, t, cnt, queue, nullptr, sink, it_lo, n_it, (const uint32_t *)stash);
     } else if constexpr (NT >= 2) {
-      if (t == 0) walk_tile<BLOCK, UNROLL, NT, true, false, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink);
-      else walk_tile<BLOCK, UNROLL, NT, false, true, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink);
+      if (t == 0) walk_tile<BLOCK, UNROLL, NT, true, false, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink, it_lo, n_it);
+      else walk_tile<BLOCK, UNROLL, NT, false, true, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink, it_lo, n_it);
     } else {
-      walk_tile<BLOCK, UNROLL, 1, false, false, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink);
+      walk_tile<BLOCK, UNROLL, 1, false, false, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink, it_lo, n_it);
     }
     if (MODE != 0) cnt[tid % n_words] ^= sink;
     __syncthreads();
-    uint16_t *row = counts + (uint64_t)q * stride;
+    uint16_t *row = plane + (uint64_t)q * stride;
     if (v.stripe && v.n_tiles > 1) {
       // striped tiles: the tile's i-th counter belongs to genome i * n_tiles + t
       for (uint32_t i = tid; i < n_t; i += BLOCK) {
@@ -452,6 +458,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     }
     __syncthreads();
   }
+  }
 }
 
 hipError_t launch_order(const IndexView &v, const int32_t *sketches, uint32_t nq, uint32_t *keys,
@@ -472,10 +479,11 @@ bool gather_variant_valid(int variant) {
   return variant >= 0 && variant <= 5;
 }
 
-hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq, uint16_t *counts,
+hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq, uint16_t *counts, uint16_t *counts2,
                          uint64_t stride, Entry *stash, const uint32_t *order, int variant, bool pre,
                          hipStream_t stream) {
   if (nq == 0 || v.n_tiles == 0) return hipSuccess;
+  if (v.f_local > kPassSlots && (!counts2 || v.accumulate)) return hipErrorInvalidValue;
 #define NQ_GATHER_LDS(B) ((size_t)((v.tile + 1) / 2 + (v.padded ? kPadWords : 0u)) * 4 + (size_t)(B / 64) * kQueue * sizeof(Item))
   // with a locality order the grid is padded to whole groups on every XCD
   const uint32_t per_round = kXcds * kOrderGroup;
@@ -487,7 +495,7 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     const size_t lds = NQ_GATHER_LDS(B);                                                         \
     e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                               \
-    hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, v, sketches, counts, stride, stash, order, nq); \
+    hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, v, sketches, counts, counts2, stride, stash, order, nq); \
   } while (0)
 #define NQ_BY_TILES(B, U, ...)                                                                   \
   do {                                                                                           \
@@ -556,7 +564,8 @@ __global__ __launch_bounds__(1024) void hits_count_kernel(HitsArgs a) {
   if (threadIdx.x == 0) s_sum = 0;
   __syncthreads();
   const uint16_t *row = a.counts + (uint64_t)q * a.stride + a.gid_begin;
-  const bool vec = (((uintptr_t)row) & 15) == 0;   // uniform
+  const uint16_t *row2 = a.counts2 ? a.counts2 + (uint64_t)q * a.stride + a.gid_begin : nullptr;
+  const bool vec = (((uintptr_t)row) & 15) == 0 && !row2;   // uniform
   uint32_t mine = 0;
   for (uint32_t b = wave; b < a.n_blk; b += 16) {
     const uint32_t lo = b * kHitsBlk;
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(1024) void hits_count_kernel(HitsArgs a) {
         }
       }
     } else {
-      for (uint32_t i = lo + lane; i < hi; i += 64) c += (row[i] >= a.min_score);
+      for (uint32_t i = lo + lane; i < hi; i += 64) c += ((uint32_t)row[i] + (row2 ? (uint32_t)row2[i] : 0u) >= a.min_score);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
@@ -635,13 +644,14 @@ __global__ __launch_bounds__(256) void hits_compact_kernel(HitsArgs a) {
   }
   const unsigned long long seg0 = a.hit_off[q], seg1 = a.hit_off[q + 1];
   const uint16_t *row = a.counts + (uint64_t)q * a.stride + a.gid_begin;
+  const uint16_t *row2 = a.counts2 ? a.counts2 + (uint64_t)q * a.stride + a.gid_begin : nullptr;
   const uint32_t lo = b * kHitsBlk;
   const uint32_t hi = (lo + kHitsBlk < a.n_gids) ? lo + kHitsBlk : a.n_gids;
   __syncthreads();
   uint32_t run = s_before;  // hits of this query with smaller gid, so far
   for (uint32_t base = lo; base < hi; base += 256) {
     uint32_t i = base + tid;
-    uint32_t c = (i < hi) ? (uint32_t)row[i] : 0u;
+    uint32_t c = (i < hi) ? (uint32_t)row[i] + (row2 ? (uint32_t)row2[i] : 0u) : 0u;
     bool hit = (i < hi) && c >= a.min_score;
     uint64_t bal = __ballot(hit);
     uint32_t rank = __popcll(bal & ((1ULL << lane) - 1ULL));
@@ -722,6 +732,12 @@ __global__ __launch_bounds__(256) void hits_sort_kernel(HitsArgs a) {
   radix_pass_desc(hc, hg, tc, tg, n, 0, curs[wave], lane);
   __threadfence_block();
   radix_pass_desc(tc, tg, hc, hg, n, 8, curs[wave], lane);
+  if (a.counts2) {  // S = 16: a count can be 2^16, 17 bits (two more passes bring the result back into hit_*)
+    __threadfence_block();
+    radix_pass_desc(hc, hg, tc, tg, n, 16, curs[wave], lane);
+    __threadfence_block();
+    radix_pass_desc(tc, tg, hc, hg, n, 24, curs[wave], lane);
+  }
 }
 
 // Candidate genomes of every query: ids with counts[q][g] >= thr, at most `cap`
@@ -752,6 +768,25 @@ hipError_t launch_candidates(const uint16_t *counts, uint64_t stride, uint32_t n
                              uint32_t cap, int32_t *cand, int32_t *n, hipStream_t stream) {
   if (nq == 0) return hipSuccess;
   hipLaunchKernelGGL(candidates_kernel, dim3(nq), dim3(256), 0, stream, counts, stride, n_gids, thr, cap, cand, n);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void plane_add16_kernel(uint16_t *a, const uint16_t *b, uint64_t n) {
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) a[i] = (uint16_t)(a[i] + b[i]);
+}
+__global__ __launch_bounds__(256) void plane_sum32_kernel(const uint16_t *a, const uint16_t *b, uint32_t *out, uint64_t n) {
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) out[i] = (uint32_t)a[i] + (b ? (uint32_t)b[i] : 0u);
+}
+hipError_t launch_plane_add16(uint16_t *a, const uint16_t *b, uint64_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(plane_add16_kernel, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 16384)), dim3(256), 0, stream, a, b, n);
+  return hipGetLastError();
+}
+hipError_t launch_plane_sum32(const uint16_t *a, const uint16_t *b, uint32_t *out, uint64_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(plane_sum32_kernel, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 16384)), dim3(256), 0, stream, a, b, out, n);
   return hipGetLastError();
 }
 

@@ -202,9 +202,15 @@ __device__ __forceinline__ uint64_t roll_step(uint32_t e, uint64_t &fw, uint64_t
 }
 
 // slot + fingerprint of a canonical k-mer and the per-slot min (:346-355)
-__device__ __forceinline__ void sketch_update(uint64_t canon, const Derived &d, uint32_t *sk, bool live) {
+// hsel: 0 = sk holds all F cells; 1 / 2 = sk holds the lower / upper half of the slots (S = 16: the
+// cells of a whole sketch do not fit LDS) and k-mers of the other half change nothing
+__device__ __forceinline__ void sketch_update(uint64_t canon, const Derived &d, uint32_t *sk, bool live, uint32_t hsel = 0) {
   uint32_t slot = slot_of(canon, d.S);
   uint32_t fp = fingerprint(rev64(canon), d.M, d.mask_m, d.max_rem);
+  if (hsel) {  // uniform
+    live = live && (slot >> (d.S - 1)) == hsel - 1u;
+    slot &= (d.F >> 1) - 1u;
+  }
   fp = live ? fp : kEmpty32;  // a min with "empty" changes nothing
   atomicMin(&sk[slot], fp);
 }
@@ -228,7 +234,7 @@ constexpr uint32_t kRingAlloc = kRing + 64;  // + one scratch slot per lane
 // unfiltered if any slot is still empty afterwards, so the result is exact.
 template <int BLOCK, int GROUPS, int KFIX, bool FILTER>
 __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part, uint32_t *sk, const uint8_t *lut,
-                             uint64_t *ring_base, uint32_t thr) {
+                             uint64_t *ring_base, uint32_t thr, uint32_t hsel) {
   const Derived &d = a.d;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   constexpr uint32_t CHUNK = 16u * GROUPS;
@@ -239,7 +245,7 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
   auto drain64 = [&](bool partial) {
     uint64_t c = ring[(q_head + lane) & (kRing - 1)];
     const bool live = !partial || lane < q_count;
-    sketch_update(live ? c : 0ull, d, sk, live);
+    sketch_update(live ? c : 0ull, d, sk, live, hsel);
     q_head = (q_head + 64) & (kRing - 1);
     q_count = partial ? 0u : q_count - 64;
   };
@@ -352,7 +358,7 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
             const uint64_t canon = roll_step<KFIX>(e[j], fw, rc, d, rc_shift);
             const bool live = (uint32_t)(g * 16 + j) < cnt;
             if (!FILTER) {
-              sketch_update(canon, d, sk, live);
+              sketch_update(canon, d, sk, live, hsel);
             } else {
               // dead steps get an all-ones hash word and never pass
               filtered(canon, live ? rev64_hi(canon) : 0xFFFFFFFFu);
@@ -370,20 +376,23 @@ template <int BLOCK, int GROUPS, int KFIX>
 __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
   extern __shared__ __align__(16) uint32_t smem[];
   const Derived &d = a.d;
-  uint32_t *sk = smem;                              // F cells
-  uint32_t *s_flag = smem + d.F;                    // 4 words
-  uint8_t *lut = (uint8_t *)(smem + d.F + 4);       // 256 bytes
-  uint32_t *aux = smem + d.F + 4 + 64;              // distinct-value tables or the filter rings
+  const uint32_t Fc = d.F / a.halves;               // cells this workgroup keeps
+  uint32_t *sk = smem;                              // Fc cells
+  uint32_t *s_flag = smem + Fc;                     // 4 words
+  uint8_t *lut = (uint8_t *)(smem + Fc + 4);        // 256 bytes
+  uint32_t *aux = smem + Fc + 4 + 64;               // distinct-value tables or the filter rings
   const uint32_t tid = threadIdx.x;
-  const uint32_t entry = blockIdx.x / a.splits;
   const uint32_t part = blockIdx.x % a.splits;
+  const uint32_t half = (blockIdx.x / a.splits) % a.halves;
+  const uint32_t entry = blockIdx.x / (a.splits * a.halves);
+  const uint32_t hsel = a.halves > 1 ? half + 1u : 0u;
 
   if (tid < 256) lut[tid] = code_entry(tid);
   if (a.accumulate) {
-    const uint32_t *src = (const uint32_t *)a.sketches + (uint64_t)entry * d.F;
-    for (uint32_t i = tid; i < d.F; i += BLOCK) sk[i] = src[i];
+    const uint32_t *src = (const uint32_t *)a.sketches + (uint64_t)entry * d.F + (uint64_t)half * Fc;
+    for (uint32_t i = tid; i < Fc; i += BLOCK) sk[i] = src[i];
   } else {
-    for (uint32_t i = tid; i < d.F; i += BLOCK) sk[i] = kEmpty32;
+    for (uint32_t i = tid; i < Fc; i += BLOCK) sk[i] = kEmpty32;
   }
   __syncthreads();
 
@@ -408,28 +417,28 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
       thr = T ? (1u << (32 - T)) : 0u;
     }
     if (thr) {
-      roll_records<BLOCK, GROUPS, KFIX, true>(a, entry, part, sk, lut, (uint64_t *)aux, thr);
+      roll_records<BLOCK, GROUPS, KFIX, true>(a, entry, part, sk, lut, (uint64_t *)aux, thr, hsel);
       __syncthreads();
       uint32_t local = 0;
-      for (uint32_t i = tid; i < d.F; i += BLOCK) local += (sk[i] == kEmpty32);
+      for (uint32_t i = tid; i < Fc; i += BLOCK) local += (sk[i] == kEmpty32);
       if (tid == 0) s_flag[2] = 0;
       __syncthreads();
       if (local) atomicAdd(&s_flag[2], local);
       __syncthreads();
       // a slot without a candidate may still have skipped k-mers: exact re-run.
       // (With splits > 1 another part may hold the candidates, so every part re-runs.)
-      if (s_flag[2] != 0) roll_records<BLOCK, GROUPS, KFIX, false>(a, entry, part, sk, lut, nullptr, 0);
+      if (s_flag[2] != 0) roll_records<BLOCK, GROUPS, KFIX, false>(a, entry, part, sk, lut, nullptr, 0, hsel);
     } else {
-      roll_records<BLOCK, GROUPS, KFIX, false>(a, entry, part, sk, lut, nullptr, 0);
+      roll_records<BLOCK, GROUPS, KFIX, false>(a, entry, part, sk, lut, nullptr, 0, hsel);
     }
   }
   __syncthreads();
 
-  uint32_t *out = (uint32_t *)a.sketches + (uint64_t)entry * d.F;
-  if (a.splits > 1) {
-    // partial sketch of a split record: merged in global memory, densified
-    // by a second launch once all parts are in
-    for (uint32_t i = tid; i < d.F; i += BLOCK) {
+  uint32_t *out = (uint32_t *)a.sketches + (uint64_t)entry * d.F + (uint64_t)half * Fc;
+  if (a.splits > 1 || a.halves > 1) {
+    // partial sketch (a part of a split record, or one half of the slots): merged in global
+    // memory, densified by a second launch once all workgroups are in
+    for (uint32_t i = tid; i < Fc; i += BLOCK) {
       uint32_t v = sk[i];
       if (v != kEmpty32) atomicMin(&out[i], v);
     }
@@ -659,14 +668,74 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
   for (uint32_t i = lane; i < F; i += 64) out[i] = sk[i];
 }
 
-static size_t sketch_lds_bytes(const Derived &d, bool distinct, uint32_t ring_waves) {
-  return (size_t)d.F * 4 + 16 + 256 + (distinct ? (size_t)d.R * 12 : 0) + (size_t)ring_waves * kRingAlloc * 8;
+static size_t sketch_lds_bytes(const Derived &d, bool distinct, uint32_t ring_waves, uint32_t halves = 1) {
+  return (size_t)(d.F / halves) * 4 + 16 + 256 + (distinct ? (size_t)d.R * 12 : 0) + (size_t)ring_waves * kRingAlloc * 8;
+}
+constexpr size_t kLdsLimit = 160 * 1024;
+
+bool sketch_needs_merge(const Derived &d) { return sketch_lds_bytes(d, false, 16) > kLdsLimit; }
+
+// Densification of sketches whose F cells do not fit LDS (S = 16): the same pass-parallel algorithm as
+// densify_lds on the cells in global memory.  One workgroup per sketch; the cells are read and
+// written with agent-scope atomics only (a plain load could see a stale L1 line behind another
+// wave's atomicMin).  Rare path: a 5 Mbp genome has no empty cell at S = 16 and leaves after the count.
+__global__ __launch_bounds__(1024) void densify_global_kernel(SketchArgs a) {
+  __shared__ uint32_t s_flag[2];
+  const Derived &d = a.d;
+  const uint32_t F = d.F, tid = threadIdx.x;
+  uint32_t *sk = (uint32_t *)a.sketches + (uint64_t)blockIdx.x * F;
+  auto ld = [&](uint32_t i) { return __hip_atomic_load(&sk[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto st = [&](uint32_t i, uint32_t v) { __hip_atomic_store(&sk[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  uint32_t local = 0;
+  for (uint32_t i = tid; i < F; i += 1024) local += (ld(i) == kEmpty32);
+  if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+  __syncthreads();
+  if (local) atomicAdd(&s_flag[0], local);
+  __syncthreads();
+  uint32_t empty = s_flag[0];
+  if (empty == 0 || empty == F) return;
+  uint32_t step = 0, idle = 0;
+  while (true) {
+    for (uint32_t i = tid; i < F; i += 1024) {
+      const uint32_t v = ld(i);
+      if (v < 0x80000000u) {
+        const uint32_t t = ((uint32_t)unrev64(v) + step * (uint32_t)rev64(v)) & (F - 1u);  // :308-310, :319
+        atomicMin(&sk[t], 0x80000000u | i);
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    uint32_t filled = 0;
+    for (uint32_t i = tid; i < F; i += 1024) {
+      const uint32_t v = ld(i);
+      if (v >= 0x80000000u && v != kEmpty32) { st(i, ld(v & 0x7FFFFFFFu)); ++filled; }
+    }
+    if (filled) atomicAdd(&s_flag[1], filled);
+    __threadfence();
+    __syncthreads();
+    const uint32_t tot = s_flag[1];
+    __syncthreads();
+    if (tid == 0) s_flag[1] = 0;
+    empty -= tot;
+    ++step;
+    idle = tot ? 0u : idle + 1u;
+    if (empty == 0 || idle >= F) break;
+    __syncthreads();
+  }
 }
 
 hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_len,
                          hipStream_t stream) {
   if (n_entry == 0) return hipSuccess;
   SketchArgs a = a_in;
+  a.halves = sketch_needs_merge(a.d) ? 2u : 1u;
+  if (a.halves > 1) {
+    if (a.seqs == nullptr) {  // densify-only launch
+      hipLaunchKernelGGL(densify_global_kernel, dim3(n_entry), dim3(1024), 0, stream, a);
+      return hipGetLastError();
+    }
+    if (a.densify) return hipErrorInvalidValue;  // see sketch_needs_merge
+  }
   // Launch shape by the average input length of a sketch: a 256-thread workgroup for
   // reads, else 1024 threads with chunks of 32 / 128 / 512 k-mers per lane (long chunks
   // amortise the K-1 warm-up steps, short ones keep all lanes busy on short records).
@@ -675,7 +744,7 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   {
     const char *wv = std::getenv("NIQKI_SKETCH_WAVE");
     const size_t wl = sketch_reads_lds_bytes(a.d);
-    if (avg_len <= 4096 && a.splits == 1 && wl <= 40 * 1024 && !(wv && std::atoi(wv) == 0)) {
+    if (avg_len <= 4096 && a.splits == 1 && a.halves == 1 && wl <= 40 * 1024 && !(wv && std::atoi(wv) == 0)) {
       hipError_t e = hipFuncSetAttribute((const void *)sketch_reads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(sketch_reads_kernel, dim3(n_entry), dim3(64), wl, stream, a);
@@ -690,15 +759,15 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   // ... and cells this launch produced itself: a caller's sketch (niqki_densify, accumulate) may hold
   // any value, the value-indexed tables only values below 2^W
   const bool own_cells = a.seqs != nullptr && !a.accumulate;
-  a.distinct = (regular && own_cells && short_records && sketch_lds_bytes(a.d, true, 0) <= 64 * 1024) ? 1u : 0u;
+  a.distinct = (regular && own_cells && short_records && a.halves == 1 && sketch_lds_bytes(a.d, true, 0) <= 64 * 1024) ? 1u : 0u;
   // candidate filter: long records only (the kernel picks its strength per sketch);
   // NIQKI_SKETCH_FILTER=0 switches it off
   // NIQKI_SKETCH_FILTER: 0 = off, unset/1 = automatic, n >= 2 = force n-1 leading zeros (tests)
   const char *fv = std::getenv("NIQKI_SKETCH_FILTER");
   const uint32_t fmode = fv ? (uint32_t)std::atoi(fv) : 1u;
   a.filter = (regular && !short_records && a.seqs != nullptr) ? fmode : 0u;
-  const size_t lds = sketch_lds_bytes(a.d, a.distinct != 0, a.filter ? (short_records ? 4 : 16) : 0);
-  dim3 grid(n_entry * a.splits);
+  const size_t lds = sketch_lds_bytes(a.d, a.distinct != 0, a.filter ? (short_records ? 4 : 16) : 0, a.halves);
+  dim3 grid(n_entry * a.splits * a.halves);
 #define NQ_LAUNCH_SKETCH(B, G, KF)                                                               \
   do {                                                                                           \
     auto k = sketch_kernel<B, G, KF>;                                                            \

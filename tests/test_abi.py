@@ -51,7 +51,7 @@ def test_no_gpu_means_no_engine(native):
 
 
 def test_invalid_parameters_rejected_before_touching_a_device(native):
-    for kw in (dict(K=32), dict(S=16), dict(W=16), dict(H=13, W=12), dict(K=0)):
+    for kw in (dict(K=32), dict(S=17), dict(W=16), dict(S=16, W=15), dict(H=13, W=12), dict(K=0)):
         with pytest.raises(native.NiqkiError) as ei:
             native.Engine(**kw)
         assert ei.value.code == 1, kw

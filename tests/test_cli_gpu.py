@@ -243,3 +243,16 @@ def test_host_program_sharded_over_gpus(workdir, gold, gpus, monkeypatch):
         run(workdir, g + ["-I", "fof.txt", "-l", "many.fa", "-S", "10", "-W", "10", "-J", "0.002", "-O", "mg_many.gz"])
         one = gunzip(workdir / "sg_many.gz")
         assert gunzip(workdir / "mg_many.gz") == one and one.count(b":") > 1000
+
+
+def test_sketch_size_16(workdir):
+    """-S 16: the reference's uint32-counter branch (src/niqki_index.cpp:668-682) -- self hits count
+    2^16 -- and its uint16 matrix counters, which wrap to 0 on the diagonal (:572).  Goldens from the
+    reference CLI (oracle/make_goldens_s16.py)."""
+    import json
+    exp = json.load(open(os.path.join(GOLD, "reference_s16.json")))["cli_s16"]
+    run(workdir, ["-I", "fof.txt", "-Q", "fof.txt", "-S", "16", "-W", "8", "-J", "0.1", "-O", "s16_hits.gz"])
+    assert_same_text(gunzip(workdir / "s16_hits.gz").decode(), exp["hits"])
+    run(workdir, ["-M", "fof.txt", "-S", "16", "-W", "8", "-J", "0.1", "-O", "s16_matrix.gz"])
+    assert_same_text(gunzip(workdir / "s16_matrix.gz").decode(), exp["matrix"])
+    assert "syn00.fa\t0\t0.970917" in exp["matrix"]

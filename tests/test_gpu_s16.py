@@ -1,0 +1,109 @@
+"""GPU: S = 16 (2^16 sketch slots), the reference's lF > 15 branch with uint32 counters
+(src/niqki_index.cpp:668-682).  A count can reach 2^16, one more than a u16 counter holds: the
+gather kernel walks the slots in two passes into two counter planes that the hit kernels sum in 32
+bits; the sketch kernel keeps one half of the 256 KB of cells per workgroup and densifies in global
+memory.  Golden D5 comes from the real reference (oracle/make_goldens_s16.py)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def d5():
+    vec = np.load(os.path.join(GOLD, "reference_s16.npz"))
+    meta = json.load(open(os.path.join(GOLD, "reference_s16.json")))
+    return vec, meta["D5"], meta["seed"]
+
+
+def test_s16_sketch_insert_query_dump_vs_reference(native, po, d5):
+    vec, m, seed = d5
+    e = native.Engine(K=m["K"], S=m["S"], W=m["W"], H=m["H"], J=m["J"])
+    assert e.min_score == int(vec["D5_min_score"][0])
+    genomes = [native.synth_genome_host(seed, a, b, c, m["len"]) for a, b, c in zip(m["fam"], m["mem"], m["rate"])]
+    sk = e.sketch(genomes)
+    assert np.array_equal(sk, vec["D5_sketches"].astype(np.int32))
+    # a 500-base record: 470 k-mers, 65 066 cells filled by densification (in global memory at S = 16)
+    assert np.array_equal(e.sketch([vec["D5_short_seq"]])[0], vec["D5_short_sketch"].astype(np.int32))
+    assert np.array_equal(e.densify(np.where(np.arange(1 << 16) % 7 == 0, sk[0], -1).astype(np.int32).reshape(1, -1))[0],
+                          po.densify(po.make_params(m["K"], m["S"], m["W"], m["H"], m["J"]),
+                                     np.where(np.arange(1 << 16) % 7 == 0, sk[0], -1).astype(np.int32))[0])
+    e.insert(sk)
+    qsk = vec["D5_qsketches"].astype(np.int32)
+    off, hc, hg = e.query(qsk)
+    assert np.array_equal(off, vec["D5_hit_off"])
+    assert np.array_equal(hc, vec["D5_hit_counts"]) and np.array_equal(hg, vec["D5_hit_gids"])
+    assert int(hc.max()) == 1 << 16                     # the self hits: F matching slots
+    # sequences in, hits out
+    queries = [native.synth_genome_host(seed, a, b, c, m["len"]) for a, b, c in zip(m["qfam"], m["qmem"], m["qrate"])]
+    off2, hc2, hg2 = e.query_sequences(queries)
+    assert np.array_equal(off2, off) and np.array_equal(hc2, hc) and np.array_equal(hg2, hg)
+    # exact dense counters (uint32) against the oracle
+    p = po.make_params(m["K"], m["S"], m["W"], m["H"], m["J"])
+    ix = po.Index(p, sk)
+    c32 = e.query_counts32(qsk)
+    for q in range(qsk.shape[0]):
+        assert np.array_equal(c32[q], ix.counts(qsk[q])), q
+    # the u16 counter calls cannot hold 2^16: refused, not wrapped
+    with pytest.raises(native.NiqkiError) as ei:
+        e.query_counts(qsk[:1])
+    assert ei.value.code == 1
+    # the matrix has uint16 counters in the reference whatever S (:572): identical genomes read 0
+    mat = e.matrix_range(0, len(genomes))
+    exp = ix.matrix_range(0, len(genomes))
+    assert np.array_equal(mat, exp.T) and int(mat[0, 0]) == 0
+    # dump bytes = the reference's, and back
+    raw = e.export_dump() + "".join("g%d\n" % i for i in range(len(genomes))).encode()
+    assert len(raw) == m["dump_len"] and hashlib.md5(raw).hexdigest() == m["dump_md5"]
+    e2 = native.Engine.import_dump(raw)
+    assert (e2.S, e2.W, e2.n_genomes) == (16, m["W"], len(genomes))
+    assert all(np.array_equal(a, b) for a, b in zip(e2.query(qsk), (off, hc, hg)))
+    e2.close()
+    e.close()
+
+
+def test_s16_many_genomes_two_tiles_and_device_path(native, po):
+    """Random sketches: 70 000 genomes (two counter tiles) at S = 16 would be 9 GB of int32 -- 3000 genomes with a
+    small tile instead (several tiles, ragged), device-memory query path, locality order off/on irrelevant."""
+    import torch
+    rng = np.random.default_rng(16)
+    S, W, N = 16, 6, 700
+    F = 1 << S
+    fam = rng.integers(0, 1 << W, (5, F)).astype(np.int32)
+    sk = fam[rng.integers(0, 5, N)].copy()
+    noise = rng.random((N, F)) < 0.3
+    sk[noise] = rng.integers(0, 1 << W, int(noise.sum()))
+    sk[0] = fam[0]
+    e = native.Engine(K=31, S=S, W=W, H=3, J=0.7, tile_genomes=256)
+    e.insert(sk)
+    q = np.concatenate([fam, sk[:3]])
+    p = po.make_params(31, S, W, 3, 0.7)
+    ix = po.Index(p, sk)
+    off, hc, hg = e.query(q)
+    for i in range(q.shape[0]):
+        ehc, ehg = ix.query(q[i])
+        assert np.array_equal(hc[int(off[i]):int(off[i + 1])], ehc) and np.array_equal(hg[int(off[i]):int(off[i + 1])], ehg), i
+    assert int(hc.max()) == F
+    dev = torch.device("cuda")
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    dq = torch.from_numpy(q).to(dev)
+    cap = q.shape[0] * N
+    ho = torch.zeros(q.shape[0] + 1, dtype=torch.int64, device=dev)
+    dc = torch.zeros(cap, dtype=torch.int32, device=dev)
+    dg = torch.zeros(cap, dtype=torch.int32, device=dev)
+    e.query_dev(dq, q.shape[0], ho, dc, dg, cap)
+    e.synchronize()
+    assert np.array_equal(ho.cpu().numpy().astype(np.uint64), off)
+    assert np.array_equal(dc.cpu().numpy()[:int(off[-1])].astype(np.uint32), hc)
+    # what S = 16 does not offer is refused
+    with pytest.raises(native.NiqkiError):
+        e.set_option("resident_bytes", 1 << 20)
+    with pytest.raises(native.NiqkiError):
+        native.Engine(K=31, S=16, W=8, H=3, resident_mib=4)
+    e.close()

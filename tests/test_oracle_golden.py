@@ -243,3 +243,29 @@ def test_reference_binary_loads_our_dump_fixture(tmp_path, po, native, gold):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert gzip.open(td / "ref_on_ours.gz", "rb").read().decode() == meta["cli"]["hits_loaded"]
+
+
+def test_s16_case_vs_reference(po, native):
+    """Golden D5 (oracle/make_goldens_s16.py): S = 16, the reference's uint32-counter branch
+    (src/niqki_index.cpp:668-682) -- self hits count 2^16."""
+    import json
+    from conftest import GOLD
+    vec = np.load(os.path.join(GOLD, "reference_s16.npz"))
+    m = json.load(open(os.path.join(GOLD, "reference_s16.json")))["D5"]
+    p = po.make_params(m["K"], m["S"], m["W"], m["H"], m["J"])
+    assert p.min_score == int(vec["D5_min_score"][0])
+    seed = json.load(open(os.path.join(GOLD, "reference_s16.json")))["seed"]
+    genomes = [native.synth_genome_host(seed, a, b, c, m["len"]) for a, b, c in zip(m["fam"], m["mem"], m["rate"])]
+    sk = np.stack([po.compute_sketch(p, g) for g in genomes])
+    assert np.array_equal(sk, vec["D5_sketches"].astype(np.int32))
+    assert np.array_equal(po.compute_sketch(p, vec["D5_short_seq"]), vec["D5_short_sketch"].astype(np.int32))
+    ix = po.Index(p, sk)
+    qsk = vec["D5_qsketches"].astype(np.int32)
+    off = vec["D5_hit_off"]
+    for q in range(qsk.shape[0]):
+        hc, hg = ix.query(qsk[q])
+        assert np.array_equal(hc, vec["D5_hit_counts"][int(off[q]):int(off[q + 1])])
+        assert np.array_equal(hg, vec["D5_hit_gids"][int(off[q]):int(off[q + 1])])
+    assert int(vec["D5_hit_counts"].max()) == 1 << 16
+    raw = ix.dump_bytes() + "".join("g%d\n" % i for i in range(len(genomes))).encode()
+    assert len(raw) == m["dump_len"] and hashlib.md5(raw).hexdigest() == m["dump_md5"]
