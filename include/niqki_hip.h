@@ -123,6 +123,9 @@ int niqki_synchronize(niqki_index *ix);
  * once per launch, slot block by slot block, for all its queries instead of one random
  * table line per query and slot inside the gather kernel, wherever the index shape
  * allows: less HBM traffic, no faster on MI355X, so the default (-1, like 0) is off),
+ * "incremental_build" (1 = default: genomes inserted after a build get a delta index of their own
+ * -- a query walks both -- until they pass an eighth of the main index, then everything is rebuilt;
+ * 0 = every insert after a query rebuilds the whole index at the next query),
  * "resident_bytes" (indexes beyond the memory one wants to give them -- or beyond HBM: with a
  * value > 0, set before the first insert, the sketch store (2 bytes per genome and slot) lives
  * in page-locked host memory and the inverted index is built for one PAGE of slots at a time,
@@ -411,7 +414,8 @@ enum niqki_kernel_class {
  * accumulated device time and launch count since the last reset. */
 /* Sizes of the handle's state: "store_bytes" (sketch store), "index_bytes" (table + id lists of
  * the built index or resident page), "tiles", "pages" / "page_slots" (pages a query walks and
- * slots per page; 1 / all slots unless the index is paged). */
+ * slots per page; 1 / all slots unless the index is paged), "delta_genomes" (genomes indexed by
+ * the delta segment, see option "incremental_build"). */
 int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value);
 int niqki_profile_enable(niqki_index *ix, int on);
 int niqki_profile_reset(niqki_index *ix);

@@ -103,7 +103,8 @@ int derive(const niqki_params &p, nq::Derived &d, std::string &why) {
 nq::IndexView view(const niqki_index *ix) {
   nq::IndexView v;
   v.d = ix->d;
-  v.n_genomes = ix->built_n;
+  v.n_genomes = ix->seg_n;
+  v.g_base = ix->g_base;
   v.tile = ix->tile;
   v.n_tiles = ix->n_tiles;
   v.f_local = ix->d.slot_end - ix->d.slot_begin;
@@ -211,12 +212,47 @@ bool two_planes(const niqki_index *ix) { return !ix->resident_bytes && ix->d.slo
 // first slot of the handle in a whole sketch row (while a page is resident d.slot_begin is the page's)
 uint32_t first_slot(const niqki_index *ix) { return ix->resident_bytes ? ix->full_begin : ix->d.slot_begin; }
 
+// flat index members <-> alt (nq_handle.h, "Delta segment")
+void swap_segment(niqki_index *ix) {
+  auto &a = ix->alt;
+  std::swap(ix->entries, a.entries); std::swap(ix->gids, a.gids);
+  std::swap(ix->tile_base, a.tile_base); std::swap(ix->slot_units, a.slot_units);
+  std::swap(ix->entries_bytes, a.entries_bytes); std::swap(ix->gids_bytes, a.gids_bytes);
+  std::swap(ix->tile_base_bytes, a.tile_base_bytes); std::swap(ix->slot_units_bytes, a.slot_units_bytes);
+  std::swap(ix->tile, a.tile); std::swap(ix->n_tiles, a.n_tiles); std::swap(ix->seg_n, a.seg_n);
+  std::swap(ix->g_base, a.g_base); std::swap(ix->align_log2, a.align_log2);
+  std::swap(ix->padded, a.padded); std::swap(ix->stripe, a.stripe);
+}
+
+int build_range(niqki_index *ix, uint32_t g_base, uint32_t N);
+
 int build_if_needed(niqki_index *ix) {
   if (ix->resident_bytes) {   // paged: pages are built while a query walks them
     ix->built_n = ix->n_genomes;
     return NIQKI_OK;
   }
   if (ix->built && ix->built_n == ix->n_genomes) return NIQKI_OK;
+  // Genomes inserted after a build: a delta segment for them while they are few (the fixed part of a
+  // build -- one table row per slot -- is ~10 ms at the north-star shape, a full rebuild of 100 000
+  // genomes 65 ms), a full rebuild once the delta would pass an eighth of the main index.
+  const uint32_t main_n = ix->seg_n;
+  if (ix->incremental && main_n >= 4096 && ix->n_genomes > main_n &&
+      ix->n_genomes - main_n <= std::min<uint32_t>(main_n / 8, nq::kPadMaxTile)) {
+    swap_segment(ix);
+    int rc = build_range(ix, main_n, ix->n_genomes - main_n);
+    swap_segment(ix);
+    if (rc) { ix->built = false; return rc; }
+    ix->delta_n = ix->n_genomes - main_n;
+    ix->built_n = ix->n_genomes;
+    ix->built = true;
+    return NIQKI_OK;
+  }
+  return niqki_build(ix);
+}
+
+// before anything that needs ONE index over all genomes (dump export, per-bucket statistics)
+int build_single(niqki_index *ix) {
+  if (ix->resident_bytes || (ix->built && ix->built_n == ix->n_genomes && ix->delta_n == 0)) return build_if_needed(ix);
   return niqki_build(ix);
 }
 
@@ -292,6 +328,15 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
   if (stride < ix->built_n || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
   if ((uintptr_t)counts & 3) return fail(ix, NIQKI_E_INVALID, "counts must be 4-byte aligned (rows are written as packed u16 pairs)");
   if (ix->built_n == 0) return NIQKI_OK;
+  if (ix->delta_n && !ix->resident_bytes) {  // the delta segment first (its columns are its own), then the main index below
+    const uint32_t dn = ix->delta_n;
+    ix->delta_n = 0;
+    swap_segment(ix);
+    rc = counts_resident(ix, sketches, q_stride, q_off, nq, counts, stride, accumulate, counts2);
+    swap_segment(ix);
+    ix->delta_n = dn;
+    if (rc) return rc;
+  }
   // launches of at most `chunk` queries bound the per-query stash (one Entry per
   // slot and extra tile) whatever the caller's batch size is
   const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
@@ -315,8 +360,8 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
     if (rc) return rc;
   }
   // locality order of each launch: worth its probe on large indexes and real batches
-  const bool ordered = ix->query_order && chunk <= 4096 && ix->built_n >= 16384 &&
-                       ix->built_n < (1u << 20) - 1 && f_local >= 1024;
+  const bool ordered = ix->query_order && chunk <= 4096 && ix->seg_n >= 16384 &&
+                       ix->seg_n < (1u << 20) - 1 && f_local >= 1024;
   if (ordered && (rc = ensure(ix, ix->ws_order, (size_t)chunk * 8))) return rc;
   for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
     const uint32_t n = std::min(chunk, nq - q0);
@@ -573,6 +618,8 @@ void niqki_destroy(niqki_index *ix) {
     if (b->p) (void)hipFree(b->p);
   if (ix->store && !ix->resident_bytes) (void)hipFree(ix->store);
   if (ix->host_store) (void)hipHostFree(ix->host_store);
+  for (void *p : {(void *)ix->alt.entries, (void *)ix->alt.gids, (void *)ix->alt.tile_base, (void *)ix->alt.slot_units})
+    if (p) (void)hipFree(p);
   if (ix->entries) (void)hipFree(ix->entries);
   if (ix->gids) (void)hipFree(ix->gids);
   if (ix->tile_base) (void)hipFree(ix->tile_base);
@@ -620,8 +667,9 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
     ix->gather_variant = (int)value;
     return NIQKI_OK;
   }
-  if (!std::strcmp(key, "tile_stripe")) { ix->stripe_opt = value != 0; ix->built = false; return NIQKI_OK; }
+  if (!std::strcmp(key, "tile_stripe")) { ix->stripe_opt = value != 0; ix->built = false; ix->seg_n = 0; return NIQKI_OK; }
   if (!std::strcmp(key, "query_order")) { ix->query_order = value != 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "incremental_build")) { ix->incremental = value != 0; return NIQKI_OK; }
   if (!std::strcmp(key, "lookup_prepass")) {
     if (value < -1 || value > 1) return fail(ix, NIQKI_E_INVALID, "lookup_prepass: -1 = when it pays, 0 = never, 1 = whenever usable");
     ix->lookup_prepass = (int)value;
@@ -632,12 +680,14 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
     if (value < 0 || value > 65536 || (value & 63)) return fail(ix, NIQKI_E_INVALID, "tile_genomes must be a multiple of 64, <= 65536");
     ix->p.tile_genomes = (uint32_t)value;
     ix->built = false;
+    ix->seg_n = 0;   // the next build is a full one
     return NIQKI_OK;
   }
   if (!std::strcmp(key, "bucket_align_log2")) {
     if (value < -1 || value > 6) return fail(ix, NIQKI_E_INVALID, "bucket_align_log2 must be -1 (choose) .. 6");
     ix->bucket_align = (int)value;
     ix->built = false;
+    ix->seg_n = 0;
     return NIQKI_OK;
   }
   if (!std::strcmp(key, "resident_bytes")) {
@@ -755,7 +805,17 @@ int niqki_build(niqki_index *ix) {
     ix->built_n = ix->n_genomes;
     return NIQKI_OK;
   }
-  const uint32_t N = ix->n_genomes;
+  ix->delta_n = 0;   // one index over everything inserted so far
+  int rc = build_range(ix, 0, ix->n_genomes);
+  if (rc == NIQKI_OK) ix->built_n = ix->n_genomes;
+  return rc;
+}
+
+}  // extern "C"
+
+namespace nqi {
+// the index of store columns [g_base, g_base + N) into the current segment's buffers
+int build_range(niqki_index *ix, uint32_t g_base, uint32_t N) {
   const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
   uint32_t tile = ix->p.tile_genomes;
   if (const char *v = std::getenv("NIQKI_TILE_GENOMES")) tile = (uint32_t)std::atoi(v);
@@ -786,7 +846,8 @@ int niqki_build(niqki_index *ix) {
   if ((rc = grow((void **)&ix->tile_base, ix->tile_base_bytes, (size_t)(n_tiles + 1) * 8))) return rc;
   ix->tile = tile;
   ix->n_tiles = n_tiles;
-  ix->built_n = N;
+  ix->seg_n = N;
+  ix->g_base = g_base;
   ix->align_log2 = (uint32_t)al;
   // line-aligned buckets carry padding ids behind their last id (see IndexView::padded)
   ix->padded = (al == 6 && tile <= nq::kPadMaxTile) ? 1u : 0u;
@@ -819,6 +880,9 @@ int niqki_build(niqki_index *ix) {
   ix->built = true;
   return NIQKI_OK;
 }
+}  // namespace nqi
+
+extern "C" {
 
 int niqki_query_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *counts,
                        uint64_t stride, int mem) {
@@ -1234,7 +1298,7 @@ namespace {
 // slot_word (F+1 word positions, header excluded) computed on the device, copied to the host
 int export_layout(niqki_index *ix, std::vector<uint64_t> &slot_word) {
   if (ix->resident_bytes) return fail(ix, NIQKI_E_STATE, "dump export is not available on a paged index (resident_bytes)");
-  int rc = build_if_needed(ix);
+  int rc = build_single(ix);
   if (rc) return rc;
   nq::IndexView v = view(ix);
   slot_word.assign((size_t)v.f_local + 1, 0);
@@ -1442,7 +1506,7 @@ int niqki_query_gathered(niqki_index *ix, const int32_t *sketches, uint32_t nq, 
   if (!ix || (!sketches && nq) || (!gathered && nq)) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
   if (ix->resident_bytes) return fail(ix, NIQKI_E_STATE, "niqki_query_gathered is not available on a paged index (resident_bytes)");
-  int rc = build_if_needed(ix);
+  int rc = build_single(ix);
   if (rc) return rc;
   if (nq == 0) return NIQKI_OK;
   const int32_t *d_sk = sketches;
@@ -1463,7 +1527,8 @@ int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value) {
   if (!ix || !key || !value) return NIQKI_E_INVALID;
   const uint32_t f_all = ix->resident_bytes ? ix->full_end - ix->full_begin : ix->d.slot_end - ix->d.slot_begin;
   if (!std::strcmp(key, "store_bytes")) { *value = (uint64_t)f_all * (ix->resident_bytes ? ix->host_cap : ix->cap) * 2; return NIQKI_OK; }
-  if (!std::strcmp(key, "index_bytes")) { *value = ix->built ? (uint64_t)ix->entries_bytes + ix->gids_bytes : 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "index_bytes")) { *value = ix->built ? (uint64_t)ix->entries_bytes + ix->gids_bytes + ix->alt.entries_bytes + ix->alt.gids_bytes : 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "delta_genomes")) { *value = ix->delta_n; return NIQKI_OK; }
   if (!std::strcmp(key, "tiles")) { *value = ix->n_tiles; return NIQKI_OK; }
   if (!std::strcmp(key, "page_slots")) { *value = ix->resident_bytes ? page_slots(ix) : f_all; return NIQKI_OK; }
   if (!std::strcmp(key, "pages")) {

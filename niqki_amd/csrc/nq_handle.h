@@ -59,6 +59,23 @@ struct niqki_index {
   int stripe_opt = 1;              // option: 1 = stripe when there are several tiles
   int bucket_align = -1;           // option: log2 ids per bucket alignment unit, -1 = choose
   bool built = false;
+  // Delta segment: genomes inserted after the last full build get an index of their own (same
+  // layout, over store columns [g_base, g_base + seg_n)) instead of a rebuild of everything; a query
+  // walks both, the counter columns are disjoint.  The flat members above describe the CURRENT
+  // segment -- the main one except while swap_segment() has put the delta there (its build, its
+  // gather launch); `alt` keeps the other one's state.
+  struct Seg {
+    nq::Entry *entries = nullptr;
+    uint16_t *gids = nullptr;
+    uint64_t *tile_base = nullptr;
+    uint32_t *slot_units = nullptr;
+    size_t entries_bytes = 0, gids_bytes = 0, tile_base_bytes = 0, slot_units_bytes = 0;
+    uint32_t tile = 0, n_tiles = 0, seg_n = 0, g_base = 0, align_log2 = 0, padded = 0, stripe = 0;
+  } alt;
+  uint32_t seg_n = 0;      // genomes of the current segment
+  uint32_t g_base = 0;     // its first genome
+  uint32_t delta_n = 0;    // genomes the delta segment covers (0 = there is none)
+  int incremental = 1;     // option "incremental_build"
 
   int gather_variant = 0;
   uint64_t record_len_hint = 0;  // avg bytes per sketch for device-side batches (0 = read it back)

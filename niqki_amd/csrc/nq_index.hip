@@ -108,7 +108,7 @@ __global__ void build_kernel(IndexView v, uint32_t *slot_units, Entry *entries, 
   uint32_t *cur = smem + (size_t)wave * R;
   const uint32_t n_t = tile_count(v, t);
   const uint16_t *srow = v.store + (uint64_t)s * v.cap;
-  auto row_at = [&](uint32_t i) -> uint32_t { return srow[tile_gid(v, t, i)]; };  // i-th genome of the tile
+  auto row_at = [&](uint32_t i) -> uint32_t { return srow[v.g_base + tile_gid(v, t, i)]; };  // i-th genome of the tile
   auto units_of = [&](uint32_t h) -> uint32_t { return (h + round) >> a; };  // units a bucket of h ids needs
 
   for (uint32_t i = lane; i < R; i += 64) cur[i] = 0;

@@ -44,7 +44,9 @@ struct Entry {
 };
 struct IndexView {
   Derived d;
-  uint32_t n_genomes;
+  uint32_t n_genomes;   // genomes of this segment
+  uint32_t g_base;      // ... which are genomes [g_base, g_base + n_genomes) of the store / of the counter rows
+                        // (0 for the main index; the delta segment of genomes inserted after the last full build)
   uint32_t tile;     // T, genomes per tile (multiple of 64, <= 65536)
   uint32_t n_tiles;
   uint32_t f_local;  // slot_end - slot_begin

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     }
     if (MODE != 0) cnt[tid % n_words] ^= sink;
     __syncthreads();
-    uint16_t *row = plane + (uint64_t)q * stride;
+    uint16_t *row = plane + (uint64_t)q * stride + v.g_base;
     if (v.stripe && v.n_tiles > 1) {
       // striped tiles: the tile's i-th counter belongs to genome i * n_tiles + t
       for (uint32_t i = tid; i < n_t; i += BLOCK) {
@@ -447,11 +447,18 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     } else {
       // dense counter row of this tile: u16 counts[q*stride + g0 + i], written as the packed words
       const uint32_t g0 = t * v.tile;
+      // (packed words need an even first column: odd g_base or g0 -> element-wise)
+      const bool packed = ((v.g_base + g0) & 1u) == 0;
       uint32_t *out = (uint32_t *)(row + g0);
-      const uint32_t full = n_t / 2;
+      const uint32_t full = packed ? n_t / 2 : 0;
+      if (!packed)
+        for (uint32_t i = tid; i < n_t; i += BLOCK) {
+          const uint16_t c = (uint16_t)(cnt[i >> 1] >> ((i & 1u) * 16u));
+          row[g0 + i] = v.accumulate ? (uint16_t)(row[g0 + i] + c) : c;
+        }
       // (accumulating: sums stay <= F <= 2^15 per half, so the packed add cannot carry)
       for (uint32_t i = tid; i < full; i += BLOCK) out[i] = v.accumulate ? out[i] + cnt[i] : cnt[i];
-      if ((n_t & 1u) && tid == 0) {
+      if (packed && (n_t & 1u) && tid == 0) {
         const uint16_t c = (uint16_t)(cnt[full] & 0xFFFFu);
         row[g0 + n_t - 1] = v.accumulate ? (uint16_t)(row[g0 + n_t - 1] + c) : c;
       }

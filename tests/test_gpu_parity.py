@@ -558,3 +558,62 @@ def test_more_genomes_than_one_tile_holds(native, po):
     assert off[3] - off[0] > 300                           # the family queries do have hits
     assert e.export_dump() == ix.dump_bytes()
     e.close()
+
+
+def test_inserts_after_a_query_get_a_delta_segment(native, po):
+    """Genomes inserted after a build are indexed by a delta segment (no rebuild of the main index) until
+    they pass an eighth of it; queries walk both segments.  Same answers as one index built at once, the
+    dump is that of one index, and with incremental_build = 0 every flip rebuilds."""
+    rng = np.random.default_rng(44)
+    S, W = 8, 8
+    F = 1 << S
+    fam = rng.integers(0, 1 << W, (30, F)).astype(np.int32)
+    N = 21001
+    sk = fam[rng.integers(0, 30, N)].copy()
+    noise = rng.random((N, F)) < 0.3
+    sk[noise] = rng.integers(0, 1 << W, int(noise.sum()))
+    q = np.concatenate([fam[:6], sk[[0, 16999, 17000, 17001, 17333, N - 1]]])
+    q = np.concatenate([q] * 6)                      # 72 queries
+    p = po.make_params(31, S, W, 3, 0.4)
+    e = native.Engine(K=31, S=S, W=W, H=3, J=0.4)
+    e.insert(sk[:17001])                             # odd count: the delta's first column is odd
+    ref0 = po.Index(p, sk[:17001])
+    off, hc, hg = e.query(q[:3])
+    for i in range(3):
+        ehc, ehg = ref0.query(q[i])
+        assert np.array_equal(hc[int(off[i]):int(off[i + 1])], ehc) and np.array_equal(hg[int(off[i]):int(off[i + 1])], ehg)
+    assert e.stat("delta_genomes") == 0
+    for n1 in (17334, 18000):                        # two growths of the delta
+        e.insert(sk[e.n_genomes:n1])
+        ix = po.Index(p, sk[:n1])
+        cnt = e.query_counts(q)
+        assert e.stat("delta_genomes") == n1 - 17001
+        off, hc, hg = e.query(q)
+        for i in range(q.shape[0]):
+            assert np.array_equal(cnt[i].astype(np.uint32), ix.counts(q[i])), (n1, i)
+            ehc, ehg = ix.query(q[i])
+            assert np.array_equal(hc[int(off[i]):int(off[i + 1])], ehc) and np.array_equal(hg[int(off[i]):int(off[i + 1])], ehg), (n1, i)
+        assert np.array_equal(e.matrix_range(16990, 17030), ix.matrix_range(16990, 17030).T)   # rows on both sides of the segment border
+    assert e.export_dump() == ix.dump_bytes()        # needs one index: merges
+    assert e.stat("delta_genomes") == 0
+    e.insert(sk[18000:18100])
+    e.query_counts(q[:2])
+    assert e.stat("delta_genomes") == 100
+    e.insert(sk[18100:])                             # 3001 genomes > 18000 / 8: everything is rebuilt
+    ix = po.Index(p, sk)
+    cnt = e.query_counts(q)
+    assert e.stat("delta_genomes") == 0
+    for i in range(0, q.shape[0], 5):
+        assert np.array_equal(cnt[i].astype(np.uint32), ix.counts(q[i])), i
+    e.close()
+    e = native.Engine(K=31, S=S, W=W, H=3, J=0.4)
+    e.set_option("incremental_build", 0)
+    e.insert(sk[:17001])
+    e.query_counts(q[:2])
+    e.insert(sk[17001:17100])
+    cnt = e.query_counts(q[:12])
+    assert e.stat("delta_genomes") == 0
+    ix = po.Index(p, sk[:17100])
+    for i in range(12):
+        assert np.array_equal(cnt[i].astype(np.uint32), ix.counts(q[i])), i
+    e.close()
