@@ -513,8 +513,8 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     else NQ_LAUNCH_GATHER(B, U, 1, ##__VA_ARGS__);                                               \
   } while (0)
   switch (variant) {
-    case 1: NQ_BY_TILES(1024, 8); break;
-    case 2: NQ_BY_TILES(1024, 32); break;
+    case 1: if (v.padded) NQ_BY_TILES(1024, 8, 0, true); else NQ_BY_TILES(1024, 8); break;
+    case 2: if (v.padded) NQ_BY_TILES(1024, 32, 0, true); else NQ_BY_TILES(1024, 32); break;
     case 3: NQ_BY_TILES(512, 16); break;
     case 4: NQ_BY_TILES(256, 16); break;
     case 5: NQ_BY_TILES(128, 16); break;
