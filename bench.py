@@ -176,7 +176,7 @@ def main():
     hit_off = torch.zeros((n_steps_all, per + 1), dtype=torch.int64, device=dev)
     hc = torch.zeros(cap, dtype=torch.int32, device=dev)
     hg = torch.zeros(cap, dtype=torch.int32, device=dev)
-    stride = (N + 1) & ~1
+    stride = niqki_amd.row_stride(N)
     counts = None if use_dist else torch.zeros((nq_gather, stride), dtype=torch.int16, device=dev)
     allsk = None
     if emu:
@@ -544,7 +544,7 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
     e.build()
     del skb
     rows = 1024
-    mstride = (NM + 1) & ~1
+    mstride = niqki_amd.row_stride(NM)
     mat = torch.zeros((rows, mstride), dtype=torch.int16, device=dev)
 
     def matrix_all():
@@ -594,7 +594,7 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
     e.set_option("record_len_hint", RL)
     rro = t64(np.arange(RB + 1, dtype=np.int64) * RL)
     rsk = torch.empty((RB, F4), dtype=torch.int32, device=dev)
-    rstride = (N4 + 1) & ~1
+    rstride = niqki_amd.row_stride(N4)
     rcnt = torch.zeros((RB, rstride), dtype=torch.int16, device=dev)
     # the threshold: reads share few slots with 5 Mbp genomes, so J is set where hits exist -- the count
     # the source genome of a read typically reaches (calibrated on the first batch, then fixed)

@@ -113,8 +113,10 @@ int niqki_synchronize(niqki_index *ix);
  * "gather_variant" (launch shape of the gather kernel, 0 = choose .. 5), "query_batch",
  * "tile_genomes" (multiple of 64, <= 65536; takes effect at the next build),
  * "bucket_align_log2" (-1 = choose, 0..6: buckets start on multiples of 2^a ids),
- * "tile_stripe" (1 = default: with several tiles genome g goes to tile g mod tiles, so a
- * run of related genomes is spread over all tiles; 0 = tiles are ranges of genome ids),
+ * "tile_stripe" (B = 1, 2, 4 .. 64, default 32: with several tiles, blocks of B consecutive
+ * genomes are dealt to the tiles round-robin, so a run of related genomes is spread over all
+ * tiles; blocks of 32 are 64 bytes of a counter row, the smallest piece HBM writes without
+ * a read-modify-write; 0 = tiles are ranges of genome ids),
  * "min_score", "record_len_hint" (average bytes per sketch of NIQKI_MEM_DEVICE
  * batches, so that niqki_sketch need not read rec_off back to pick a launch
  * shape; 0 = read it back), "query_order" (1 = default: the queries of a launch
@@ -177,8 +179,11 @@ int niqki_build(niqki_index *ix);
  * query q, counts[q*stride + g] = number of this shard's slots whose bucket
  * holds genome g.  uint16 counters like the reference's lF<=15 branch.
  * stride >= genome_count (in elements), even; a NIQKI_MEM_DEVICE `counts` must be
- * 4-byte aligned (rows are written as packed u16 pairs).  This is the per-genome
- * hit vector the multi-GPU path sums across slot shards. */
+ * 4-byte aligned (rows are written as packed u16 pairs).  Fastest when every row
+ * starts on a 128-byte line: NIQKI_ROW_STRIDE(genome_count) and a 128-byte aligned
+ * buffer (a partial 64-byte block costs HBM a read-modify-write).  This is the
+ * per-genome hit vector the multi-GPU path sums across slot shards. */
+#define NIQKI_ROW_STRIDE(n) ((((uint64_t)(n)) + 63u) & ~(uint64_t)63u)
 int niqki_query_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq,
                        uint16_t *counts, uint64_t stride, int mem);
 

@@ -149,6 +149,11 @@ def lib():
     return _lib
 
 
+def row_stride(n):
+    """NIQKI_ROW_STRIDE of the header: counter rows that start on 128-byte lines."""
+    return (int(n) + 63) & ~63
+
+
 def min_score(J, S):
     return lib().niqki_min_score(J, S)
 
@@ -290,7 +295,7 @@ class Engine:
     def query_counts(self, sketches):
         sk = np.ascontiguousarray(sketches, dtype=np.int32).reshape(-1, self.F)
         n = self.n_genomes
-        stride = (n + 1) & ~1
+        stride = row_stride(n)
         out = np.zeros((sk.shape[0], max(stride, 2)), dtype=np.uint16)
         self._ck(self.L.niqki_query_counts(self.h, _p(sk), sk.shape[0], _p(out), out.shape[1], MEM_HOST))
         return out[:, :n]
@@ -298,7 +303,7 @@ class Engine:
     def query_counts32(self, sketches):
         sk = np.ascontiguousarray(sketches, dtype=np.int32).reshape(-1, self.F)
         n = self.n_genomes
-        stride = (n + 1) & ~1
+        stride = row_stride(n)
         out = np.zeros((sk.shape[0], max(stride, 2)), dtype=np.uint32)
         self._ck(self.L.niqki_query_counts32(self.h, _p(sk), sk.shape[0], _p(out), out.shape[1], MEM_HOST))
         return out[:, :n]
@@ -388,7 +393,7 @@ class Engine:
 
     def matrix_range(self, begin, end):
         n = self.n_genomes
-        stride = max((n + 1) & ~1, 2)
+        stride = max(row_stride(n), 2)
         out = np.zeros((end - begin, stride), dtype=np.uint16)
         self._ck(self.L.niqki_matrix_range(self.h, begin, end, _p(out), stride, MEM_HOST))
         return out[:, :n]

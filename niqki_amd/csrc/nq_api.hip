@@ -430,7 +430,7 @@ int query_to_host(niqki_index *ix, const int32_t *sketches, bool sk_dev, uint32_
                   uint32_t *hit_counts, uint32_t *hit_gids, uint64_t capacity) {
   int rc;
   const uint32_t N = ix->built_n;
-  const uint64_t stride = ((uint64_t)N + 1) & ~1ull;
+  const uint64_t stride = NIQKI_ROW_STRIDE(N);
   uint64_t base = 0;
   bool overflow = false;
   hit_off[0] = 0;
@@ -667,7 +667,7 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
     ix->gather_variant = (int)value;
     return NIQKI_OK;
   }
-  if (!std::strcmp(key, "tile_stripe")) { ix->stripe_opt = value != 0; ix->built = false; ix->seg_n = 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "tile_stripe")) { ix->stripe_opt = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 64); ix->built = false; ix->seg_n = 0; return NIQKI_OK; }
   if (!std::strcmp(key, "query_order")) { ix->query_order = value != 0; return NIQKI_OK; }
   if (!std::strcmp(key, "incremental_build")) { ix->incremental = value != 0; return NIQKI_OK; }
   if (!std::strcmp(key, "lookup_prepass")) {
@@ -819,10 +819,18 @@ int build_range(niqki_index *ix, uint32_t g_base, uint32_t N) {
   const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
   uint32_t tile = ix->p.tile_genomes;
   if (const char *v = std::getenv("NIQKI_TILE_GENOMES")) tile = (uint32_t)std::atoi(v);
+  // genomes are dealt to the tiles round-robin in blocks (option "tile_stripe": 0 = ranges, B = block size)
+  int stripe = ix->stripe_opt;
+  if (const char *v = std::getenv("NIQKI_TILE_STRIPE")) stripe = std::atoi(v);
+  uint32_t B = 1;
+  while (stripe > 0 && B * 2 <= (uint32_t)stripe && B < 64) B *= 2;
   if (tile == 0 || tile > 65536 || (tile & 63)) {
     // as few tiles as the 16-bit tile-local ids (padding ids included) and the LDS counter array allow
     uint32_t nt = std::max<uint32_t>(1, (N + nq::kPadMaxTile - 1) / nq::kPadMaxTile);
     tile = ((N + nt - 1) / nt + 63) / 64 * 64;
+    // room for the fullest tile of a block-striped index, if that does not cost a tile
+    const uint32_t want = (((N + B - 1) / B + nt - 1) / nt * B + 63) / 64 * 64;
+    if (stripe > 0 && nt > 1 && want <= nq::kPadMaxTile && (N + want - 1) / want == nt) tile = std::max(tile, want);
     if (tile == 0) tile = 64;
   }
   const uint32_t n_tiles = (N + tile - 1) / tile;
@@ -851,10 +859,12 @@ int build_range(niqki_index *ix, uint32_t g_base, uint32_t N) {
   ix->align_log2 = (uint32_t)al;
   // line-aligned buckets carry padding ids behind their last id (see IndexView::padded)
   ix->padded = (al == 6 && tile <= nq::kPadMaxTile) ? 1u : 0u;
-  // genomes are dealt to the tiles round-robin (option "tile_stripe", default on)
-  int stripe = ix->stripe_opt;
-  if (const char *v = std::getenv("NIQKI_TILE_STRIPE")) stripe = std::atoi(v);
-  ix->stripe = (stripe != 0 && n_tiles > 1 && n_tiles <= 64) ? 1u : 0u;
+  ix->stripe = 0;
+  if (stripe > 0 && n_tiles > 1 && n_tiles <= 64) {
+    // the fullest tile must fit the tile size (it always does for B = 1)
+    while (B > 1 && ((N + B - 1) / B + n_tiles - 1) / n_tiles * B > tile) B /= 2;
+    ix->stripe = B;
+  }
   if (n_tiles == 0) { ix->built = true; return NIQKI_OK; }
   {
     Span sp(ix, NIQKI_KC_BUILD);
@@ -986,7 +996,7 @@ int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint64_t 
   int rc = build_if_needed(ix);
   if (rc) return rc;
   const uint32_t N = ix->built_n;
-  const uint64_t stride = ((uint64_t)N + 1) & ~1ull;
+  const uint64_t stride = NIQKI_ROW_STRIDE(N);
   if (mem == NIQKI_MEM_DEVICE) {
     const size_t plane = std::max<size_t>((size_t)nq * stride * 2, 2);
     if ((rc = ensure(ix, ix->ws_counts, plane * (two_planes(ix) ? 2 : 1)))) return rc;

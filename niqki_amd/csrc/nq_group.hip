@@ -455,7 +455,7 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
     if (g->sh[l]->built_n != g->sh[0]->built_n) return gfail(g, NIQKI_E_STATE, "the shards hold different numbers of genomes");
   }
   const uint32_t N = g->sh[0]->built_n;
-  const uint64_t stride = ((uint64_t)N + 1) & ~1ull;
+  const uint64_t stride = NIQKI_ROW_STRIDE(N);
   if (per == 0) return NIQKI_OK;
   int rc = exchange_slices(g, local_sketches, per);
   if (rc) return rc;

@@ -56,7 +56,7 @@ struct niqki_index {
   uint32_t *slot_units = nullptr;  // n_tiles x (f_local+1), device
   size_t entries_bytes = 0, gids_bytes = 0, tile_base_bytes = 0, slot_units_bytes = 0;
   uint32_t stripe = 0;             // tiles are dealt round-robin
-  int stripe_opt = 1;              // option: 1 = stripe when there are several tiles
+  int stripe_opt = 32;             // option: block size of the stripes when there are several tiles (0 = ranges)
   int bucket_align = -1;           // option: log2 ids per bucket alignment unit, -1 = choose
   bool built = false;
   // Delta segment: genomes inserted after the last full build get an index of their own (same

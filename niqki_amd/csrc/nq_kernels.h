@@ -55,8 +55,8 @@ struct IndexView {
                      // a line holds id tile + 2p, which the gather kernel counts into 64 dummy words behind
                      // the tile's counters -- its bucket walk then needs no per-lane length test.  Every
                      // tile's id array ends with one line of padding only (the walk's "no chunk").
-  uint32_t stripe;   // genomes are dealt to the tiles round-robin (tile = gid % n_tiles, local id =
-                     // gid / n_tiles) instead of in ranges: a run of related genomes is spread over
+  uint32_t stripe;   // 0: tiles are ranges.  B = 1, 2, 4 .. 64: blocks of B consecutive genomes are dealt to the
+                     // tiles round-robin (tile = (gid / B) % n_tiles): a run of related genomes is spread over
                      // all tiles, which keeps their buckets short in every tile
   uint64_t cap;      // row stride of the sketch store (genomes)
   const uint16_t *store;
@@ -72,12 +72,17 @@ struct IndexView {
 
 // genomes of tile t / global id of its i-th genome
 NQ_HD uint32_t tile_count(const IndexView &v, uint32_t t) {
-  if (v.stripe) return v.n_genomes > t ? (v.n_genomes - t + v.n_tiles - 1) / v.n_tiles : 0u;
+  if (v.stripe) {  // blocks of `stripe` genomes dealt round-robin
+    const uint32_t nb = v.n_genomes / v.stripe, r = v.n_genomes % v.stripe;
+    return (nb / v.n_tiles) * v.stripe + (t < nb % v.n_tiles ? v.stripe : 0u) + (t == nb % v.n_tiles ? r : 0u);
+  }
   const uint32_t g0 = t * v.tile;
   return (v.n_genomes - g0) < v.tile ? (v.n_genomes - g0) : v.tile;
 }
 NQ_HD uint32_t tile_gid(const IndexView &v, uint32_t t, uint32_t i) {
-  return v.stripe ? i * v.n_tiles + t : t * v.tile + i;
+  if (!v.stripe) return t * v.tile + i;
+  const uint32_t sh = (uint32_t)__builtin_ctz(v.stripe);   // a power of two
+  return (((i >> sh) * v.n_tiles + t) << sh) + (i & (v.stripe - 1u));
 }
 
 // sk_stride / sk_off: as q_stride / q_off of IndexView

@@ -62,7 +62,7 @@ __device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t 
   auto apply = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      if (PAD && MODE == 0) {
+      if (PAD && (MODE == 0 || MODE == 7)) {
         // word (g >> 1), increment 1 or 1 << 16: 1 + (g & 1) * 0xFFFF
         atomicAdd((uint32_t *)((char *)cnt + ((g[u] << 1) & 0x3FFFCu)), __umul24(g[u] & 1u, 0xFFFFu) + 1u);
         continue;
@@ -92,7 +92,7 @@ __device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t 
 // wave-private LDS queue, so the walk always runs on full batches of 64 chunks
 // whatever the bucket lengths are.
 // MODE is a measurement aid (results are wrong for MODE != 0): 1 = no LDS
-// atomics, 6 = lookups only.  MODE != 0 is instantiated only in -DNQ_ABLATION builds;
+// atomics, 6 = lookups only, 7 = counters not written back, 8 = no walk (zero + write-back only).  MODE != 0 is instantiated only in -DNQ_ABLATION builds;
 // the shipped library cannot be switched into it.
 //   PRE      : entries come from the slot-major look-up pre-pass (lookup_kernel below): one
 //              packed word per (query, tile, slot) = bucket start relative to the slot's first
@@ -426,7 +426,8 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     const uint32_t n_words = (n_t + 1) / 2;
     for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
     __syncthreads();
-    if constexpr (NT < 0) {
+    if constexpr (MODE == 8) {
+    } else if constexpr (NT < 0) {
       walk_tile<BLOCK, UNROLL, 1, false, false, MODE, true, PAD>(v, sk, q, t, cnt, queue, nullptr, sink, it_lo, n_it, (const uint32_t *)stash);
     } else if constexpr (NT >= 2) {
       if (t == 0) walk_tile<BLOCK, UNROLL, NT, true, false, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink, it_lo, n_it);
@@ -436,9 +437,19 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     }
     if (MODE != 0) cnt[tid % n_words] ^= sink;
     __syncthreads();
+    if (MODE == 7) continue;
     uint16_t *row = plane + (uint64_t)q * stride + v.g_base;
-    if (v.stripe && v.n_tiles > 1) {
-      // striped tiles: the tile's i-th counter belongs to genome i * n_tiles + t
+    if (v.stripe > 1 && v.n_tiles > 1 && ((uintptr_t)row & 3u) == 0) {
+      // tiles striped in blocks of an even number of genomes: local ids 2w, 2w + 1 are neighbours in
+      // the row, a wave writes whole blocks (64-byte blocks are what HBM takes without a
+      // read-modify-write, tools/ubench_partial_write.hip)
+      for (uint32_t w = tid; w < n_words; w += BLOCK) {
+        uint32_t *dst = (uint32_t *)(row + tile_gid(v, t, 2 * w));
+        if (2 * w + 1 < n_t) *dst = v.accumulate ? *dst + cnt[w] : cnt[w];
+        else { uint16_t *d = (uint16_t *)dst; *d = v.accumulate ? (uint16_t)(*d + cnt[w]) : (uint16_t)cnt[w]; }
+      }
+    } else if (v.stripe && v.n_tiles > 1) {
+      // striped tiles: the tile's i-th counter belongs to genome tile_gid(t, i)
       for (uint32_t i = tid; i < n_t; i += BLOCK) {
         const uint16_t c = (uint16_t)(cnt[i >> 1] >> ((i & 1u) * 16u));
         uint16_t *dst = row + tile_gid(v, t, i);
@@ -481,7 +492,7 @@ hipError_t launch_order(const IndexView &v, const int32_t *sketches, uint32_t nq
 
 bool gather_variant_valid(int variant) {
 #ifdef NQ_ABLATION
-  if (variant == 11 || variant == 16) return true;
+  if (variant == 11 || variant == 16 || variant == 17 || variant == 18) return true;
 #endif
   return variant >= 0 && variant <= 5;
 }
@@ -521,6 +532,8 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
 #ifdef NQ_ABLATION  // measurement builds only (make ABLATION=1): these variants return wrong counters
     case 11: NQ_BY_TILES(1024, 16, 1); break;
     case 16: NQ_BY_TILES(1024, 16, 6); break;
+    case 17: NQ_BY_TILES(1024, 16, 7, true); break;
+    case 18: NQ_BY_TILES(1024, 16, 8, true); break;
 #endif
     default:
       // small tiles (short-read indexes): counters of <= 24 KB leave room for several

@@ -35,6 +35,8 @@ count of a genome is a sum over slots, so a query step has exactly one exchange 
 import torch
 import torch.distributed as dist
 
+from .capi import row_stride
+
 
 def slot_range(rank, world, F):
     """Slots [begin, end) owned by `rank`; F = 2^S and world need not divide it."""
@@ -106,7 +108,7 @@ class TorchExchange:
         self.world = dist.get_world_size(group)
         self.N = n_genomes
         self.F = F
-        self.stride = (n_genomes + 1) & ~1
+        self.stride = row_stride(n_genomes)
         self.device = torch.device(device)
         self.min_score = engine.min_score if min_score is None else min_score
         self.cand_cap = cand_cap

@@ -338,7 +338,7 @@ query_output Index::query_sketch(const std::vector<int32_t> &sketch) const {
   std::vector<uint32_t> hc(n ? n : 1), hg(n ? n : 1);
   uint64_t off[2] = {0, 0};
   if (grp_) {  // the shards' partial hit vectors summed on the host (a single sketch: API parity, not a fast path)
-    const uint64_t stride = ((uint64_t)n + 1) & ~1ull;
+    const uint64_t stride = NIQKI_ROW_STRIDE(n);
     std::vector<uint16_t> sum(std::max<uint64_t>(stride, 2), 0), part(std::max<uint64_t>(stride, 2));
     for (auto *h : sh_) {
       check(niqki_query_counts(h, sketch.data(), 1, part.data(), stride, NIQKI_MEM_HOST), "niqki_query_counts");
@@ -873,7 +873,7 @@ void Index::query_matrix() {
   head += '\n';
   outfile->write(head);
   const uint32_t n = (uint32_t)filenames.size();
-  const uint64_t stride = ((uint64_t)n + 1) & ~1ull;
+  const uint64_t stride = NIQKI_ROW_STRIDE(n);
   const uint32_t rows = 256;
   std::vector<uint16_t> counts((size_t)rows * std::max<uint64_t>(stride, 2));
   std::vector<uint16_t> part(grp_ ? counts.size() : 0);

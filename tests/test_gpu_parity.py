@@ -11,13 +11,14 @@ from conftest import family_spec, synth_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["striped", "ranges", "striped+prepass", "ranges+prepass"])
+@pytest.fixture(autouse=True, params=["blocks", "ranges", "striped+prepass", "blocks+prepass"])
 def tile_layout(request, monkeypatch):
-    """Every test runs under both tilings of DESIGN.md section 3 (genomes dealt to the counter
-    tiles round-robin = default, or tiles as ranges of genome ids) and under both table look-up
-    paths of the gather kernel: inside the kernel, or by the slot-major pre-pass (forced wherever
-    the index shape allows it; the default picks by batch size)."""
-    monkeypatch.setenv("NIQKI_TILE_STRIPE", "0" if request.param.startswith("ranges") else "1")
+    """Every test runs under the tilings of DESIGN.md section 3 (blocks of 32 genomes dealt to the
+    counter tiles round-robin = default, single genomes dealt round-robin, or tiles as ranges of
+    genome ids) and under both table look-up paths of the gather kernel: inside the kernel, or by
+    the slot-major pre-pass (forced wherever the index shape allows it; the default is off)."""
+    layout = request.param.split("+")[0]
+    monkeypatch.setenv("NIQKI_TILE_STRIPE", {"blocks": "32", "striped": "1", "ranges": "0"}[layout])
     monkeypatch.setenv("NIQKI_LOOKUP_PREPASS", "1" if request.param.endswith("prepass") else "0")
     return request.param
 
@@ -558,6 +559,46 @@ def test_more_genomes_than_one_tile_holds(native, po):
     assert off[3] - off[0] > 300                           # the family queries do have hits
     assert e.export_dump() == ix.dump_bytes()
     e.close()
+
+
+@pytest.mark.parametrize("n,tile", [(65, 64), (129, 64), (1000, 256), (1023, 192), (2049, 1024), (4097, 2048)])
+def test_block_stripes_of_every_size_and_row_alignment(native, po, n, tile, monkeypatch):
+    """Blocks of B genomes dealt to the tiles (B = 2 .. 64; a last partial block, tiles of unequal
+    size, B that does not fit and falls back) with counter rows that start on 128-byte lines or
+    just on 4-byte boundaries: the same dense counters, hits and dump as the oracle."""
+    import torch
+    rng = np.random.default_rng(n)
+    S, W = 6, 6
+    F = 1 << S
+    fam = rng.integers(0, 1 << W, (8, F)).astype(np.int32)
+    sk = fam[(np.arange(n) // 50) % 8].copy()
+    noise = rng.random((n, F)) < 0.3
+    sk[noise] = rng.integers(0, 1 << W, int(noise.sum()))
+    sk[rng.random((n, F)) < 0.02] = -1
+    q = np.concatenate([fam[:3], sk[[0, n // 2, n - 1]]])
+    p = po.make_params(31, S, W, 3, 0.3)
+    ix = po.Index(p, sk)
+    want = np.stack([ix.counts(x) for x in q]).astype(np.uint16)
+    dump = ix.dump_bytes()
+    for B in (2, 8, 32, 64):
+        monkeypatch.setenv("NIQKI_TILE_STRIPE", str(B))
+        e = native.Engine(K=31, S=S, W=W, H=3, J=0.3, tile_genomes=tile)
+        e.insert(sk)
+        assert np.array_equal(e.query_counts(q), want), B
+        off, hc, hg = e.query(q)
+        for i in range(q.shape[0]):
+            ehc, ehg = ix.query(q[i])
+            assert np.array_equal(hc[off[i]:off[i + 1]], ehc) and np.array_equal(hg[off[i]:off[i + 1]], ehg), (B, i)
+        assert e.export_dump() == dump, B
+        # device rows at other alignments: stride just even (rows start on 4-byte boundaries only)
+        dq = torch.from_numpy(q).cuda()
+        for stride, shift in ((native.row_stride(n), 0), ((n + 1) & ~1, 0), ((n + 1) & ~1, 2), (native.row_stride(n) + 2, 2)):
+            buf = torch.zeros(q.shape[0] * stride + 64, dtype=torch.int16, device="cuda")
+            e.query_counts_dev(dq, q.shape[0], buf[shift:], stride)
+            e.synchronize()
+            got = buf[shift:shift + q.shape[0] * stride].view(q.shape[0], stride)[:, :n].cpu().numpy().view(np.uint16)
+            assert np.array_equal(got, want), (B, stride, shift)
+        e.close()
 
 
 def test_inserts_after_a_query_get_a_delta_segment(native, po):
