@@ -202,8 +202,7 @@ def main():
         elif emu:
             # rank 0's compute of one step: its share sketched above, partial hit vectors of ALL
             # queries over its slots, its candidate lists, threshold + order of its own rows
-            eng.query_counts_dev(allsk[bi], nq_all, counts, stride)
-            eng.candidates_dev(counts, nq_all, stride, N, -(-eng.min_score // G), 256, cand, ncand)
+            eng.query_counts_candidates_dev(allsk[bi], nq_all, counts, stride, -(-eng.min_score // G), 256, cand, ncand)
             eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[si], hc, hg, cap)
         else:
             eng.query_counts_dev(qsk[bi], per, counts, stride)

@@ -215,6 +215,15 @@ int niqki_candidates_from_counts(niqki_index *ix, const uint16_t *counts, uint32
                                  uint64_t stride, uint32_t n_gids, uint32_t threshold,
                                  uint32_t cap, int32_t *cand, int32_t *n_cand, int mem);
 
+/* niqki_query_counts and niqki_candidates_from_counts in one pass (NIQKI_MEM_DEVICE
+ * only): the candidates are picked while a query's counters leave the gather kernel's
+ * LDS, so the hit vectors are not read again (6.5 GB per 32 768 queries at 100 000
+ * genomes).  Same outputs, the candidates of a query in another order.  Not on paged
+ * or whole-range S = 16 handles.  What a slot shard of a niqki_group runs. */
+int niqki_query_counts_candidates(niqki_index *ix, const int32_t *sketches, uint32_t nq,
+                                  uint16_t *counts, uint64_t stride, uint32_t threshold,
+                                  uint32_t cap, int32_t *cand, int32_t *n_cand, int mem);
+
 /* Index::query_sketch (src/niqki_index.cpp:633-687), batched: both halves. */
 int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq,
                 uint64_t *hit_off, uint32_t *hit_counts, uint32_t *hit_gids,

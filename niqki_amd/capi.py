@@ -82,6 +82,7 @@ ABI = [
     ("niqki_query_counts32", _int, [_vp, _vp, _u32, _vp, _u64, _int]),
     ("niqki_hits_from_counts", _int, [_vp, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_candidates_from_counts", _int, [_vp, _vp, _u32, _u64, _u32, _u32, _u32, _vp, _vp, _int]),
+    ("niqki_query_counts_candidates", _int, [_vp, _vp, _u32, _vp, _u64, _u32, _u32, _vp, _vp, _int]),
     ("niqki_query", _int, [_vp, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_query_sequences", _int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_stage_raw", _int, [_vp, C.POINTER(RawBatch), _int, C.POINTER(StageInfo), _vp]),
@@ -492,6 +493,10 @@ class Engine:
     def candidates_dev(self, counts, nq, stride, n_gids, threshold, cap, cand, n_cand):
         self._ck(self.L.niqki_candidates_from_counts(self.h, _p(counts), nq, stride, n_gids, threshold, cap,
                                                      _p(cand), _p(n_cand), MEM_DEVICE))
+
+    def query_counts_candidates_dev(self, sketches, nq, counts, stride, threshold, cap, cand, n_cand):
+        self._ck(self.L.niqki_query_counts_candidates(self.h, _p(sketches), nq, _p(counts), stride, threshold, cap,
+                                                      _p(cand), _p(n_cand), MEM_DEVICE))
 
     def query_dev(self, sketches, nq, hit_off, hc, hg, capacity):
         self._ck(self.L.niqki_query(self.h, _p(sketches), nq, _p(hit_off), _p(hc), _p(hg), capacity,

@@ -293,7 +293,8 @@ int load_page(niqki_index *ix, uint32_t s0, uint32_t s1) {
 }
 
 int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
-                    uint16_t *counts, uint64_t stride, bool accumulate, uint16_t *counts2 = nullptr);
+                    uint16_t *counts, uint64_t stride, bool accumulate, uint16_t *counts2 = nullptr,
+                    const nq::CandOut *co = nullptr);
 
 // counts over a paged index: page after page, the gather kernel adding to the rows from the second on
 int counts_paged(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq, uint16_t *counts,
@@ -314,14 +315,20 @@ int counts_paged(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, ui
 
 // counts for nq device-resident sketches into a device buffer
 int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
-               uint16_t *counts, uint64_t stride, uint16_t *counts2) {
+               uint16_t *counts, uint64_t stride, uint16_t *counts2, const nq::CandOut *co) {
+  if (co && (ix->resident_bytes || two_planes(ix) || !co->cand || !co->n || !co->cap))
+    return fail(ix, NIQKI_E_INVALID, "candidate lists: not on a paged or whole-range S = 16 handle; cand, n_cand and cap > 0 needed");
   if (ix->resident_bytes) return counts_paged(ix, sketches, q_stride, q_off, nq, counts, stride);
   if (two_planes(ix) && !counts2) return fail(ix, NIQKI_E_INVALID, "S = 16: counts reach 2^16, use niqki_query_counts32 (or the hit calls)");
-  return counts_resident(ix, sketches, q_stride, q_off, nq, counts, stride, false, counts2);
+  if (co && nq) {
+    NQ_HIP(ix, hipMemsetAsync(co->n, 0, (size_t)nq * 4, ix->stream));
+    NQ_HIP(ix, hipMemsetAsync(co->cand, 0xFF, (size_t)nq * co->cap * 4, ix->stream));
+  }
+  return counts_resident(ix, sketches, q_stride, q_off, nq, counts, stride, false, counts2, co);
 }
 
 int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
-                    uint16_t *counts, uint64_t stride, bool accumulate, uint16_t *counts2) {
+                    uint16_t *counts, uint64_t stride, bool accumulate, uint16_t *counts2, const nq::CandOut *co) {
   int rc = ix->resident_bytes ? NIQKI_OK : build_if_needed(ix);
   if (rc) return rc;
   if (nq == 0) return NIQKI_OK;
@@ -332,7 +339,7 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
     const uint32_t dn = ix->delta_n;
     ix->delta_n = 0;
     swap_segment(ix);
-    rc = counts_resident(ix, sketches, q_stride, q_off, nq, counts, stride, accumulate, counts2);
+    rc = counts_resident(ix, sketches, q_stride, q_off, nq, counts, stride, accumulate, counts2, co);
     swap_segment(ix);
     ix->delta_n = dn;
     if (rc) return rc;
@@ -374,10 +381,12 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
     }
     if (pre)
       NQ_HIP(ix, nq::launch_lookup(v, sketches + (size_t)q0 * q_stride, n, (uint32_t *)ix->ws_pre.p, ix->stream));
+    nq::CandOut c;
+    if (co) { c = *co; c.cand += (size_t)q0 * co->cap; c.n += q0; }
     NQ_HIP(ix, nq::launch_gather(v, sketches + (size_t)q0 * q_stride, n, counts + (size_t)q0 * stride,
                                  counts2 ? counts2 + (size_t)q0 * stride : nullptr, stride,
                                  pre ? (nq::Entry *)ix->ws_pre.p : (nq::Entry *)ix->ws_stash.p, order, ix->gather_variant,
-                                 pre, ix->stream));
+                                 pre, ix->stream, c));
   }
   return NIQKI_OK;
 }
@@ -987,6 +996,19 @@ int niqki_candidates_from_counts(niqki_index *ix, const uint16_t *counts, uint32
   Span sp(ix, NIQKI_KC_HITS);
   NQ_HIP(ix, nq::launch_candidates(counts, stride, nq, n_gids, threshold, cap, cand, n_cand, ix->stream));
   return NIQKI_OK;
+}
+
+int niqki_query_counts_candidates(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *counts, uint64_t stride,
+                                  uint32_t threshold, uint32_t cap, int32_t *cand, int32_t *n_cand, int mem) {
+  if (!ix || (nq && (!sketches || !counts || !cand || !n_cand)) || cap == 0) return NIQKI_E_INVALID;
+  if (mem != NIQKI_MEM_DEVICE) return fail(ix, NIQKI_E_INVALID, "niqki_query_counts_candidates is device-memory only");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  nq::CandOut co;
+  co.cand = cand;
+  co.n = n_cand;
+  co.thr = threshold;
+  co.cap = cap;
+  return counts_dev(ix, sketches, ix->d.F, first_slot(ix), nq, counts, stride, nullptr, &co);
 }
 
 int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint64_t *hit_off,

@@ -459,36 +459,43 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
   if (per == 0) return NIQKI_OK;
   int rc = exchange_slices(g, local_sketches, per);
   if (rc) return rc;
-  // 3. partial hit vectors of all queries over the local slots
-  for (uint32_t l = 0; l < g->n_local; ++l) {
-    niqki_index *ix = g->sh[l];
-    NQ_GH(g, hipSetDevice(ix->device));
-    NQ_G(g, l, nqi::ensure(ix, g->ws[l].counts, std::max<size_t>((size_t)nq * stride * 2, 4)));
-    if (N == 0) NQ_GH(g, hipMemsetAsync(g->ws[l].counts.p, 0, std::max<size_t>((size_t)nq * stride * 2, 4), ix->stream));
-    NQ_G(g, l, nqi::counts_dev(ix, (const int32_t *)g->ws[l].allsk.p, ix->d.slot_end - ix->d.slot_begin, 0, nq,
-                               (uint16_t *)g->ws[l].counts.p, stride));
-  }
-  // 4. cross-shard sum, scattered by query
   const uint32_t min_score = g->sh[0]->d.min_score;
   bool sparse = g->exchange == 1 || (g->exchange == 0 && min_score >= 4 * G);
   if (min_score < G || N == 0) sparse = false;   // ceil(min_score / G) must be >= 1
+  const uint32_t C = g->cand_cap, thr = (min_score + G - 1) / G;
+  // 3. partial hit vectors of all queries over the local slots; for the sparse exchange the gather kernel
+  //    also leaves every query's candidates (partial count >= ceil(min_score / G))
+  for (uint32_t l = 0; l < g->n_local; ++l) {
+    niqki_index *ix = g->sh[l];
+    NQ_GH(g, hipSetDevice(ix->device));
+    auto &w = g->ws[l];
+    NQ_G(g, l, nqi::ensure(ix, w.counts, std::max<size_t>((size_t)nq * stride * 2, 4)));
+    if (N == 0) NQ_GH(g, hipMemsetAsync(w.counts.p, 0, std::max<size_t>((size_t)nq * stride * 2, 4), ix->stream));
+    nq::CandOut co;
+    if (sparse) {
+      NQ_G(g, l, nqi::ensure(ix, w.cand, (size_t)nq * C * 4));
+      NQ_G(g, l, nqi::ensure(ix, w.ncand, (size_t)nq * 4));
+      co.cand = (int32_t *)w.cand.p;
+      co.n = (int32_t *)w.ncand.p;
+      co.thr = thr;
+      co.cap = C;
+    }
+    NQ_G(g, l, nqi::counts_dev(ix, (const int32_t *)w.allsk.p, ix->d.slot_end - ix->d.slot_begin, 0, nq,
+                               (uint16_t *)w.counts.p, stride, nullptr, sparse ? &co : nullptr));
+  }
+  // 4. cross-shard sum, scattered by query
   Buf niqki_group::Ws::*red = &niqki_group::Ws::red;
   if (sparse) {
-    const uint32_t C = g->cand_cap, thr = (min_score + G - 1) / G;
     for (uint32_t l = 0; l < g->n_local; ++l) {
       niqki_index *ix = g->sh[l];
       NQ_GH(g, hipSetDevice(ix->device));
       auto &w = g->ws[l];
-      NQ_G(g, l, nqi::ensure(ix, w.cand, (size_t)nq * C * 4));
-      NQ_G(g, l, nqi::ensure(ix, w.ncand, (size_t)nq * 4));
       NQ_G(g, l, nqi::ensure(ix, w.cand_all, (size_t)G * nq * C * 4));
       NQ_G(g, l, nqi::ensure(ix, w.ncand_all, (size_t)G * nq * 4));
       NQ_G(g, l, nqi::ensure(ix, w.mine, (size_t)nq * G * C * 4));
       NQ_G(g, l, nqi::ensure(ix, w.tot, (size_t)per * G * C * 4));
       NQ_G(g, l, nqi::ensure(ix, w.red, (size_t)per * stride * 2));
       NQ_G(g, l, nqi::ensure(ix, w.flag, 4));
-      nqi::Span sp(ix, NIQKI_KC_EXCHANGE);
-      NQ_GH(g, nq::launch_candidates((const uint16_t *)w.counts.p, stride, nq, N, thr, C, (int32_t *)w.cand.p, (int32_t *)w.ncand.p, ix->stream));
     }
     if ((rc = all_gather(g, &niqki_group::Ws::cand, &niqki_group::Ws::cand_all, (size_t)nq * C * 4))) return rc;
     if ((rc = all_gather(g, &niqki_group::Ws::ncand, &niqki_group::Ws::ncand_all, (size_t)nq * 4))) return rc;

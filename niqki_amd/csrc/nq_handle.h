@@ -110,8 +110,9 @@ nq::IndexView view(const niqki_index *ix);
 int build_if_needed(niqki_index *ix);
 // hit counters of nq device-resident sketches (rows q_stride apart, this shard's slots at q_off)
 // counts2: the second counter plane of a whole-range S = 16 handle (nq_kernels.h, kPassSlots), else nullptr
+// co: also the candidate lists of the rows (nq_kernels.h CandOut; presets them itself), not on paged or S = 16 handles
 int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
-               uint16_t *counts, uint64_t stride, uint16_t *counts2 = nullptr);
+               uint16_t *counts, uint64_t stride, uint16_t *counts2 = nullptr, const nq::CandOut *co = nullptr);
 int hits_dev(niqki_index *ix, const uint16_t *counts, uint32_t nq, uint64_t stride, uint32_t gid_begin,
              uint32_t n_gids, unsigned long long *hit_off, uint32_t *hc, uint32_t *hg, uint64_t capacity,
              bool check_capacity, uint64_t *total_out, const uint16_t *counts2 = nullptr);

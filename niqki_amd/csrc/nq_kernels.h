@@ -124,9 +124,18 @@ hipError_t launch_import(const Derived &d, const uint32_t *words, const uint64_t
 // (S = 16 on a whole-range handle): a count can then reach 2^16, so the slots are walked in two
 // passes of <= 2^15 and plane p holds pass p's counters; the true count is the 32-bit sum.
 constexpr uint32_t kPassSlots = 32768;
+// Candidate output of a gather launch (multi-GPU path): while a query's counters leave LDS, the genomes
+// with a count >= thr are appended to cand[q*cap ..] (unordered, at most cap kept) and n[q] grows by how
+// many qualified.  The caller presets n to 0 and cand to -1; launches over further segments of the same
+// index append.  Not with accumulate (slot pages) or a second plane.
+struct CandOut {
+  int32_t *cand = nullptr;
+  int32_t *n = nullptr;
+  uint32_t thr = 0, cap = 0;
+};
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq,
                          uint16_t *counts, uint16_t *counts2, uint64_t stride, Entry *stash, const uint32_t *order,
-                         int variant, bool pre, hipStream_t stream);
+                         int variant, bool pre, hipStream_t stream, const CandOut &co = CandOut());
 // out[i] = a[i] + b[i]: as u16 with wrap-around (the reference's uint16 matrix counters, src/niqki_index.cpp:572)
 // or as u32
 hipError_t launch_plane_add16(uint16_t *a, const uint16_t *b, uint64_t n, hipStream_t stream);

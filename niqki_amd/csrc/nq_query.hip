@@ -401,7 +401,7 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *keys, uint3
 template <int BLOCK, int UNROLL, int NT, int MODE = 0, bool PAD = false>
 __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_t *sketches,
                                                        uint16_t *counts, uint16_t *counts2, uint64_t stride, Entry *stash,
-                                                       const uint32_t *order, uint32_t nq) {
+                                                       const uint32_t *order, uint32_t nq, CandOut co) {
   extern __shared__ __align__(16) uint32_t cnt[];
   uint32_t q = blockIdx.x;
   if (order) {
@@ -417,6 +417,13 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
   const int32_t *sk = NT < 0 ? nullptr : sketches + (uint64_t)q * v.q_stride + v.q_off;
   Item *queue = (Item *)(cnt + (v.tile + 1) / 2 + (PAD ? kPadWords : 0u));  // behind the counters: kQueue items per wave
   uint32_t sink = 0;
+  const bool want_cand = co.cand != nullptr;
+  auto emit = [&](uint32_t c, uint32_t col) {   // col: column of the row = genome id - g_base
+    if (c >= co.thr) {   // rare: a global atomic per candidate (the LDS is full: kPadMaxTile)
+      const uint32_t i = atomicAdd((uint32_t *)&co.n[q], 1u);
+      if (i < co.cap) co.cand[(uint64_t)q * co.cap + i] = (int32_t)(v.g_base + col);
+    }
+  };
   const uint32_t n_it_all = (v.f_local + 63) / 64, it_pass = kPassSlots / 64;
   for (uint32_t it_lo = 0; it_lo < n_it_all; it_lo += it_pass) {   // one pass unless f_local > 2^15 (S = 16)
   const uint32_t n_it = it_lo + it_pass < n_it_all ? it_lo + it_pass : n_it_all;
@@ -444,9 +451,14 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
       // the row, a wave writes whole blocks (64-byte blocks are what HBM takes without a
       // read-modify-write, tools/ubench_partial_write.hip)
       for (uint32_t w = tid; w < n_words; w += BLOCK) {
-        uint32_t *dst = (uint32_t *)(row + tile_gid(v, t, 2 * w));
-        if (2 * w + 1 < n_t) *dst = v.accumulate ? *dst + cnt[w] : cnt[w];
-        else { uint16_t *d = (uint16_t *)dst; *d = v.accumulate ? (uint16_t)(*d + cnt[w]) : (uint16_t)cnt[w]; }
+        const uint32_t col = tile_gid(v, t, 2 * w), c = cnt[w];
+        uint32_t *dst = (uint32_t *)(row + col);
+        if (2 * w + 1 < n_t) *dst = v.accumulate ? *dst + c : c;
+        else { uint16_t *d = (uint16_t *)dst; *d = v.accumulate ? (uint16_t)(*d + c) : (uint16_t)c; }
+        if (want_cand) {
+          emit(c & 0xFFFFu, col);
+          if (2 * w + 1 < n_t) emit(c >> 16, col + 1);
+        }
       }
     } else if (v.stripe && v.n_tiles > 1) {
       // striped tiles: the tile's i-th counter belongs to genome tile_gid(t, i)
@@ -454,6 +466,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
         const uint16_t c = (uint16_t)(cnt[i >> 1] >> ((i & 1u) * 16u));
         uint16_t *dst = row + tile_gid(v, t, i);
         *dst = v.accumulate ? (uint16_t)(*dst + c) : c;
+        if (want_cand) emit(c, tile_gid(v, t, i));
       }
     } else {
       // dense counter row of this tile: u16 counts[q*stride + g0 + i], written as the packed words
@@ -466,12 +479,18 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
         for (uint32_t i = tid; i < n_t; i += BLOCK) {
           const uint16_t c = (uint16_t)(cnt[i >> 1] >> ((i & 1u) * 16u));
           row[g0 + i] = v.accumulate ? (uint16_t)(row[g0 + i] + c) : c;
+          if (want_cand) emit(c, g0 + i);
         }
       // (accumulating: sums stay <= F <= 2^15 per half, so the packed add cannot carry)
-      for (uint32_t i = tid; i < full; i += BLOCK) out[i] = v.accumulate ? out[i] + cnt[i] : cnt[i];
+      for (uint32_t i = tid; i < full; i += BLOCK) {
+        const uint32_t c = cnt[i];
+        out[i] = v.accumulate ? out[i] + c : c;
+        if (want_cand) { emit(c & 0xFFFFu, g0 + 2 * i); emit(c >> 16, g0 + 2 * i + 1); }
+      }
       if (packed && (n_t & 1u) && tid == 0) {
         const uint16_t c = (uint16_t)(cnt[full] & 0xFFFFu);
         row[g0 + n_t - 1] = v.accumulate ? (uint16_t)(row[g0 + n_t - 1] + c) : c;
+        if (want_cand) emit(c, g0 + n_t - 1);
       }
     }
     __syncthreads();
@@ -499,9 +518,10 @@ bool gather_variant_valid(int variant) {
 
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq, uint16_t *counts, uint16_t *counts2,
                          uint64_t stride, Entry *stash, const uint32_t *order, int variant, bool pre,
-                         hipStream_t stream) {
+                         hipStream_t stream, const CandOut &co) {
   if (nq == 0 || v.n_tiles == 0) return hipSuccess;
   if (v.f_local > kPassSlots && (!counts2 || v.accumulate)) return hipErrorInvalidValue;
+  if (co.cand && (v.accumulate || v.f_local > kPassSlots || !co.n)) return hipErrorInvalidValue;
 #define NQ_GATHER_LDS(B) ((size_t)((v.tile + 1) / 2 + (v.padded ? kPadWords : 0u)) * 4 + (size_t)(B / 64) * kQueue * sizeof(Item))
   // with a locality order the grid is padded to whole groups on every XCD
   const uint32_t per_round = kXcds * kOrderGroup;
@@ -513,7 +533,7 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     const size_t lds = NQ_GATHER_LDS(B);                                                         \
     e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                               \
-    hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, v, sketches, counts, counts2, stride, stash, order, nq); \
+    hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, v, sketches, counts, counts2, stride, stash, order, nq, co); \
   } while (0)
 #define NQ_BY_TILES(B, U, ...)                                                                   \
   do {                                                                                           \

@@ -601,6 +601,59 @@ def test_block_stripes_of_every_size_and_row_alignment(native, po, n, tile, monk
         e.close()
 
 
+@pytest.mark.parametrize("n,tile,n_late", [(300, 0, 0), (1000, 256, 0), (2049, 1024, 0), (70001, 0, 0), (21001, 0, 700)])
+def test_candidates_picked_by_the_gather_kernel(native, n, tile, n_late):
+    """niqki_query_counts_candidates = niqki_query_counts followed by niqki_candidates_from_counts:
+    the same counters, the same candidate sets (any order, -1 padding, exact n_cand when a list
+    overflows), over one tile, several tiles of every layout, and a main index plus delta segment."""
+    import torch
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(n)
+    S, W = 6, 6
+    F = 1 << S
+    fam = rng.integers(0, 1 << W, (8, F)).astype(np.int32)
+    sk = fam[(np.arange(n) // 50) % 8].copy()
+    noise = rng.random((n, F)) < 0.3
+    sk[noise] = rng.integers(0, 1 << W, int(noise.sum()))
+    q = np.concatenate([fam[:3], sk[[0, n // 2, n - 1]], rng.integers(0, 1 << W, (2, F)).astype(np.int32)])
+    nq = q.shape[0]
+    e = native.Engine(K=31, S=S, W=W, H=3, J=0.3, tile_genomes=tile)
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    e.insert(sk[:n - n_late])
+    if n_late:
+        e.query(q[:1])                               # builds; the late genomes then go to a delta segment
+        e.insert(sk[n - n_late:])
+    stride = native.row_stride(n)
+    dq = torch.from_numpy(q).to(dev)
+    for thr, cap in ((1, 64), (8, 256), (30, 16), (F + 1, 4)):
+        c0 = torch.zeros((nq, stride), dtype=torch.int16, device=dev)
+        e.query_counts_dev(dq, nq, c0, stride)
+        cand0 = torch.full((nq, cap), 7, dtype=torch.int32, device=dev)
+        n0 = torch.full((nq,), 7, dtype=torch.int32, device=dev)
+        e.candidates_dev(c0, nq, stride, n, thr, cap, cand0, n0)
+        c1 = torch.full((nq, stride), 9, dtype=torch.int16, device=dev)
+        cand1 = torch.full((nq, cap), 7, dtype=torch.int32, device=dev)
+        n1 = torch.full((nq,), 7, dtype=torch.int32, device=dev)
+        e.query_counts_candidates_dev(dq, nq, c1, stride, thr, cap, cand1, n1)
+        e.synchronize()
+        assert torch.equal(c0[:, :n], c1[:, :n])
+        assert torch.equal(n0, n1), (thr, cap)
+        cnt = c0[:, :n].cpu().numpy().view(np.uint16)
+        cand1, n1 = cand1.cpu().numpy(), n1.cpu().numpy()
+        for i in range(nq):
+            want = np.nonzero(cnt[i] >= thr)[0]
+            assert n1[i] == len(want), (i, thr)
+            k = min(len(want), cap)
+            assert (cand1[i, k:] == -1).all()
+            got = cand1[i, :k].tolist()
+            assert len(set(got)) == k and set(got) <= set(want.tolist()), (i, thr)
+            if len(want) <= cap:
+                assert sorted(got) == want.tolist()
+    if n_late:
+        assert e.stat("delta_genomes") == n_late
+    e.close()
+
+
 def test_inserts_after_a_query_get_a_delta_segment(native, po):
     """Genomes inserted after a build are indexed by a delta segment (no rebuild of the main index) until
     they pass an eighth of it; queries walk both segments.  Same answers as one index built at once, the
