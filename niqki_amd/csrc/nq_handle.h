@@ -80,7 +80,7 @@ struct niqki_index {
   int gather_variant = 0;
   uint64_t record_len_hint = 0;  // avg bytes per sketch for device-side batches (0 = read it back)
   uint32_t query_batch = 1024;
-  int query_order = 1;           // option: order the queries of a launch for cache locality
+  int query_order = 1;           // option: order the queries of a launch for cache locality (1 = where it pays, 2 = wherever possible)
   int lookup_prepass = -1;       // option: slot-major table look-up pre-pass: -1 = when it pays, 0 = never, 1 = whenever usable
 
   nqi::Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
