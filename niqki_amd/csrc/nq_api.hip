@@ -1638,7 +1638,11 @@ int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate) {
   NQ_HIP(ix, hipSetDevice(ix->device));
   int rc = ensure(ix, ix->ws_misc, 256);
   if (rc) return rc;
-  hipEvent_t a, b;
+  hipEvent_t a = nullptr, b = nullptr;
+  struct Events {   // destroyed on every way out
+    hipEvent_t &a, &b;
+    ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } guard{a, b};
   NQ_HIP(ix, hipEventCreate(&a));
   NQ_HIP(ix, hipEventCreate(&b));
   auto run = [&](uint32_t iters, double &t_ms, uint64_t &units) -> hipError_t {
@@ -1657,8 +1661,6 @@ int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate) {
   NQ_HIP(ix, run(iters, t, units));                       // warm-up + calibration
   iters = (uint32_t)std::min<double>(1e7, std::max<double>(256, iters * ms / std::max(t, 1e-3)));
   NQ_HIP(ix, run(iters, t, units));
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
   *rate = t > 0 ? (double)units / (t * 1e-3) : 0.0;
   return NIQKI_OK;
 }

@@ -22,6 +22,10 @@ rm -rf /tmp/kt2; NIQKI_LOOKUP_PREPASS=1 timeout -k 10 600 rocprofv3 --kernel-tra
 cd $R
 python3 tools/prof_summary.py /tmp/kt2 | grep -E "gather_kernel|lookup_kernel|probe_kernel|order_kernel|^==|kernel " > gpurun_out/${TAG}_prepass_kernel_trace_summary.txt
 timeout -k 10 600 python3 bench.py --shard-of 8 --no-cpu > gpurun_out/${TAG}_shard_of_8.json 2> gpurun_out/${TAG}_shard_of_8.err || exit 1
+# the weak-scaling shape of --gpus 8 on rank 0 (every rank brings 4096 queries), and all 8 ranks of the group on this one GPU
+timeout -k 10 600 python3 bench.py --shard-of 8 --batch 32768 --ring 2 --steps 5 --warmup 2 --no-cpu --no-extra > gpurun_out/${TAG}_shard_of_8_weak.json 2> gpurun_out/${TAG}_shard_of_8_weak.err || exit 1
+timeout -k 10 600 python3 tools/bench_group_local.py --steps 3 > gpurun_out/${TAG}_group_local_8_shards.json 2> gpurun_out/${TAG}_group_local.err || exit 1
+hipcc -O3 --offload-arch=gfx950 tools/ubench_partial_write.hip -o /tmp/ubench_partial_write 2>/dev/null && /tmp/ubench_partial_write > gpurun_out/${TAG}_ubench_partial_write.txt
 NIQKI_FORCE_DIST=1 timeout -k 10 600 python3 bench.py --no-cpu --no-extra > gpurun_out/${TAG}_force_dist_world1.json 2> gpurun_out/${TAG}_force_dist_world1.err || exit 1
 hipcc -O3 --offload-arch=gfx950 tools/ubench_sector.hip -o /tmp/ubench_sector 2>/dev/null && /tmp/ubench_sector > gpurun_out/${TAG}_ubench_sector.txt
 cd /tmp
