@@ -358,7 +358,10 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
   // off a launch but not its time -- both forms are bound by the number of random line requests a
   // CU keeps in flight, and inside the gather kernel the look-ups overlap with the bucket walk.
   // So the default keeps them there; the pre-pass is opt-in (lookup_prepass = 1).
-  if (ix->lookup_prepass < 0) pre = false;
+  // An index of more than 4 tiles (> 261 632 genomes) is different: inside the kernel only 4 tiles'
+  // entries can be parked per look-up, so every further tile would cost its own random table line
+  // per query and slot; there the pre-pass is the default for real batches.
+  if (ix->lookup_prepass < 0) pre = pre && ix->n_tiles > 4 && nq >= 256;
   // locality order of each launch: worth its probe on large indexes and real batches.  It takes ~8 % off
   // the gather kernel and costs 0.28 ms per 4096 queries at 100 000 genomes whatever the slot count, so
   // a slot shard of <= 8192 slots (1.6 ms per 4096 queries at 4096 slots) runs in input order.
@@ -371,6 +374,7 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
   uint32_t chunk = nq;
   if (per_query) chunk = (uint32_t)std::max<size_t>(4096, ((size_t)128 << 20) / per_query);
   if (ordered || pre) chunk = 4096;
+  if (pre && per_query * chunk > ((size_t)2 << 30)) chunk = std::max<uint32_t>(256, (uint32_t)((((size_t)2 << 30) / per_query) & ~(size_t)255));
   if (pre) {
     if ((rc = ensure(ix, ix->ws_pre, nq::lookup_pre_bytes(v, std::min(nq, chunk))))) return rc;
   } else if (ix->n_tiles > 1) {

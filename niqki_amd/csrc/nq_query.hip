@@ -234,9 +234,10 @@ constexpr uint32_t kXcds = 8;
 constexpr uint32_t kPreBlock = 256;      // queries per lookup workgroup, one per thread
 constexpr uint32_t kPreFlight = 8;       // look-ups in flight per thread
 
+// NT tiles from tile t0 on per launch: an index of more than 4 tiles takes several launches.
 template <int NT, int PS>
 __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const int32_t *sketches, uint32_t nq,
-                                                           uint32_t n_qchunk, uint32_t *pre) {
+                                                           uint32_t n_qchunk, uint32_t *pre, uint32_t t0) {
   const uint32_t tid = threadIdx.x;
   const uint32_t n_sb = v.f_local / PS;
   const uint32_t x = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const in
     for (int j = 0; j < (int)kPreFlight; ++j) {   // all loads of the group first
       const int i = i0 + j;
       const bool ok = fp[i] >= 0 && (uint32_t)fp[i] < R;
-      const Entry *e = v.entries + ((uint64_t)(sb * PS + i) * R + (ok ? (uint32_t)fp[i] : 0u)) * NT;
+      const Entry *e = v.entries + ((uint64_t)(sb * PS + i) * R + (ok ? (uint32_t)fp[i] : 0u)) * v.n_tiles + t0;
 #pragma unroll
       for (int t = 0; t < NT; ++t) en[j][t] = e[t];
     }
@@ -273,14 +274,14 @@ __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const in
       const bool ok = fp[i] >= 0 && (uint32_t)fp[i] < R;
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const uint32_t base = v.slot_units[(uint64_t)t * (v.f_local + 1) + sb * PS + i];
+        const uint32_t base = v.slot_units[(uint64_t)(t0 + t) * (v.f_local + 1) + sb * PS + i];
         res[t][i] = ok ? (((en[j][t].start - base) << 16) | en[j][t].len) : 0u;
       }
     }
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    uint4 *dst = (uint4 *)(pre + ((uint64_t)q * NT + t) * v.f_local + (uint64_t)sb * PS);
+    uint4 *dst = (uint4 *)(pre + ((uint64_t)q * v.n_tiles + t0 + t) * v.f_local + (uint64_t)sb * PS);
 #pragma unroll
     for (int u = 0; u < PS / 4; ++u) dst[u] = make_uint4(res[t][4 * u], res[t][4 * u + 1], res[t][4 * u + 2], res[t][4 * u + 3]);
   }
@@ -288,11 +289,10 @@ __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const in
 
 static uint32_t lookup_slots(const IndexView &v) { return v.n_tiles <= 2 ? 32u : 16u; }
 
-// Can the pre-pass serve this index?  Tiles 1..4, whole slot blocks, and both halves of the
-// packed word within 16 bits (bucket lengths <= tile, starts relative to the slot <= tile / unit
-// + R units).
+// Can the pre-pass serve this index?  Whole slot blocks, and both halves of the packed word
+// within 16 bits (bucket lengths <= tile, starts relative to the slot <= tile / unit + R units).
 bool launch_lookup_usable(const IndexView &v) {
-  if (v.n_tiles < 1 || v.n_tiles > 4 || v.f_local % lookup_slots(v)) return false;
+  if (v.n_tiles < 1 || v.f_local % lookup_slots(v)) return false;
   if (v.tile > 65535u) return false;
   return (uint64_t)(v.tile >> v.align_log2) + v.d.R + 1 <= 65535u;
 }
@@ -306,12 +306,14 @@ hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t n
   const uint64_t grid = (uint64_t)((n_sb + kXcds - 1) / kXcds * kXcds) * n_qchunk;
   if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
 #define NQ_LAUNCH_LOOKUP(NT, PS) \
-  hipLaunchKernelGGL((lookup_kernel<NT, PS>), dim3((uint32_t)grid), dim3(kPreBlock), 0, stream, v, sketches, nq, n_qchunk, pre)
-  switch (v.n_tiles) {
-    case 1: NQ_LAUNCH_LOOKUP(1, 32); break;
-    case 2: NQ_LAUNCH_LOOKUP(2, 32); break;
-    case 3: NQ_LAUNCH_LOOKUP(3, 16); break;
-    default: NQ_LAUNCH_LOOKUP(4, 16); break;
+  hipLaunchKernelGGL((lookup_kernel<NT, PS>), dim3((uint32_t)grid), dim3(kPreBlock), 0, stream, v, sketches, nq, n_qchunk, pre, t0)
+  for (uint32_t t0 = 0; t0 < v.n_tiles; t0 += 4) {   // (blocks of 16 slots whenever there are more than 2 tiles)
+    const uint32_t nt = v.n_tiles - t0 < 4 ? v.n_tiles - t0 : 4;
+    if (ps == 32) { if (nt == 1) NQ_LAUNCH_LOOKUP(1, 32); else NQ_LAUNCH_LOOKUP(2, 32); }
+    else if (nt == 1) NQ_LAUNCH_LOOKUP(1, 16);
+    else if (nt == 2) NQ_LAUNCH_LOOKUP(2, 16);
+    else if (nt == 3) NQ_LAUNCH_LOOKUP(3, 16);
+    else NQ_LAUNCH_LOOKUP(4, 16);
   }
 #undef NQ_LAUNCH_LOOKUP
   return hipGetLastError();

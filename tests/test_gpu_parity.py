@@ -654,6 +654,45 @@ def test_candidates_picked_by_the_gather_kernel(native, n, tile, n_late):
     e.close()
 
 
+@pytest.mark.parametrize("n,tile", [(1000, 64), (1500, 128), (700, 64)])
+def test_more_than_four_tiles(native, po, n, tile):
+    """5 to 16 counter tiles (what > 261 632 genomes get at the default tile size): the look-up
+    pre-pass walks the tiles four at a time and is the default there for real batches; the same
+    counters and hits with it, without it, and as the oracle; the dump merges all tiles."""
+    rng = np.random.default_rng(n + tile)
+    S, W = 6, 6
+    F = 1 << S
+    fam = rng.integers(0, 1 << W, (8, F)).astype(np.int32)
+    sk = fam[(np.arange(n) // 50) % 8].copy()
+    noise = rng.random((n, F)) < 0.3
+    sk[noise] = rng.integers(0, 1 << W, int(noise.sum()))
+    nq = 300
+    q = sk[rng.integers(0, n, nq)].copy()
+    m = rng.random((nq, F)) < 0.1
+    q[m] = rng.integers(0, 1 << W, int(m.sum()))
+    q[7] = -1
+    p = po.make_params(31, S, W, 3, 0.3)
+    ix = po.Index(p, sk)
+    e = native.Engine(K=31, S=S, W=W, H=3, J=0.3, tile_genomes=tile)
+    e.insert(sk)
+    e.build()
+    assert e.stat("tiles") == -(-n // tile) and e.stat("tiles") > 4
+    res = {}
+    for mode in (-1, 0, 1):
+        e.set_option("lookup_prepass", mode)
+        res[mode] = (e.query_counts(q), e.query(q))
+    for mode in (0, 1):
+        assert np.array_equal(res[-1][0], res[mode][0]), mode
+        assert all(np.array_equal(x, y) for x, y in zip(res[-1][1], res[mode][1])), mode
+    cnt, (off, hc, hg) = res[-1]
+    for i in (0, 1, 7, 150, nq - 1):
+        assert np.array_equal(cnt[i].astype(np.uint32), ix.counts(q[i])), i
+        ehc, ehg = ix.query(q[i])
+        assert np.array_equal(hc[off[i]:off[i + 1]], ehc) and np.array_equal(hg[off[i]:off[i + 1]], ehg), i
+    assert e.export_dump() == ix.dump_bytes()
+    e.close()
+
+
 def test_inserts_after_a_query_get_a_delta_segment(native, po):
     """Genomes inserted after a build are indexed by a delta segment (no rebuild of the main index) until
     they pass an eighth of it; queries walk both segments.  Same answers as one index built at once, the
