@@ -600,16 +600,24 @@ hipError_t launch_gathered(const IndexView &v, const int32_t *sketches, uint32_t
 // blk_counts[q][b] = number of genomes of block b with count >= min_score, and the query's total
 // in hit_off[q] (scanned into offsets by hits_scan_kernel).  One workgroup per query: wave w takes
 // blocks w, w+16, ...; a lane reads 8 counters (16 bytes) at a time.
+// WIDE: the 16 waves of a workgroup share one query (large indexes).  !WIDE (fewer than 8 blocks,
+// i.e. < 32 768 genomes: the short-read indexes): a wave per query, 16 queries per workgroup.
+template <bool WIDE>
 __global__ __launch_bounds__(1024) void hits_count_kernel(HitsArgs a) {
   __shared__ uint32_t s_sum;
-  const uint32_t q = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) s_sum = 0;
-  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t q = WIDE ? blockIdx.x : blockIdx.x * 16u + wave;
+  if (WIDE) {
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+  } else if (q >= a.nq) {
+    return;   // (no barrier on this path)
+  }
   const uint16_t *row = a.counts + (uint64_t)q * a.stride + a.gid_begin;
   const uint16_t *row2 = a.counts2 ? a.counts2 + (uint64_t)q * a.stride + a.gid_begin : nullptr;
-  const bool vec = (((uintptr_t)row) & 15) == 0 && !row2;   // uniform
+  const bool vec = (((uintptr_t)row) & 15) == 0 && !row2;   // uniform per wave
   uint32_t mine = 0;
-  for (uint32_t b = wave; b < a.n_blk; b += 16) {
+  for (uint32_t b = WIDE ? wave : 0u; b < a.n_blk; b += WIDE ? 16u : 1u) {
     const uint32_t lo = b * kHitsBlk;
     const uint32_t hi = (lo + kHitsBlk < a.n_gids) ? lo + kHitsBlk : a.n_gids;
     uint32_t c = 0;
@@ -631,43 +639,44 @@ __global__ __launch_bounds__(1024) void hits_count_kernel(HitsArgs a) {
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
     if (lane == 0) { a.blk_counts[(uint64_t)q * a.n_blk + b] = c; mine += c; }
   }
+  if (!WIDE) {
+    if (lane == 0) a.hit_off[q] = mine;
+    return;
+  }
   if (lane == 0 && mine) atomicAdd(&s_sum, mine);
   __syncthreads();
   if (threadIdx.x == 0) a.hit_off[q] = s_sum;
 }
 
-// hit_off[0..nq): per-query totals -> exclusive prefix, hit_off[nq] = grand total.  One workgroup:
-// every thread scans a run of queries, the 16 wave totals are combined through LDS.
+// hit_off[0..nq): per-query totals -> exclusive prefix, hit_off[nq] = grand total.  One workgroup walks
+// the totals 1024 at a time (coalesced): wave scan, the 16 wave totals through LDS, a running base.
 __global__ __launch_bounds__(1024) void hits_scan_kernel(HitsArgs a) {
-  __shared__ unsigned long long wave_tot[16];
+  __shared__ unsigned long long wave_tot[2][16];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t per = (a.nq + 1023) / 1024;
-  const uint32_t lo = tid * per < a.nq ? tid * per : a.nq;
-  const uint32_t hi = lo + per < a.nq ? lo + per : a.nq;
-  unsigned long long sum = 0;
-  for (uint32_t q = lo; q < hi; ++q) sum += a.hit_off[q];
-  unsigned long long incl = sum;
+  unsigned long long base = 0;
+  uint32_t flip = 0;
+  for (uint32_t q0 = 0; q0 < a.nq; q0 += 1024, flip ^= 1u) {
+    const uint32_t q = q0 + tid;
+    const unsigned long long x = q < a.nq ? a.hit_off[q] : 0ull;
+    unsigned long long incl = x;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned long long y = __shfl_up(incl, o, 64);
-    if (lane >= (uint32_t)o) incl += y;
-  }
-  if (lane == 63) wave_tot[wave] = incl;
-  __syncthreads();
-  unsigned long long base = 0, total = 0;
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long y = __shfl_up(incl, o, 64);
+      if (lane >= (uint32_t)o) incl += y;
+    }
+    if (lane == 63) wave_tot[flip][wave] = incl;
+    __syncthreads();   // (the other half of wave_tot is what the previous round may still be reading)
+    unsigned long long before = 0, total = 0;
 #pragma unroll
-  for (uint32_t w = 0; w < 16; ++w) {
-    const unsigned long long x = wave_tot[w];
-    if (w < wave) base += x;
-    total += x;
+    for (uint32_t w = 0; w < 16; ++w) {
+      const unsigned long long t = wave_tot[flip][w];
+      if (w < wave) before += t;
+      total += t;
+    }
+    if (q < a.nq) a.hit_off[q] = base + before + incl - x;
+    base += total;
   }
-  unsigned long long run = base + incl - sum;
-  for (uint32_t q = lo; q < hi; ++q) {
-    const unsigned long long x = a.hit_off[q];
-    a.hit_off[q] = run;
-    run += x;
-  }
-  if (tid == 0) a.hit_off[a.nq] = total;
+  if (tid == 0) a.hit_off[a.nq] = base;
 }
 
 // Each (query, block) writes its hits at the mirrored position so that a
@@ -834,7 +843,8 @@ hipError_t launch_plane_sum32(const uint16_t *a, const uint16_t *b, uint32_t *ou
 
 hipError_t launch_hits_count(const HitsArgs &a, hipStream_t stream) {
   if (a.nq == 0 || a.n_blk == 0) return hipSuccess;
-  hipLaunchKernelGGL(hits_count_kernel, dim3(a.nq), dim3(1024), 0, stream, a);
+  if (a.n_blk >= 8) hipLaunchKernelGGL(hits_count_kernel<true>, dim3(a.nq), dim3(1024), 0, stream, a);
+  else hipLaunchKernelGGL(hits_count_kernel<false>, dim3((a.nq + 15) / 16), dim3(1024), 0, stream, a);
   hipLaunchKernelGGL(hits_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
   return hipGetLastError();
 }
