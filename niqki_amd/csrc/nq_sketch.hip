@@ -515,6 +515,15 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Orders the wave's LDS instructions on either side in the instruction stream without waiting for
+// them: the LDS serves one wave's instructions in issue order, so a later instruction of ANY lane
+// sees the effect of an earlier one of any lane.
+__device__ __forceinline__ void wave_lds_order() {
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // The passes over R register entries per lane (entry e = k*64 + lane of elist).
 template <int R>
 __device__ __forceinline__ void densify_wave_entries(uint32_t *sk, const uint32_t *elist, uint32_t n_ent,
@@ -535,13 +544,15 @@ __device__ __forceinline__ void densify_wave_entries(uint32_t *sk, const uint32_
   for (;;) {
 #pragma unroll
     for (int k = 0; k < R; ++k) atomicMin(&sk[T[k] & Fm], mk[k]);
-    wave_lds_sync();
-    // all targets are read back before any winner writes: every read sees the surviving
-    // proposal of its cell, which names exactly one entry
+    wave_lds_order();
+    // all proposals of the wave are issued before any read-back: a read sees the surviving proposal
+    // of its cell (which names exactly one entry), or, behind another entry's winner write of this
+    // pass, that winner's value -- not its own proposal either way.  One LDS round trip per pass:
+    // only the read-back is waited for; the winner writes and the next pass's proposals follow in order.
     uint32_t back[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) back[k] = sk[T[k] & Fm];
-    wave_lds_sync();
+    wave_lds_order();
     uint32_t tot = 0;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
@@ -555,7 +566,7 @@ __device__ __forceinline__ void densify_wave_entries(uint32_t *sk, const uint32_
       tot += (uint32_t)__popcll(__ballot(won));
       T[k] += B[k];
     }
-    wave_lds_sync();
+    wave_lds_order();
     empty -= tot;
     idle = tot ? 0u : idle + 1u;
     if (empty == 0 || idle >= F) break;
