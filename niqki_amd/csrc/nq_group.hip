@@ -112,19 +112,22 @@ __global__ __launch_bounds__(256) void slice_unpack_kernel(const int16_t *in, ui
   for (uint32_t j = threadIdx.x; j < f_local; j += 256) out[(uint64_t)q * f_local + j] = in[(uint64_t)q * w_max + j];
 }
 
+// A rank's candidates travel as one blob: nq lists of C ids, then the nq list sizes (one all-gather).
+__host__ __device__ inline uint64_t cand_blob_ints(uint32_t nq, uint32_t C) { return (uint64_t)nq * C + nq; }
+
 // mine[q][g*C + c] = this shard's partial count of candidate c of rank g for query q (0 where the
 // list has no entry); flag |= some list overflowed its capacity
 __global__ __launch_bounds__(256) void cand_lookup_kernel(const uint16_t *counts, uint64_t stride, uint32_t nq, uint32_t G,
-                                                         uint32_t C, const int32_t *cand_all, const int32_t *ncand_all,
-                                                         uint32_t *mine, uint32_t *flag) {
+                                                         uint32_t C, const int32_t *cand_all, uint32_t *mine, uint32_t *flag) {
   const uint32_t q = blockIdx.x;
   const uint16_t *row = counts + (uint64_t)q * stride;
+  const uint64_t blob = cand_blob_ints(nq, C);
   for (uint32_t i = threadIdx.x; i < G * C; i += 256) {
     const uint32_t g = i / C, c = i % C;
-    const int32_t id = cand_all[((uint64_t)g * nq + q) * C + c];
+    const int32_t id = cand_all[g * blob + (uint64_t)q * C + c];
     mine[(uint64_t)q * G * C + i] = id >= 0 ? (uint32_t)row[id] : 0u;
   }
-  if (threadIdx.x < G && (uint32_t)ncand_all[(uint64_t)threadIdx.x * nq + q] > C) atomicOr(flag, 1u);
+  if (threadIdx.x < G && (uint32_t)cand_all[threadIdx.x * blob + (uint64_t)nq * C + q] > C) atomicOr(flag, 1u);
 }
 
 // summed candidate counts into the (zeroed) counter rows of this rank's own queries
@@ -132,9 +135,10 @@ __global__ __launch_bounds__(256) void cand_scatter_kernel(const uint32_t *tot, 
                                                           uint32_t G, uint32_t C, const int32_t *cand_all, uint16_t *red,
                                                           uint64_t stride) {
   const uint32_t ql = blockIdx.x, q = first_q + ql;
+  const uint64_t blob = cand_blob_ints(nq, C);
   for (uint32_t i = threadIdx.x; i < G * C; i += 256) {
     const uint32_t g = i / C, c = i % C;
-    const int32_t id = cand_all[((uint64_t)g * nq + q) * C + c];
+    const int32_t id = cand_all[g * blob + (uint64_t)q * C + c];
     if (id >= 0) red[(uint64_t)ql * stride + id] = (uint16_t)tot[(uint64_t)ql * G * C + i];  // duplicates write the same sum
   }
 }
@@ -162,7 +166,7 @@ struct niqki_group {
   uint64_t overflows = 0;            // sparse steps redone densely
   std::string err;
   struct Ws {
-    Buf send, recv, allsk, counts, cand, ncand, cand_all, ncand_all, mine, tot, red, flag, hitoff, hc, hg, stpad;
+    Buf send, recv, allsk, counts, cand, cand_all, mine, tot, red, flag, hitoff, hc, hg, stpad;
     hipEvent_t ev = nullptr;
   };
   std::vector<Ws> ws;
@@ -392,7 +396,7 @@ void niqki_group_destroy(niqki_group *g) {
       (void)hipStreamSynchronize(g->sh[l]->stream);
     }
     auto &w = g->ws[l];
-    for (Buf *b : {&w.send, &w.recv, &w.allsk, &w.counts, &w.cand, &w.ncand, &w.cand_all, &w.ncand_all, &w.mine, &w.tot, &w.red,
+    for (Buf *b : {&w.send, &w.recv, &w.allsk, &w.counts, &w.cand, &w.cand_all, &w.mine, &w.tot, &w.red,
                    &w.flag, &w.hitoff, &w.hc, &w.hg, &w.stpad})
       if (b->p) (void)hipFree(b->p);
     if (w.ev) (void)hipEventDestroy(w.ev);
@@ -473,10 +477,9 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
     if (N == 0) NQ_GH(g, hipMemsetAsync(w.counts.p, 0, std::max<size_t>((size_t)nq * stride * 2, 4), ix->stream));
     nq::CandOut co;
     if (sparse) {
-      NQ_G(g, l, nqi::ensure(ix, w.cand, (size_t)nq * C * 4));
-      NQ_G(g, l, nqi::ensure(ix, w.ncand, (size_t)nq * 4));
+      NQ_G(g, l, nqi::ensure(ix, w.cand, (size_t)nq::cand_blob_ints(nq, C) * 4));
       co.cand = (int32_t *)w.cand.p;
-      co.n = (int32_t *)w.ncand.p;
+      co.n = (int32_t *)w.cand.p + (size_t)nq * C;
       co.thr = thr;
       co.cap = C;
     }
@@ -490,15 +493,13 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
       niqki_index *ix = g->sh[l];
       NQ_GH(g, hipSetDevice(ix->device));
       auto &w = g->ws[l];
-      NQ_G(g, l, nqi::ensure(ix, w.cand_all, (size_t)G * nq * C * 4));
-      NQ_G(g, l, nqi::ensure(ix, w.ncand_all, (size_t)G * nq * 4));
+      NQ_G(g, l, nqi::ensure(ix, w.cand_all, (size_t)G * nq::cand_blob_ints(nq, C) * 4));
       NQ_G(g, l, nqi::ensure(ix, w.mine, (size_t)nq * G * C * 4));
       NQ_G(g, l, nqi::ensure(ix, w.tot, (size_t)per * G * C * 4));
       NQ_G(g, l, nqi::ensure(ix, w.red, (size_t)per * stride * 2));
       NQ_G(g, l, nqi::ensure(ix, w.flag, 4));
     }
-    if ((rc = all_gather(g, &niqki_group::Ws::cand, &niqki_group::Ws::cand_all, (size_t)nq * C * 4))) return rc;
-    if ((rc = all_gather(g, &niqki_group::Ws::ncand, &niqki_group::Ws::ncand_all, (size_t)nq * 4))) return rc;
+    if ((rc = all_gather(g, &niqki_group::Ws::cand, &niqki_group::Ws::cand_all, (size_t)nq::cand_blob_ints(nq, C) * 4))) return rc;
     for (uint32_t l = 0; l < g->n_local; ++l) {
       niqki_index *ix = g->sh[l];
       NQ_GH(g, hipSetDevice(ix->device));
@@ -506,7 +507,7 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
       nqi::Span sp(ix, NIQKI_KC_EXCHANGE);
       NQ_GH(g, hipMemsetAsync(w.flag.p, 0, 4, ix->stream));
       hipLaunchKernelGGL(nq::cand_lookup_kernel, dim3(nq), dim3(256), 0, ix->stream, (const uint16_t *)w.counts.p, stride, nq, G, C,
-                         (const int32_t *)w.cand_all.p, (const int32_t *)w.ncand_all.p, (uint32_t *)w.mine.p, (uint32_t *)w.flag.p);
+                         (const int32_t *)w.cand_all.p, (uint32_t *)w.mine.p, (uint32_t *)w.flag.p);
       NQ_GH(g, hipGetLastError());
     }
     if ((rc = reduce_scatter_u32(g, &niqki_group::Ws::mine, &niqki_group::Ws::tot, (size_t)per * G * C))) return rc;

@@ -651,6 +651,28 @@ def test_candidates_picked_by_the_gather_kernel(native, n, tile, n_late):
                 assert sorted(got) == want.tolist()
     if n_late:
         assert e.stat("delta_genomes") == n_late
+    if n == 1000:
+        # more queries than one launch takes (4096): the lists of the later launches land in their own rows
+        big = np.tile(q, (600, 1))[:4500]
+        big[4100:] = np.roll(big[4100:], 3, axis=0)
+        dbig = torch.from_numpy(big).to(dev)
+        thr, cap = 8, 512
+        c0 = torch.zeros((4500, stride), dtype=torch.int16, device=dev)
+        e.query_counts_dev(dbig, 4500, c0, stride)
+        cand1 = torch.full((4500, cap), 7, dtype=torch.int32, device=dev)
+        n1 = torch.full((4500,), 7, dtype=torch.int32, device=dev)
+        c1 = torch.zeros((4500, stride), dtype=torch.int16, device=dev)
+        e.query_counts_candidates_dev(dbig, 4500, c1, stride, thr, cap, cand1, n1)
+        e.synchronize()
+        assert torch.equal(c0, c1)
+        cnt = c0[:, :n].cpu().numpy().view(np.uint16)
+        cand1, n1 = cand1.cpu().numpy(), n1.cpu().numpy()
+        for i in (0, 4095, 4096, 4097, 4499):
+            want = np.nonzero(cnt[i] >= thr)[0]
+            assert n1[i] == len(want), i
+            k = min(len(want), cap)
+            assert set(cand1[i, :k].tolist()) <= set(want.tolist()) and len(set(cand1[i, :k].tolist())) == k, i
+            assert (cand1[i, k:] == -1).all(), i
     e.close()
 
 
