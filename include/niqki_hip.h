@@ -121,7 +121,7 @@ int niqki_synchronize(niqki_index *ix);
  * batches, so that niqki_sketch need not read rec_off back to pick a launch
  * shape; 0 = read it back), "query_order" (1 = default: the queries of a launch
  * are processed in an order that puts similar ones on the same XCD where that pays --
- * >= 16384 genomes and > 8192 slots on the handle; 2 = on every index; results are
+ * >= 16384 genomes and >= 8192 slots on the handle; 2 = on every index; results are
  * unaffected; 0 = input order), "lookup_prepass" (1 = the index table is walked
  * once per launch, slot block by slot block, for all its queries instead of one random
  * table line per query and slot inside the gather kernel, wherever the index shape

@@ -363,10 +363,10 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
   // per query and slot; there the pre-pass is the default for real batches.
   if (ix->lookup_prepass < 0) pre = pre && ix->n_tiles > 4 && nq >= 256;
   // locality order of each launch: worth its probe on large indexes and real batches.  It takes ~8 % off
-  // the gather kernel and costs 0.28 ms per 4096 queries at 100 000 genomes whatever the slot count, so
-  // a slot shard of <= 8192 slots (1.6 ms per 4096 queries at 4096 slots) runs in input order.
+  // the gather kernel and costs 0.1 ms per 4096 queries at 100 000 genomes whatever the slot count:
+  // measured even on a slot shard of 4096 slots (1.56 against 1.57 ms per 4096 queries), +4 % at 8192.
   const bool ordered = ix->query_order && nq >= 64 && ix->seg_n < (1u << 20) - 1 &&
-                       (ix->query_order >= 2 || (ix->seg_n >= 16384 && f_local > 8192));
+                       (ix->query_order >= 2 || (ix->seg_n >= 16384 && f_local >= 8192));
   // launches of at most `chunk` queries: the order kernel sorts <= 4096, and the per-query scratch
   // (stash or pre-pass words) stays <= 128 MiB whatever the caller's batch size is (bigger launches are
   // no faster: 32 768 query shards in one launch take 8 x the time of 4096)

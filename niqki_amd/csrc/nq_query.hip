@@ -330,6 +330,10 @@ constexpr uint32_t kOrderGroup = 8;
 constexpr uint32_t kProbeSlots = 16;
 constexpr uint32_t kOrderMax = 4096;   // queries per launch (12 index bits next to a 20-bit key)
 
+// Counters per block of kProbeBlock consecutive genomes (a key only has to bring the queries of one
+// family together): a few KB of LDS instead of the gather kernel's whole tile, so many probes share
+// a CU and hide each other's three dependent memory round trips (sketch -> entry -> ids).
+constexpr uint32_t kProbeBlock = 64;
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void probe_kernel(IndexView v, const int32_t *sketches, uint32_t *keys) {
   extern __shared__ __align__(16) uint32_t cnt[];
@@ -337,37 +341,32 @@ __global__ __launch_bounds__(BLOCK) void probe_kernel(IndexView v, const int32_t
   const uint32_t q = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const int32_t *sk = sketches + (uint64_t)q * v.q_stride + v.q_off;
   const uint32_t n_probe = v.f_local < kProbeSlots ? v.f_local : kProbeSlots;
+  const uint32_t n_blocks = (v.n_genomes + kProbeBlock - 1) / kProbeBlock;
   if (tid == 0) s_best = 0;
-  for (uint32_t t = 0; t < v.n_tiles; ++t) {
-    const uint32_t n_t = tile_count(v, t);
-    const uint32_t n_words = (n_t + 1) / 2;
-    for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
-    __syncthreads();
-    const uint16_t *gl = v.gids + v.tile_base[t];
-    for (uint32_t s = wave; s < n_probe; s += BLOCK / 64) {
-      const int32_t fp = sk[s];
-      if (fp < 0 || (uint32_t)fp >= v.d.R) continue;  // wave uniform
-      const Entry e = v.entries[((uint64_t)s * v.d.R + (uint32_t)fp) * v.n_tiles + t];
-      const uint16_t *b = gl + ((uint64_t)e.start << v.align_log2);
-      for (uint32_t o = lane; o < e.len; o += 64) bump(cnt, b[o]);
-    }
-    __syncthreads();
-    uint32_t best = 0;  // count << 20 | gid
-    for (uint32_t i = tid; i < n_words; i += BLOCK) {
-      const uint32_t w = cnt[i];
-      const uint32_t a = ((w & 0xFFFFu) << 20) | tile_gid(v, t, 2 * i);
-      const uint32_t b2 = ((w >> 16) << 20) | tile_gid(v, t, 2 * i + 1);
-      best = best > a ? best : a;
-      best = best > b2 ? best : b2;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const uint32_t y = __shfl_xor(best, o, 64);
-      best = best > y ? best : y;
-    }
-    if (lane == 0) atomicMax(&s_best, best);
-    __syncthreads();
+  for (uint32_t i = tid; i < n_blocks; i += BLOCK) cnt[i] = 0;
+  __syncthreads();
+  for (uint32_t w = wave; w < n_probe * v.n_tiles; w += BLOCK / 64) {
+    const uint32_t s = w / v.n_tiles, t = w % v.n_tiles;
+    const int32_t fp = sk[s];
+    if (fp < 0 || (uint32_t)fp >= v.d.R) continue;  // wave uniform
+    const Entry e = v.entries[((uint64_t)s * v.d.R + (uint32_t)fp) * v.n_tiles + t];
+    const uint16_t *b = v.gids + v.tile_base[t] + ((uint64_t)e.start << v.align_log2);
+    for (uint32_t o = lane; o < e.len; o += 64) atomicAdd(&cnt[tile_gid(v, t, b[o]) / kProbeBlock], 1u);
   }
+  __syncthreads();
+  uint32_t best = 0;  // count << 20 | block
+  for (uint32_t i = tid; i < n_blocks; i += BLOCK) {
+    const uint32_t c = cnt[i] < 4095u ? cnt[i] : 4095u;
+    const uint32_t a = (c << 20) | i;
+    best = best > a ? best : a;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t y = __shfl_xor(best, o, 64);
+    best = best > y ? best : y;
+  }
+  if (lane == 0) atomicMax(&s_best, best);
+  __syncthreads();
   if (tid == 0) {
     const uint32_t c = s_best >> 20;
     const uint32_t key = c >= 2 ? (s_best & 0xFFFFFu) : 0xFFFFFu;  // unrelated queries: one group at the end
@@ -503,10 +502,10 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
 hipError_t launch_order(const IndexView &v, const int32_t *sketches, uint32_t nq, uint32_t *keys,
                         uint32_t *order, hipStream_t stream) {
   if (nq == 0 || nq > kOrderMax || v.n_genomes >= (1u << 20) - 1) return hipErrorInvalidValue;
-  const size_t lds = (size_t)((v.tile + 1) / 2) * 4;
-  hipError_t e = hipFuncSetAttribute((const void *)probe_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t lds = (size_t)((v.n_genomes + kProbeBlock - 1) / kProbeBlock) * 4;   // <= 64 KB (n_genomes < 2^20)
+  hipError_t e = hipFuncSetAttribute((const void *)probe_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(probe_kernel<1024>, dim3(nq), dim3(1024), lds, stream, v, sketches, keys);
+  hipLaunchKernelGGL(probe_kernel<256>, dim3(nq), dim3(256), lds, stream, v, sketches, keys);
   hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, stream, keys, nq, order);
   return hipGetLastError();
 }

@@ -520,7 +520,7 @@ def test_locality_order_changes_nothing(native, po):
         m = rng.random((nq, F)) < 0.2
         q[m] = rng.integers(0, 1 << W, int(m.sum()))
         q[nq // 2] = -1                                            # a query without any hit
-        e.set_option("query_order", 2)                             # (1 would order > 8192 slots only)
+        e.set_option("query_order", 2)                             # (1 orders from 8192 slots on only)
         c1 = e.query_counts(q)
         h1 = e.query(q)
         e.set_option("query_order", 0)
