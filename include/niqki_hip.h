@@ -125,8 +125,10 @@ int niqki_synchronize(niqki_index *ix);
  * unaffected; 0 = input order), "lookup_prepass" (1 = the index table is walked
  * once per launch, slot block by slot block, for all its queries instead of one random
  * table line per query and slot inside the gather kernel, wherever the index shape
- * allows: less HBM traffic, no faster on MI355X up to 4 counter tiles, so the default (-1) uses it
- * only for indexes of more than 4 tiles, > 261 632 genomes, where it is 25 % faster),
+ * allows: 16 % less HBM traffic.  The default (-1) uses it where it is also faster: batches of
+ * >= 1024 queries on indexes of 1 or 2 counter tiles with W <= 12 (whole table rows are then
+ * streamed through LDS from a packed copy of the table, +4 bytes per table entry: 8 % faster), and
+ * indexes of more than 4 tiles, > 261 632 genomes (25 % faster); 0 = never),
  * "incremental_build" (1 = default: genomes inserted after a build get a delta index of their own
  * -- a query walks both -- until they pass an eighth of the main index, then everything is rebuilt;
  * 0 = every insert after a query rebuilds the whole index at the next query),

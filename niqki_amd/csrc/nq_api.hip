@@ -120,6 +120,7 @@ nq::IndexView view(const niqki_index *ix) {
   v.gids = ix->gids;
   v.tile_base = ix->tile_base;
   v.slot_units = ix->slot_units;
+  v.ptab = ix->ptab_ok ? ix->ptab : nullptr;
   return v;
 }
 
@@ -222,6 +223,7 @@ void swap_segment(niqki_index *ix) {
   std::swap(ix->tile, a.tile); std::swap(ix->n_tiles, a.n_tiles); std::swap(ix->seg_n, a.seg_n);
   std::swap(ix->g_base, a.g_base); std::swap(ix->align_log2, a.align_log2);
   std::swap(ix->padded, a.padded); std::swap(ix->stripe, a.stripe);
+  std::swap(ix->ptab, a.ptab); std::swap(ix->ptab_bytes, a.ptab_bytes); std::swap(ix->ptab_ok, a.ptab_ok);
 }
 
 int build_range(niqki_index *ix, uint32_t g_base, uint32_t N);
@@ -354,14 +356,17 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
   // Table look-ups: inside the gather kernel (one random table line per query and slot), or
   // by the slot-major pre-pass, which walks the table once per launch for all its queries.
   bool pre = ix->lookup_prepass != 0 && nq::launch_lookup_usable(v) && (((uintptr_t)(sketches + q_off)) & 15) == 0 && (q_stride & 3) == 0;
-  // Measured at the north-star shape (profiles/r02_*): the pre-pass takes 19 % of the HBM traffic
-  // off a launch but not its time -- both forms are bound by the number of random line requests a
-  // CU keeps in flight, and inside the gather kernel the look-ups overlap with the bucket walk.
-  // So the default keeps them there; the pre-pass is opt-in (lookup_prepass = 1).
+  // Measured at the north-star shape (profiles/r02_*): with random 16-byte look-ups (lookup_kernel) the
+  // pre-pass takes 16 % of the HBM traffic off a launch but not its time -- both forms are bound by the
+  // number of random line requests a CU keeps in flight, and inside the gather kernel the look-ups
+  // overlap with the bucket walk.  The default (-1) therefore takes the pre-pass only where it wins:
   // An index of more than 4 tiles (> 261 632 genomes) is different: inside the kernel only 4 tiles'
   // entries can be parked per look-up, so every further tile would cost its own random table line
   // per query and slot; there the pre-pass is the default for real batches.
-  if (ix->lookup_prepass < 0) pre = pre && ix->n_tiles > 4 && nq >= 256;
+  // Up to 2 tiles of W <= 12 the pre-pass has a form that streams whole table rows through LDS from a
+  // packed copy of the table (lookup_rows_kernel): 0.75 ms per 4096 queries, the launch 8 % faster than
+  // with the look-ups inside the gather kernel -- the default for batches of >= 1024 queries.
+  if (ix->lookup_prepass < 0) pre = pre && ((ix->n_tiles > 4 && nq >= 256) || (nq::lookup_wants_packed(v) && nq >= 1024));
   // locality order of each launch: worth its probe on large indexes and real batches.  It takes ~8 % off
   // the gather kernel and costs 0.1 ms per 4096 queries at 100 000 genomes whatever the slot count:
   // measured even on a slot shard of 4096 slots (1.56 against 1.57 ms per 4096 queries), +4 % at 8192.
@@ -376,6 +381,18 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
   if (ordered || pre) chunk = 4096;
   if (pre && per_query * chunk > ((size_t)2 << 30)) chunk = std::max<uint32_t>(256, (uint32_t)((((size_t)2 << 30) / per_query) & ~(size_t)255));
   if (pre) {
+    if (nq::lookup_wants_packed(v) && !ix->ptab_ok) {   // packed copy of the table, once per build
+      const size_t want = (size_t)f_local * ix->d.R * ix->n_tiles * 4;
+      if (want > ix->ptab_bytes) {
+        if (ix->ptab) NQ_HIP(ix, hipFree(ix->ptab));
+        ix->ptab = nullptr; ix->ptab_bytes = 0;
+        NQ_HIP(ix, hipMalloc((void **)&ix->ptab, want));
+        ix->ptab_bytes = want;
+      }
+      NQ_HIP(ix, nq::launch_pack_entries(v, ix->ptab, ix->stream));
+      ix->ptab_ok = true;
+      v.ptab = ix->ptab;
+    }
     if ((rc = ensure(ix, ix->ws_pre, nq::lookup_pre_bytes(v, std::min(nq, chunk))))) return rc;
   } else if (ix->n_tiles > 1) {
     rc = ensure(ix, ix->ws_stash, (size_t)std::min(nq, chunk) * (ix->n_tiles - 1) * f_local * sizeof(nq::Entry));
@@ -639,7 +656,8 @@ void niqki_destroy(niqki_index *ix) {
     if (b->p) (void)hipFree(b->p);
   if (ix->store && !ix->resident_bytes) (void)hipFree(ix->store);
   if (ix->host_store) (void)hipHostFree(ix->host_store);
-  for (void *p : {(void *)ix->alt.entries, (void *)ix->alt.gids, (void *)ix->alt.tile_base, (void *)ix->alt.slot_units})
+  for (void *p : {(void *)ix->alt.entries, (void *)ix->alt.gids, (void *)ix->alt.tile_base, (void *)ix->alt.slot_units,
+                  (void *)ix->alt.ptab, (void *)ix->ptab})
     if (p) (void)hipFree(p);
   if (ix->entries) (void)hipFree(ix->entries);
   if (ix->gids) (void)hipFree(ix->gids);
@@ -875,6 +893,7 @@ int build_range(niqki_index *ix, uint32_t g_base, uint32_t N) {
   if ((rc = grow((void **)&ix->tile_base, ix->tile_base_bytes, (size_t)(n_tiles + 1) * 8))) return rc;
   ix->tile = tile;
   ix->n_tiles = n_tiles;
+  ix->ptab_ok = false;
   ix->seg_n = N;
   ix->g_base = g_base;
   ix->align_log2 = (uint32_t)al;

@@ -55,6 +55,9 @@ struct niqki_index {
   uint64_t *tile_base = nullptr;   // n_tiles+1, device
   uint32_t *slot_units = nullptr;  // n_tiles x (f_local+1), device
   size_t entries_bytes = 0, gids_bytes = 0, tile_base_bytes = 0, slot_units_bytes = 0;
+  uint32_t *ptab = nullptr;        // packed copy of `entries` for the look-up pre-pass (made at its first launch)
+  size_t ptab_bytes = 0;
+  bool ptab_ok = false;
   uint32_t stripe = 0;             // tiles are dealt round-robin
   int stripe_opt = 32;             // option: block size of the stripes when there are several tiles (0 = ranges)
   int bucket_align = -1;           // option: log2 ids per bucket alignment unit, -1 = choose
@@ -69,8 +72,10 @@ struct niqki_index {
     uint16_t *gids = nullptr;
     uint64_t *tile_base = nullptr;
     uint32_t *slot_units = nullptr;
-    size_t entries_bytes = 0, gids_bytes = 0, tile_base_bytes = 0, slot_units_bytes = 0;
+    uint32_t *ptab = nullptr;   // packed copy of `entries` for the look-up pre-pass (made at its first launch)
+    size_t entries_bytes = 0, gids_bytes = 0, tile_base_bytes = 0, slot_units_bytes = 0, ptab_bytes = 0;
     uint32_t tile = 0, n_tiles = 0, seg_n = 0, g_base = 0, align_log2 = 0, padded = 0, stripe = 0;
+    bool ptab_ok = false;
   } alt;
   uint32_t seg_n = 0;      // genomes of the current segment
   uint32_t g_base = 0;     // its first genome

@@ -68,6 +68,7 @@ struct IndexView {
   const uint16_t *gids;
   const uint64_t *tile_base;   // n_tiles+1 (in ids), device
   const uint32_t *slot_units;  // n_tiles x (f_local+1): units before slot s of tile t
+  const uint32_t *ptab = nullptr;   // [F_local][R][n_tiles] (start - first unit of the slot) << 16 | len, or nullptr
 };
 
 // genomes of tile t / global id of its i-th genome
@@ -143,6 +144,9 @@ hipError_t launch_plane_sum32(const uint16_t *a, const uint16_t *b, uint32_t *ou
 // Slot-major look-up pre-pass for the queries of a launch (nq_query.hip): fills
 // pre[q][tile][slot] (lookup_pre_bytes of scratch) from the table streamed once.
 bool launch_lookup_usable(const IndexView &v);
+// The pre-pass reads a packed copy of the table (4 bytes per entry) where its row-staging kernel applies
+bool lookup_wants_packed(const IndexView &v);
+hipError_t launch_pack_entries(const IndexView &v, uint32_t *ptab, hipStream_t stream);
 size_t lookup_pre_bytes(const IndexView &v, uint32_t nq);
 hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t nq, uint32_t *pre, hipStream_t stream);
 // launch shapes selectable through the "gather_variant" option (0 = choose)

@@ -287,6 +287,122 @@ __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const in
   }
 }
 
+// The same pre-pass with the table rows staged in LDS (1 or 2 tiles, R * tiles * 4 = 16 or 32 KB),
+// from the PACKED copy of the table (IndexView::ptab: the 4-byte word of every entry): one workgroup
+// = 16 consecutive slots x 1024 queries (one per thread).  Slot by slot the 1024 threads copy the
+// slot's whole row (coalesced 16-byte loads: the table is streamed, not hit at random) into LDS,
+// three rows ahead in registers, double-buffered in LDS, and every thread picks its query's word(s)
+// with one LDS read.  At the end the 16 words per (query, tile) go through LDS once more so that
+// four neighbouring lanes store one 64-byte block of pre[q][t][s] together.  The workgroups of one
+// slot block (nq / 1024) are neighbours in one XCD's dispatch order: the row comes from HBM once.
+constexpr uint32_t kRowSlots = 16, kRowBlock = 1024;
+__device__ __forceinline__ void wave_lds_fence() {   // this wave's LDS traffic so far has completed
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void lds_barrier() {   // a workgroup barrier that waits for LDS traffic only:
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the row loads in flight stay in flight
+}
+template <int NT, int PER>   // PER: 16-byte pieces of a packed row per thread (R * NT / 4096)
+__global__ __launch_bounds__(kRowBlock) void lookup_rows_kernel(IndexView v, const int32_t *sketches, uint32_t nq,
+                                                                uint32_t n_qchunk, uint32_t *pre) {
+  extern __shared__ __align__(16) uint32_t rows[];   // 2 buffers of R * NT words; at the end 1024 x 17 words
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t n_sb = v.f_local / kRowSlots;
+  const uint32_t x = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
+  const uint32_t sb = (k / n_qchunk) * kXcds + x;
+  if (sb >= n_sb) return;   // padding block (uniform)
+  const uint32_t q0 = (k % n_qchunk) * kRowBlock, q = q0 + tid;
+  const bool live = q < nq;   // the others still help to stage the rows
+  const uint32_t R = v.d.R, RW = R * NT;
+  int32_t fp[kRowSlots];
+  {
+    const int4 *src = (const int4 *)(sketches + (uint64_t)(live ? q : 0u) * v.q_stride + v.q_off + (uint64_t)sb * kRowSlots);
+#pragma unroll
+    for (int u = 0; u < (int)kRowSlots / 4; ++u) {
+      const int4 a = src[u];
+      fp[4 * u] = a.x; fp[4 * u + 1] = a.y; fp[4 * u + 2] = a.z; fp[4 * u + 3] = a.w;
+    }
+  }
+  const uint4 *row0 = (const uint4 *)(v.ptab + (uint64_t)sb * kRowSlots * RW) + tid;
+  const uint32_t row_u4 = RW / 4;   // 16-byte pieces per row
+  struct Row { uint4 p[PER]; };
+  auto load_row = [&](int i) -> Row {
+    Row r;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) r.p[j] = row0[(uint64_t)i * row_u4 + (uint32_t)j * kRowBlock];
+    return r;
+  };
+  uint32_t res[NT][kRowSlots];
+  uint32_t *buf0 = rows, *buf1 = rows + RW;
+  // rows i + 1 .. i + 3 are in flight (registers r0 .. r2 in turn) while row i is staged and looked up
+  // (a fourth row in flight measured no faster)
+  Row r0 = load_row(0), r1 = load_row(1), r2 = load_row(2);
+#define NQ_ROW_STEP(I, CUR)                                                                           \
+  {                                                                                                   \
+    uint32_t *buf = ((I) & 1) ? buf1 : buf0;                                                          \
+    _Pragma("unroll") for (int j = 0; j < PER; ++j) *(uint4 *)(buf + 4 * (tid + (uint32_t)j * kRowBlock)) = CUR.p[j]; \
+    if ((I) + 3 < (int)kRowSlots) CUR = load_row((I) + 3); /* (its registers are free again) */          \
+    lds_barrier();                                                                                    \
+    const bool ok = fp[(I)] >= 0 && (uint32_t)fp[(I)] < R; /* src/niqki_index.cpp:654 */              \
+    const uint32_t *e = buf + (ok ? (uint32_t)fp[(I)] : 0u) * NT;                                     \
+    res[0][(I)] = ok ? e[0] : 0u;                                                                     \
+    res[NT - 1][(I)] = ok ? e[NT - 1] : 0u;                                                           \
+  }
+  NQ_ROW_STEP(0, r0)  NQ_ROW_STEP(1, r1)  NQ_ROW_STEP(2, r2)  NQ_ROW_STEP(3, r0)
+  NQ_ROW_STEP(4, r1)  NQ_ROW_STEP(5, r2)  NQ_ROW_STEP(6, r0)  NQ_ROW_STEP(7, r1)
+  NQ_ROW_STEP(8, r2)  NQ_ROW_STEP(9, r0)  NQ_ROW_STEP(10, r1) NQ_ROW_STEP(11, r2)
+  NQ_ROW_STEP(12, r0) NQ_ROW_STEP(13, r1) NQ_ROW_STEP(14, r2) NQ_ROW_STEP(15, r0)
+#undef NQ_ROW_STEP
+  static_assert(kRowSlots == 16, "the steps above are written out");
+  // Out: thread q holds 16 words per tile; lanes 4j .. 4j + 3 of a wave store the four 16-byte
+  // pieces of query (wave base + 16 r + j)'s block, r = 0 .. 3, so one store instruction writes 16
+  // whole 64-byte blocks.  The transposition goes through LDS (17-word rows: no bank conflicts).
+  lds_barrier();   // all look-ups of the last row are done: the row buffers are free
+  uint32_t *mine = rows + tid * 17u;
+#define NQ_STORE_TILE(T)                                                                                             \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < (int)kRowSlots; ++i) mine[i] = res[(T)][i];                               \
+    wave_lds_fence(); /* (one wave reads what its own lanes wrote) */                                                \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                  \
+      const uint32_t src_t = (tid & ~63u) + 16u * (uint32_t)r + (lane >> 2); /* whose block this lane helps to store */ \
+      const uint32_t piece = lane & 3u;                                                                              \
+      const uint32_t *sp = rows + src_t * 17u + piece * 4u;                                                          \
+      const uint4 w = make_uint4(sp[0], sp[1], sp[2], sp[3]);                                                        \
+      const uint32_t qq = q0 + src_t;                                                                                \
+      if (qq < nq) *(uint4 *)(pre + ((uint64_t)qq * NT + (T)) * v.f_local + (uint64_t)sb * kRowSlots + piece * 4u) = w; \
+    }                                                                                                                \
+    wave_lds_fence(); /* before the next tile overwrites the wave's words */                                         \
+  }
+  NQ_STORE_TILE(0)
+  if (NT == 2) NQ_STORE_TILE(NT - 1)
+#undef NQ_STORE_TILE
+}
+// packed rows that two LDS buffers hold, dealt to 1024 threads in whole 16-byte loads
+bool lookup_wants_packed(const IndexView &v) {
+  const uint32_t rw = v.d.R * v.n_tiles;
+  if (!launch_lookup_usable(v) || v.n_tiles > 2 || v.f_local % kRowSlots || rw * 4u > 32768u || rw % (4u * kRowBlock)) return false;
+  const uint32_t per = rw / (4u * kRowBlock);
+  return per == 1 || per == 2;
+}
+
+__global__ __launch_bounds__(256) void pack_entries_kernel(IndexView v, uint32_t *ptab) {
+  const uint64_t n = (uint64_t)v.f_local * v.d.R * v.n_tiles, step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const uint32_t t = (uint32_t)(i % v.n_tiles);
+    const uint32_t s = (uint32_t)(i / ((uint64_t)v.d.R * v.n_tiles));
+    const Entry e = v.entries[i];
+    ptab[i] = ((e.start - v.slot_units[(uint64_t)t * (v.f_local + 1) + s]) << 16) | e.len;
+  }
+}
+hipError_t launch_pack_entries(const IndexView &v, uint32_t *ptab, hipStream_t stream) {
+  const uint64_t n = (uint64_t)v.f_local * v.d.R * v.n_tiles;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_entries_kernel, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 65536)), dim3(256), 0, stream, v, ptab);
+  return hipGetLastError();
+}
+
 static uint32_t lookup_slots(const IndexView &v) { return v.n_tiles <= 2 ? 32u : 16u; }
 
 // Can the pre-pass serve this index?  Whole slot blocks, and both halves of the packed word
@@ -301,6 +417,24 @@ size_t lookup_pre_bytes(const IndexView &v, uint32_t nq) { return (size_t)v.f_lo
 
 hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t nq, uint32_t *pre, hipStream_t stream) {
   if (nq == 0 || !launch_lookup_usable(v)) return hipErrorInvalidValue;
+  if (v.ptab && lookup_wants_packed(v) && nq >= kRowBlock / 2) {
+    const uint32_t n_sb = v.f_local / kRowSlots, n_qchunk = (nq + kRowBlock - 1) / kRowBlock;
+    const uint64_t grid = (uint64_t)((n_sb + kXcds - 1) / kXcds * kXcds) * n_qchunk;
+    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const size_t lds = std::max<size_t>((size_t)v.d.R * v.n_tiles * 4 * 2, (size_t)kRowBlock * 17 * 4);
+    const uint32_t per = v.d.R * v.n_tiles / (4u * kRowBlock);
+    hipError_t e = hipSuccess;
+#define NQ_LAUNCH_ROWS(NT, PER)                                                                                        \
+  do {                                                                                                                 \
+    e = hipFuncSetAttribute((const void *)lookup_rows_kernel<NT, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                                                     \
+    hipLaunchKernelGGL((lookup_rows_kernel<NT, PER>), dim3((uint32_t)grid), dim3(kRowBlock), lds, stream, v, sketches, nq, n_qchunk, pre); \
+  } while (0)
+    if (v.n_tiles == 1) { if (per == 1) NQ_LAUNCH_ROWS(1, 1); else NQ_LAUNCH_ROWS(1, 2); }
+    else { if (per == 1) NQ_LAUNCH_ROWS(2, 1); else NQ_LAUNCH_ROWS(2, 2); }
+#undef NQ_LAUNCH_ROWS
+    return hipGetLastError();
+  }
   const uint32_t ps = lookup_slots(v);
   const uint32_t n_sb = v.f_local / ps, n_qchunk = (nq + kPreBlock - 1) / kPreBlock;
   const uint64_t grid = (uint64_t)((n_sb + kXcds - 1) / kXcds * kXcds) * n_qchunk;

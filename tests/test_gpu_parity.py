@@ -715,6 +715,44 @@ def test_more_than_four_tiles(native, po, n, tile):
     e.close()
 
 
+@pytest.mark.parametrize("tile", [0, 256])
+def test_prepass_with_table_rows_staged_in_lds(native, po, tile):
+    """The pre-pass form for W = 12 indexes of one or two tiles and real batches (a slot's whole
+    entry row copied into LDS, 1024 queries per workgroup; a last workgroup with idle threads):
+    same counters and hits as with the look-ups inside the gather kernel and as the oracle."""
+    rng = np.random.default_rng(77 + tile)
+    S, W, n = 6, 12, 300
+    F = 1 << S
+    fam = rng.integers(0, 1 << W, (5, F)).astype(np.int32)
+    sk = fam[(np.arange(n) // 60) % 5].copy()
+    noise = rng.random((n, F)) < 0.3
+    sk[noise] = rng.integers(0, 1 << W, int(noise.sum()))
+    nq = 1500
+    q = sk[rng.integers(0, n, nq)].copy()
+    m = rng.random((nq, F)) < 0.1
+    q[m] = rng.integers(0, 1 << W, int(m.sum()))
+    q[3] = -1
+    q[4, ::2] = 1 << W                      # out-of-range cells have no bucket
+    p = po.make_params(31, S, W, 4, 0.3)
+    ix = po.Index(p, sk)
+    e = native.Engine(K=31, S=S, W=W, H=4, J=0.3, tile_genomes=tile)
+    e.insert(sk)
+    e.build()
+    assert e.stat("tiles") == (2 if tile else 1)
+    res = {}
+    for mode in (0, 1):
+        e.set_option("lookup_prepass", mode)
+        res[mode] = (e.query_counts(q), e.query(q))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert all(np.array_equal(x, y) for x, y in zip(res[0][1], res[1][1]))
+    cnt, (off, hc, hg) = res[1]
+    for i in (0, 3, 4, 1023, 1024, nq - 1):
+        assert np.array_equal(cnt[i].astype(np.uint32), ix.counts(q[i])), i
+        ehc, ehg = ix.query(q[i])
+        assert np.array_equal(hc[off[i]:off[i + 1]], ehc) and np.array_equal(hg[off[i]:off[i + 1]], ehg), i
+    e.close()
+
+
 def test_inserts_after_a_query_get_a_delta_segment(native, po):
     """Genomes inserted after a build are indexed by a delta segment (no rebuild of the main index) until
     they pass an eighth of it; queries walk both segments.  Same answers as one index built at once, the

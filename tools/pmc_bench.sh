@@ -20,5 +20,5 @@ for grp in \
   timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 $R/bench.py --no-cpu --steps 2 "$@" > $OUT/g$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/g$i.log; exit 1; }
 done
 cd $R
-python tools/prof_summary.py $OUT | grep -E "gather_kernel|lookup_kernel|block_kernel|probe_kernel|order_kernel|sketch_kernel|hits_|^==" | sed 's/  */ /g' > $R/gpurun_out/pmc_$TAG.summary.txt
+python tools/prof_summary.py $OUT | grep -E "gather_kernel|lookup_kernel|lookup_rows_kernel|block_kernel|probe_kernel|order_kernel|sketch_kernel|hits_|^==" | sed 's/  */ /g' > $R/gpurun_out/pmc_$TAG.summary.txt
 rm -rf $OUT

@@ -20,7 +20,7 @@ NIQKI_LOOKUP_PREPASS=1 bash tools/pmc_bench.sh ${TAG}_prepass --no-extra || exit
 cd /tmp
 rm -rf /tmp/kt2; NIQKI_LOOKUP_PREPASS=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python3 $R/bench.py --no-cpu --no-extra > $R/gpurun_out/${TAG}_prepass_bench_under_rocprof.json 2> /tmp/kt2.log || exit 1
 cd $R
-python3 tools/prof_summary.py /tmp/kt2 | grep -E "gather_kernel|lookup_kernel|probe_kernel|order_kernel|^==|kernel " > gpurun_out/${TAG}_prepass_kernel_trace_summary.txt
+python3 tools/prof_summary.py /tmp/kt2 | grep -E "gather_kernel|lookup_kernel|lookup_rows_kernel|probe_kernel|order_kernel|^==|kernel " > gpurun_out/${TAG}_prepass_kernel_trace_summary.txt
 timeout -k 10 600 python3 bench.py --shard-of 8 --no-cpu > gpurun_out/${TAG}_shard_of_8.json 2> gpurun_out/${TAG}_shard_of_8.err || exit 1
 # the weak-scaling shape of --gpus 8 on rank 0 (every rank brings 4096 queries), and all 8 ranks of the group on this one GPU
 timeout -k 10 600 python3 bench.py --shard-of 8 --batch 32768 --ring 2 --steps 5 --warmup 2 --no-cpu --no-extra > gpurun_out/${TAG}_shard_of_8_weak.json 2> gpurun_out/${TAG}_shard_of_8_weak.err || exit 1
