@@ -1,16 +1,15 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out; rm -f gpurun_out/ord.txt
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/pt.log 2>&1 || { tail -40 gpurun_out/pt.log; exit 1; }
-tail -2 gpurun_out/pt.log
-for shape in "--steps 10 --warmup 3" "--shard-of 8 --batch 32768 --ring 2 --steps 4 --warmup 1" "--shard-of 8 --steps 10 --warmup 2" "--shard-of 2 --batch 8192 --ring 2 --steps 4 --warmup 1" ; do
-  echo "=== $shape" >> gpurun_out/ord.txt
-  timeout -k 10 300 python bench.py $shape --no-cpu --no-extra 2> gpurun_out/ord_err.txt | python3 -c "
+mkdir -p gpurun_out; rm -f gpurun_out/var.txt
+for v in 0 0; do
+  echo "=== variant $v" >> gpurun_out/var.txt
+  NIQKI_GATHER_VARIANT=$v timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu --no-extra 2> gpurun_out/var_err.txt | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        d = json.loads(l); print('ms/step %.2f  value %.0f gather %.3f ms/launch x %d  frac %.3f' % (d['ms_per_step'], d['value'], d['roofline']['avg_launch_ms'], d['roofline']['launches'], d['roofline']['frac']))
-" >> gpurun_out/ord.txt || { tail -5 gpurun_out/ord_err.txt >> gpurun_out/ord.txt; cat gpurun_out/ord.txt; exit 1; }
+        d = json.loads(l); print('ms/step %.2f  gather %.3f ms/launch  frac %.3f' % (d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac']))
+" >> gpurun_out/var.txt || { tail -5 gpurun_out/var_err.txt >> gpurun_out/var.txt; cat gpurun_out/var.txt; exit 1; }
 done
-cat gpurun_out/ord.txt
-timeout -k 10 300 python tools/bench_group_local.py --steps 3 2>/dev/null | tail -1
+cat gpurun_out/var.txt
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py -x -q > gpurun_out/pt.log 2>&1 || { tail -30 gpurun_out/pt.log; exit 1; }
+tail -1 gpurun_out/pt.log

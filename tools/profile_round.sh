@@ -5,7 +5,7 @@
 # 3) separate --pmc passes (no tracing flags) for HBM traffic and the SQ counters of the query
 #    path's kernels (tools/pmc_bench.sh: FETCH_SIZE, WRITE_SIZE, TCC_EA0_RDREQ[_128B], SQ_*;
 #    MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled)
-# 4) the same with the look-up pre-pass on, the 8-way shard emulation, the world-1 RCCL run
+# 4) the same with the look-ups inside the gather kernel (pre-pass off), the 8-way shard emulation, the world-1 RCCL run
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r02}
 cd $R; mkdir -p gpurun_out
@@ -16,11 +16,11 @@ cd $R
 python3 tools/prof_summary.py /tmp/kt > gpurun_out/${TAG}_bench_kernel_trace_summary.txt
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_bench_rocprofv3_kernel_stats.csv
 bash tools/pmc_bench.sh ${TAG}_default --no-extra || exit 1
-NIQKI_LOOKUP_PREPASS=1 bash tools/pmc_bench.sh ${TAG}_prepass --no-extra || exit 1
+NIQKI_LOOKUP_PREPASS=0 bash tools/pmc_bench.sh ${TAG}_noprepass --no-extra || exit 1
 cd /tmp
-rm -rf /tmp/kt2; NIQKI_LOOKUP_PREPASS=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python3 $R/bench.py --no-cpu --no-extra > $R/gpurun_out/${TAG}_prepass_bench_under_rocprof.json 2> /tmp/kt2.log || exit 1
+rm -rf /tmp/kt2; NIQKI_LOOKUP_PREPASS=0 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt2 -- python3 $R/bench.py --no-cpu --no-extra > $R/gpurun_out/${TAG}_noprepass_bench_under_rocprof.json 2> /tmp/kt2.log || exit 1
 cd $R
-python3 tools/prof_summary.py /tmp/kt2 | grep -E "gather_kernel|lookup_kernel|lookup_rows_kernel|probe_kernel|order_kernel|^==|kernel " > gpurun_out/${TAG}_prepass_kernel_trace_summary.txt
+python3 tools/prof_summary.py /tmp/kt2 | grep -E "gather_kernel|lookup_kernel|lookup_rows_kernel|probe_kernel|order_kernel|^==|kernel " > gpurun_out/${TAG}_noprepass_kernel_trace_summary.txt
 timeout -k 10 600 python3 bench.py --shard-of 8 --no-cpu > gpurun_out/${TAG}_shard_of_8.json 2> gpurun_out/${TAG}_shard_of_8.err || exit 1
 # the weak-scaling shape of --gpus 8 on rank 0 (every rank brings 4096 queries), and all 8 ranks of the group on this one GPU
 timeout -k 10 600 python3 bench.py --shard-of 8 --batch 32768 --ring 2 --steps 5 --warmup 2 --no-cpu --no-extra > gpurun_out/${TAG}_shard_of_8_weak.json 2> gpurun_out/${TAG}_shard_of_8_weak.err || exit 1
