@@ -296,7 +296,7 @@ __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const in
 // from the PACKED copy of the table (IndexView::ptab: the 4-byte word of every entry): one workgroup
 // = 16 consecutive slots x 1024 queries (one per thread).  Slot by slot the 1024 threads copy the
 // slot's whole row (coalesced 16-byte loads: the table is streamed, not hit at random) into LDS,
-// three rows ahead in registers, double-buffered in LDS, and every thread picks its query's word(s)
+// three rows ahead in registers and three more in LDS, and every thread picks its query's word(s)
 // with one LDS read.  At the end the 16 words per (query, tile) go through LDS once more so that
 // four neighbouring lanes store one 64-byte block of pre[q][t][s] together.  The workgroups of one
 // slot block (nq / 1024) are neighbours in one XCD's dispatch order: the row comes from HBM once.
@@ -312,7 +312,7 @@ __device__ __forceinline__ void lds_barrier() {   // a workgroup barrier that wa
 template <int NT, int PER>   // PER: 16-byte pieces of a packed row per thread (R * NT / 4096)
 __global__ __launch_bounds__(kRowBlock) void lookup_rows_kernel(IndexView v, const int32_t *sketches, uint32_t nq,
                                                                 uint32_t n_qchunk, uint32_t *pre) {
-  extern __shared__ __align__(16) uint32_t rows[];   // 2 buffers of R * NT words; at the end 1024 x 17 words
+  extern __shared__ __align__(16) uint32_t rows[];   // 4 buffers of R * NT words; at the end 1024 x 17 words
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t n_sb = v.f_local / kRowSlots;
   const uint32_t x = blockIdx.x % kXcds, k = blockIdx.x / kXcds;
@@ -340,26 +340,34 @@ __global__ __launch_bounds__(kRowBlock) void lookup_rows_kernel(IndexView v, con
     return r;
   };
   uint32_t res[NT][kRowSlots];
-  uint32_t *buf0 = rows, *buf1 = rows + RW;
-  // rows i + 1 .. i + 3 are in flight (registers r0 .. r2 in turn) while row i is staged and looked up
-  // (a fourth row in flight measured no faster)
-  Row r0 = load_row(0), r1 = load_row(1), r2 = load_row(2);
-#define NQ_ROW_STEP(I, CUR)                                                                           \
+  // Pipeline: row i is looked up in LDS buffer i % 4 while row i + 3 is copied from registers into buffer
+  // (i + 3) % 4 and row i + 6 is requested from memory (register sets r0 .. r2 in turn): six rows of
+  // slack between the request and the first use, one barrier per row.
+#define NQ_ROW_STAGE(I, SET)                                                                          \
   {                                                                                                   \
-    uint32_t *buf = ((I) & 1) ? buf1 : buf0;                                                          \
-    _Pragma("unroll") for (int j = 0; j < PER; ++j) *(uint4 *)(buf + 4 * (tid + (uint32_t)j * kRowBlock)) = CUR.p[j]; \
-    if ((I) + 3 < (int)kRowSlots) CUR = load_row((I) + 3); /* (its registers are free again) */          \
-    lds_barrier();                                                                                    \
+    uint32_t *dst = rows + (uint32_t)((I) & 3) * RW;                                                  \
+    _Pragma("unroll") for (int j = 0; j < PER; ++j) *(uint4 *)(dst + 4 * (tid + (uint32_t)j * kRowBlock)) = SET.p[j]; \
+    if ((I) + 3 < (int)kRowSlots) SET = load_row((I) + 3); /* (its registers are free again) */        \
+  }
+#define NQ_ROW_STEP(I, SET)                                                                           \
+  {                                                                                                   \
+    if ((I) + 3 < (int)kRowSlots) NQ_ROW_STAGE((I) + 3, SET)                                          \
+    const uint32_t *buf = rows + (uint32_t)((I) & 3) * RW;                                            \
     const bool ok = fp[(I)] >= 0 && (uint32_t)fp[(I)] < R; /* src/niqki_index.cpp:654 */              \
     const uint32_t *e = buf + (ok ? (uint32_t)fp[(I)] : 0u) * NT;                                     \
     res[0][(I)] = ok ? e[0] : 0u;                                                                     \
     res[NT - 1][(I)] = ok ? e[NT - 1] : 0u;                                                           \
+    lds_barrier();                                                                                    \
   }
+  Row r0 = load_row(0), r1 = load_row(1), r2 = load_row(2);
+  NQ_ROW_STAGE(0, r0) NQ_ROW_STAGE(1, r1) NQ_ROW_STAGE(2, r2)
+  lds_barrier();
   NQ_ROW_STEP(0, r0)  NQ_ROW_STEP(1, r1)  NQ_ROW_STEP(2, r2)  NQ_ROW_STEP(3, r0)
   NQ_ROW_STEP(4, r1)  NQ_ROW_STEP(5, r2)  NQ_ROW_STEP(6, r0)  NQ_ROW_STEP(7, r1)
   NQ_ROW_STEP(8, r2)  NQ_ROW_STEP(9, r0)  NQ_ROW_STEP(10, r1) NQ_ROW_STEP(11, r2)
   NQ_ROW_STEP(12, r0) NQ_ROW_STEP(13, r1) NQ_ROW_STEP(14, r2) NQ_ROW_STEP(15, r0)
 #undef NQ_ROW_STEP
+#undef NQ_ROW_STAGE
   static_assert(kRowSlots == 16, "the steps above are written out");
   // Out: thread q holds 16 words per tile; lanes 4j .. 4j + 3 of a wave store the four 16-byte
   // pieces of query (wave base + 16 r + j)'s block, r = 0 .. 3, so one store instruction writes 16
@@ -426,7 +434,7 @@ hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t n
     const uint32_t n_sb = v.f_local / kRowSlots, n_qchunk = (nq + kRowBlock - 1) / kRowBlock;
     const uint64_t grid = (uint64_t)((n_sb + kXcds - 1) / kXcds * kXcds) * n_qchunk;
     if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const size_t lds = std::max<size_t>((size_t)v.d.R * v.n_tiles * 4 * 2, (size_t)kRowBlock * 17 * 4);
+    const size_t lds = std::max<size_t>((size_t)v.d.R * v.n_tiles * 4 * 4, (size_t)kRowBlock * 17 * 4);
     const uint32_t per = v.d.R * v.n_tiles / (4u * kRowBlock);
     hipError_t e = hipSuccess;
 #define NQ_LAUNCH_ROWS(NT, PER)                                                                                        \
