@@ -366,7 +366,9 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
   // Up to 2 tiles of W <= 12 the pre-pass has a form that streams whole table rows through LDS from a
   // packed copy of the table (lookup_rows_kernel): 0.75 ms per 4096 queries, the launch 8 % faster than
   // with the look-ups inside the gather kernel -- the default for batches of >= 1024 queries.
-  if (ix->lookup_prepass < 0) pre = pre && ((ix->n_tiles > 4 && nq >= 256) || (nq::lookup_wants_packed(v) && nq >= 1024));
+  // (not on a paged index: the packed copy would be made again for every page, outside its memory budget)
+  if (ix->lookup_prepass < 0)
+    pre = pre && ((ix->n_tiles > 4 && nq >= 256) || (nq::lookup_wants_packed(v) && nq >= 1024 && !ix->resident_bytes));
   // locality order of each launch: worth its probe on large indexes and real batches.  It takes ~8 % off
   // the gather kernel and costs 0.1 ms per 4096 queries at 100 000 genomes whatever the slot count:
   // measured even on a slot shard of 4096 slots (1.56 against 1.57 ms per 4096 queries), +4 % at 8192.
@@ -1590,7 +1592,7 @@ int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value) {
   if (!ix || !key || !value) return NIQKI_E_INVALID;
   const uint32_t f_all = ix->resident_bytes ? ix->full_end - ix->full_begin : ix->d.slot_end - ix->d.slot_begin;
   if (!std::strcmp(key, "store_bytes")) { *value = (uint64_t)f_all * (ix->resident_bytes ? ix->host_cap : ix->cap) * 2; return NIQKI_OK; }
-  if (!std::strcmp(key, "index_bytes")) { *value = ix->built ? (uint64_t)ix->entries_bytes + ix->gids_bytes + ix->alt.entries_bytes + ix->alt.gids_bytes : 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "index_bytes")) { *value = ix->built ? (uint64_t)ix->entries_bytes + ix->gids_bytes + ix->ptab_bytes + ix->alt.entries_bytes + ix->alt.gids_bytes + ix->alt.ptab_bytes : 0; return NIQKI_OK; }
   if (!std::strcmp(key, "delta_genomes")) { *value = ix->delta_n; return NIQKI_OK; }
   if (!std::strcmp(key, "tiles")) { *value = ix->n_tiles; return NIQKI_OK; }
   if (!std::strcmp(key, "page_slots")) { *value = ix->resident_bytes ? page_slots(ix) : f_all; return NIQKI_OK; }
