@@ -24,6 +24,8 @@
 namespace nq {
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_cvoid;
 
 __device__ __forceinline__ void bump(uint32_t *cnt, uint32_t g) {
   atomicAdd(&cnt[g >> 1], 1u << ((g & 1u) * 16u));  // ds_add_u32, result unused
@@ -294,13 +296,12 @@ __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const in
 
 // The same pre-pass with the table rows staged in LDS (1 or 2 tiles, R * tiles * 4 = 16 or 32 KB),
 // from the PACKED copy of the table (IndexView::ptab: the 4-byte word of every entry): one workgroup
-// = 16 consecutive slots x 1024 queries (one per thread).  Slot by slot the 1024 threads copy the
-// slot's whole row (coalesced 16-byte loads: the table is streamed, not hit at random) into LDS,
-// three rows ahead in registers and three more in LDS, and every thread picks its query's word(s)
-// with one LDS read.  At the end the 16 words per (query, tile) go through LDS once more so that
-// four neighbouring lanes store one 64-byte block of pre[q][t][s] together.  The workgroups of one
+// = 32 consecutive slots x 1024 queries (one per thread).  Slot by slot the 1024 threads copy the
+// slot's whole row (coalesced 16-byte loads straight into LDS: the table is streamed, not hit at
+// random), three rows ahead, and every thread picks its query's word(s) with one LDS read.  At the end the 32 words per (query, tile) go through LDS once more so that
+// eight neighbouring lanes store one 128-byte line of pre[q][t][s] together.  The workgroups of one
 // slot block (nq / 1024) are neighbours in one XCD's dispatch order: the row comes from HBM once.
-constexpr uint32_t kRowSlots = 16, kRowBlock = 1024;
+constexpr uint32_t kRowSlots = 32, kRowBlock = 1024;
 __device__ __forceinline__ void wave_lds_fence() {   // this wave's LDS traffic so far has completed
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -330,58 +331,67 @@ __global__ __launch_bounds__(kRowBlock) void lookup_rows_kernel(IndexView v, con
       fp[4 * u] = a.x; fp[4 * u + 1] = a.y; fp[4 * u + 2] = a.z; fp[4 * u + 3] = a.w;
     }
   }
+  // Rows travel memory -> LDS directly (global_load_lds_dwordx4: a wave's 64 lanes fill 1 KB of LDS from
+  // the wave-uniform base on, no registers, no ds_write).  The compiler would wait for ALL such loads in
+  // flight before any LDS read it can see, so the pipeline's waits and the look-up read are written by
+  // hand: loads of one kind retire in issue order (vmcnt), and a wave passes the row's barrier only when
+  // its own pieces of that row have landed.
   const uint4 *row0 = (const uint4 *)(v.ptab + (uint64_t)sb * kRowSlots * RW) + tid;
   const uint32_t row_u4 = RW / 4;   // 16-byte pieces per row
-  struct Row { uint4 p[PER]; };
-  auto load_row = [&](int i) -> Row {
-    Row r;
+  const uint32_t wbase = tid & ~63u;
+  auto request = [&](int i) {
+    uint32_t *dst = rows + (uint32_t)(i & 3) * RW;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) r.p[j] = row0[(uint64_t)i * row_u4 + (uint32_t)j * kRowBlock];
-    return r;
+    for (int j = 0; j < PER; ++j)
+      __builtin_amdgcn_global_load_lds((glb_cvoid *)(row0 + (uint64_t)i * row_u4 + (uint32_t)j * kRowBlock),
+                                       (lds_void *)(dst + ((uint32_t)j * kRowBlock + wbase) * 4u), 16, 0, 0);
   };
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void *)rows;   // LDS byte address of the row buffers
   uint32_t res[NT][kRowSlots];
-  // Pipeline: row i is looked up in LDS buffer i % 4 while row i + 3 is copied from registers into buffer
-  // (i + 3) % 4 and row i + 6 is requested from memory (register sets r0 .. r2 in turn): six rows of
-  // slack between the request and the first use, one barrier per row.
-#define NQ_ROW_STAGE(I, SET)                                                                          \
+  request(0);
+  request(1);
+  request(2);
+  // step I: own pieces of row I landed (only the 2 newer rows' loads may be outstanding) -> barrier: the
+  // whole row is in LDS and everybody is done with row I - 1, whose buffer row I + 3 may now overwrite
+#define NQ_ROW_STEP(I)                                                                                \
   {                                                                                                   \
-    uint32_t *dst = rows + (uint32_t)((I) & 3) * RW;                                                  \
-    _Pragma("unroll") for (int j = 0; j < PER; ++j) *(uint4 *)(dst + 4 * (tid + (uint32_t)j * kRowBlock)) = SET.p[j]; \
-    if ((I) + 3 < (int)kRowSlots) SET = load_row((I) + 3); /* (its registers are free again) */        \
-  }
-#define NQ_ROW_STEP(I, SET)                                                                           \
-  {                                                                                                   \
-    if ((I) + 3 < (int)kRowSlots) NQ_ROW_STAGE((I) + 3, SET)                                          \
-    const uint32_t *buf = rows + (uint32_t)((I) & 3) * RW;                                            \
-    const bool ok = fp[(I)] >= 0 && (uint32_t)fp[(I)] < R; /* src/niqki_index.cpp:654 */              \
-    const uint32_t *e = buf + (ok ? (uint32_t)fp[(I)] : 0u) * NT;                                     \
-    res[0][(I)] = ok ? e[0] : 0u;                                                                     \
-    res[NT - 1][(I)] = ok ? e[NT - 1] : 0u;                                                           \
+    if ((I) + 2 < (int)kRowSlots) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");      \
+    else if ((I) + 1 < (int)kRowSlots) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");     \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
     lds_barrier();                                                                                    \
+    if ((I) + 3 < (int)kRowSlots) request((I) + 3);                                                   \
+    const bool ok = fp[(I)] >= 0 && (uint32_t)fp[(I)] < R; /* src/niqki_index.cpp:654 */              \
+    const uint32_t at = lds0 + ((uint32_t)((I) & 3) * RW + (ok ? (uint32_t)fp[(I)] : 0u) * NT) * 4u;   \
+    uint32_t w0, w1 = 0;                                                                              \
+    if (NT == 2) {                                                                                    \
+      uint2 w;                                                                                        \
+      asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(at) : "memory");      \
+      w0 = w.x; w1 = w.y;                                                                             \
+    } else {                                                                                          \
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w0) : "v"(at) : "memory");     \
+    }                                                                                                 \
+    res[0][(I)] = ok ? w0 : 0u;                                                                       \
+    res[NT - 1][(I)] = ok ? (NT == 2 ? w1 : w0) : 0u;                                                 \
   }
-  Row r0 = load_row(0), r1 = load_row(1), r2 = load_row(2);
-  NQ_ROW_STAGE(0, r0) NQ_ROW_STAGE(1, r1) NQ_ROW_STAGE(2, r2)
-  lds_barrier();
-  NQ_ROW_STEP(0, r0)  NQ_ROW_STEP(1, r1)  NQ_ROW_STEP(2, r2)  NQ_ROW_STEP(3, r0)
-  NQ_ROW_STEP(4, r1)  NQ_ROW_STEP(5, r2)  NQ_ROW_STEP(6, r0)  NQ_ROW_STEP(7, r1)
-  NQ_ROW_STEP(8, r2)  NQ_ROW_STEP(9, r0)  NQ_ROW_STEP(10, r1) NQ_ROW_STEP(11, r2)
-  NQ_ROW_STEP(12, r0) NQ_ROW_STEP(13, r1) NQ_ROW_STEP(14, r2) NQ_ROW_STEP(15, r0)
+#define NQ_ROW_STEP8(B) NQ_ROW_STEP((B)) NQ_ROW_STEP((B) + 1) NQ_ROW_STEP((B) + 2) NQ_ROW_STEP((B) + 3) \
+                        NQ_ROW_STEP((B) + 4) NQ_ROW_STEP((B) + 5) NQ_ROW_STEP((B) + 6) NQ_ROW_STEP((B) + 7)
+  NQ_ROW_STEP8(0) NQ_ROW_STEP8(8) NQ_ROW_STEP8(16) NQ_ROW_STEP8(24)
+#undef NQ_ROW_STEP8
 #undef NQ_ROW_STEP
-#undef NQ_ROW_STAGE
-  static_assert(kRowSlots == 16, "the steps above are written out");
-  // Out: thread q holds 16 words per tile; lanes 4j .. 4j + 3 of a wave store the four 16-byte
-  // pieces of query (wave base + 16 r + j)'s block, r = 0 .. 3, so one store instruction writes 16
-  // whole 64-byte blocks.  The transposition goes through LDS (17-word rows: no bank conflicts).
+  static_assert(kRowSlots == 32, "the steps above are written out");
+  // Out: thread q holds 32 words per tile = one 128-byte line of pre[q][t][s]; lanes 8j .. 8j + 7 of a
+  // wave store the eight 16-byte pieces of query (wave base + 8 r + j)'s line, r = 0 .. 7, so one store
+  // instruction writes 8 whole lines.  The transposition goes through LDS (33-word rows: no bank conflicts).
   lds_barrier();   // all look-ups of the last row are done: the row buffers are free
-  uint32_t *mine = rows + tid * 17u;
+  uint32_t *mine = rows + tid * (kRowSlots + 1u);
 #define NQ_STORE_TILE(T)                                                                                             \
   {                                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < (int)kRowSlots; ++i) mine[i] = res[(T)][i];                               \
     wave_lds_fence(); /* (one wave reads what its own lanes wrote) */                                                \
-    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                                  \
-      const uint32_t src_t = (tid & ~63u) + 16u * (uint32_t)r + (lane >> 2); /* whose block this lane helps to store */ \
-      const uint32_t piece = lane & 3u;                                                                              \
-      const uint32_t *sp = rows + src_t * 17u + piece * 4u;                                                          \
+    _Pragma("unroll") for (int r = 0; r < 8; ++r) {                                                                  \
+      const uint32_t src_t = (tid & ~63u) + 8u * (uint32_t)r + (lane >> 3); /* whose line this lane helps to store */ \
+      const uint32_t piece = lane & 7u;                                                                              \
+      const uint32_t *sp = rows + src_t * (kRowSlots + 1u) + piece * 4u;                                             \
       const uint4 w = make_uint4(sp[0], sp[1], sp[2], sp[3]);                                                        \
       const uint32_t qq = q0 + src_t;                                                                                \
       if (qq < nq) *(uint4 *)(pre + ((uint64_t)qq * NT + (T)) * v.f_local + (uint64_t)sb * kRowSlots + piece * 4u) = w; \
@@ -434,7 +444,7 @@ hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t n
     const uint32_t n_sb = v.f_local / kRowSlots, n_qchunk = (nq + kRowBlock - 1) / kRowBlock;
     const uint64_t grid = (uint64_t)((n_sb + kXcds - 1) / kXcds * kXcds) * n_qchunk;
     if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const size_t lds = std::max<size_t>((size_t)v.d.R * v.n_tiles * 4 * 4, (size_t)kRowBlock * 17 * 4);
+    const size_t lds = std::max<size_t>((size_t)v.d.R * v.n_tiles * 4 * 4, (size_t)kRowBlock * (kRowSlots + 1) * 4);
     const uint32_t per = v.d.R * v.n_tiles / (4u * kRowBlock);
     hipError_t e = hipSuccess;
 #define NQ_LAUNCH_ROWS(NT, PER)                                                                                        \
