@@ -405,13 +405,25 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
     const uint32_t n = std::min(chunk, nq - q0);
     Span sp(ix, NIQKI_KC_GATHER);
     const uint32_t *order = nullptr;
+    const bool fork = ordered && n >= 64 && pre;   // probe + order beside the pre-pass (both only read the sketches)
+    if (fork) {
+      if (!ix->aux_stream) {
+        NQ_HIP(ix, hipStreamCreateWithFlags(&ix->aux_stream, hipStreamNonBlocking));
+        NQ_HIP(ix, hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming));
+        NQ_HIP(ix, hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
+      }
+      NQ_HIP(ix, hipEventRecord(ix->ev_fork, ix->stream));
+      NQ_HIP(ix, hipStreamWaitEvent(ix->aux_stream, ix->ev_fork, 0));
+    }
     if (ordered && n >= 64) {
       uint32_t *keys = (uint32_t *)ix->ws_order.p;
-      NQ_HIP(ix, nq::launch_order(v, sketches + (size_t)q0 * q_stride, n, keys, keys + chunk, ix->stream));
+      NQ_HIP(ix, nq::launch_order(v, sketches + (size_t)q0 * q_stride, n, keys, keys + chunk, fork ? ix->aux_stream : ix->stream));
       order = keys + chunk;
+      if (fork) NQ_HIP(ix, hipEventRecord(ix->ev_join, ix->aux_stream));
     }
     if (pre)
       NQ_HIP(ix, nq::launch_lookup(v, sketches + (size_t)q0 * q_stride, n, (uint32_t *)ix->ws_pre.p, ix->stream));
+    if (fork) NQ_HIP(ix, hipStreamWaitEvent(ix->stream, ix->ev_join, 0));
     nq::CandOut c;
     if (co) { c = *co; c.cand += (size_t)q0 * co->cap; c.n += q0; }
     NQ_HIP(ix, nq::launch_gather(v, sketches + (size_t)q0 * q_stride, n, counts + (size_t)q0 * stride,
@@ -667,6 +679,9 @@ void niqki_destroy(niqki_index *ix) {
   if (ix->slot_units) (void)hipFree(ix->slot_units);
   for (auto &s : ix->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : ix->ev_pool) (void)hipEventDestroy(e);
+  if (ix->aux_stream) { (void)hipStreamSynchronize(ix->aux_stream); (void)hipStreamDestroy(ix->aux_stream); }
+  if (ix->ev_fork) (void)hipEventDestroy(ix->ev_fork);
+  if (ix->ev_join) (void)hipEventDestroy(ix->ev_join);
   if (ix->own_stream) (void)hipStreamDestroy(ix->stream);
   delete ix;
 }

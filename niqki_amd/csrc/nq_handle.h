@@ -104,6 +104,9 @@ struct niqki_index {
   uint64_t prof_n[NIQKI_KC_COUNT] = {0};
   std::vector<nqi::ProfSpan> spans;
   std::vector<hipEvent_t> ev_pool;
+  // side stream: the locality probe + order of a launch run beside its look-up pre-pass
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 
