@@ -328,7 +328,7 @@ def main():
                 "hits_per_query": total_hits / max(1, args.steps * per), "hit_overflow": overflow,
             },
             "roofline": {
-                "kernel": "nq::gather_kernel (gather-histogram, rank 0's slot shard) incl. its probe / order passes",
+                "kernel": "nq::gather_kernel (gather-histogram, rank 0's slot shard) incl. its look-up pre-pass and probe / order passes",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
