@@ -609,7 +609,19 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
       // tiles striped in blocks of an even number of genomes: local ids 2w, 2w + 1 are neighbours in
       // the row, a wave writes whole blocks (64-byte blocks are what HBM takes without a
       // read-modify-write, tools/ubench_partial_write.hip)
-      for (uint32_t w = tid; w < n_words; w += BLOCK) {
+      // blocks of >= 8 genomes on 16-byte aligned rows: 8 counters (4 words) per lane and store
+      const uint32_t quads = (v.stripe % 8u == 0 && ((uintptr_t)row & 15u) == 0 && !v.accumulate) ? n_t / 8 : 0u;
+      for (uint32_t k = tid; k < quads; k += BLOCK) {
+        const uint32_t col = tile_gid(v, t, 8 * k);
+        const uint4 c = *(const uint4 *)(cnt + 4 * k);
+        *(uint4 *)(row + col) = c;
+        if (want_cand) {
+          const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { emit(cw[j] & 0xFFFFu, col + 2 * j); emit(cw[j] >> 16, col + 2 * j + 1); }
+        }
+      }
+      for (uint32_t w = 4 * quads + tid; w < n_words; w += BLOCK) {
         const uint32_t col = tile_gid(v, t, 2 * w), c = cnt[w];
         uint32_t *dst = (uint32_t *)(row + col);
         if (2 * w + 1 < n_t) *dst = v.accumulate ? *dst + c : c;
