@@ -296,7 +296,7 @@ def main():
         xbytes = nq_all * (F // world) * 2 * g1                          # all-to-all of F/G-slot sketch slices (int16)
         if sq.exchange == "sparse":
             xbytes += nq_all * sq.cand_cap * 4 * g1 + nq_all * 4 * g1    # all-gather of candidates + their counts
-            xbytes += nq_all * world * sq.cand_cap * 4 * g1              # reduce-scatter of the candidates' partial counts
+            xbytes += nq_all * world * sq.cand_cap * 2 * g1              # reduce-scatter of the candidates' partial counts (u16)
         else:
             xbytes += nq_all * (stride // 2) * 4 * g1                    # dense u16 counters as u32 pairs
     if rank == 0:

@@ -385,8 +385,8 @@ void niqki_group_destroy(niqki_group *g); /* the shard handles stay the caller's
 const char *niqki_group_last_error(const niqki_group *g);
 /* "exchange": 0 = choose (sparse when min_score >= 4 * world), 1 = sparse (candidate
  * genomes only), 2 = dense (reduce-scatter of whole hit vectors); "cand_cap": candidate
- * ids per query and rank of the sparse form (a step whose lists overflow is redone
- * densely, never answered wrongly). */
+ * ids per query and rank of the sparse form, even, default 256 (a step whose lists
+ * overflow is redone densely, never answered wrongly). */
 int niqki_group_set_option(niqki_group *g, const char *key, int64_t value);
 /* "overflows" (sparse steps redone densely so far), "rccl" (1 = RCCL transport),
  * "sparse" (1 = the sparse exchange is selected). */

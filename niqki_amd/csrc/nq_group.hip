@@ -116,22 +116,24 @@ __global__ __launch_bounds__(256) void slice_unpack_kernel(const int16_t *in, ui
 __host__ __device__ inline uint64_t cand_blob_ints(uint32_t nq, uint32_t C) { return (uint64_t)nq * C + nq; }
 
 // mine[q][g*C + c] = this shard's partial count of candidate c of rank g for query q (0 where the
-// list has no entry); flag |= some list overflowed its capacity
+// list has no entry), as u16: the cross-shard sums stay <= F <= 2^15, so the ranks add them as packed
+// pairs in u32 words without a carry (half the bytes of the reduce-scatter); flag |= some list
+// overflowed its capacity
 __global__ __launch_bounds__(256) void cand_lookup_kernel(const uint16_t *counts, uint64_t stride, uint32_t nq, uint32_t G,
-                                                         uint32_t C, const int32_t *cand_all, uint32_t *mine, uint32_t *flag) {
+                                                         uint32_t C, const int32_t *cand_all, uint16_t *mine, uint32_t *flag) {
   const uint32_t q = blockIdx.x;
   const uint16_t *row = counts + (uint64_t)q * stride;
   const uint64_t blob = cand_blob_ints(nq, C);
   for (uint32_t i = threadIdx.x; i < G * C; i += 256) {
     const uint32_t g = i / C, c = i % C;
     const int32_t id = cand_all[g * blob + (uint64_t)q * C + c];
-    mine[(uint64_t)q * G * C + i] = id >= 0 ? (uint32_t)row[id] : 0u;
+    mine[(uint64_t)q * G * C + i] = id >= 0 ? row[id] : (uint16_t)0;
   }
   if (threadIdx.x < G && (uint32_t)cand_all[threadIdx.x * blob + (uint64_t)nq * C + q] > C) atomicOr(flag, 1u);
 }
 
 // summed candidate counts into the (zeroed) counter rows of this rank's own queries
-__global__ __launch_bounds__(256) void cand_scatter_kernel(const uint32_t *tot, uint32_t per, uint32_t first_q, uint32_t nq,
+__global__ __launch_bounds__(256) void cand_scatter_kernel(const uint16_t *tot, uint32_t per, uint32_t first_q, uint32_t nq,
                                                           uint32_t G, uint32_t C, const int32_t *cand_all, uint16_t *red,
                                                           uint64_t stride) {
   const uint32_t ql = blockIdx.x, q = first_q + ql;
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void cand_scatter_kernel(const uint32_t *tot, 
   for (uint32_t i = threadIdx.x; i < G * C; i += 256) {
     const uint32_t g = i / C, c = i % C;
     const int32_t id = cand_all[g * blob + (uint64_t)q * C + c];
-    if (id >= 0) red[(uint64_t)ql * stride + id] = (uint16_t)tot[(uint64_t)ql * G * C + i];  // duplicates write the same sum
+    if (id >= 0) red[(uint64_t)ql * stride + id] = tot[(uint64_t)ql * G * C + i];  // duplicates write the same sum
   }
 }
 
@@ -415,7 +417,7 @@ int niqki_group_set_option(niqki_group *g, const char *key, int64_t value) {
     return NIQKI_OK;
   }
   if (!std::strcmp(key, "cand_cap")) {
-    if (value < 1 || value > 65536) return gfail(g, NIQKI_E_INVALID, "cand_cap must be in 1..65536");
+    if (value < 2 || value > 65536 || (value & 1)) return gfail(g, NIQKI_E_INVALID, "cand_cap must be even, in 2..65536");
     g->cand_cap = (uint32_t)value;
     return NIQKI_OK;
   }
@@ -494,8 +496,8 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
       NQ_GH(g, hipSetDevice(ix->device));
       auto &w = g->ws[l];
       NQ_G(g, l, nqi::ensure(ix, w.cand_all, (size_t)G * nq::cand_blob_ints(nq, C) * 4));
-      NQ_G(g, l, nqi::ensure(ix, w.mine, (size_t)nq * G * C * 4));
-      NQ_G(g, l, nqi::ensure(ix, w.tot, (size_t)per * G * C * 4));
+      NQ_G(g, l, nqi::ensure(ix, w.mine, (size_t)nq * G * C * 2));
+      NQ_G(g, l, nqi::ensure(ix, w.tot, (size_t)per * G * C * 2));
       NQ_G(g, l, nqi::ensure(ix, w.red, (size_t)per * stride * 2));
       NQ_G(g, l, nqi::ensure(ix, w.flag, 4));
     }
@@ -507,10 +509,10 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
       nqi::Span sp(ix, NIQKI_KC_EXCHANGE);
       NQ_GH(g, hipMemsetAsync(w.flag.p, 0, 4, ix->stream));
       hipLaunchKernelGGL(nq::cand_lookup_kernel, dim3(nq), dim3(256), 0, ix->stream, (const uint16_t *)w.counts.p, stride, nq, G, C,
-                         (const int32_t *)w.cand_all.p, (uint32_t *)w.mine.p, (uint32_t *)w.flag.p);
+                         (const int32_t *)w.cand_all.p, (uint16_t *)w.mine.p, (uint32_t *)w.flag.p);
       NQ_GH(g, hipGetLastError());
     }
-    if ((rc = reduce_scatter_u32(g, &niqki_group::Ws::mine, &niqki_group::Ws::tot, (size_t)per * G * C))) return rc;
+    if ((rc = reduce_scatter_u32(g, &niqki_group::Ws::mine, &niqki_group::Ws::tot, (size_t)per * G * C / 2))) return rc;
     // every rank saw the same all-gathered list sizes, so all ranks (and processes) take the same branch
     uint32_t over = 0;
     NQ_GH(g, hipSetDevice(g->sh[0]->device));
@@ -526,7 +528,7 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
         auto &w = g->ws[l];
         nqi::Span sp(ix, NIQKI_KC_EXCHANGE);
         NQ_GH(g, hipMemsetAsync(w.red.p, 0, (size_t)per * stride * 2, ix->stream));
-        hipLaunchKernelGGL(nq::cand_scatter_kernel, dim3(per), dim3(256), 0, ix->stream, (const uint32_t *)w.tot.p, per,
+        hipLaunchKernelGGL(nq::cand_scatter_kernel, dim3(per), dim3(256), 0, ix->stream, (const uint16_t *)w.tot.p, per,
                            (g->first + l) * per, nq, G, C, (const int32_t *)w.cand_all.p, (uint16_t *)w.red.p, stride);
         NQ_GH(g, hipGetLastError());
       }
