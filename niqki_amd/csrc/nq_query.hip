@@ -16,7 +16,10 @@
 // algorithmic bytes per query = 4T + 20F.  On large indexes the
 // queries of a launch are first put into a locality order (probe_kernel,
 // order_kernel): similar queries then run on the same XCD at the same time and
-// share their table and bucket lines through its L2.
+// share their table and bucket lines through its L2.  For real batches the table
+// look-ups are taken out of the kernel altogether by a pre-pass (lookup_rows_kernel
+// / lookup_kernel) that walks the table slot block by slot block for all queries of
+// the launch; the gather kernel then reads one packed word per (tile, slot).
 #include "nq_kernels.h"
 
 #include <algorithm>
