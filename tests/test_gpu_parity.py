@@ -715,13 +715,13 @@ def test_more_than_four_tiles(native, po, n, tile):
     e.close()
 
 
-@pytest.mark.parametrize("tile", [0, 256])
-def test_prepass_with_table_rows_staged_in_lds(native, po, tile):
+@pytest.mark.parametrize("W,tile", [(12, 0), (12, 256), (11, 256)])
+def test_prepass_with_table_rows_staged_in_lds(native, po, W, tile):
     """The pre-pass form for W = 12 indexes of one or two tiles and real batches (a slot's whole
     entry row copied into LDS, 1024 queries per workgroup; a last workgroup with idle threads):
     same counters and hits as with the look-ups inside the gather kernel and as the oracle."""
-    rng = np.random.default_rng(77 + tile)
-    S, W, n = 6, 12, 300
+    rng = np.random.default_rng(77 + tile + W)
+    S, n = 6, 300
     F = 1 << S
     fam = rng.integers(0, 1 << W, (5, F)).astype(np.int32)
     sk = fam[(np.arange(n) // 60) % 5].copy()
