@@ -60,8 +60,9 @@ typedef struct niqki_index niqki_index; /* opaque */
  * src/niqki_index.cpp:13-38 (output-file handling stays in the host program).
  * Supported: 1<=K<=31 (K=32 is UB in the reference, :28-29), 1<=S<=16,
  * H<=W<=15, S+W<=30.  S = 16 is the reference's lF>15 branch (uint32 counters, :668-682): a
- * count can reach 2^16, so the u16 counter calls (niqki_query_counts, niqki_hits_from_counts),
- * groups and paging refuse it; niqki_query* / niqki_staged_query / niqki_query_counts32 are exact
+ * count can reach 2^16, so the u16 counter calls (niqki_query_counts, niqki_hits_from_counts)
+ * and groups refuse it; niqki_query* / niqki_staged_query / niqki_query_counts32 are exact (also
+ * on a paged handle, whose pages add up per half of the slots)
  * and niqki_matrix_range wraps like the reference's uint16 matrix counters (:572). */
 typedef struct niqki_params {
   uint32_t K;          /* k-mer length */

@@ -208,7 +208,11 @@ int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, ui
 }
 
 // a whole-range S = 16 handle counts in two planes of <= 2^15 slots each (nq_kernels.h, kPassSlots)
-bool two_planes(const niqki_index *ix) { return !ix->resident_bytes && ix->d.slot_end - ix->d.slot_begin > nq::kPassSlots; }
+// more than 2^15 slots on the handle (whole-range S = 16): counts reach 2^16, the slots are walked in two halves
+// into two counter planes (a paged handle: its pages never straddle the halves)
+bool two_planes(const niqki_index *ix) {
+  return (ix->resident_bytes ? ix->full_end - ix->full_begin : ix->d.slot_end - ix->d.slot_begin) > nq::kPassSlots;
+}
 
 // first slot of the handle in a whole sketch row (while a page is resident d.slot_begin is the page's)
 uint32_t first_slot(const niqki_index *ix) { return ix->resident_bytes ? ix->full_begin : ix->d.slot_begin; }
@@ -269,7 +273,7 @@ uint32_t page_slots(const niqki_index *ix) {
   uint64_t f = ix->resident_bytes / per_slot / 32 * 32;
   const uint32_t f_all = ix->full_end - ix->full_begin;
   if (f < 32) f = 32;
-  return (uint32_t)std::min<uint64_t>(f, f_all);
+  return (uint32_t)std::min<uint64_t>({f, (uint64_t)f_all, (uint64_t)nq::kPassSlots});
 }
 
 // Makes slots [s0, s1) (relative to the handle's first slot) the resident page: store rows from host
@@ -300,17 +304,23 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
 
 // counts over a paged index: page after page, the gather kernel adding to the rows from the second on
 int counts_paged(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq, uint16_t *counts,
-                 uint64_t stride) {
+                 uint64_t stride, uint16_t *counts2) {
   const uint32_t f_all = ix->full_end - ix->full_begin, f_page = page_slots(ix);
   if (stride < ix->n_genomes || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
+  if (f_all > nq::kPassSlots && !counts2) return fail(ix, NIQKI_E_INVALID, "S = 16: counts reach 2^16, use niqki_query_counts32 (or the hit calls)");
   ix->built_n = ix->n_genomes;
   if (nq == 0 || ix->n_genomes == 0) return NIQKI_OK;
-  for (uint32_t s0 = 0; s0 < f_all; s0 += f_page) {
-    const uint32_t s1 = std::min(f_all, s0 + f_page);
-    int rc = load_page(ix, s0, s1);
-    if (rc) return rc;
-    // q_off addresses the handle's first slot in a sketch row; the page starts s0 slots further
-    if ((rc = counts_resident(ix, sketches, q_stride, q_off + s0, nq, counts, stride, s0 != 0))) return rc;
+  // the pages of slots [0, 2^15) add up in `counts`, those of the slots behind (S = 16 only) in `counts2`:
+  // either sum stays <= 2^15
+  for (uint32_t h0 = 0; h0 < f_all; h0 += nq::kPassSlots) {
+    const uint32_t h1 = std::min(f_all, h0 + nq::kPassSlots);
+    for (uint32_t s0 = h0; s0 < h1; s0 += f_page) {
+      const uint32_t s1 = std::min(h1, s0 + f_page);
+      int rc = load_page(ix, s0, s1);
+      if (rc) return rc;
+      // q_off addresses the handle's first slot in a sketch row; the page starts s0 slots further
+      if ((rc = counts_resident(ix, sketches, q_stride, q_off + s0, nq, h0 ? counts2 : counts, stride, s0 != h0))) return rc;
+    }
   }
   return NIQKI_OK;
 }
@@ -320,7 +330,7 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint
                uint16_t *counts, uint64_t stride, uint16_t *counts2, const nq::CandOut *co) {
   if (co && (ix->resident_bytes || two_planes(ix) || !co->cand || !co->n || !co->cap))
     return fail(ix, NIQKI_E_INVALID, "candidate lists: not on a paged or whole-range S = 16 handle; cand, n_cand and cap > 0 needed");
-  if (ix->resident_bytes) return counts_paged(ix, sketches, q_stride, q_off, nq, counts, stride);
+  if (ix->resident_bytes) return counts_paged(ix, sketches, q_stride, q_off, nq, counts, stride, counts2);
   if (two_planes(ix) && !counts2) return fail(ix, NIQKI_E_INVALID, "S = 16: counts reach 2^16, use niqki_query_counts32 (or the hit calls)");
   if (co && nq) {
     NQ_HIP(ix, hipMemsetAsync(co->n, 0, (size_t)nq * 4, ix->stream));
@@ -644,7 +654,6 @@ int niqki_create(const niqki_params *params, niqki_index **out) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return bail(NIQKI_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is gfx950 only");
   ix->device = dev;
   ix->resident_bytes = (uint64_t)params->resident_mib << 20;
-  if (ix->resident_bytes && ix->d.S > 15) return bail(NIQKI_E_INVALID, "paged indexes need S <= 15 (pages accumulate u16 counters)");
   ix->full_begin = ix->d.slot_begin;
   ix->full_end = ix->d.slot_end;
   if ((e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking)) != hipSuccess) return bail(NIQKI_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -749,7 +758,6 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
   if (!std::strcmp(key, "resident_bytes")) {
     if (value < 0) return fail(ix, NIQKI_E_INVALID, "resident_bytes must be >= 0");
     if (ix->n_genomes || ix->store) return fail(ix, NIQKI_E_STATE, "resident_bytes must be set before the first insert");
-    if (value && ix->d.S > 15) return fail(ix, NIQKI_E_INVALID, "paged indexes need S <= 15 (pages accumulate u16 counters)");
     ix->resident_bytes = (uint64_t)value;
     return NIQKI_OK;
   }
@@ -1613,7 +1621,10 @@ int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value) {
   if (!std::strcmp(key, "page_slots")) { *value = ix->resident_bytes ? page_slots(ix) : f_all; return NIQKI_OK; }
   if (!std::strcmp(key, "pages")) {
     const uint32_t ps = ix->resident_bytes ? page_slots(ix) : f_all;
-    *value = ps ? (f_all + ps - 1) / ps : 0;
+    uint64_t n = 0;   // (a paged handle's pages do not straddle the halves of 2^15 slots)
+    for (uint32_t h0 = 0; ps && h0 < f_all; h0 += ix->resident_bytes ? nq::kPassSlots : f_all)
+      n += (std::min(f_all - h0, ix->resident_bytes ? nq::kPassSlots : f_all) + ps - 1) / ps;
+    *value = n;
     return NIQKI_OK;
   }
   return NIQKI_E_INVALID;

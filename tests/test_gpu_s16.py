@@ -101,9 +101,15 @@ def test_s16_many_genomes_two_tiles_and_device_path(native, po):
     e.synchronize()
     assert np.array_equal(ho.cpu().numpy().astype(np.uint64), off)
     assert np.array_equal(dc.cpu().numpy()[:int(off[-1])].astype(np.uint32), hc)
-    # what S = 16 does not offer is refused
-    with pytest.raises(native.NiqkiError):
-        e.set_option("resident_bytes", 1 << 20)
-    with pytest.raises(native.NiqkiError):
-        native.Engine(K=31, S=16, W=8, H=3, resident_mib=4)
+    # the same index paged (pages never straddle the two halves of the slots: each half's counters
+    # add up in a plane of its own): same hits, same exact counters
+    c32 = e.query_counts32(q)
+    pg = native.Engine(K=31, S=S, W=W, H=3, J=0.7, tile_genomes=256, resident_mib=8)
+    pg.insert(sk)
+    assert pg.stat("pages") >= 4 and pg.stat("pages") % 2 == 0
+    poff, phc, phg = pg.query(q)
+    assert np.array_equal(poff, off) and np.array_equal(phc, hc) and np.array_equal(phg, hg)
+    assert np.array_equal(pg.query_counts32(q), c32)
+    assert np.array_equal(c32[0].astype(np.int64), ix.counts(q[0]))
+    pg.close()
     e.close()
