@@ -37,7 +37,7 @@ __device__ __forceinline__ void bump(uint32_t *cnt, uint32_t g) {
 // word of their own (no exec-mask juggling, no same-address serialisation).
 __device__ __forceinline__ void bump_if(uint32_t *cnt, uint32_t g, bool on, uint32_t lane) {
   const uint32_t gg = on ? g : 2u * lane;
-  const uint32_t inc = on ? (1u << ((g & 1u) * 16u)) : 0u;
+  const uint32_t inc = on ? (1u << ((g << 4) & 31u)) : 0u;   // 1 << 16 * (g & 1): the shifter takes the low 5 bits
   atomicAdd(&cnt[gg >> 1], inc);
 }
 
