@@ -66,6 +66,57 @@ def query_spec(q, n_fam):
     return fam, mem, rate
 
 
+def measure_traffic(args):
+    """HBM bytes per gather launch (gather kernel + look-up pre-pass + locality probe) from rocprofv3 PMC
+    passes of a short run of this same command: 2 x FETCH_SIZE (gfx950 tallies 128-byte requests at 64
+    bytes, MI355X_MICROARCH.md) + WRITE_SIZE, both in KB.  None if anything goes wrong."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    rx = re.compile(r"gather_kernel<|lookup(_rows)?_kernel<|probe_kernel<")
+    kb = {}
+    launches = None
+    t0 = time.time()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = tempfile.mkdtemp(prefix="niqki_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "2", "--warmup", "1",
+                   "--genomes", str(args.genomes), "--batch", str(args.batch), "--len", str(args.len),
+                   "--family", str(args.family), "--seed", str(args.seed), "--ring", "2"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                shutil.rmtree(out, ignore_errors=True)
+                return None
+            total, n_gather = 0.0, 0
+            with open(files[0], newline="") as f:
+                for row in csv.DictReader(f):
+                    name = row.get("Kernel_Name", "")
+                    if row.get("Counter_Name") == counter and rx.search(name):
+                        total += float(row["Counter_Value"])
+                        n_gather += "gather_kernel<" in name
+            shutil.rmtree(out, ignore_errors=True)
+            if n_gather == 0:
+                return None
+            kb[counter] = total / n_gather
+            launches = n_gather
+    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+        return None
+    log("[bench] HBM traffic of the gather path: FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB per launch (%d launches, %.0f s)"
+        % (kb["FETCH_SIZE"], kb["WRITE_SIZE"], launches, time.time() - t0))
+    return {"bytes_per_launch": (2 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024,
+            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over %d launches of this same command, run by "
+                      "bench.py before its timed run: 2 x FETCH_SIZE (gfx950) + WRITE_SIZE of gather_kernel, the look-up "
+                      "pre-pass and the locality probe" % launches}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,7 +135,21 @@ def main():
                     help="cross-shard sum: auto | sparse | reduce_scatter (include/niqki_hip.h, niqki_group_set_option)")
     ap.add_argument("--shard-of", type=int, default=0,
                     help="one GPU as rank 0 of a slot shard of this many GPUs (no exchange; see the module docstring)")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure the gather path's HBM traffic with rocprofv3 --pmc passes before the run "
+                         "(roofline.traffic then comes from profiles/gather_traffic.json)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        args.no_cpu = args.no_extra = args.no_pmc = True
+
+    # HBM bytes per launch of the gather path, measured now: two rocprofv3 --pmc passes (FETCH_SIZE,
+    # WRITE_SIZE: passes of their own, no trace flags) over a 3-launch run of this same command, as
+    # child processes started BEFORE this process touches the GPU.  Full default runs on one GPU only.
+    live_traffic = None
+    if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.shard_of and not args.no_cpu
+            and not args.no_extra and not args.no_pmc and os.environ.get("NIQKI_BENCH_PMC", "1") != "0"):
+        live_traffic = measure_traffic(args)
 
     # Only the JSON line may reach stdout: libraries (RCCL prints a version banner)
     # get stderr for the whole run, the result is written to the saved descriptor.
@@ -259,14 +324,18 @@ def main():
     overflow = bool((hit_off[:, per] > cap).any().item())
 
     # HBM bytes of the gather kernel from the committed PMC passes (separate rocprofv3
-    # --pmc runs of this same command; bench.py cannot collect counters itself)
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "gather_traffic.json")))
-        if (tj["index_genomes"], tj["query_batch"], tj["tile_genomes"]) == (N, nq_gather, eng.tile_genomes()) and world == 1 and not emu:
-            traffic = tj["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    # --pmc runs of this same command), unless this run measured it itself (measure_traffic)
+    traffic, traffic_source = None, None
+    if live_traffic is not None:
+        traffic, traffic_source = live_traffic["bytes_per_launch"], live_traffic["source"]
+    else:
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "gather_traffic.json")))
+            if (tj["index_genomes"], tj["query_batch"], tj["tile_genomes"]) == (N, nq_gather, eng.tile_genomes()) and world == 1 and not emu:
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_source = "profiles/gather_traffic.json (committed rocprofv3 --pmc passes of this command)"
+        except (OSError, KeyError, ValueError):
+            pass
 
     # ---- sketch kernel against integer-ALU ceilings measured now, on this device ----
     kmers = args.steps * per * max(L - K, 0)
@@ -331,7 +400,7 @@ def main():
                 "kernel": "nq::gather_kernel (gather-histogram, rank 0's slot shard) incl. its look-up pre-pass and probe / order passes",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": alg_bytes / max(1, gather_launches),
                 "layout_min_bytes_per_launch": layout_min / max(1, gather_launches),
                 "launches": gather_launches, "avg_launch_ms": gather_ms / max(1, gather_launches),
