@@ -15,6 +15,7 @@
 // hash steps.  The kernel is integer-ALU bound (4 64-bit multiplies per
 // k-mer), HBM traffic is 1 byte per base.
 #include "nq_kernels.h"
+#include "../../include/niqki_hip.h"
 
 #include <cstdlib>
 
@@ -35,21 +36,26 @@ __device__ __forceinline__ uint8_t code_entry(uint32_t c) {
 }
 
 // 16 bytes of a byte stream that starts at an arbitrary address: the stream is
-// fetched as dword-aligned uint4 loads and re-aligned with v_alignbyte.
+// fetched as dword-aligned uint4 loads and re-aligned with v_alignbyte.  Two loads are
+// in flight: the one next16() issues is consumed by the call after it, so a caller that
+// does a group's worth of work between calls never waits for memory.  Reads at most 35
+// bytes past the last byte handed out (NIQKI_SEQ_PAD covers the end of the buffer).
 struct ByteStream {
   const uint32_t *q;  // dword-aligned cursor
   uint32_t sh;        // byte phase 0..3
-  uint4 cur;
+  uint4 cur, nxt;
   __device__ __forceinline__ void open(const uint8_t *p) {
     uintptr_t a = (uintptr_t)p;
     sh = (uint32_t)(a & 3u);
     q = (const uint32_t *)(a & ~(uintptr_t)3);
-    cur = *(const uint4 *)q;  // dword aligned 16-byte load
-    q += 4;
+    cur = *(const uint4 *)q;  // dword aligned 16-byte loads
+    nxt = *(const uint4 *)(q + 4);
+    q += 8;
   }
-  // returns the next 16 stream bytes as 4 dwords (little endian)
-  __device__ __forceinline__ uint4 next16() {
-    uint4 nxt = *(const uint4 *)q;
+  // returns the next 16 stream bytes as 4 dwords (little endian); loads never go past qmax (a lane
+  // that steps through more groups than its own chunk holds, beside lanes with longer chunks)
+  __device__ __forceinline__ uint4 next16(const uint32_t *qmax = nullptr) {
+    const uint4 nn = *(const uint4 *)((qmax && q > qmax) ? qmax : q);
     q += 4;
     uint4 r;
     r.x = __builtin_amdgcn_alignbyte(cur.y, cur.x, sh);
@@ -57,6 +63,7 @@ struct ByteStream {
     r.z = __builtin_amdgcn_alignbyte(cur.w, cur.z, sh);
     r.w = __builtin_amdgcn_alignbyte(nxt.x, cur.w, sh);
     cur = nxt;
+    nxt = nn;
     return r;
   }
 };
@@ -215,6 +222,33 @@ __device__ __forceinline__ void sketch_update(uint64_t canon, const Derived &d, 
   atomicMin(&sk[slot], fp);
 }
 
+// ---- the filtered long-record path ------------------------------------------------------------
+// Issue costs on gfx950 (tools/ubench_opcodes.hip, profiles/r03_opcode_costs.txt): v_add / v_sub /
+// v_and / v_or / v_xor / v_mov / v_lshrrev_b32 take ~2.4 SIMD cycles per wave instruction, EVERY other
+// vector opcode ~4.3 -- 32-bit multiplies, v_mad_u64_u32 (4.4), 64-bit shifts and compares included.
+// So the step below is written for the fewest instructions, multiplies are not what to avoid:
+//   * the code table for K = 31 holds 8-byte entries {forward code, rc code << 28}: both rolling
+//     updates are one 64-bit shift plus an `or` (5 instructions instead of 7);
+//   * the 64 x 64 -> 64 multiplies run as chains of v_mad_u64_u32 (the addend carries the cross terms);
+//   * candidates are stored under the exec mask (compare, 2 x mbcnt, 1 address instruction) into a
+//     wave-private LIFO stack whose top lives in a scalar register: no ring wrap, no scratch slot.
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
+
+// a * b (32 x 32 -> 64) and a * b + c as ONE v_mad_u64_u32 each: the empty asm makes the whole 64-bit
+// result "used", so the compiler cannot narrow the expression back into v_mul_lo_u32 + adds
+__device__ __forceinline__ uint64_t mul64(uint32_t a, uint32_t b) {
+  uint64_t r = (uint64_t)a * (uint64_t)b;
+  asm("" : "+v"(r));
+  return r;
+}
+__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
+  uint64_t r = (uint64_t)a * (uint64_t)b + c;
+  asm("" : "+v"(r));
+  return r;
+}
+
 // High word of rev64(canon): enough to bound the fingerprint from below.
 __device__ __forceinline__ uint32_t rev64_hi(uint64_t canon) {
   uint64_t x = ((canon >> 32) ^ canon) * kRevMul;
@@ -222,32 +256,161 @@ __device__ __forceinline__ uint32_t rev64_hi(uint64_t canon) {
   return (uint32_t)(x >> 32);
 }
 
-constexpr uint32_t kRing = 128;  // candidate k-mers per wave-private ring (filtered path)
-constexpr uint32_t kRingAlloc = kRing + 64;  // + one scratch slot per lane
+// One xorshift-multiply round of mix64 (src/niqki_index.cpp:292,:301): x = ((x >> 32) ^ x) * c with c
+// = chi:clo.  The low 32 bits of the product of the high words' cross terms ride in the addend.
+__device__ __forceinline__ void mix_round(uint32_t &lo, uint32_t &hi, uint32_t clo, uint32_t chi) {
+  const uint32_t y = lo ^ hi;
+  const uint64_t t = mul64(hi, clo);
+  const uint64_t p = mad64(y, chi, t);   // low word: y * chi + hi * clo
+  const uint64_t q = mul64(y, clo);
+  lo = (uint32_t)q;
+  hi = (uint32_t)p + (uint32_t)(q >> 32);
+}
+// the same round when only the high word of the product is wanted
+__device__ __forceinline__ uint32_t mix_round_hi(uint32_t lo, uint32_t hi, uint32_t clo, uint32_t chi) {
+  const uint32_t y = lo ^ hi;
+  const uint64_t t = mul64(hi, clo);
+  const uint64_t p = mad64(y, chi, t);
+  return (uint32_t)p + __umulhi(y, clo);
+}
+__device__ __forceinline__ uint32_t rev64_hi_mad(uint64_t canon) {
+  uint32_t lo = (uint32_t)canon, hi = (uint32_t)(canon >> 32);
+  mix_round(lo, hi, (uint32_t)kRevMul, (uint32_t)(kRevMul >> 32));
+  return mix_round_hi(lo, hi, (uint32_t)kRevMul, (uint32_t)(kRevMul >> 32));
+}
+
+constexpr uint32_t kStack = 192;  // candidate k-mers per wave-private stack: < 64 left by a drain + two steps of <= 64
+
+// Candidate store of one step: lanes whose hash word hh is below thr push canon onto the wave's stack
+// (LDS byte address of its top in `top`, wave-uniform, advanced here).  gfx950 wants two wait states
+// between a vector compare and a vector instruction that reads its mask as an operand (the mbcnt): the two
+// scalar instructions in between are that.
+__device__ __forceinline__ void push_candidates(uint32_t hh, uint32_t thr, uint64_t canon, uint32_t &top) {
+  uint32_t n, r;
+  uint64_t save;
+  asm volatile(
+      "v_cmp_gt_u32 vcc, %[thr], %[hh]\n\t"
+      "s_and_saveexec_b64 %[save], vcc\n\t"
+      "s_bcnt1_i32_b64 %[n], vcc\n\t"
+      "v_mbcnt_lo_u32_b32 %[r], vcc_lo, 0\n\t"
+      "v_mbcnt_hi_u32_b32 %[r], vcc_hi, %[r]\n\t"
+      "v_lshl_add_u32 %[r], %[r], 3, %[top]\n\t"
+      "ds_write_b64 %[r], %[canon]\n\t"
+      "s_mov_b64 exec, %[save]\n\t"
+      "s_lshl3_add_u32 %[top], %[n], %[top]"
+      : [n] "=&s"(n), [r] "=&v"(r), [save] "=&s"(save), [top] "+s"(top)
+      : [thr] "s"(thr), [hh] "v"(hh), [canon] "v"(canon)
+      : "vcc", "scc", "memory");
+}
+
+// LDS layout of sketch_kernel (byte offsets from the start of its dynamic LDS, which is LDS address 0: the
+// kernel has no static LDS): the K = 31 code table first, so that a look-up address is the byte value
+// times 8 (one SDWA shift), and the sketch cells at a fixed offset (an instruction immediate).
+constexpr uint32_t kLut64Off = 0;       // 256 x {forward code, rc code << 28}
+constexpr uint32_t kLutOff = 2048;      // 256 code_entry bytes
+constexpr uint32_t kFlagOff = 2304;     // 4 words
+constexpr uint32_t kCellOff = 2320;     // the sketch cells; behind them the distinct-value tables or the candidate stacks
+
+// byte B of w, times 8: the offset of its 8-byte code table entry
+template <int B>
+__device__ __forceinline__ uint32_t byte_x8(uint32_t w) {
+  uint32_t r;
+  if (B == 0) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(w));
+  if (B == 1) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(w));
+  if (B == 2) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(w));
+  if (B == 3) asm("v_lshlrev_b32_sdwa %0, 3, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(w));
+  return r;
+}
+// the 16 code table entries of 16 stream bytes
+__device__ __forceinline__ void lut64_16(const uint4 &v, uint32_t lds0, uint64_t (&e)[16]) {
+#define NQ_E(J, W, B) e[J] = *(lds_u64_t *)(uintptr_t)(lds0 + kLut64Off + byte_x8<B>(W));
+  NQ_E(0, v.x, 0) NQ_E(1, v.x, 1) NQ_E(2, v.x, 2) NQ_E(3, v.x, 3)
+  NQ_E(4, v.y, 0) NQ_E(5, v.y, 1) NQ_E(6, v.y, 2) NQ_E(7, v.y, 3)
+  NQ_E(8, v.z, 0) NQ_E(9, v.z, 1) NQ_E(10, v.z, 2) NQ_E(11, v.z, 3)
+  NQ_E(12, v.w, 0) NQ_E(13, v.w, 1) NQ_E(14, v.w, 2) NQ_E(15, v.w, 3)
+#undef NQ_E
+}
+// ... of the first (HALF = 0) or last eight of them, into e[0..8) or e[8..16)
+template <int HALF>
+__device__ __forceinline__ void lut64_8(const uint4 &v, uint32_t lds0, uint64_t (&e)[16]) {
+#define NQ_E(J, W, B) e[J] = *(lds_u64_t *)(uintptr_t)(lds0 + kLut64Off + byte_x8<B>(W));
+  if (HALF == 0) {
+    NQ_E(0, v.x, 0) NQ_E(1, v.x, 1) NQ_E(2, v.x, 2) NQ_E(3, v.x, 3)
+    NQ_E(4, v.y, 0) NQ_E(5, v.y, 1) NQ_E(6, v.y, 2) NQ_E(7, v.y, 3)
+  } else {
+    NQ_E(8, v.z, 0) NQ_E(9, v.z, 1) NQ_E(10, v.z, 2) NQ_E(11, v.z, 3)
+    NQ_E(12, v.w, 0) NQ_E(13, v.w, 1) NQ_E(14, v.w, 2) NQ_E(15, v.w, 3)
+  }
+#undef NQ_E
+}
+// 64-bit shifts the compiler cannot look into (it otherwise re-derives halves of the result with extra
+// instructions)
+__device__ __forceinline__ uint64_t shl2_64(uint64_t x) {
+  uint64_t r;
+  asm("v_lshlrev_b64 %0, 2, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ uint64_t shr2_64(uint64_t x) {
+  uint64_t r;
+  asm("v_lshrrev_b64 %0, 2, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// slot + fingerprint + per-slot min of up to 64 candidates (:346-355), whole sketch in LDS at kCellOff
+// upwards (S <= 15).  The hash of the filter is recomputed: passing its words through the stack costs
+// more register traffic than the 5 instructions saved.
+__device__ __forceinline__ void candidate_update(uint64_t canon, const Derived &d, uint32_t lds0, bool live) {
+  uint32_t lo = (uint32_t)canon, hi = (uint32_t)(canon >> 32);
+  uint32_t ulo = lo, uhi = hi;
+  mix_round(ulo, uhi, (uint32_t)kUnrevMul, (uint32_t)(kUnrevMul >> 32));
+  const uint32_t uh = mix_round_hi(ulo, uhi, (uint32_t)kUnrevMul, (uint32_t)(kUnrevMul >> 32));
+  mix_round(lo, hi, (uint32_t)kRevMul, (uint32_t)(kRevMul >> 32));
+  mix_round(lo, hi, (uint32_t)kRevMul, (uint32_t)(kRevMul >> 32));
+  const uint64_t h = ((uint64_t)hi << 32) | (lo ^ hi);
+  uint32_t fp = fingerprint(h, d.M, d.mask_m, d.max_rem);
+  fp = live ? fp : kEmpty32;  // a min with "empty" changes nothing
+  const uint32_t cell = (uh >> (30u - d.S)) & ~3u;   // byte offset of the slot's cell
+  __hip_atomic_fetch_min((lds_u32_t *)(uintptr_t)(lds0 + kCellOff + cell), fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // All records of one sketch, this workgroup's share of the chunks.
 // FILTER (long inputs only): a k-mer whose hash has fewer than T leading zeros
 // (hi word >= thr) has a larger fingerprint than any k-mer with at least T, so it
 // can only matter for a slot that no such k-mer reaches.  Those k-mers (7 of 8 at
-// T = 3) skip the slot hash and the LDS min; the others are compacted into a
-// wave-private ring and finished 64 at a time.  The caller re-runs the records
+// T = 3) skip the slot hash and the LDS min; the others are pushed onto a
+// wave-private stack and finished 64 at a time.  The caller re-runs the records
 // unfiltered if any slot is still empty afterwards, so the result is exact.
-template <int BLOCK, int GROUPS, int KFIX, bool FILTER>
+// GROUPS: most 16-base groups per chunk; a record's chunks are sized so that its last round of
+// chunks over the workgroup's lanes is nearly full (5 Mbp over 1024 lanes: 10 rounds of 496 k-mers).
+// ZERO: the kernel's LDS layout starts at LDS address 0 (checked at kernel entry), so the fast path
+// addresses the code table and the cells with instruction immediates.
+template <int BLOCK, int GROUPS, int KFIX, bool FILTER, bool HALF, bool ZERO>
 __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part, uint32_t *sk, const uint8_t *lut,
-                             uint64_t *ring_base, uint32_t thr, uint32_t hsel) {
+                             uint64_t *stack_base, uint32_t thr, uint32_t hsel) {
   const Derived &d = a.d;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
-  constexpr uint32_t CHUNK = 16u * GROUPS;
   const uint32_t Km1 = d.K - 1u;
   const uint32_t rc_shift = 2u * d.K - 2u;
-  uint64_t *ring = ring_base + (tid >> 6) * kRingAlloc;
-  uint32_t q_head = 0, q_tail = 0, q_count = 0;  // wave-uniform (scalar registers)
-  auto drain64 = [&](bool partial) {
-    uint64_t c = ring[(q_head + lane) & (kRing - 1)];
-    const bool live = !partial || lane < q_count;
-    sketch_update(live ? c : 0ull, d, sk, live, hsel);
-    q_head = (q_head + 64) & (kRing - 1);
-    q_count = partial ? 0u : q_count - 64;
+  constexpr bool FAST = FILTER && KFIX == 31 && !HALF && ZERO;   // 8-byte code table, mad chains, S <= 15
+  constexpr uint32_t lds0 = 0;
+  uint64_t *stack = stack_base + (tid >> 6) * kStack;
+  // LDS byte address of the stack's bottom / top (wave-uniform: scalar registers)
+  const uint32_t bottom = FILTER ? __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_u64_t *)stack) : 0u;
+  uint32_t top = bottom;
+  const uint32_t lane8 = lane * 8u;
+  auto drain64 = [&]() {   // the 64 youngest candidates
+    const uint64_t c = *(lds_u64_t *)(uintptr_t)(top - 512u + lane8);
+    if (FAST) candidate_update(c, d, lds0, true);
+    else sketch_update(c, d, sk, true, hsel);
+    top -= 512u;
+  };
+  auto drain_rest = [&]() {   // fewer than 64 left
+    const uint32_t n = (top - bottom) >> 3;
+    const bool live = lane < n;
+    const uint64_t c = live ? stack[lane] : 0ull;
+    if (FAST) candidate_update(c, d, lds0, live);
+    else sketch_update(c, d, sk, live, hsel);
+    top = bottom;
   };
 
   uint32_t r0 = a.entry_rec ? a.entry_rec[entry] : entry;
@@ -257,12 +420,22 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
     const uint64_t len = b1 - b0;
     if (len <= d.K) continue;              // src/niqki_index.cpp:395,:450
     const uint64_t n_kmers = len - d.K;    // last k-mer skipped, :342
+    // chunk length: the fewest rounds of GROUPS-group chunks, then the shortest chunks that still fit them
+    uint32_t groups = 1;
+    if (GROUPS > 1) {
+      const uint64_t share = n_kmers / a.splits + 1u;
+      const uint64_t rounds = (share + (uint64_t)BLOCK * 16u * GROUPS - 1u) / ((uint64_t)BLOCK * 16u * GROUPS);
+      groups = (uint32_t)((share + rounds * BLOCK * 16u - 1u) / (rounds * BLOCK * 16u));
+      groups = groups < 1u ? 1u : groups > (uint32_t)GROUPS ? (uint32_t)GROUPS : groups;
+      groups = __builtin_amdgcn_readfirstlane(groups);
+    }
+    const uint32_t CHUNK = 16u * groups;
     const uint64_t n_chunks = (n_kmers + CHUNK - 1) / CHUNK;
     const uint64_t c_lo = n_chunks * part / a.splits;
     const uint64_t c_hi = n_chunks * (part + 1) / a.splits;
     const uint8_t *base = a.seqs + b0;
-    // Whole waves step together (uniform loop control: the filtered path's ring
-    // is wave-collective and its counters live in scalar registers).
+    // Whole waves step together (uniform loop control: the filtered path's stack
+    // is wave-collective and its top lives in a scalar register).
     const uint32_t wave0 = __builtin_amdgcn_readfirstlane(tid & ~63u);
     for (uint64_t cb = c_lo + wave0; cb < c_hi; cb += BLOCK) {
       const uint64_t c = cb + lane;
@@ -315,79 +488,138 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
       // Per 16-byte group the 16 table look-ups are issued together and one group
       // ahead of their use (LDS answers in order, so they return before the LDS
       // traffic of the group in between).
+      if (FAST && __all(cnt == CHUNK)) {
+        // Every lane of the wave has a full chunk: no per-step liveness at all.  Group g's 16 bytes sit
+        // in the five dwords at qa + 4g at byte phase sh; they are loaded a group ahead, and the eight
+        // table entries of a half group are reloaded into their own registers as soon as the half is
+        // used up (eight steps before they are needed again), so nothing is copied at the loop's end.
+        // The loop reads at most 40 bytes past the chunk's last base (NIQKI_SEQ_PAD).
+        const uintptr_t a0 = (uintptr_t)(base + i0 + Km1);
+        const uint32_t sh = (uint32_t)(a0 & 3u);
+        const uint32_t *qa = (const uint32_t *)(a0 & ~(uintptr_t)3);
+        uint64_t e[16];
+        {
+          const uint4 A = *(const uint4 *)qa;
+          const uint32_t B = qa[4];
+          uint4 w;
+          w.x = __builtin_amdgcn_alignbyte(A.y, A.x, sh);
+          w.y = __builtin_amdgcn_alignbyte(A.z, A.y, sh);
+          w.z = __builtin_amdgcn_alignbyte(A.w, A.z, sh);
+          w.w = __builtin_amdgcn_alignbyte(B, A.w, sh);
+          lut64_16(w, lds0, e);
+        }
+        auto step = [&](uint64_t ent, bool check) {
+          // :225-229 and :233-236 with the entry's pre-placed codes
+          fw = shl2_64(fw);
+          fw = (fw | (uint32_t)ent) & ((1ULL << 62) - 1ULL);
+          rc = shr2_64(rc) | (ent & 0xFFFFFFFF00000000ULL);
+          const uint64_t canon = fw < rc ? fw : rc;   // :345
+          push_candidates(rev64_hi_mad(canon), thr, canon, top);
+          // two steps add at most 128 to fewer than 64.  Unlikely: the drain is laid out behind the loop,
+          // the common path has no taken branch
+          if (check && __builtin_expect(top >= bottom + 512u, 0)) {
+            drain64();
+            if (top >= bottom + 512u) drain64();
+          }
+        };
+        for (uint32_t g = 0; g < groups; ++g) {
+          qa += 4;
+          const uint4 A = *(const uint4 *)qa;   // the next group's bytes
+          const uint32_t B = qa[4];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) step(e[j], (j & 1) != 0);
+          uint4 w;
+          w.x = __builtin_amdgcn_alignbyte(A.y, A.x, sh);
+          w.y = __builtin_amdgcn_alignbyte(A.z, A.y, sh);
+          w.z = __builtin_amdgcn_alignbyte(A.w, A.z, sh);
+          w.w = __builtin_amdgcn_alignbyte(B, A.w, sh);
+          lut64_8<0>(w, lds0, e);
+#pragma unroll
+          for (int j = 8; j < 16; ++j) step(e[j], (j & 1) != 0);
+          lut64_8<1>(w, lds0, e);
+        }
+        continue;
+      }
       ByteStream bs;
       bs.open(base + i0 + Km1);
+      // last dword-aligned address a 16-byte load may start at: the record's end plus the pad
+      const uint32_t *qmax = (const uint32_t *)(((uintptr_t)(base + len) + NIQKI_SEQ_PAD - 16) & ~(uintptr_t)3);
       uint32_t en[16];
       {
-        const uint4 v = bs.next16();
+        const uint4 v = bs.next16(qmax);
 #pragma unroll
         for (int j = 0; j < 16; ++j) en[j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
       }
-      const uint32_t cnt_wave = FILTER ? CHUNK : cnt;  // filtered: all lanes run all groups
-      for (int g = 0; g < GROUPS; ++g) {
-        if ((uint32_t)(g * 16) >= cnt_wave) break;
+      // filtered: all lanes of the wave run the groups its longest chunk needs (the stack is wave-collective);
+      // no lane reads more than two groups past its own bases
+      uint32_t cnt_wave = cnt;
+      if (FILTER) {
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+          const uint32_t o = (uint32_t)__shfl_xor((int)cnt_wave, dd, 64);
+          cnt_wave = o > cnt_wave ? o : cnt_wave;
+        }
+        cnt_wave = __builtin_amdgcn_readfirstlane(cnt_wave);
+      }
+      for (uint32_t g = 0; g < groups; ++g) {
+        if (g * 16u >= cnt_wave) break;
         uint32_t e[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) e[j] = en[j];
-        if (g + 1 < GROUPS) {
-          const uint4 v = bs.next16();
+        if ((g + 1) * 16u < cnt_wave) {
+          const uint4 v = bs.next16(qmax);
 #pragma unroll
           for (int j = 0; j < 16; ++j) en[j] = lut[(dword_of(v, j >> 2) >> (8 * (j & 3))) & 0xFFu];
         }
-        auto filtered = [&](uint64_t canon, uint32_t hh) {
-          const uint64_t bal = __ballot(hh < thr);
-          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-          // every lane stores: candidates into the ring, the others into a scratch
-          // slot of their own behind it (cheaper than masking the store)
-          ring[hh < thr ? ((q_tail + rank) & (kRing - 1)) : kRing + lane] = canon;
-          const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)__popcll(bal));
-          q_tail = (q_tail + n) & (kRing - 1);
-          q_count += n;
-          if (q_count >= 64) drain64(false);
-        };
-        if (FILTER && __all(cnt == CHUNK)) {
-          // every lane of the wave has a full chunk: no per-step liveness at all
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const uint64_t canon = roll_step<KFIX>(e[j], fw, rc, d, rc_shift);
-            filtered(canon, rev64_hi(canon));
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const uint64_t canon = roll_step<KFIX>(e[j], fw, rc, d, rc_shift);
-            const bool live = (uint32_t)(g * 16 + j) < cnt;
-            if (!FILTER) {
-              sketch_update(canon, d, sk, live, hsel);
-            } else {
-              // dead steps get an all-ones hash word and never pass
-              filtered(canon, live ? rev64_hi(canon) : 0xFFFFFFFFu);
-            }
+        for (int j = 0; j < 16; ++j) {
+          const uint64_t canon = roll_step<KFIX>(e[j], fw, rc, d, rc_shift);
+          const bool live = g * 16u + (uint32_t)j < cnt;
+          if (!FILTER) {
+            sketch_update(canon, d, sk, live, hsel);
+          } else {
+            // dead steps get an all-ones hash word and never pass
+            push_candidates(live ? rev64_hi(canon) : 0xFFFFFFFFu, thr, canon, top);
+            if (top >= bottom + 512u) drain64();
           }
         }
       }
     }
   }
-  if (FILTER && q_count) drain64(true);
+  if (FILTER && top != bottom) drain_rest();
 }
 
 // GROUPS 16-byte groups of hash steps per chunk: CHUNK = 16*GROUPS k-mers.
+#ifdef NQ_SKETCH_CLOCK
+__device__ unsigned long long nq_sketch_clk[2];   // shader cycles / 100 MHz ticks spent by one workgroup (tools/ubench_sketch.hip)
+__device__ unsigned long long nq_sketch_trace[3 * 8192];   // per workgroup: start, end (100 MHz ticks), hardware id
+#endif
+
 template <int BLOCK, int GROUPS, int KFIX>
 __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
   extern __shared__ __align__(16) uint32_t smem[];
+#ifdef NQ_SKETCH_CLOCK
+  const unsigned long long clk_c0 = __builtin_readcyclecounter(), clk_r0 = wall_clock64();
+#endif
   const Derived &d = a.d;
   const uint32_t Fc = d.F / a.halves;               // cells this workgroup keeps
-  uint32_t *sk = smem;                              // Fc cells
-  uint32_t *s_flag = smem + Fc;                     // 4 words
-  uint8_t *lut = (uint8_t *)(smem + Fc + 4);        // 256 bytes
-  uint32_t *aux = smem + Fc + 4 + 64;               // distinct-value tables or the filter rings
+  uint2 *lut64 = (uint2 *)(smem + kLut64Off / 4);   // 256 x {forward code, rc code << 28} (K = 31 filtered path)
+  uint8_t *lut = (uint8_t *)(smem + kLutOff / 4);   // 256 bytes
+  uint32_t *s_flag = smem + kFlagOff / 4;           // 4 words
+  uint32_t *sk = smem + kCellOff / 4;               // Fc cells
+  uint32_t *aux = sk + Fc;                          // distinct-value tables or the candidate stacks
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u32_t *)smem;   // LDS address of the layout's start
   const uint32_t tid = threadIdx.x;
   const uint32_t part = blockIdx.x % a.splits;
   const uint32_t half = (blockIdx.x / a.splits) % a.halves;
   const uint32_t entry = blockIdx.x / (a.splits * a.halves);
   const uint32_t hsel = a.halves > 1 ? half + 1u : 0u;
 
-  if (tid < 256) lut[tid] = code_entry(tid);
+  for (uint32_t i = tid; i < 256; i += BLOCK) {
+    const uint32_t e = code_entry(i);
+    lut[i] = (uint8_t)e;
+    lut64[i] = make_uint2(e & 3u, ((e >> 2) & 3u) << 28);
+  }
   if (a.accumulate) {
     const uint32_t *src = (const uint32_t *)a.sketches + (uint64_t)entry * d.F + (uint64_t)half * Fc;
     for (uint32_t i = tid; i < Fc; i += BLOCK) sk[i] = src[i];
@@ -416,8 +648,11 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
       if (T > d.max_rem || T > 16) T = 0;
       thr = T ? (1u << (32 - T)) : 0u;
     }
+    thr = __builtin_amdgcn_readfirstlane(thr);
     if (thr) {
-      roll_records<BLOCK, GROUPS, KFIX, true>(a, entry, part, sk, lut, (uint64_t *)aux, thr, hsel);
+      // the generic filtered form also serves a layout that does not start at LDS address 0
+      if (hsel || lds0 != 0) roll_records<BLOCK, GROUPS, KFIX, true, true, false>(a, entry, part, sk, lut, (uint64_t *)aux, thr, hsel);
+      else roll_records<BLOCK, GROUPS, KFIX, true, false, true>(a, entry, part, sk, lut, (uint64_t *)aux, thr, 0);
       __syncthreads();
       uint32_t local = 0;
       for (uint32_t i = tid; i < Fc; i += BLOCK) local += (sk[i] == kEmpty32);
@@ -427,9 +662,9 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
       __syncthreads();
       // a slot without a candidate may still have skipped k-mers: exact re-run.
       // (With splits > 1 another part may hold the candidates, so every part re-runs.)
-      if (s_flag[2] != 0) roll_records<BLOCK, GROUPS, KFIX, false>(a, entry, part, sk, lut, nullptr, 0, hsel);
+      if (s_flag[2] != 0) roll_records<BLOCK, GROUPS, KFIX, false, true, false>(a, entry, part, sk, lut, nullptr, 0, hsel);
     } else {
-      roll_records<BLOCK, GROUPS, KFIX, false>(a, entry, part, sk, lut, nullptr, 0, hsel);
+      roll_records<BLOCK, GROUPS, KFIX, false, true, false>(a, entry, part, sk, lut, nullptr, 0, hsel);
     }
   }
   __syncthreads();
@@ -450,6 +685,20 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
   }
   __syncthreads();
   for (uint32_t i = tid; i < d.F; i += BLOCK) out[i] = sk[i];
+#ifdef NQ_SKETCH_CLOCK
+  if (blockIdx.x == gridDim.x / 2 && tid == 0) {
+    nq_sketch_clk[0] = __builtin_readcyclecounter() - clk_c0;
+    nq_sketch_clk[1] = wall_clock64() - clk_r0;
+  }
+  if (tid == 0 && blockIdx.x < 8192) {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    nq_sketch_trace[3 * blockIdx.x] = clk_r0;
+    nq_sketch_trace[3 * blockIdx.x + 1] = wall_clock64();
+    nq_sketch_trace[3 * blockIdx.x + 2] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
 
 
@@ -681,7 +930,7 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
 }
 
 static size_t sketch_lds_bytes(const Derived &d, bool distinct, uint32_t ring_waves, uint32_t halves = 1) {
-  return (size_t)(d.F / halves) * 4 + 16 + 256 + (distinct ? (size_t)d.R * 12 : 0) + (size_t)ring_waves * kRingAlloc * 8;
+  return (size_t)(d.F / halves) * 4 + 16 + 256 + 2048 + (distinct ? (size_t)d.R * 12 : 0) + (size_t)ring_waves * kStack * 8;
 }
 constexpr size_t kLdsLimit = 160 * 1024;
 
