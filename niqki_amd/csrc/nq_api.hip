@@ -1685,7 +1685,7 @@ int niqki_synth_reads(niqki_index *ix, uint64_t seed, const uint32_t *family, co
 }
 
 int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate) {
-  if (!ix || !rate || what < 0 || what > 2 || !(ms > 0)) return NIQKI_E_INVALID;
+  if (!ix || !rate || what < 0 || what > 3 || !(ms > 0)) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
   int rc = ensure(ix, ix->ws_misc, 256);
   if (rc) return rc;

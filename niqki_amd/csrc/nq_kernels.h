@@ -219,7 +219,8 @@ hipError_t launch_synth_reads(uint64_t seed, const uint32_t *family, const uint3
 // ---- integer-ALU ceiling probes (nq_sketch.hip; measurement support) ----------------------------
 // what = 0: independent 32-bit adds; 1: 32-bit multiplies (v_mul_lo_u32); 2: the sketch kernel's
 // per-k-mer arithmetic alone (roll, canonical choice, high word of the filter hash, K = 31) with no
-// LDS, memory or compaction.  *units = adds / multiplies / k-mers executed; timed by the caller.
+// LDS, memory or compaction; 3: v_lshl_add_u32 (the issue class of most vector opcodes).
+// *units = adds / multiplies / k-mers / instructions executed; timed by the caller.
 hipError_t launch_alu_probe(int what, uint32_t iters, uint32_t *sink, uint64_t *units, hipStream_t stream);
 
 }  // namespace nq

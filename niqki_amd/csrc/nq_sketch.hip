@@ -1054,21 +1054,38 @@ template <int WHAT>
 __global__ __launch_bounds__(1024) void alu_probe_kernel(uint32_t iters, uint32_t *sink) {
   const uint32_t t = blockIdx.x * 1024u + threadIdx.x;
   if (WHAT == 2) {
-    // the long-record path's arithmetic per k-mer: rolling update of both words, canonical choice,
-    // high word of revhash64 and the filter compare (roll_step<31> + rev64_hi), 16 k-mers per round
-    Derived d{};
+    // the long-record path's arithmetic per k-mer as the kernel does it (K = 31): rolling update of both
+    // words from pre-placed codes, canonical choice, high word of revhash64 as v_mad_u64_u32 chains and
+    // the filter compare; 16 k-mers per round
     uint64_t fw = t * 0x9E3779B97F4A7C15ULL, rc = ~fw;
     fw &= (1ULL << 62) - 1; rc &= (1ULL << 62) - 1;
     uint32_t e = t * 2654435761u, pass = 0;
     for (uint32_t i = 0; i < iters; ++i) {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        const uint64_t canon = roll_step<31>((e >> (2 * j)) & 15u, fw, rc, d, 60);
-        pass += rev64_hi(canon) < (1u << 29);
+        const uint32_t c = (e >> (2 * j)) & 3u;
+        fw = shl2_64(fw);
+        fw = (fw | c) & ((1ULL << 62) - 1ULL);
+        rc = shr2_64(rc) | ((uint64_t)((3u - c) << 28) << 32);
+        const uint64_t canon = fw < rc ? fw : rc;
+        pass += rev64_hi_mad(canon) < (1u << 29);
       }
       e = e * 1664525u + 1013904223u;
     }
     if (pass == 0xFFFFFFFFu) sink[0] = pass;
+  } else if (WHAT == 3) {
+    // a three-operand integer instruction (v_lshl_add_u32): the issue rate of every vector opcode outside the
+    // add / sub / and / or / xor / mov / shift-right class on gfx950 (profiles/r03_opcode_costs.txt)
+    uint32_t a0 = t, a1 = t * 3 + 1, a2 = t ^ 0x1234567, a3 = t + 77, a4 = t * 5, a5 = ~t, a6 = t + 9, a7 = t * 7;
+    for (uint32_t i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a0 = (a0 << 3) + a1; a1 = (a1 << 3) + a2; a2 = (a2 << 3) + a3; a3 = (a3 << 3) + a4;
+        a4 = (a4 << 3) + a5; a5 = (a5 << 3) + a6; a6 = (a6 << 3) + a7; a7 = (a7 << 3) + a0;
+      }
+    }
+    const uint32_t x = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    if (x == 0x12345u) sink[0] = x;
   } else {
     uint32_t a0 = t, a1 = t * 3 + 1, a2 = t ^ 0x1234567, a3 = t + 77, a4 = t * 5, a5 = ~t, a6 = t + 9, a7 = t * 7;
     for (uint32_t i = 0; i < iters; ++i) {
@@ -1089,6 +1106,7 @@ hipError_t launch_alu_probe(int what, uint32_t iters, uint32_t *sink, uint64_t *
   if (what == 0) { hipLaunchKernelGGL(alu_probe_kernel<0>, dim3(blocks), dim3(1024), 0, stream, iters, sink); *units = threads * iters * 64; }
   else if (what == 1) { hipLaunchKernelGGL(alu_probe_kernel<1>, dim3(blocks), dim3(1024), 0, stream, iters, sink); *units = threads * iters * 64; }
   else if (what == 2) { hipLaunchKernelGGL(alu_probe_kernel<2>, dim3(blocks), dim3(1024), 0, stream, iters, sink); *units = threads * iters * 16; }
+  else if (what == 3) { hipLaunchKernelGGL(alu_probe_kernel<3>, dim3(blocks), dim3(1024), 0, stream, iters, sink); *units = threads * iters * 64; }
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
