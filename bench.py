@@ -139,6 +139,13 @@ def main():
                     help="do not measure the gather path's HBM traffic with rocprofv3 --pmc passes before the run "
                          "(roofline.traffic then comes from profiles/gather_traffic.json)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--transport", default=os.environ.get("NIQKI_GROUP_TRANSPORT", "auto"),
+                    help="exchange transport for N > 1: auto (rccl; ipc when the ranks share devices) | rccl | ipc "
+                         "(direct peer access through HIP IPC handles, include/niqki_hip.h)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: do not run the next batch's sketch kernel beside the exchange of the current one")
+    ap.add_argument("--verify", action="store_true",
+                    help="N > 1, small indexes: every rank checks the hit lists of its last step against a whole-range handle")
     args = ap.parse_args()
     if args.pmc_child:
         args.no_cpu = args.no_extra = args.no_pmc = True
@@ -167,17 +174,31 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ranks that share a device (more ranks than GPUs: a one-GPU box rehearsing N > 1): RCCL refuses that,
+    # the library's ipc transport does not; torch.distributed then runs over gloo
+    n_dev = max(1, torch.cuda.device_count())
+    shared = world > n_dev
+    transport = args.transport if args.transport != "auto" else ("ipc" if shared else "rccl")
+    if transport == "ipc":
+        os.environ["NIQKI_GROUP_TRANSPORT"] = "ipc"
+    else:
+        os.environ.pop("NIQKI_GROUP_TRANSPORT", None)
+    local_dev = local_rank % n_dev
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     # NIQKI_FORCE_DIST=1 runs the sharded (collective) code path even on one rank
     use_dist = world > 1 or os.environ.get("NIQKI_FORCE_DIST") == "1"
     emu = args.shard_of if (args.shard_of > 1 and not use_dist) else 0
+    on_gloo = use_dist and shared
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if on_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     K, S, W, H, J = 31, 15, 12, 4, 0.1
     F = 1 << S
@@ -185,7 +206,7 @@ def main():
     n_fam = max(1, N // args.family)
     G = emu if emu else world                  # shards the index is cut into
     sb, se = niqki_amd.group_slot_range(0 if emu else rank, G, S)
-    eng = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_rank, slot_begin=sb, slot_end=se)
+    eng = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev, slot_begin=sb, slot_end=se)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_option("record_len_hint", L)
     stride_b = L  # records are stored back to back; NIQKI_SEQ_PAD bytes follow the last one
@@ -259,8 +280,42 @@ def main():
         ncand = torch.zeros(nq_all, dtype=torch.int32, device=dev)
     eng.synchronize()
 
+    # N > 1: batch i's exchange (slices, candidate lists, sums: the GPU mostly waits for its peers) runs
+    # beside batch i+1's sketch kernel: a second handle sketches on a side stream, niqki_group_query_begin
+    # returns without waiting, niqki_group_query_end is the step's one host wait.
+    overlap = use_dist and not args.no_overlap
+    if overlap:
+        sk_eng = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev)
+        side = torch.cuda.Stream(device=dev)
+        sk_eng.set_stream(side.cuda_stream)
+        sk_eng.set_option("record_len_hint", L)
+        ev_sk = [torch.cuda.Event() for _ in range(n_batches)]      # sketches of ring slot b are complete
+        ev_used = [torch.cuda.Event() for _ in range(n_batches)]    # ... have been consumed by their batch
+        sketched = [-1] * n_batches                                   # step whose sketches slot b holds
+
+        def sketch_ahead(sj):
+            bj = sj % n_batches
+            # (the last timed step sketches one batch beyond the run, as the first one found its own
+            # batch sketched by the warm-up: K sketch launches inside the K timed steps)
+            if sj > n_steps_all or sketched[bj] == sj:
+                return
+            with torch.cuda.stream(side):
+                if sketched[bj] >= 0:
+                    side.wait_event(ev_used[bj])
+                sk_eng.sketch_dev(qseq[bj * per * stride_b:], d_ro, per, qsk[bj])
+                ev_sk[bj].record(side)
+            sketched[bj] = sj
+
     def step(si):
         bi = si % n_batches
+        if overlap:
+            sketch_ahead(si)                       # (only the first step finds its batch not sketched yet)
+            torch.cuda.current_stream().wait_event(ev_sk[bi])
+            sq.begin(qsk[bi], hit_off[si], hc, hg, cap)
+            ev_used[bi].record(torch.cuda.current_stream())
+            sketch_ahead(si + 1)
+            sq.end()
+            return
         eng.sketch_dev(qseq[bi * per * stride_b:], d_ro, per, qsk[bi])
         if use_dist:
             sq.step(qsk[bi], hit_off[si], hc, hg, cap)
@@ -283,6 +338,9 @@ def main():
     torch.cuda.synchronize()
     eng.profile(True)
     eng.profile_reset()
+    if overlap:
+        sk_eng.profile(True)
+        sk_eng.profile_reset()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -293,13 +351,44 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if on_gloo else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     prof = {name: eng.profile_read(kc) for name, kc in (
         ("sketch", niqki_amd.KC_SKETCH), ("densify", niqki_amd.KC_DENSIFY), ("gather", niqki_amd.KC_GATHER),
         ("hits", niqki_amd.KC_HITS), ("exchange", niqki_amd.KC_EXCHANGE))}
     eng.profile(False)
+    if overlap:
+        prof["sketch"] = sk_eng.profile_read(niqki_amd.KC_SKETCH)
+        sk_eng.profile(False)
+
+    # --verify (N > 1, small indexes): this rank's hit lists of the last timed step against a whole-range
+    # handle that holds every genome of the index
+    verify = None
+    if args.verify and use_dist and N <= 20000:
+        ref = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev)
+        ref.set_stream(torch.cuda.current_stream().cuda_stream)
+        ref.set_option("record_len_hint", L)
+        vseq = torch.zeros(GB * stride_b + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
+        vsk = torch.full((GB, F), -1, dtype=torch.int32, device=dev)
+        for g0 in range(0, N, GB):
+            n = min(GB, N - g0)
+            fam, mem, rate = genome_spec(np.arange(g0, g0 + n), n_fam, args.family)
+            ref.synth_dev(args.seed, dev_u32(fam), dev_u32(mem), dev_u32(rate), n, L, stride_b, vseq)
+            ref.sketch_dev(vseq, rec_offsets(n), n, vsk)
+            ref.insert_dev(vsk, n)
+        si = n_steps_all - 1
+        r_off = torch.zeros(per + 1, dtype=torch.int64, device=dev)
+        r_hc, r_hg = torch.zeros(cap, dtype=torch.int32, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
+        ref.query_dev(qsk[si % n_batches], per, r_off, r_hc, r_hg, cap)
+        ref.synchronize()
+        nh = int(r_off[per].item())
+        same = bool(torch.equal(r_off, hit_off[si]) and torch.equal(r_hc[:nh], hc[:nh]) and torch.equal(r_hg[:nh], hg[:nh]))
+        ok = torch.tensor([1 if same else 0], dtype=torch.int32, device="cpu" if on_gloo else dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        verify = {"hit_lists_equal_whole_range_handle": bool(ok.item()), "queries_per_rank": per, "hits_rank0": nh}
+        ref.close()
+        del vseq, vsk
 
     # ---- roofline of the gather kernel: algorithmic bytes 4T + 20F per query ----
     f_local = se - sb
@@ -307,8 +396,13 @@ def main():
     for si in range(args.warmup, n_steps_all):
         bi = si % n_batches
         if use_dist:   # measurement only: whole sketches of every rank, this shard's slots are what counts
-            full = torch.empty((world * per, F), dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(full.view(-1), qsk[bi].reshape(-1))
+            if on_gloo:
+                fc = torch.empty((world * per, F), dtype=torch.int32)
+                dist.all_gather_into_tensor(fc.view(-1), qsk[bi].reshape(-1).cpu())
+                full = fc.to(dev)
+            else:
+                full = torch.empty((world * per, F), dtype=torch.int32, device=dev)
+                dist.all_gather_into_tensor(full.view(-1), qsk[bi].reshape(-1))
             T += int(eng.gathered_dev(full, world * per).sum())
         else:
             T += int(eng.gathered_dev(allsk[bi] if emu else qsk[bi], nq_gather).sum())
@@ -388,8 +482,11 @@ def main():
                             "%d query genomes per step resident in HBM, K=31 S=15 W=12 H=4 J=0.1"
                             % (N, L, args.family, nq_all),
                 "index_genomes": N, "query_batch": nq_all, "genome_len": L,
-                "parallelism": ("slot-shard x%d (%s exchange, RCCL inside libniqki_hip.so)" % (world, sq.exchange)) if use_dist
+                "parallelism": ("slot-shard x%d (%s exchange, %s transport inside libniqki_hip.so%s)"
+                                % (world, sq.exchange, sq.transport, ", next batch sketched beside the exchange" if overlap else "")) if use_dist
                 else ("1 GPU as rank 0 of a %d-way slot shard" % emu if emu else "1 GPU"),
+                "transport": sq.transport if use_dist else None,
+                "ranks_share_devices": bool(shared) if use_dist else None,
                 "exchange_redone_densely": sq.overflows if use_dist else 0,
                 "exchange_bytes_per_rank_per_step": xbytes,
                 "exchange_avg_gbs_per_rank": (xbytes / (dt / args.steps) / 1e9) if xbytes else None,
@@ -429,9 +526,13 @@ def main():
             }
         if extra is not None:
             out["extra_workloads"] = extra
+        if verify is not None:
+            out["verify"] = verify
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         sq.close()
+    if overlap:
+        sk_eng.close()
     eng.close()
     if use_dist:
         dist.destroy_process_group()

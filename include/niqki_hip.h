@@ -361,6 +361,12 @@ int niqki_query_gathered(niqki_index *ix, const int32_t *sketches, uint32_t nq,
  * genome is a sum over slots, so a batch needs one exchange of partial results,
  * done with RCCL over xGMI inside the library (librccl is loaded when the first
  * group is made).  Results are exactly those of one whole-range handle.
+ * NIQKI_GROUP_TRANSPORT=ipc (environment, read by niqki_group_create and
+ * niqki_group_new_id; one rank per process) replaces RCCL by direct peer access: every
+ * rank maps its peers' exchange buffers through HIP IPC handles and pulls its part with
+ * copy / summing kernels, ordered by sequence words in device memory -- a direct
+ * all-to-all over all xGMI links, no host synchronisation inside a step, and ranks may
+ * share a device (which RCCL refuses).
  *
  * A niqki_group is the set of ranks that live in the calling process:
  *   - one rank per process (n_local = 1, first_rank = this process' rank; `id` made
@@ -390,6 +396,7 @@ const char *niqki_group_last_error(const niqki_group *g);
  * overflow is redone densely, never answered wrongly). */
 int niqki_group_set_option(niqki_group *g, const char *key, int64_t value);
 /* "overflows" (sparse steps redone densely so far), "rccl" (1 = RCCL transport),
+ * "transport" (0 = device copies inside one process, 1 = RCCL, 2 = ipc),
  * "sparse" (1 = the sparse exchange is selected). */
 int niqki_group_get_stat(const niqki_group *g, const char *key, uint64_t *value);
 /* Index::insert_sketch for a batch of world * per sketches of which rank r holds rows
@@ -403,6 +410,19 @@ int niqki_group_insert(niqki_group *g, const int32_t *const *local_sketches, uin
 int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint32_t per,
                       uint64_t *const *hit_off, uint32_t *const *hit_counts,
                       uint32_t *const *hit_gids, uint64_t capacity, int mem);
+/* The same in two halves.  _begin enqueues the whole batch on the shards' streams (slice
+ * exchange, gather, sparse or dense sum, threshold + order into the caller's device buffers)
+ * and returns without waiting for the device: the caller can enqueue other work -- the sketch
+ * kernel of the next batch on another handle's stream -- that then runs beside the exchange.
+ * _end is the one place the host waits: it checks the batch's candidate-overflow word (a
+ * sparse batch whose lists overflowed is redone densely here), copies host results out
+ * (NIQKI_MEM_HOST) and reports a peer that never answered (ipc transport).  One batch in
+ * flight per group; the argument arrays of _begin may go away after it returns, the buffers
+ * they point to must stay until _end.  niqki_group_query = _begin + _end. */
+int niqki_group_query_begin(niqki_group *g, const int32_t *const *local_sketches, uint32_t per,
+                            uint64_t *const *hit_off, uint32_t *const *hit_counts,
+                            uint32_t *const *hit_gids, uint64_t capacity, int mem);
+int niqki_group_query_end(niqki_group *g);
 
 /* The two calls above on the shards' STAGED batches (niqki_stage_raw on each shard handle --
  * how the `niqki` host program feeds a multi-GPU index from files; all ranks in one process):

@@ -111,6 +111,8 @@ ABI = [
     ("niqki_group_get_stat", _int, [_vp, C.c_char_p, C.POINTER(_u64)]),
     ("niqki_group_insert", _int, [_vp, _vp, _u32, _u32]),
     ("niqki_group_query", _int, [_vp, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_group_query_begin", _int, [_vp, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_group_query_end", _int, [_vp]),
     ("niqki_group_staged_insert", _int, [_vp, _u32, _vp]),
     ("niqki_group_staged_query", _int, [_vp, _u32, _vp, _vp, _vp, _vp, _u64, _int]),
     ("niqki_get_stat", _int, [_vp, C.c_char_p, C.POINTER(_u64)]),
@@ -583,6 +585,14 @@ class Group:
         """Per-rank device outputs (torch tensors / addresses): hit_off[i] int64 [per+1]."""
         self._ck(self.L.niqki_group_query(self.g, self._ptrs(local_sketches), per, self._ptrs(hit_off),
                                           self._ptrs(hit_counts), self._ptrs(hit_gids), capacity, MEM_DEVICE))
+
+    def query_begin_dev(self, local_sketches, per, hit_off, hit_counts, hit_gids, capacity):
+        """niqki_group_query_begin with device outputs: returns without waiting for the device."""
+        self._ck(self.L.niqki_group_query_begin(self.g, self._ptrs(local_sketches), per, self._ptrs(hit_off),
+                                                self._ptrs(hit_counts), self._ptrs(hit_gids), capacity, MEM_DEVICE))
+
+    def query_end(self):
+        self._ck(self.L.niqki_group_query_end(self.g))
 
     def query(self, local_sketches, per, capacity=None):
         """Device sketches in, numpy hits out: list of (off, counts, gids) per local rank."""

@@ -47,22 +47,45 @@ hipEvent_t get_event(niqki_index *ix) {
     return e;
   }
   hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
+  if (hipEventCreate(&e) != hipSuccess) {
+    (void)hipGetLastError();   // a span that cannot be timed is dropped, the error must not stick
+    return nullptr;
+  }
   return e;
 }
 
+// The events belong to the handle's device: a caller that walks several shards (nq_group.hip) may
+// have another one current.
 Span::Span(niqki_index *ix_, int kc_) : ix(ix_), kc(kc_) {
-  if (ix->prof) {
-    a = get_event(ix);
-    b = get_event(ix);
-    (void)hipEventRecord(a, ix->stream);
+  if (!ix->prof) return;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || (cur != ix->device && hipSetDevice(ix->device) != hipSuccess)) {
+    (void)hipGetLastError();
+    return;
   }
+  a = get_event(ix);
+  b = get_event(ix);
+  if (!a || !b || hipEventRecord(a, ix->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    if (a) ix->ev_pool.push_back(a);
+    if (b) ix->ev_pool.push_back(b);
+    a = b = nullptr;
+  }
+  if (cur != ix->device) (void)hipSetDevice(cur);
 }
 Span::~Span() {
-  if (ix->prof && a && b) {
-    (void)hipEventRecord(b, ix->stream);
+  if (!ix->prof || !a || !b) return;
+  int cur = -1;
+  (void)hipGetDevice(&cur);
+  if (cur != ix->device) (void)hipSetDevice(ix->device);
+  if (hipEventRecord(b, ix->stream) == hipSuccess) {
     ix->spans.push_back({kc, a, b});
+  } else {
+    (void)hipGetLastError();
+    ix->ev_pool.push_back(a);
+    ix->ev_pool.push_back(b);
   }
+  if (cur != ix->device && cur >= 0) (void)hipSetDevice(cur);
 }
 
 int collect_spans(niqki_index *ix) {

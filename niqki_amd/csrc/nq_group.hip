@@ -18,17 +18,32 @@
 //                overflows its capacity makes every rank redo the step densely.
 //   5. every rank thresholds + orders the hits of its own `per` queries          hits_* kernels
 //
-// Transport: RCCL (librccl, loaded on first use) -- one communicator per local rank, so the same
-// code serves one rank per process (bench.py under torch.distributed.run) and all ranks in one
-// process (`niqki --gpus N`).  When two shards of a single-process group share a device (tests,
-// emulation of G shards on one GPU), which RCCL refuses, plain device-to-device copies and a
-// summing kernel stand in for the collectives.
+// Transports:
+//   rccl   librccl, loaded on first use -- one communicator per local rank, so the same code serves one
+//          rank per process (bench.py under torch.distributed.run) and all ranks in one process
+//          (`niqki --gpus N`).
+//   local  all ranks in one process and two shards share a device (tests, emulation of G shards on one
+//          GPU), which RCCL refuses: plain device-to-device copies and a summing kernel stand in for
+//          the collectives.
+//   ipc    NIQKI_GROUP_TRANSPORT=ipc, one rank per process: every rank maps its peers' exchange buffers
+//          (hipIpcGetMemHandle / hipIpcOpenMemHandle, handles passed through a POSIX shared-memory block
+//          named by the group id) and PULLS what it needs with a copy or summing kernel -- over xGMI
+//          that is a direct all-to-all on all links instead of a ring.  Ordering is by sequence numbers in
+//          device memory: tiny signal / wait kernels on the ranks' streams, no host synchronisation in a
+//          step.  Ranks may share a device (how the N > 1 path runs on a one-GPU box).
 #include "nq_handle.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -84,6 +99,23 @@ Rccl &rccl() {
 
 constexpr uint32_t kMaxWorld = 64;
 
+// ---- ipc transport: the block the processes of a group share ------------------------------------
+constexpr uint32_t kIpcBufs = 4;      // exchange buffers a rank exposes: send (slices), cand, mine, counts
+constexpr uint32_t kIpcMagic = 0x4E514950u;
+struct IpcRank {
+  hipIpcMemHandle_t flags;            // the rank's sequence words (below)
+  hipIpcMemHandle_t buf[kIpcBufs];
+  uint64_t gen[kIpcBufs];             // bumped when buf[i] names a new allocation
+  int32_t device;
+};
+struct IpcShared {
+  std::atomic<uint32_t> init, bar_count, bar_gen, abort;
+  IpcRank r[kMaxWorld];
+};
+// sequence words of a rank (device memory, mapped by every peer): ready[b] = uses of buffer b whose data
+// is complete, done[b] = uses whose data this rank has finished reading from ALL peers, err = a wait timed out
+constexpr uint32_t kFlagReady = 0, kFlagDone = kIpcBufs, kFlagErr = 2 * kIpcBufs, kFlagWords = 64;
+
 }  // namespace
 
 namespace nq {
@@ -94,12 +126,13 @@ __host__ __device__ inline uint32_t cut(uint32_t F, uint32_t r, uint32_t G) { re
 
 // [per][F] int32 sketches -> [G][per][w_max] int16 slices (slot slice of destination g; cells that
 // are empty or outside [0, R) -- never indexed or queried, src/niqki_index.cpp:364,:654 -- travel as -1)
+// (dst_stride: int16 cells between two destinations' parts, >= per * w_max)
 __global__ __launch_bounds__(256) void slice_pack_kernel(const int32_t *sk, uint32_t per, uint32_t F, uint32_t R, uint32_t G,
-                                                        uint32_t w_max, int16_t *out) {
+                                                        uint32_t w_max, int16_t *out, uint64_t dst_stride) {
   const uint32_t q = blockIdx.x, g = blockIdx.y;
   const uint32_t b = cut(F, g, G), w = cut(F, g + 1, G) - b;
   const int32_t *row = sk + (uint64_t)q * F + b;
-  int16_t *dst = out + ((uint64_t)g * per + q) * w_max;
+  int16_t *dst = out + (uint64_t)g * dst_stride + (uint64_t)q * w_max;
   for (uint32_t j = threadIdx.x; j < w_max; j += 256) {
     int32_t x = j < w ? row[j] : -1;
     dst[j] = (x >= 0 && (uint32_t)x < R) ? (int16_t)x : (int16_t)-1;
@@ -107,9 +140,12 @@ __global__ __launch_bounds__(256) void slice_pack_kernel(const int32_t *sk, uint
 }
 
 // [nq][w_max] int16 slices of MY slots -> [nq][f_local] int32 sketch rows for the query kernels
-__global__ __launch_bounds__(256) void slice_unpack_kernel(const int16_t *in, uint32_t w_max, uint32_t f_local, int32_t *out) {
+// (row q = source rank q / per, its query q % per; src_stride: int16 cells between two sources' parts)
+__global__ __launch_bounds__(256) void slice_unpack_kernel(const int16_t *in, uint32_t w_max, uint32_t f_local, int32_t *out, uint32_t per,
+                                                          uint64_t src_stride) {
   const uint32_t q = blockIdx.x;
-  for (uint32_t j = threadIdx.x; j < f_local; j += 256) out[(uint64_t)q * f_local + j] = in[(uint64_t)q * w_max + j];
+  const int16_t *src = in + (uint64_t)(q / per) * src_stride + (uint64_t)(q % per) * w_max;
+  for (uint32_t j = threadIdx.x; j < f_local; j += 256) out[(uint64_t)q * f_local + j] = src[j];
 }
 
 // A rank's candidates travel as one blob: nq lists of C ids, then the nq list sizes (one all-gather).
@@ -119,11 +155,12 @@ __host__ __device__ inline uint64_t cand_blob_ints(uint32_t nq, uint32_t C) { re
 // list has no entry), as u16: the cross-shard sums stay <= F <= 2^15, so the ranks add them as packed
 // pairs in u32 words without a carry (half the bytes of the reduce-scatter); flag |= some list
 // overflowed its capacity
+// (blob: ints between two ranks' candidate blobs in cand_all, >= cand_blob_ints)
 __global__ __launch_bounds__(256) void cand_lookup_kernel(const uint16_t *counts, uint64_t stride, uint32_t nq, uint32_t G,
-                                                         uint32_t C, const int32_t *cand_all, uint16_t *mine, uint32_t *flag) {
+                                                         uint32_t C, const int32_t *cand_all, uint64_t blob, uint16_t *mine,
+                                                         uint32_t *flag) {
   const uint32_t q = blockIdx.x;
   const uint16_t *row = counts + (uint64_t)q * stride;
-  const uint64_t blob = cand_blob_ints(nq, C);
   for (uint32_t i = threadIdx.x; i < G * C; i += 256) {
     const uint32_t g = i / C, c = i % C;
     const int32_t id = cand_all[g * blob + (uint64_t)q * C + c];
@@ -134,15 +171,47 @@ __global__ __launch_bounds__(256) void cand_lookup_kernel(const uint16_t *counts
 
 // summed candidate counts into the (zeroed) counter rows of this rank's own queries
 __global__ __launch_bounds__(256) void cand_scatter_kernel(const uint16_t *tot, uint32_t per, uint32_t first_q, uint32_t nq,
-                                                          uint32_t G, uint32_t C, const int32_t *cand_all, uint16_t *red,
-                                                          uint64_t stride) {
+                                                          uint32_t G, uint32_t C, const int32_t *cand_all, uint64_t blob,
+                                                          uint16_t *red, uint64_t stride) {
   const uint32_t ql = blockIdx.x, q = first_q + ql;
-  const uint64_t blob = cand_blob_ints(nq, C);
   for (uint32_t i = threadIdx.x; i < G * C; i += 256) {
     const uint32_t g = i / C, c = i % C;
     const int32_t id = cand_all[g * blob + (uint64_t)q * C + c];
     if (id >= 0) red[(uint64_t)ql * stride + id] = tot[(uint64_t)ql * G * C + i];  // duplicates write the same sum
   }
+}
+
+// ---- ipc transport kernels ------------------------------------------------------------------------
+struct FlagPtrs { uint32_t *p[kMaxWorld]; };
+struct PeerSrc { const uint8_t *p[kMaxWorld]; };
+
+// everything enqueued before on this stream is complete and visible: publish sequence number `seq`
+__global__ void ipc_signal_kernel(uint32_t *word, uint32_t seq) {
+  __threadfence_system();
+  __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// lane r waits until rank r's word has reached seq (one wave; every lane leaves after `timeout` ticks
+// of the 100 MHz clock at the latest and reports through *err)
+__global__ __launch_bounds__(64) void ipc_wait_kernel(FlagPtrs f, uint32_t world, uint32_t word, uint32_t seq, uint32_t *err,
+                                                     unsigned long long timeout) {
+  const uint32_t r = threadIdx.x;
+  if (r >= world) return;
+  const unsigned long long t0 = wall_clock64();
+  while ((int32_t)(__hip_atomic_load(f.p[r] + word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+    if (wall_clock64() - t0 > timeout) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(32);
+  }
+}
+// dst[s * bytes ..] = src.p[s][off ..  off + bytes) for every rank s (bytes and off multiples of 16)
+__global__ __launch_bounds__(256) void ipc_pull_kernel(PeerSrc src, uint64_t off, uint64_t bytes, uint8_t *dst) {
+  const uint32_t s = blockIdx.y;
+  const uint4 *in = (const uint4 *)(src.p[s] + off);
+  uint4 *out = (uint4 *)(dst + (uint64_t)s * bytes);
+  const uint64_t n = bytes / 16, step = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += step) out[i] = in[i];
 }
 
 struct SumSrc { const uint32_t *p[kMaxWorld]; };
@@ -161,8 +230,8 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(SumSrc src, uint32_t G, u
 struct niqki_group {
   uint32_t world = 1, n_local = 1, first = 0;
   std::vector<niqki_index *> sh;     // local shards, rank first + l
-  bool use_rccl = false;
-  std::vector<ncclComm_t> comm;      // per local rank (use_rccl)
+  enum Transport { kLocal, kRccl, kIpc } transport = kLocal;
+  std::vector<ncclComm_t> comm;      // per local rank (kRccl)
   int exchange = 0;                  // 0 = choose, 1 = sparse, 2 = dense reduce-scatter
   uint32_t cand_cap = 256;
   uint64_t overflows = 0;            // sparse steps redone densely
@@ -172,6 +241,29 @@ struct niqki_group {
     hipEvent_t ev = nullptr;
   };
   std::vector<Ws> ws;
+  // ipc transport (n_local == 1)
+  struct Ipc {
+    IpcShared *shm = nullptr;
+    std::string name;
+    uint32_t *flags = nullptr;                 // my sequence words (device)
+    uint32_t *peer_flags[kMaxWorld] = {};      // every rank's, mine included
+    void *peer_buf[kMaxWorld][kIpcBufs] = {};  // mapped exchange buffers (mine: the local pointer)
+    uint64_t peer_gen[kMaxWorld][kIpcBufs] = {};
+    void *my_ptr[kIpcBufs] = {};               // what my published handles name
+    uint32_t seq[kIpcBufs] = {};               // uses of each exchange buffer so far
+  } ipc;
+  // a query batch between niqki_group_query_begin and _end
+  struct Pending {
+    bool active = false, sparse = false, host = false;
+    uint32_t per = 0, N = 0;
+    uint64_t stride = 0, capacity = 0;
+    uint64_t *const *hit_off = nullptr;
+    uint32_t *const *hit_counts = nullptr, *const *hit_gids = nullptr;
+    std::vector<uint64_t *> off_v;
+    std::vector<uint32_t *> hc_v, hg_v;
+  } pend;
+  uint32_t *host_flags = nullptr;    // pinned: {candidate overflow, ipc wait timeout} of the batch in flight
+  hipEvent_t ev_flags = nullptr;
 };
 
 namespace {
@@ -197,6 +289,190 @@ int gfail(niqki_group *g, int code, const std::string &msg) {
     if (r_ != ncclSuccess) return gfail(g, NIQKI_E_HIP, std::string(#call) + ": " + rccl().GetErrorString(r_)); \
   } while (0)
 
+// ---- ipc transport, host side ---------------------------------------------------------------------
+double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+constexpr double kIpcHostTimeout = 120.0;                       // seconds a process waits for its peers
+constexpr unsigned long long kIpcDeviceTimeout = 3000000000ull; // 30 s of the 100 MHz clock for a wait kernel
+
+// all processes of the group have arrived (sense-reversing counter in the shared block)
+int ipc_barrier(niqki_group *g) {
+  IpcShared *sh = g->ipc.shm;
+  const uint32_t gen = sh->bar_gen.load(std::memory_order_acquire);
+  if (sh->bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == g->world) {
+    sh->bar_count.store(0, std::memory_order_relaxed);
+    sh->bar_gen.fetch_add(1, std::memory_order_release);
+    return NIQKI_OK;
+  }
+  const double t0 = now_s();
+  while (sh->bar_gen.load(std::memory_order_acquire) == gen) {
+    if (sh->abort.load(std::memory_order_relaxed)) return gfail(g, NIQKI_E_STATE, "a peer process of the group gave up");
+    if (now_s() - t0 > kIpcHostTimeout) {
+      sh->abort.store(1, std::memory_order_relaxed);
+      return gfail(g, NIQKI_E_STATE, "timed out waiting for the other processes of the group");
+    }
+    usleep(50);
+  }
+  return NIQKI_OK;
+}
+
+Buf niqki_group::Ws::*const kIpcBufMember[kIpcBufs] = {&niqki_group::Ws::send, &niqki_group::Ws::cand, &niqki_group::Ws::mine,
+                                                        &niqki_group::Ws::counts};
+int ipc_buf_index(Buf niqki_group::Ws::*m) {
+  for (uint32_t i = 0; i < kIpcBufs; ++i)
+    if (kIpcBufMember[i] == m) return (int)i;
+  return -1;
+}
+
+int ipc_setup(niqki_group *g, const uint8_t *id) {
+  auto &ic = g->ipc;
+  niqki_index *ix = g->sh[0];
+  char name[64];
+  std::snprintf(name, sizeof name, "/niqki_grp_%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x%02x", id[0], id[1], id[2], id[3], id[4],
+                id[5], id[6], id[7], id[8], id[9], id[10], id[11]);
+  ic.name = name;
+  int fd = -1;
+  const double t0 = now_s();
+  if (g->first == 0) {
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0) return gfail(g, NIQKI_E_STATE, std::string("shm_open(create) failed for ") + name);
+    if (ftruncate(fd, (off_t)sizeof(IpcShared)) != 0) { close(fd); shm_unlink(name); return gfail(g, NIQKI_E_STATE, "ftruncate of the group block failed"); }
+  } else {
+    for (;;) {
+      fd = shm_open(name, O_RDWR, 0600);
+      struct stat st;
+      if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(IpcShared)) break;
+      if (fd >= 0) { close(fd); fd = -1; }
+      if (now_s() - t0 > kIpcHostTimeout) return gfail(g, NIQKI_E_STATE, "rank 0 of the group never created its shared block");
+      usleep(200);
+    }
+  }
+  void *m = mmap(nullptr, sizeof(IpcShared), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) return gfail(g, NIQKI_E_STATE, "mmap of the group block failed");
+  ic.shm = (IpcShared *)m;
+  if (g->first == 0) ic.shm->init.store(kIpcMagic, std::memory_order_release);
+  else
+    while (ic.shm->init.load(std::memory_order_acquire) != kIpcMagic) {
+      if (now_s() - t0 > kIpcHostTimeout) return gfail(g, NIQKI_E_STATE, "the group's shared block was never initialised");
+      usleep(50);
+    }
+  // my sequence words
+  NQ_GH(g, hipSetDevice(ix->device));
+  NQ_GH(g, hipMalloc((void **)&ic.flags, kFlagWords * 4));
+  NQ_GH(g, hipMemset(ic.flags, 0, kFlagWords * 4));
+  NQ_GH(g, hipDeviceSynchronize());
+  IpcRank &me = ic.shm->r[g->first];
+  NQ_GH(g, hipIpcGetMemHandle(&me.flags, ic.flags));
+  me.device = ix->device;
+  int rc = ipc_barrier(g);
+  if (rc) return rc;
+  for (uint32_t s = 0; s < g->world; ++s) {
+    if (s == g->first) { ic.peer_flags[s] = ic.flags; continue; }
+    void *q = nullptr;
+    NQ_GH(g, hipIpcOpenMemHandle(&q, ic.shm->r[s].flags, hipIpcMemLazyEnablePeerAccess));
+    ic.peer_flags[s] = (uint32_t *)q;
+  }
+  if ((rc = ipc_barrier(g))) return rc;
+  if (g->first == 0) shm_unlink(name);   // everybody has it mapped: the name can go
+  return NIQKI_OK;
+}
+
+void ipc_teardown(niqki_group *g) {
+  auto &ic = g->ipc;
+  if (!ic.shm) return;
+  for (uint32_t s = 0; s < g->world; ++s) {
+    if (s == g->first) continue;
+    for (uint32_t b = 0; b < kIpcBufs; ++b)
+      if (ic.peer_buf[s][b]) (void)hipIpcCloseMemHandle(ic.peer_buf[s][b]);
+    if (ic.peer_flags[s]) (void)hipIpcCloseMemHandle(ic.peer_flags[s]);
+  }
+  if (ic.flags) (void)hipFree(ic.flags);
+  if (g->first == 0) shm_unlink(ic.name.c_str());   // (no-op once setup has finished)
+  munmap(ic.shm, sizeof(IpcShared));
+  ic.shm = nullptr;
+}
+
+// The exchange buffers of this batch, sized BEFORE any of them is used: every rank takes the same
+// decisions (same shapes), so either nobody reallocates -- the steady state, no host traffic at all --
+// or everybody does: then all streams drain, the old mappings are closed, the new buffers made, their
+// handles published and mapped.
+int ipc_prepare(niqki_group *g, const size_t need[kIpcBufs]) {
+  auto &ic = g->ipc;
+  auto &w = g->ws[0];
+  niqki_index *ix = g->sh[0];
+  bool grow = false;
+  for (uint32_t b = 0; b < kIpcBufs; ++b) grow |= need[b] > (w.*kIpcBufMember[b]).n;
+  if (!grow) return NIQKI_OK;
+  NQ_GH(g, hipSetDevice(ix->device));
+  NQ_GH(g, hipStreamSynchronize(ix->stream));
+  int rc = ipc_barrier(g);
+  if (rc) return rc;
+  for (uint32_t b = 0; b < kIpcBufs; ++b) {
+    if (need[b] <= (w.*kIpcBufMember[b]).n) continue;
+    for (uint32_t s = 0; s < g->world; ++s)
+      if (s != g->first && ic.peer_buf[s][b]) {
+        NQ_GH(g, hipIpcCloseMemHandle(ic.peer_buf[s][b]));
+        ic.peer_buf[s][b] = nullptr;
+      }
+  }
+  if ((rc = ipc_barrier(g))) return rc;
+  IpcRank &me = ic.shm->r[g->first];
+  for (uint32_t b = 0; b < kIpcBufs; ++b) {
+    Buf &buf = w.*kIpcBufMember[b];
+    const bool grown = need[b] > buf.n;   // (a new allocation even if the allocator hands the old address back)
+    if (grown) NQ_G(g, 0, nqi::ensure(ix, buf, need[b]));
+    if (buf.p && (grown || buf.p != ic.my_ptr[b])) {
+      NQ_GH(g, hipIpcGetMemHandle(&me.buf[b], buf.p));
+      me.gen[b] += 1;
+      ic.my_ptr[b] = buf.p;
+    }
+    ic.peer_buf[g->first][b] = buf.p;
+  }
+  if ((rc = ipc_barrier(g))) return rc;
+  for (uint32_t s = 0; s < g->world; ++s) {
+    if (s == g->first) continue;
+    const IpcRank &pr = ic.shm->r[s];
+    for (uint32_t b = 0; b < kIpcBufs; ++b) {
+      if (pr.gen[b] == ic.peer_gen[s][b]) continue;
+      if (ic.peer_buf[s][b]) NQ_GH(g, hipIpcCloseMemHandle(ic.peer_buf[s][b]));
+      void *q = nullptr;
+      NQ_GH(g, hipIpcOpenMemHandle(&q, pr.buf[b], hipIpcMemLazyEnablePeerAccess));
+      ic.peer_buf[s][b] = q;
+      ic.peer_gen[s][b] = pr.gen[b];
+    }
+  }
+  return ipc_barrier(g);
+}
+
+// on my stream: wait until word `word` of every rank has reached seq
+int ipc_wait_all(niqki_group *g, uint32_t word, uint32_t seq) {
+  auto &ic = g->ipc;
+  nq::FlagPtrs f{};
+  for (uint32_t s = 0; s < g->world; ++s) f.p[s] = ic.peer_flags[s];
+  hipLaunchKernelGGL(nq::ipc_wait_kernel, dim3(1), dim3(64), 0, g->sh[0]->stream, f, g->world, word, seq, ic.flags + kFlagErr,
+                     kIpcDeviceTimeout);
+  NQ_GH(g, hipGetLastError());
+  return NIQKI_OK;
+}
+int ipc_signal(niqki_group *g, uint32_t word, uint32_t seq) {
+  hipLaunchKernelGGL(nq::ipc_signal_kernel, dim3(1), dim3(1), 0, g->sh[0]->stream, g->ipc.flags + word, seq);
+  NQ_GH(g, hipGetLastError());
+  return NIQKI_OK;
+}
+
+// Before this rank overwrites exchange buffer `m`: its previous contents have been read by everybody.
+// (A no-op on the other transports, whose collectives are ordered by their own streams / RCCL.)
+int pre_produce(niqki_group *g, Buf niqki_group::Ws::*m) {
+  if (g->transport != niqki_group::kIpc) return NIQKI_OK;
+  const int b = ipc_buf_index(m);
+  NQ_GH(g, hipSetDevice(g->sh[0]->device));
+  return ipc_wait_all(g, kFlagDone + (uint32_t)b, g->ipc.seq[b]);
+}
+
 // every local stream waits for everything enqueued so far on all local streams (local transport)
 int cross_wait(niqki_group *g) {
   for (uint32_t l = 0; l < g->n_local; ++l) {
@@ -211,9 +487,26 @@ int cross_wait(niqki_group *g) {
   return NIQKI_OK;
 }
 
-// recv[l] = [world][bytes] <- send[s] + l * bytes of every rank s
+// ipc form of the three collectives: publish my buffer, wait for everybody's, pull (copy or sum), say so
+template <typename Pull>
+int ipc_collective(niqki_group *g, Buf niqki_group::Ws::*send, Pull &&pull) {
+  auto &ic = g->ipc;
+  const int b = ipc_buf_index(send);
+  if (b < 0) return gfail(g, NIQKI_E_INVALID, "not an exchange buffer");
+  NQ_GH(g, hipSetDevice(g->sh[0]->device));
+  const uint32_t seq = ++ic.seq[b];
+  int rc = ipc_signal(g, kFlagReady + (uint32_t)b, seq);
+  if (!rc) rc = ipc_wait_all(g, kFlagReady + (uint32_t)b, seq);
+  if (rc) return rc;
+  for (uint32_t s = 0; s < g->world; ++s)
+    if (!ic.peer_buf[s][b]) return gfail(g, NIQKI_E_STATE, "a peer's exchange buffer is not mapped");
+  if ((rc = pull(b))) return rc;
+  return ipc_signal(g, kFlagDone + (uint32_t)b, seq);
+}
+
+// recv[l] = [world][bytes] <- send[s] + l * bytes of every rank s (bytes: a multiple of 16)
 int all_to_all(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::*recv, size_t bytes) {
-  if (g->use_rccl) {
+  if (g->transport == niqki_group::kRccl) {
     NQ_GN(g, rccl().GroupStart());
     for (uint32_t l = 0; l < g->n_local; ++l) {
       const char *s = (const char *)(g->ws[l].*send).p;
@@ -226,6 +519,16 @@ int all_to_all(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::
     NQ_GN(g, rccl().GroupEnd());
     return NIQKI_OK;
   }
+  if (g->transport == niqki_group::kIpc)
+    return ipc_collective(g, send, [&](int b) {
+      nq::PeerSrc src{};
+      for (uint32_t s = 0; s < g->world; ++s) src.p[s] = (const uint8_t *)g->ipc.peer_buf[s][b];
+      const uint32_t bx = (uint32_t)std::min<uint64_t>((bytes / 16 + 255) / 256, 1024);
+      hipLaunchKernelGGL(nq::ipc_pull_kernel, dim3(std::max(bx, 1u), g->world), dim3(256), 0, g->sh[0]->stream, src,
+                         (uint64_t)g->first * bytes, (uint64_t)bytes, (uint8_t *)(g->ws[0].*recv).p);
+      NQ_GH(g, hipGetLastError());
+      return (int)NIQKI_OK;
+    });
   int rc = cross_wait(g);
   if (rc) return rc;
   for (uint32_t l = 0; l < g->n_local; ++l) {
@@ -237,15 +540,25 @@ int all_to_all(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::
   return cross_wait(g);
 }
 
-// recv[l] = [world][bytes] <- send[s] of every rank s
+// recv[l] = [world][bytes] <- send[s] of every rank s (bytes: a multiple of 16)
 int all_gather(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::*recv, size_t bytes) {
-  if (g->use_rccl) {
+  if (g->transport == niqki_group::kRccl) {
     NQ_GN(g, rccl().GroupStart());
     for (uint32_t l = 0; l < g->n_local; ++l)
       NQ_GN(g, rccl().AllGather((g->ws[l].*send).p, (g->ws[l].*recv).p, bytes, ncclUint8, g->comm[l], g->sh[l]->stream));
     NQ_GN(g, rccl().GroupEnd());
     return NIQKI_OK;
   }
+  if (g->transport == niqki_group::kIpc)
+    return ipc_collective(g, send, [&](int b) {
+      nq::PeerSrc src{};
+      for (uint32_t s = 0; s < g->world; ++s) src.p[s] = (const uint8_t *)g->ipc.peer_buf[s][b];
+      const uint32_t bx = (uint32_t)std::min<uint64_t>((bytes / 16 + 255) / 256, 1024);
+      hipLaunchKernelGGL(nq::ipc_pull_kernel, dim3(std::max(bx, 1u), g->world), dim3(256), 0, g->sh[0]->stream, src, (uint64_t)0,
+                         (uint64_t)bytes, (uint8_t *)(g->ws[0].*recv).p);
+      NQ_GH(g, hipGetLastError());
+      return (int)NIQKI_OK;
+    });
   int rc = cross_wait(g);
   if (rc) return rc;
   for (uint32_t l = 0; l < g->n_local; ++l) {
@@ -259,13 +572,24 @@ int all_gather(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::
 
 // recv[l][i] = sum over ranks s of send[s][rank(l) * count + i], u32 words
 int reduce_scatter_u32(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::*recv, size_t count) {
-  if (g->use_rccl) {
+  if (g->transport == niqki_group::kRccl) {
     NQ_GN(g, rccl().GroupStart());
     for (uint32_t l = 0; l < g->n_local; ++l)
       NQ_GN(g, rccl().ReduceScatter((g->ws[l].*send).p, (g->ws[l].*recv).p, count, ncclUint32, ncclSum, g->comm[l], g->sh[l]->stream));
     NQ_GN(g, rccl().GroupEnd());
     return NIQKI_OK;
   }
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((count + 255) / 256, 8192);
+  if (g->transport == niqki_group::kIpc)
+    return ipc_collective(g, send, [&](int b) {
+      if (count == 0) return (int)NIQKI_OK;
+      nq::SumSrc src{};
+      for (uint32_t s = 0; s < g->world; ++s) src.p[s] = (const uint32_t *)g->ipc.peer_buf[s][b];
+      hipLaunchKernelGGL(nq::sum_rows_kernel, dim3(blocks), dim3(256), 0, g->sh[0]->stream, src, g->world, (uint64_t)g->first * count,
+                         (uint64_t)count, (uint32_t *)(g->ws[0].*recv).p);
+      NQ_GH(g, hipGetLastError());
+      return (int)NIQKI_OK;
+    });
   int rc = cross_wait(g);
   if (rc) return rc;
   nq::SumSrc src{};
@@ -273,7 +597,6 @@ int reduce_scatter_u32(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_gro
   for (uint32_t l = 0; l < g->n_local; ++l) {
     NQ_GH(g, hipSetDevice(g->sh[l]->device));
     if (count == 0) continue;
-    const uint32_t blocks = (uint32_t)std::min<uint64_t>((count + 255) / 256, 8192);
     hipLaunchKernelGGL(nq::sum_rows_kernel, dim3(blocks), dim3(256), 0, g->sh[l]->stream, src, g->world, (uint64_t)l * count,
                        (uint64_t)count, (uint32_t *)(g->ws[l].*recv).p);
     NQ_GH(g, hipGetLastError());
@@ -281,12 +604,18 @@ int reduce_scatter_u32(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_gro
   return cross_wait(g);
 }
 
+// bytes of one destination's slices of `per` queries (16-byte granular for the pull kernel)
+size_t slice_bytes(uint32_t per, uint32_t w_max) { return (((size_t)per * w_max * 2) + 15) & ~(size_t)15; }
+size_t blob_bytes(uint32_t nq_, uint32_t C) { return (((size_t)nq::cand_blob_ints(nq_, C) * 4) + 15) & ~(size_t)15; }
+
 // steps 1-3 shared by insert and query: local sketches -> compact rows of all world*per sketches
 // restricted to each rank's slots (ws.allsk, stride f_local)
 int exchange_slices(niqki_group *g, const int32_t *const *local_sketches, uint32_t per) {
   const uint32_t G = g->world, F = g->sh[0]->d.F, R = g->sh[0]->d.R;
   const uint32_t w_max = (F + G - 1) / G;
-  const size_t bytes = (size_t)per * w_max * 2;
+  const size_t bytes = slice_bytes(per, w_max);
+  int rc = pre_produce(g, &niqki_group::Ws::send);
+  if (rc) return rc;
   for (uint32_t l = 0; l < g->n_local; ++l) {
     niqki_index *ix = g->sh[l];
     NQ_GH(g, hipSetDevice(ix->device));
@@ -294,11 +623,13 @@ int exchange_slices(niqki_group *g, const int32_t *const *local_sketches, uint32
     NQ_G(g, l, nqi::ensure(ix, g->ws[l].recv, bytes * G));
     nqi::Span sp(ix, NIQKI_KC_EXCHANGE);
     hipLaunchKernelGGL(nq::slice_pack_kernel, dim3(per, G), dim3(256), 0, ix->stream, local_sketches[l], per, F, R, G, w_max,
-                       (int16_t *)g->ws[l].send.p);
+                       (int16_t *)g->ws[l].send.p, (uint64_t)(bytes / 2));
     NQ_GH(g, hipGetLastError());
   }
-  int rc = all_to_all(g, &niqki_group::Ws::send, &niqki_group::Ws::recv, bytes);
-  if (rc) return rc;
+  {
+    nqi::Span sp(g->sh[0], NIQKI_KC_EXCHANGE);
+    if ((rc = all_to_all(g, &niqki_group::Ws::send, &niqki_group::Ws::recv, bytes))) return rc;
+  }
   for (uint32_t l = 0; l < g->n_local; ++l) {
     niqki_index *ix = g->sh[l];
     const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
@@ -306,10 +637,26 @@ int exchange_slices(niqki_group *g, const int32_t *const *local_sketches, uint32
     NQ_G(g, l, nqi::ensure(ix, g->ws[l].allsk, (size_t)G * per * f_local * 4));
     nqi::Span sp(ix, NIQKI_KC_EXCHANGE);
     hipLaunchKernelGGL(nq::slice_unpack_kernel, dim3(G * per), dim3(256), 0, ix->stream, (const int16_t *)g->ws[l].recv.p, w_max,
-                       f_local, (int32_t *)g->ws[l].allsk.p);
+                       f_local, (int32_t *)g->ws[l].allsk.p, per, (uint64_t)(bytes / 2));
     NQ_GH(g, hipGetLastError());
   }
   return NIQKI_OK;
+}
+
+// exchange buffer sizes of a batch (ipc: made before the first of them is used)
+int prepare_batch(niqki_group *g, uint32_t per, uint32_t N, bool query, bool sparse) {
+  if (g->transport != niqki_group::kIpc) return NIQKI_OK;
+  const uint32_t G = g->world, F = g->sh[0]->d.F, nq_ = G * per, C = g->cand_cap;
+  const uint64_t stride = NIQKI_ROW_STRIDE(N);
+  size_t need[kIpcBufs] = {slice_bytes(per, (F + G - 1) / G) * G, 0, 0, 0};
+  if (query) {
+    if (sparse) {
+      need[1] = blob_bytes(nq_, C);
+      need[2] = (size_t)nq_ * G * C * 2;
+    }
+    need[3] = std::max<size_t>((size_t)nq_ * stride * 2, 4);
+  }
+  return ipc_prepare(g, need);
 }
 
 }  // namespace
@@ -324,8 +671,15 @@ void niqki_group_slot_range(uint32_t rank, uint32_t world, uint32_t S, uint32_t 
 
 int niqki_group_new_id(uint8_t id[NIQKI_GROUP_ID_BYTES]) {
   if (!id) return NIQKI_E_INVALID;
-  if (!rccl().load()) return NIQKI_E_STATE;
   static_assert(NIQKI_GROUP_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "group id is an ncclUniqueId");
+  const char *t = std::getenv("NIQKI_GROUP_TRANSPORT");
+  if (t && !std::strcmp(t, "ipc")) {   // no RCCL involved: 128 random bytes name the group
+    FILE *f = std::fopen("/dev/urandom", "rb");
+    const bool ok = f && std::fread(id, 1, NIQKI_GROUP_ID_BYTES, f) == NIQKI_GROUP_ID_BYTES;
+    if (f) std::fclose(f);
+    return ok ? NIQKI_OK : NIQKI_E_STATE;
+  }
+  if (!rccl().load()) return NIQKI_E_STATE;
   ncclUniqueId u;
   if (rccl().GetUniqueId(&u) != ncclSuccess) return NIQKI_E_HIP;
   std::memcpy(id, &u, NIQKI_GROUP_ID_BYTES);
@@ -363,14 +717,24 @@ int niqki_group_create(niqki_index *const *shards, uint32_t n_local, uint32_t fi
       return bail(NIQKI_E_INVALID, "the shards of a group must agree in K, W, min_score and genome count");
     for (uint32_t m = 0; m < l; ++m) shared_device |= shards[m]->device == ix->device;
   }
-  if (const char *t = std::getenv("NIQKI_GROUP_TRANSPORT")) shared_device |= !std::strcmp(t, "local");
-  g->use_rccl = !(n_local == world && shared_device);
-  if (shared_device && n_local != world) return bail(NIQKI_E_INVALID, "shards that share a device need all ranks in one process");
+  const char *tenv = std::getenv("NIQKI_GROUP_TRANSPORT");
+  const bool want_ipc = tenv && !std::strcmp(tenv, "ipc"), want_local = tenv && !std::strcmp(tenv, "local");
+  if (want_ipc && n_local == 1 && world > 1) g->transport = niqki_group::kIpc;
+  else if (n_local == world && (shared_device || want_local || want_ipc)) g->transport = niqki_group::kLocal;
+  else g->transport = niqki_group::kRccl;
+  if (g->transport != niqki_group::kIpc && shared_device && n_local != world)
+    return bail(NIQKI_E_INVALID, "shards that share a device need all ranks in one process (or NIQKI_GROUP_TRANSPORT=ipc)");
+  if (g->transport == niqki_group::kIpc && n_local != 1)
+    return bail(NIQKI_E_INVALID, "the ipc transport wants one rank per process (or all ranks in one: local)");
   for (uint32_t l = 0; l < n_local; ++l) {
     if (hipSetDevice(shards[l]->device) != hipSuccess || hipEventCreateWithFlags(&g->ws[l].ev, hipEventDisableTiming) != hipSuccess)
       return bail(NIQKI_E_HIP, "hipEventCreate failed");
   }
-  if (g->use_rccl) {
+  if (hipSetDevice(shards[0]->device) != hipSuccess || hipHostMalloc((void **)&g->host_flags, 64, hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&g->ev_flags, hipEventDisableTiming) != hipSuccess)
+    return bail(NIQKI_E_HIP, "pinned flag words / event could not be made");
+  g->host_flags[0] = g->host_flags[1] = 0;
+  if (g->transport == niqki_group::kRccl) {
     if (!rccl().load()) return bail(NIQKI_E_STATE, rccl().why);
     ncclUniqueId u;
     if (id) std::memcpy(&u, id, NIQKI_GROUP_ID_BYTES);
@@ -385,6 +749,10 @@ int niqki_group_create(niqki_index *const *shards, uint32_t n_local, uint32_t fi
     const ncclResult_t r2 = rccl().GroupEnd();
     if (r != ncclSuccess || r2 != ncclSuccess)
       return bail(NIQKI_E_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r != ncclSuccess ? r : r2));
+  } else if (g->transport == niqki_group::kIpc) {
+    if (!id) return bail(NIQKI_E_INVALID, "a group spanning several processes needs the id of niqki_group_new_id");
+    const int rc = ipc_setup(g, id);
+    if (rc) return bail(rc, g->err);
   }
   *out = g;
   return NIQKI_OK;
@@ -397,6 +765,12 @@ void niqki_group_destroy(niqki_group *g) {
       (void)hipSetDevice(g->sh[l]->device);
       (void)hipStreamSynchronize(g->sh[l]->stream);
     }
+  }
+  if (g->transport == niqki_group::kIpc && g->ipc.shm) {
+    (void)ipc_barrier(g);   // nobody still reads my buffers (best effort: a dead peer only costs the timeout)
+    ipc_teardown(g);
+  }
+  for (uint32_t l = 0; l < g->n_local && l < g->ws.size(); ++l) {
     auto &w = g->ws[l];
     for (Buf *b : {&w.send, &w.recv, &w.allsk, &w.counts, &w.cand, &w.cand_all, &w.mine, &w.tot, &w.red,
                    &w.flag, &w.hitoff, &w.hc, &w.hg, &w.stpad})
@@ -404,6 +778,8 @@ void niqki_group_destroy(niqki_group *g) {
     if (w.ev) (void)hipEventDestroy(w.ev);
     if (l < g->comm.size() && g->comm[l]) (void)rccl().CommDestroy(g->comm[l]);
   }
+  if (g->host_flags) (void)hipHostFree(g->host_flags);
+  if (g->ev_flags) (void)hipEventDestroy(g->ev_flags);
   delete g;
 }
 
@@ -427,7 +803,8 @@ int niqki_group_set_option(niqki_group *g, const char *key, int64_t value) {
 int niqki_group_get_stat(const niqki_group *g, const char *key, uint64_t *value) {
   if (!g || !key || !value) return NIQKI_E_INVALID;
   if (!std::strcmp(key, "overflows")) { *value = g->overflows; return NIQKI_OK; }
-  if (!std::strcmp(key, "rccl")) { *value = g->use_rccl ? 1 : 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "rccl")) { *value = g->transport == niqki_group::kRccl ? 1 : 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "transport")) { *value = (uint64_t)g->transport; return NIQKI_OK; }   // 0 local, 1 rccl, 2 ipc
   if (!std::strcmp(key, "sparse")) {
     const uint32_t ms = g->sh[0]->d.min_score;
     *value = (g->exchange == 1 || (g->exchange == 0 && ms >= 4 * g->world)) ? 1 : 0;
@@ -438,10 +815,12 @@ int niqki_group_get_stat(const niqki_group *g, const char *key, uint64_t *value)
 
 int niqki_group_insert(niqki_group *g, const int32_t *const *local_sketches, uint32_t per, uint32_t n_total) {
   if (!g || !local_sketches) return NIQKI_E_INVALID;
+  if (g->pend.active) return gfail(g, NIQKI_E_STATE, "a query batch is in flight (niqki_group_query_end)");
   if ((uint64_t)n_total > (uint64_t)per * g->world) return gfail(g, NIQKI_E_INVALID, "n_total exceeds world * per");
   if (per == 0) return NIQKI_OK;
-  int rc = exchange_slices(g, local_sketches, per);
+  int rc = prepare_batch(g, per, 0, false, false);
   if (rc) return rc;
+  if ((rc = exchange_slices(g, local_sketches, per))) return rc;
   for (uint32_t l = 0; l < g->n_local; ++l) {
     niqki_index *ix = g->sh[l];
     NQ_GH(g, hipSetDevice(ix->device));
@@ -451,9 +830,48 @@ int niqki_group_insert(niqki_group *g, const int32_t *const *local_sketches, uin
   return NIQKI_OK;
 }
 
-int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint32_t per, uint64_t *const *hit_off,
-                      uint32_t *const *hit_counts, uint32_t *const *hit_gids, uint64_t capacity, int mem) {
+namespace {
+
+// 4b + 5 of a batch whose partial hit vectors (ws.counts) are complete: dense reduce-scatter, threshold, order
+int finish_dense(niqki_group *g, uint32_t per, uint32_t N, uint64_t stride) {
+  int rc;
+  for (uint32_t l = 0; l < g->n_local; ++l) {
+    NQ_GH(g, hipSetDevice(g->sh[l]->device));
+    NQ_G(g, l, nqi::ensure(g->sh[l], g->ws[l].red, std::max<size_t>((size_t)per * stride * 2, 4)));
+  }
+  nqi::Span sp(g->sh[0], NIQKI_KC_EXCHANGE);
+  if ((rc = reduce_scatter_u32(g, &niqki_group::Ws::counts, &niqki_group::Ws::red, (size_t)per * (stride / 2)))) return rc;
+  return NIQKI_OK;
+}
+
+// 5. threshold + order of this rank's queries from ws.red into the caller's device buffers or the
+// library's staging buffers (host results: copied out by query_end)
+int run_hits(niqki_group *g, uint32_t per, uint32_t N, uint64_t stride) {
+  auto &pd = g->pend;
+  for (uint32_t l = 0; l < g->n_local; ++l) {
+    niqki_index *ix = g->sh[l];
+    NQ_GH(g, hipSetDevice(ix->device));
+    auto &w = g->ws[l];
+    if (!pd.host) {
+      NQ_G(g, l, nqi::hits_dev(ix, (const uint16_t *)w.red.p, per, stride, 0, N, (unsigned long long *)pd.hit_off[l], pd.hit_counts[l],
+                               pd.hit_gids[l], pd.capacity, false, nullptr));
+      continue;
+    }
+    NQ_G(g, l, nqi::ensure(ix, w.hitoff, (size_t)(per + 1) * 8));
+    NQ_G(g, l, nqi::ensure(ix, w.hc, (size_t)std::max<uint64_t>(pd.capacity, 1) * 4));
+    NQ_G(g, l, nqi::ensure(ix, w.hg, (size_t)std::max<uint64_t>(pd.capacity, 1) * 4));
+    NQ_G(g, l, nqi::hits_dev(ix, (const uint16_t *)w.red.p, per, stride, 0, N, (unsigned long long *)w.hitoff.p, (uint32_t *)w.hc.p,
+                             (uint32_t *)w.hg.p, pd.capacity, false, nullptr));
+  }
+  return NIQKI_OK;
+}
+
+}  // namespace
+
+int niqki_group_query_begin(niqki_group *g, const int32_t *const *local_sketches, uint32_t per, uint64_t *const *hit_off,
+                            uint32_t *const *hit_counts, uint32_t *const *hit_gids, uint64_t capacity, int mem) {
   if (!g || !local_sketches || !hit_off) return NIQKI_E_INVALID;
+  if (g->pend.active) return gfail(g, NIQKI_E_STATE, "a query batch is already in flight (niqki_group_query_end)");
   const uint32_t G = g->world, nq = G * per;
   for (uint32_t l = 0; l < g->n_local; ++l) {
     NQ_GH(g, hipSetDevice(g->sh[l]->device));
@@ -462,15 +880,27 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
   }
   const uint32_t N = g->sh[0]->built_n;
   const uint64_t stride = NIQKI_ROW_STRIDE(N);
+  auto &pd = g->pend;
+  pd.per = per; pd.N = N; pd.stride = stride; pd.capacity = capacity; pd.host = mem != NIQKI_MEM_DEVICE;
+  pd.off_v.assign(hit_off, hit_off + g->n_local);
+  pd.hc_v.assign(hit_counts, hit_counts + g->n_local);
+  pd.hg_v.assign(hit_gids, hit_gids + g->n_local);
+  pd.hit_off = pd.off_v.data(); pd.hit_counts = pd.hc_v.data(); pd.hit_gids = pd.hg_v.data();
+  pd.sparse = false;
+  pd.active = true;
   if (per == 0) return NIQKI_OK;
-  int rc = exchange_slices(g, local_sketches, per);
-  if (rc) return rc;
   const uint32_t min_score = g->sh[0]->d.min_score;
   bool sparse = g->exchange == 1 || (g->exchange == 0 && min_score >= 4 * G);
   if (min_score < G || N == 0) sparse = false;   // ceil(min_score / G) must be >= 1
+  pd.sparse = sparse;
+  int rc = prepare_batch(g, per, N, true, sparse);
+  if (!rc) rc = exchange_slices(g, local_sketches, per);
+  if (rc) { pd.active = false; return rc; }
   const uint32_t C = g->cand_cap, thr = (min_score + G - 1) / G;
   // 3. partial hit vectors of all queries over the local slots; for the sparse exchange the gather kernel
   //    also leaves every query's candidates (partial count >= ceil(min_score / G))
+  if ((rc = pre_produce(g, &niqki_group::Ws::counts))) return rc;
+  if (sparse && (rc = pre_produce(g, &niqki_group::Ws::cand))) return rc;
   for (uint32_t l = 0; l < g->n_local; ++l) {
     niqki_index *ix = g->sh[l];
     NQ_GH(g, hipSetDevice(ix->device));
@@ -479,7 +909,7 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
     if (N == 0) NQ_GH(g, hipMemsetAsync(w.counts.p, 0, std::max<size_t>((size_t)nq * stride * 2, 4), ix->stream));
     nq::CandOut co;
     if (sparse) {
-      NQ_G(g, l, nqi::ensure(ix, w.cand, (size_t)nq::cand_blob_ints(nq, C) * 4));
+      NQ_G(g, l, nqi::ensure(ix, w.cand, blob_bytes(nq, C)));
       co.cand = (int32_t *)w.cand.p;
       co.n = (int32_t *)w.cand.p + (size_t)nq * C;
       co.thr = thr;
@@ -489,19 +919,23 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
                                (uint16_t *)w.counts.p, stride, nullptr, sparse ? &co : nullptr));
   }
   // 4. cross-shard sum, scattered by query
-  Buf niqki_group::Ws::*red = &niqki_group::Ws::red;
   if (sparse) {
+    const size_t blob = blob_bytes(nq, C);
     for (uint32_t l = 0; l < g->n_local; ++l) {
       niqki_index *ix = g->sh[l];
       NQ_GH(g, hipSetDevice(ix->device));
       auto &w = g->ws[l];
-      NQ_G(g, l, nqi::ensure(ix, w.cand_all, (size_t)G * nq::cand_blob_ints(nq, C) * 4));
+      NQ_G(g, l, nqi::ensure(ix, w.cand_all, (size_t)G * blob));
       NQ_G(g, l, nqi::ensure(ix, w.mine, (size_t)nq * G * C * 2));
       NQ_G(g, l, nqi::ensure(ix, w.tot, (size_t)per * G * C * 2));
       NQ_G(g, l, nqi::ensure(ix, w.red, (size_t)per * stride * 2));
       NQ_G(g, l, nqi::ensure(ix, w.flag, 4));
     }
-    if ((rc = all_gather(g, &niqki_group::Ws::cand, &niqki_group::Ws::cand_all, (size_t)nq::cand_blob_ints(nq, C) * 4))) return rc;
+    {
+      nqi::Span sp(g->sh[0], NIQKI_KC_EXCHANGE);
+      if ((rc = all_gather(g, &niqki_group::Ws::cand, &niqki_group::Ws::cand_all, blob))) return rc;
+    }
+    if ((rc = pre_produce(g, &niqki_group::Ws::mine))) return rc;
     for (uint32_t l = 0; l < g->n_local; ++l) {
       niqki_index *ix = g->sh[l];
       NQ_GH(g, hipSetDevice(ix->device));
@@ -509,65 +943,82 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
       nqi::Span sp(ix, NIQKI_KC_EXCHANGE);
       NQ_GH(g, hipMemsetAsync(w.flag.p, 0, 4, ix->stream));
       hipLaunchKernelGGL(nq::cand_lookup_kernel, dim3(nq), dim3(256), 0, ix->stream, (const uint16_t *)w.counts.p, stride, nq, G, C,
-                         (const int32_t *)w.cand_all.p, (uint16_t *)w.mine.p, (uint32_t *)w.flag.p);
+                         (const int32_t *)w.cand_all.p, (uint64_t)(blob / 4), (uint16_t *)w.mine.p, (uint32_t *)w.flag.p);
       NQ_GH(g, hipGetLastError());
     }
-    if ((rc = reduce_scatter_u32(g, &niqki_group::Ws::mine, &niqki_group::Ws::tot, (size_t)per * G * C / 2))) return rc;
-    // every rank saw the same all-gathered list sizes, so all ranks (and processes) take the same branch
-    uint32_t over = 0;
-    NQ_GH(g, hipSetDevice(g->sh[0]->device));
-    NQ_GH(g, hipMemcpyAsync(&over, g->ws[0].flag.p, 4, hipMemcpyDeviceToHost, g->sh[0]->stream));
-    NQ_GH(g, hipStreamSynchronize(g->sh[0]->stream));
-    if (over) {
-      ++g->overflows;
-      sparse = false;
-    } else {
-      for (uint32_t l = 0; l < g->n_local; ++l) {
-        niqki_index *ix = g->sh[l];
-        NQ_GH(g, hipSetDevice(ix->device));
-        auto &w = g->ws[l];
-        nqi::Span sp(ix, NIQKI_KC_EXCHANGE);
-        NQ_GH(g, hipMemsetAsync(w.red.p, 0, (size_t)per * stride * 2, ix->stream));
-        hipLaunchKernelGGL(nq::cand_scatter_kernel, dim3(per), dim3(256), 0, ix->stream, (const uint16_t *)w.tot.p, per,
-                           (g->first + l) * per, nq, G, C, (const int32_t *)w.cand_all.p, (uint16_t *)w.red.p, stride);
-        NQ_GH(g, hipGetLastError());
-      }
+    {
+      nqi::Span sp(g->sh[0], NIQKI_KC_EXCHANGE);
+      if ((rc = reduce_scatter_u32(g, &niqki_group::Ws::mine, &niqki_group::Ws::tot, (size_t)per * G * C / 2))) return rc;
     }
-  }
-  if (!sparse) {
+    // The overflow word stays on the device: the sparse result is scattered and thresholded right away, and
+    // query_end -- the one place the host waits -- redoes the batch densely in the (rare) case that a list
+    // overflowed.  Every rank saw the same all-gathered list sizes, so all ranks (and processes) decide alike.
     for (uint32_t l = 0; l < g->n_local; ++l) {
-      NQ_GH(g, hipSetDevice(g->sh[l]->device));
-      NQ_G(g, l, nqi::ensure(g->sh[l], g->ws[l].red, std::max<size_t>((size_t)per * stride * 2, 4)));
+      niqki_index *ix = g->sh[l];
+      NQ_GH(g, hipSetDevice(ix->device));
+      auto &w = g->ws[l];
+      nqi::Span sp(ix, NIQKI_KC_EXCHANGE);
+      NQ_GH(g, hipMemsetAsync(w.red.p, 0, (size_t)per * stride * 2, ix->stream));
+      hipLaunchKernelGGL(nq::cand_scatter_kernel, dim3(per), dim3(256), 0, ix->stream, (const uint16_t *)w.tot.p, per,
+                         (g->first + l) * per, nq, G, C, (const int32_t *)w.cand_all.p, (uint64_t)(blob / 4), (uint16_t *)w.red.p, stride);
+      NQ_GH(g, hipGetLastError());
     }
-    nqi::Span sp(g->sh[0], NIQKI_KC_EXCHANGE);
-    if ((rc = reduce_scatter_u32(g, &niqki_group::Ws::counts, red, (size_t)per * (stride / 2)))) return rc;
+  } else if ((rc = finish_dense(g, per, N, stride))) {
+    return rc;
   }
-  // 5. threshold + order of this rank's queries
+  if ((rc = run_hits(g, per, N, stride))) return rc;
+  // the two words query_end looks at, on their way to pinned memory behind everything above
+  NQ_GH(g, hipSetDevice(g->sh[0]->device));
+  g->host_flags[0] = g->host_flags[1] = 0;
+  if (sparse) NQ_GH(g, hipMemcpyAsync(&g->host_flags[0], g->ws[0].flag.p, 4, hipMemcpyDeviceToHost, g->sh[0]->stream));
+  if (g->transport == niqki_group::kIpc)
+    NQ_GH(g, hipMemcpyAsync(&g->host_flags[1], g->ipc.flags + kFlagErr, 4, hipMemcpyDeviceToHost, g->sh[0]->stream));
+  NQ_GH(g, hipEventRecord(g->ev_flags, g->sh[0]->stream));
+  return NIQKI_OK;
+}
+
+int niqki_group_query_end(niqki_group *g) {
+  if (!g) return NIQKI_E_INVALID;
+  auto &pd = g->pend;
+  if (!pd.active) return gfail(g, NIQKI_E_STATE, "no query batch in flight");
+  pd.active = false;
+  const uint32_t per = pd.per, N = pd.N;
+  if (per == 0) return NIQKI_OK;
+  NQ_GH(g, hipSetDevice(g->sh[0]->device));
+  NQ_GH(g, hipEventSynchronize(g->ev_flags));
+  if (g->host_flags[1]) return gfail(g, NIQKI_E_HIP, "a peer of the group did not answer in time (ipc transport)");
+  int rc;
+  if (pd.sparse && g->host_flags[0]) {
+    ++g->overflows;
+    if ((rc = finish_dense(g, per, N, pd.stride))) return rc;
+    if ((rc = run_hits(g, per, N, pd.stride))) return rc;
+  }
+  if (!pd.host) return NIQKI_OK;
   for (uint32_t l = 0; l < g->n_local; ++l) {
     niqki_index *ix = g->sh[l];
     NQ_GH(g, hipSetDevice(ix->device));
     auto &w = g->ws[l];
-    if (mem == NIQKI_MEM_DEVICE) {
-      NQ_G(g, l, nqi::hits_dev(ix, (const uint16_t *)(w.*red).p, per, stride, 0, N, (unsigned long long *)hit_off[l], hit_counts[l],
-                               hit_gids[l], capacity, false, nullptr));
-      continue;
-    }
-    NQ_G(g, l, nqi::ensure(ix, w.hitoff, (size_t)(per + 1) * 8));
-    NQ_G(g, l, nqi::ensure(ix, w.hc, (size_t)std::max<uint64_t>(capacity, 1) * 4));
-    NQ_G(g, l, nqi::ensure(ix, w.hg, (size_t)std::max<uint64_t>(capacity, 1) * 4));
-    uint64_t total = 0;
-    rc = nqi::hits_dev(ix, (const uint16_t *)(w.*red).p, per, stride, 0, N, (unsigned long long *)w.hitoff.p, (uint32_t *)w.hc.p,
-                       (uint32_t *)w.hg.p, capacity, true, &total);
-    if (rc && rc != NIQKI_E_CAPACITY) return gfail(g, rc, niqki_last_error(ix));
-    NQ_GH(g, hipMemcpyAsync(hit_off[l], w.hitoff.p, (size_t)(per + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
-    if (rc == NIQKI_OK && total) {
-      NQ_GH(g, hipMemcpyAsync(hit_counts[l], w.hc.p, (size_t)total * 4, hipMemcpyDeviceToHost, ix->stream));
-      NQ_GH(g, hipMemcpyAsync(hit_gids[l], w.hg.p, (size_t)total * 4, hipMemcpyDeviceToHost, ix->stream));
-    }
+    NQ_GH(g, hipMemcpyAsync(pd.hit_off[l], w.hitoff.p, (size_t)(per + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
     NQ_GH(g, hipStreamSynchronize(ix->stream));
-    if (rc == NIQKI_E_CAPACITY) return gfail(g, rc, "hit capacity too small; hit_off holds the sizes needed");
+    const uint64_t total = pd.hit_off[l][per];
+    if (total > pd.capacity) return gfail(g, NIQKI_E_CAPACITY, "hit capacity too small; hit_off holds the sizes needed");
+    if (total) {
+      NQ_GH(g, hipMemcpyAsync(pd.hit_counts[l], w.hc.p, (size_t)total * 4, hipMemcpyDeviceToHost, ix->stream));
+      NQ_GH(g, hipMemcpyAsync(pd.hit_gids[l], w.hg.p, (size_t)total * 4, hipMemcpyDeviceToHost, ix->stream));
+      NQ_GH(g, hipStreamSynchronize(ix->stream));
+    }
   }
   return NIQKI_OK;
+}
+
+int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint32_t per, uint64_t *const *hit_off,
+                      uint32_t *const *hit_counts, uint32_t *const *hit_gids, uint64_t capacity, int mem) {
+  int rc = niqki_group_query_begin(g, local_sketches, per, hit_off, hit_counts, hit_gids, capacity, mem);
+  if (rc) {
+    if (g) g->pend.active = false;
+    return rc;
+  }
+  return niqki_group_query_end(g);
 }
 
 namespace {

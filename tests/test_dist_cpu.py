@@ -1,4 +1,5 @@
-"""CPU, world_size 2 over gloo: the slot-shard exchange of niqki_amd/dist.py
+"""CPU, world_size 2 over gloo: the slot-shard exchange protocol (tests/torch_exchange.py, the torch
+restatement of niqki_amd/csrc/nq_group.hip)
 (all_gather of sketches, reduce of packed u16 hit vectors, per-rank threshold)
 gives exactly the single-index answer.  The local compute is played by an
 oracle-backed stand-in engine with the *_dev method names of niqki_amd.Engine."""
@@ -11,7 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from niqki_amd.dist import ShardedQuery, padded_batch, slot_range
+from torch_exchange import TorchExchange as ShardedQuery, padded_batch, slot_range
 
 S, W, N, NQ = 9, 8, 333, 6
 
