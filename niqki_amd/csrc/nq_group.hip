@@ -103,9 +103,14 @@ constexpr uint32_t kMaxWorld = 64;
 constexpr uint32_t kIpcBufs = 4;      // exchange buffers a rank exposes: send (slices), cand, mine, counts
 constexpr uint32_t kIpcMagic = 0x4E514950u;
 struct IpcRank {
+  // Handles name whole allocations (hipMalloc may carve a pointer out of a larger block, whose base is what
+  // hipIpcGetMemHandle takes): the pointer is base + offset in the owner's and in every peer's mapping.
   hipIpcMemHandle_t flags;            // the rank's sequence words (below)
-  hipIpcMemHandle_t buf[kIpcBufs];
-  uint64_t gen[kIpcBufs];             // bumped when buf[i] names a new allocation
+  uint64_t flags_off;
+  hipIpcMemHandle_t arena;            // ONE allocation holds the rank's exchange buffers
+  uint64_t arena_off;
+  uint64_t buf_off[kIpcBufs];         // ... buffer i at arena + buf_off[i]
+  uint64_t gen;                       // bumped when `arena` names a new allocation
   int32_t device;
 };
 struct IpcShared {
@@ -248,8 +253,11 @@ struct niqki_group {
     uint32_t *flags = nullptr;                 // my sequence words (device)
     uint32_t *peer_flags[kMaxWorld] = {};      // every rank's, mine included
     void *peer_buf[kMaxWorld][kIpcBufs] = {};  // mapped exchange buffers (mine: the local pointer)
-    uint64_t peer_gen[kMaxWorld][kIpcBufs] = {};
-    void *my_ptr[kIpcBufs] = {};               // what my published handles name
+    void *peer_base[kMaxWorld] = {};           // what hipIpcOpenMemHandle returned for a peer's arena / flags
+    void *peer_flags_base[kMaxWorld] = {};
+    uint64_t peer_gen[kMaxWorld] = {};
+    Buf arena;                                 // my exchange buffers (ws.send / cand / mine / counts are views of it)
+    bool ready = false;                        // ipc_setup went through: peers exist and wait in barriers
     uint32_t seq[kIpcBufs] = {};               // uses of each exchange buffer so far
   } ipc;
   // a query batch between niqki_group_query_begin and _end
@@ -366,7 +374,13 @@ int ipc_setup(niqki_group *g, const uint8_t *id) {
   NQ_GH(g, hipMemset(ic.flags, 0, kFlagWords * 4));
   NQ_GH(g, hipDeviceSynchronize());
   IpcRank &me = ic.shm->r[g->first];
-  NQ_GH(g, hipIpcGetMemHandle(&me.flags, ic.flags));
+  {
+    void *base = nullptr;
+    size_t sz = 0;
+    NQ_GH(g, hipMemGetAddressRange((hipDeviceptr_t *)&base, &sz, (hipDeviceptr_t)ic.flags));
+    NQ_GH(g, hipIpcGetMemHandle(&me.flags, base));
+    me.flags_off = (uint64_t)((char *)ic.flags - (char *)base);
+  }
   me.device = ix->device;
   int rc = ipc_barrier(g);
   if (rc) return rc;
@@ -374,10 +388,12 @@ int ipc_setup(niqki_group *g, const uint8_t *id) {
     if (s == g->first) { ic.peer_flags[s] = ic.flags; continue; }
     void *q = nullptr;
     NQ_GH(g, hipIpcOpenMemHandle(&q, ic.shm->r[s].flags, hipIpcMemLazyEnablePeerAccess));
-    ic.peer_flags[s] = (uint32_t *)q;
+    ic.peer_flags_base[s] = q;
+    ic.peer_flags[s] = (uint32_t *)((char *)q + ic.shm->r[s].flags_off);
   }
   if ((rc = ipc_barrier(g))) return rc;
   if (g->first == 0) shm_unlink(name);   // everybody has it mapped: the name can go
+  ic.ready = true;
   return NIQKI_OK;
 }
 
@@ -386,11 +402,12 @@ void ipc_teardown(niqki_group *g) {
   if (!ic.shm) return;
   for (uint32_t s = 0; s < g->world; ++s) {
     if (s == g->first) continue;
-    for (uint32_t b = 0; b < kIpcBufs; ++b)
-      if (ic.peer_buf[s][b]) (void)hipIpcCloseMemHandle(ic.peer_buf[s][b]);
-    if (ic.peer_flags[s]) (void)hipIpcCloseMemHandle(ic.peer_flags[s]);
+    if (ic.peer_base[s]) (void)hipIpcCloseMemHandle(ic.peer_base[s]);
+    if (ic.peer_flags_base[s]) (void)hipIpcCloseMemHandle(ic.peer_flags_base[s]);
   }
   if (ic.flags) (void)hipFree(ic.flags);
+  if (ic.arena.p) (void)hipFree(ic.arena.p);
+  for (uint32_t b = 0; b < kIpcBufs; ++b) g->ws[0].*kIpcBufMember[b] = Buf();   // (views of the arena)
   if (g->first == 0) shm_unlink(ic.name.c_str());   // (no-op once setup has finished)
   munmap(ic.shm, sizeof(IpcShared));
   ic.shm = nullptr;
@@ -409,41 +426,51 @@ int ipc_prepare(niqki_group *g, const size_t need[kIpcBufs]) {
   if (!grow) return NIQKI_OK;
   NQ_GH(g, hipSetDevice(ix->device));
   NQ_GH(g, hipStreamSynchronize(ix->stream));
-  int rc = ipc_barrier(g);
+  int rc = ipc_barrier(g);   // every rank's stream has drained: nobody reads anybody's buffers
   if (rc) return rc;
-  for (uint32_t b = 0; b < kIpcBufs; ++b) {
-    if (need[b] <= (w.*kIpcBufMember[b]).n) continue;
-    for (uint32_t s = 0; s < g->world; ++s)
-      if (s != g->first && ic.peer_buf[s][b]) {
-        NQ_GH(g, hipIpcCloseMemHandle(ic.peer_buf[s][b]));
-        ic.peer_buf[s][b] = nullptr;
-      }
-  }
+  for (uint32_t s = 0; s < g->world; ++s)
+    if (s != g->first && ic.peer_base[s]) {
+      NQ_GH(g, hipIpcCloseMemHandle(ic.peer_base[s]));
+      ic.peer_base[s] = nullptr;
+      for (uint32_t b = 0; b < kIpcBufs; ++b) ic.peer_buf[s][b] = nullptr;
+    }
   if ((rc = ipc_barrier(g))) return rc;
+  // one allocation for the four buffers, each with a quarter of headroom (fewer remaps while batches grow)
   IpcRank &me = ic.shm->r[g->first];
+  size_t off[kIpcBufs], size[kIpcBufs], total = 0;
+  for (uint32_t b = 0; b < kIpcBufs; ++b) {
+    const size_t have = (w.*kIpcBufMember[b]).n;
+    size[b] = need[b] > have ? need[b] + need[b] / 4 : have;
+    size[b] = (size[b] + 255) & ~(size_t)255;
+    off[b] = total;
+    total += size[b];
+  }
+  if (ic.arena.p) NQ_GH(g, hipFree(ic.arena.p));
+  ic.arena = Buf();
+  NQ_GH(g, hipMalloc(&ic.arena.p, std::max<size_t>(total, 256)));
+  ic.arena.n = std::max<size_t>(total, 256);
+  void *base = nullptr;
+  size_t sz = 0;
+  NQ_GH(g, hipMemGetAddressRange((hipDeviceptr_t *)&base, &sz, (hipDeviceptr_t)ic.arena.p));
+  NQ_GH(g, hipIpcGetMemHandle(&me.arena, base));
+  me.arena_off = (uint64_t)((char *)ic.arena.p - (char *)base);
   for (uint32_t b = 0; b < kIpcBufs; ++b) {
     Buf &buf = w.*kIpcBufMember[b];
-    const bool grown = need[b] > buf.n;   // (a new allocation even if the allocator hands the old address back)
-    if (grown) NQ_G(g, 0, nqi::ensure(ix, buf, need[b]));
-    if (buf.p && (grown || buf.p != ic.my_ptr[b])) {
-      NQ_GH(g, hipIpcGetMemHandle(&me.buf[b], buf.p));
-      me.gen[b] += 1;
-      ic.my_ptr[b] = buf.p;
-    }
+    buf.p = size[b] ? (char *)ic.arena.p + off[b] : nullptr;
+    buf.n = size[b];
+    me.buf_off[b] = off[b];
     ic.peer_buf[g->first][b] = buf.p;
   }
+  me.gen += 1;
   if ((rc = ipc_barrier(g))) return rc;
   for (uint32_t s = 0; s < g->world; ++s) {
     if (s == g->first) continue;
     const IpcRank &pr = ic.shm->r[s];
-    for (uint32_t b = 0; b < kIpcBufs; ++b) {
-      if (pr.gen[b] == ic.peer_gen[s][b]) continue;
-      if (ic.peer_buf[s][b]) NQ_GH(g, hipIpcCloseMemHandle(ic.peer_buf[s][b]));
-      void *q = nullptr;
-      NQ_GH(g, hipIpcOpenMemHandle(&q, pr.buf[b], hipIpcMemLazyEnablePeerAccess));
-      ic.peer_buf[s][b] = q;
-      ic.peer_gen[s][b] = pr.gen[b];
-    }
+    void *q = nullptr;
+    NQ_GH(g, hipIpcOpenMemHandle(&q, pr.arena, hipIpcMemLazyEnablePeerAccess));
+    ic.peer_base[s] = q;
+    ic.peer_gen[s] = pr.gen;
+    for (uint32_t b = 0; b < kIpcBufs; ++b) ic.peer_buf[s][b] = (char *)q + pr.arena_off + pr.buf_off[b];
   }
   return ipc_barrier(g);
 }
@@ -767,11 +794,11 @@ void niqki_group_destroy(niqki_group *g) {
     }
   }
   if (g->transport == niqki_group::kIpc && g->ipc.shm) {
-    (void)ipc_barrier(g);   // nobody still reads my buffers (best effort: a dead peer only costs the timeout)
+    if (g->ipc.ready) (void)ipc_barrier(g);   // nobody still reads my buffers (a dead peer costs the timeout)
     ipc_teardown(g);
   }
   for (uint32_t l = 0; l < g->n_local && l < g->ws.size(); ++l) {
-    auto &w = g->ws[l];
+    auto &w = g->ws[l];   // (ipc_teardown has dropped the views of its arena)
     for (Buf *b : {&w.send, &w.recv, &w.allsk, &w.counts, &w.cand, &w.cand_all, &w.mine, &w.tot, &w.red,
                    &w.flag, &w.hitoff, &w.hc, &w.hg, &w.stpad})
       if (b->p) (void)hipFree(b->p);
