@@ -454,7 +454,9 @@ enum niqki_kernel_class {
 /* Sizes of the handle's state: "store_bytes" (sketch store), "index_bytes" (table + id lists of
  * the built index or resident page), "tiles", "pages" / "page_slots" (pages a query walks and
  * slots per page; 1 / all slots unless the index is paged), "delta_genomes" (genomes indexed by
- * the delta segment, see option "incremental_build"). */
+ * the delta segment, see option "incremental_build"), "last_gather_form" (launch form the last
+ * counter call used: bit 0 look-up pre-pass, bit 1 its streamed-rows kernel, bit 2 locality
+ * order). */
 int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value);
 int niqki_profile_enable(niqki_index *ix, int on);
 int niqki_profile_reset(niqki_index *ix);

@@ -434,6 +434,7 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
     if (rc) return rc;
   }
   if (ordered && (rc = ensure(ix, ix->ws_order, (size_t)chunk * 8))) return rc;
+  ix->last_form = (pre ? 1u : 0u) | (pre && nq::lookup_wants_packed(v) ? 2u : 0u) | (ordered ? 4u : 0u);
   for (uint32_t q0 = 0; q0 < nq; q0 += chunk) {
     const uint32_t n = std::min(chunk, nq - q0);
     Span sp(ix, NIQKI_KC_GATHER);
@@ -1641,6 +1642,7 @@ int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value) {
   if (!std::strcmp(key, "index_bytes")) { *value = ix->built ? (uint64_t)ix->entries_bytes + ix->gids_bytes + ix->ptab_bytes + ix->alt.entries_bytes + ix->alt.gids_bytes + ix->alt.ptab_bytes : 0; return NIQKI_OK; }
   if (!std::strcmp(key, "delta_genomes")) { *value = ix->delta_n; return NIQKI_OK; }
   if (!std::strcmp(key, "tiles")) { *value = ix->n_tiles; return NIQKI_OK; }
+  if (!std::strcmp(key, "last_gather_form")) { *value = ix->last_form; return NIQKI_OK; }
   if (!std::strcmp(key, "page_slots")) { *value = ix->resident_bytes ? page_slots(ix) : f_all; return NIQKI_OK; }
   if (!std::strcmp(key, "pages")) {
     const uint32_t ps = ix->resident_bytes ? page_slots(ix) : f_all;

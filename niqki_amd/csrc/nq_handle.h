@@ -83,6 +83,7 @@ struct niqki_index {
   int incremental = 1;     // option "incremental_build"
 
   int gather_variant = 0;
+  uint32_t last_form = 0;        // stat "last_gather_form": 1 = look-up pre-pass, 2 = its streamed-rows form, 4 = locality order
   uint64_t record_len_hint = 0;  // avg bytes per sketch for device-side batches (0 = read it back)
   uint32_t query_batch = 1024;
   int query_order = 1;           // option: order the queries of a launch for cache locality (1 = where it pays, 2 = wherever possible)

@@ -21,8 +21,12 @@ N, L, FAMILY, SEED = 100_000, 5_000_000, 100, 20261003
 K, S, W, H, J = 31, 15, 12, 4, 0.1
 F = 1 << S
 NQ = 64            # checked queries (dense columns + hit lists)
+NQ_BIG = 1024      # queries of one call in the launch form bench.py times (>= 1024: streamed table rows + order)
 NQ_SKETCH = 6      # of which re-sketched by the oracle (0.1 s of CPU each)
 BLOCK = 16384
+
+
+BIG = {}   # the NQ_BIG device-resident query sketches of the fixture below
 
 
 @pytest.fixture(scope="module")
@@ -47,15 +51,22 @@ def big(native):
         e.sketch_dev(seq, ro if n == GB else torch.from_numpy(np.arange(n + 1, dtype=np.int64) * L).to(dev), n, sk)
         e.insert_dev(sk, n)
     e.build()
-    # queries 0..NQ-1 of the bench's first batch (every 10th from a family that is not indexed)
-    qfam, qmem, qrate = bench.query_spec(np.arange(NQ), n_fam)
-    e.synth_dev(SEED, t32(qfam), t32(qmem), t32(qrate), NQ, L, L, seq)
-    qsk = torch.empty((NQ, F), dtype=torch.int32, device=dev)
-    e.sketch_dev(seq, torch.from_numpy(np.arange(NQ + 1, dtype=np.int64) * L).to(dev), NQ, qsk)
+    # queries 0..NQ_BIG-1 of the bench's first batch (every 10th from a family that is not indexed), sketched in
+    # blocks of GB; the first NQ of them are the ones checked column by column
+    qfam, qmem, qrate = bench.query_spec(np.arange(NQ_BIG), n_fam)
+    qsk_big = torch.empty((NQ_BIG, F), dtype=torch.int32, device=dev)
+    qseq = None
+    for q0 in range(0, NQ_BIG, GB):
+        e.synth_dev(SEED, t32(qfam[q0:q0 + GB]), t32(qmem[q0:q0 + GB]), t32(qrate[q0:q0 + GB]), GB, L, L, seq)
+        e.sketch_dev(seq, ro, GB, qsk_big[q0:q0 + GB])
+        if q0 == 0:
+            e.synchronize()
+            qseq = seq[:NQ_SKETCH * L].cpu().numpy().reshape(NQ_SKETCH, L).copy()
     e.synchronize()
-    qseq = seq[:NQ_SKETCH * L].cpu().numpy().reshape(NQ_SKETCH, L).copy()
     del seq
-    yield e, qsk.cpu().numpy(), qseq, (qfam, qmem, qrate)
+    BIG["qsk"] = qsk_big
+    yield e, qsk_big[:NQ].cpu().numpy(), qseq, (qfam[:NQ], qmem[:NQ], qrate[:NQ])
+    BIG.clear()
     e.close()
 
 
@@ -91,8 +102,37 @@ def test_config3_all_columns_and_hit_lists_vs_oracle(native, po, big):
     e.set_option("lookup_prepass", 1)
     assert np.array_equal(e.query_counts(qsk), got)
     e.set_option("lookup_prepass", -1)
+    # the launch form bench.py times -- >= 1024 queries in one call: table rows streamed through LDS
+    # (lookup_rows_kernel), locality probe + order, gather_kernel<1024, 32, -1, 0, true> -- on the same
+    # queries: rows 0..NQ-1 of a 1024-query call are the oracle's columns, the hit lists likewise
+    import torch
+    big_sk = BIG["qsk"]
+    dev = big_sk.device
+    stride = native.row_stride(N)
+    d_counts = torch.zeros((NQ_BIG, stride), dtype=torch.int16, device=dev)
+    e.query_counts_dev(big_sk, NQ_BIG, d_counts, stride)
+    e.synchronize()
+    assert e.stat("last_gather_form") == 7                      # pre-pass, its streamed-rows kernel, locality order
+    big_rows = d_counts[:NQ, :N].cpu().numpy().view(np.uint16)
+    assert np.array_equal(big_rows.astype(np.uint32), exp)
+    # ... and rows further back in the batch equal what a small call (look-ups inside the gather kernel) gives
+    tail = slice(NQ_BIG - 48, NQ_BIG)
+    small = e.query_counts(big_sk[tail].cpu().numpy())
+    assert e.stat("last_gather_form") & 3 == 0
+    assert np.array_equal(d_counts[tail, :N].cpu().numpy().view(np.uint16), small)
+    cap_big = NQ_BIG * 256
+    b_off = torch.zeros(NQ_BIG + 1, dtype=torch.int64, device=dev)
+    b_hc, b_hg = torch.zeros(cap_big, dtype=torch.int32, device=dev), torch.zeros(cap_big, dtype=torch.int32, device=dev)
+    e.query_dev(big_sk, NQ_BIG, b_off, b_hc, b_hg, cap_big)
+    e.synchronize()
+    assert e.stat("last_gather_form") == 7
+    b_off, b_hc, b_hg = b_off.cpu().numpy(), b_hc.cpu().numpy().astype(np.uint32), b_hg.cpu().numpy().astype(np.uint32)
+    assert int(b_off[NQ_BIG]) <= cap_big
+    del d_counts
     # threshold + order from the oracle's columns: greater<pair<count, gid>>, :662-666, :685
     off, hc, hg = e.query(qsk)
+    assert np.array_equal(b_off[:NQ + 1], off[:NQ + 1].astype(np.int64))
+    assert np.array_equal(b_hc[:int(off[NQ])], hc) and np.array_equal(b_hg[:int(off[NQ])], hg)
     n_with_hits = 0
     for q in range(NQ):
         gids = np.nonzero(exp[q] >= p.min_score)[0]
