@@ -74,26 +74,41 @@ def measure_traffic(args):
     import glob
     import re
     import shutil
+    import signal
     import subprocess
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
     rx = re.compile(r"gather_kernel<|lookup(_rows)?_kernel<|probe_kernel<")
+    # not under another profiler: the nested rocprofv3 would inherit its preload / tool variables
+    if ("ROCP_TOOL_LIBRARIES" in os.environ or any(k.startswith("ROCPROF_") for k in os.environ)
+            or "rocprof" in os.environ.get("LD_PRELOAD", "")):
+        return None
     kb = {}
     launches = None
     t0 = time.time()
-    try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = tempfile.mkdtemp(prefix="niqki_pmc_", dir="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="niqki_pmc_", dir="/tmp")
+        try:
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "2", "--warmup", "1",
                    "--genomes", str(args.genomes), "--batch", str(args.batch), "--len", str(args.len),
-                   "--family", str(args.family), "--seed", str(args.seed), "--ring", "2"]
+                   "--family", str(args.family), "--seed", str(args.seed), "--ring", str(args.ring)]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            # a session of its own: on a timeout the whole group goes (rocprofv3 AND the bench under it)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                  start_new_session=True)
+            try:
+                rc = pr.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.wait()
+                return None
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                shutil.rmtree(out, ignore_errors=True)
+            if rc != 0 or not files:
                 return None
             total, n_gather = 0.0, 0
             with open(files[0], newline="") as f:
@@ -102,13 +117,14 @@ def measure_traffic(args):
                     if row.get("Counter_Name") == counter and rx.search(name):
                         total += float(row["Counter_Value"])
                         n_gather += "gather_kernel<" in name
-            shutil.rmtree(out, ignore_errors=True)
             if n_gather == 0:
                 return None
             kb[counter] = total / n_gather
             launches = n_gather
-    except (OSError, subprocess.SubprocessError, KeyError, ValueError):
-        return None
+        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
     log("[bench] HBM traffic of the gather path: FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB per launch (%d launches, %.0f s)"
         % (kb["FETCH_SIZE"], kb["WRITE_SIZE"], launches, time.time() - t0))
     return {"bytes_per_launch": (2 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024,
@@ -343,13 +359,20 @@ def main():
         sk_eng.profile_reset()
     barrier()
     torch.cuda.synchronize()
+    # per-step device times beside the wall clock of the K steps: events on torch's current stream (the
+    # engine's stream) at the step boundaries, read after the run
+    ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for si in range(args.warmup, n_steps_all):
+    ev_step[0].record()
+    for k, si in enumerate(range(args.warmup, n_steps_all)):
         step(si)
+        ev_step[k + 1].record()
     eng.synchronize()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(ev_step[k].elapsed_time(ev_step[k + 1]) for k in range(args.steps))
+    ms_median = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if on_gloo else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -431,22 +454,70 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
 
+    # ---- what a streaming copy reaches on this device, now (the practical HBM ceiling beside the 8 TB/s spec) ----
+    copy_gbs = None
+    if rank == 0:
+        n_copy = 1 << 30
+        src_c = torch.zeros(n_copy // 4, dtype=torch.float32, device=dev)
+        dst_c = torch.empty(n_copy // 4, dtype=torch.float32, device=dev)
+        dst_c.copy_(src_c)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            dst_c.copy_(src_c)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 8 * 2.0 * n_copy / (e0.elapsed_time(e1) * 1e-3) / 1e9      # bytes read + bytes written
+        del src_c, dst_c
+
     # ---- sketch kernel against integer-ALU ceilings measured now, on this device ----
     kmers = args.steps * per * max(L - K, 0)
     sk_rate = kmers / (prof["sketch"][0] * 1e-3) if prof["sketch"][0] else 0.0
     alu = None
     if rank == 0:
-        adds, muls, arith = eng.measure_alu(0), eng.measure_alu(1), eng.measure_alu(2)
-        alu = {"add_lane_ops_per_s": adds, "mul_lane_ops_per_s": muls, "arithmetic_only_kmers_per_s": arith,
+        adds, muls, arith, vop3 = eng.measure_alu(0), eng.measure_alu(1), eng.measure_alu(2), eng.measure_alu(3)
+        # 28.9 vector instructions per k-mer (profiles/r03_sketch_sq_counters.txt: SQ_INSTS_VALU over the k-mers of
+        # the launch) at the issue rate of a three-operand integer instruction, the class of 21 of them
+        valu_per_kmer = 28.9
+        alu = {"add_lane_ops_per_s": adds, "mul_lane_ops_per_s": muls, "vop3_lane_ops_per_s": vop3,
+               "arithmetic_only_kmers_per_s": arith,
                "alu_frac": sk_rate / arith if arith else None,
+               "valu_per_kmer": valu_per_kmer,
+               "issue_frac": sk_rate * valu_per_kmer / vop3 if vop3 else None,
                "note": "alu_frac = sketch kernel k-mers/s over the rate of its per-k-mer arithmetic alone (roll, canonical "
-                       "choice, filter hash; no LDS table, compaction, candidates or memory), both measured in this run"}
+                       "choice, filter hash; no LDS table, compaction, candidates or memory); issue_frac = its vector "
+                       "instructions per second (k-mers/s x valu_per_kmer, counted with SQ_INSTS_VALU) over the measured "
+                       "issue rate of v_lshl_add_u32, which every vector opcode but add/and/or/xor/mov shares on gfx950 "
+                       "(profiles/r03_opcode_costs.txt); all rates measured in this run"}
 
     cpu = None
     extra = None
+    d2h = None
     if rank == 0 and world == 1 and not emu:
         if not args.no_cpu:
             cpu = cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, (K, S, W, H, J))
+        # ---- the same steps with the hits copied back to the host (SURVEY.md 8d "end-to-end incl. D2H of hits") ----
+        if rank == 0 and world == 1 and not emu:
+            h_off = torch.empty(per + 1, dtype=torch.int64).pin_memory()
+            h_hc = torch.empty(cap, dtype=torch.int32).pin_memory()
+            h_hg = torch.empty(cap, dtype=torch.int32).pin_memory()
+            n_d2h = min(5, args.steps)
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            for si in range(args.warmup, args.warmup + n_d2h):
+                step(si)
+                h_off.copy_(hit_off[si], non_blocking=True)
+                torch.cuda.synchronize()                     # the sizes first, then exactly the hits
+                nh = int(h_off[per])
+                h_hc[:nh].copy_(hc[:nh], non_blocking=True)
+                h_hg[:nh].copy_(hg[:nh], non_blocking=True)
+                torch.cuda.synchronize()
+            td = time.perf_counter() - td
+            d2h = {"value": n_d2h * per / td, "unit": "genomes/s", "ms_per_step": td / n_d2h * 1e3, "steps": n_d2h,
+                   "hit_bytes_per_step": 8 * (per + 1) + 8 * nh,
+                   "note": "the timed step followed by the copy of hit_off, hit_counts and hit_gids into page-locked host memory"}
+
         if not args.no_extra:
             del counts
             extra = extra_workloads(niqki_amd, torch, dev, args, no_cpu=args.no_cpu)
@@ -472,6 +543,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_median": ms_median,
+            "value_at_median_step": nq_all / (ms_median * 1e-3),
+            "step_ms_min_max": [step_ms[0], step_ms[-1]],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -498,6 +572,13 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_source,
+                # what the memory system really moved per launch over the launch time: against the spec peak and
+                # against the copy this run measured (frac above counts SURVEY's 4-byte ids, the layout stores 2)
+                "real_gbs": (traffic / (gather_ms / max(1, gather_launches) * 1e-3) / 1e9) if (traffic and gather_ms) else None,
+                "real_frac": (traffic / (gather_ms / max(1, gather_launches) * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and gather_ms) else None,
+                "copy_gbs": copy_gbs,
+                "copy_ceiling_frac": (traffic / (gather_ms / max(1, gather_launches) * 1e-3) / 1e9 / copy_gbs) if (traffic and gather_ms and copy_gbs) else None,
+                "frac_box_to_box": "0.87-0.91 over the boxes of this pool (DESIGN.md 4.4)",
                 "algorithmic_bytes_per_launch": alg_bytes / max(1, gather_launches),
                 "layout_min_bytes_per_launch": layout_min / max(1, gather_launches),
                 "launches": gather_launches, "avg_launch_ms": gather_ms / max(1, gather_launches),
@@ -512,6 +593,7 @@ def main():
                 "bound": "valu", "alu": alu,
             },
             "cpu_baseline": cpu,
+            "end_to_end_d2h": d2h,
         }
         if emu:
             # what one shard of the real job computes per step; the exchange (nq * F/G * 2 bytes of slices out,
@@ -564,26 +646,25 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
     cores = best_threads
     sk_gpu = qsk[bi, :n_s].cpu().numpy()
     parity_sketch = bool(np.array_equal(sk_cpu, sk_gpu))
-    # gather leg timed on sub-indexes of the first 4096 / 16384 genomes and extrapolated linearly in N;
-    # parity over ALL columns: the oracle's counters from seven sub-indexes of <= 16384 genomes
-    pts = []
+    # gather leg: the oracle's query loop timed on EVERY sub-index of <= 16384 genomes the index is cut into
+    # (the seven of them hold all 100 000 genomes: their sum is the whole-index figure, nothing extrapolated);
+    # parity over ALL columns from the same seven sub-indexes
     n_par = min(n_s, 8)
     exp_cols = np.zeros((n_par, N), np.uint32)
     cnt = eng.query_counts(sk_gpu[:n_par])
+    t_q, n_sub_ix = 0.0, 0
     for b0 in range(0, N, 16384):
         n_sub = min(16384, N - b0)
         sub = eng.get_sketches(b0, n_sub)
         ix = po.Index(p, sub)
-        if b0 == 0:
-            for n_t in sorted({min(4096, n_sub), n_sub}):
-                ixt = ix if n_t == n_sub else po.Index(p, sub[:n_t])
-                best = None
-                for _ in range(3):        # first pass warms the pages, keep the fastest
-                    t0 = time.perf_counter()
-                    ixt.query_batch(sk_cpu, threads=cores)
-                    t = time.perf_counter() - t0
-                    best = t if best is None else min(best, t)
-                pts.append((n_t, best))
+        best = None
+        for _ in range(2):        # first pass warms the pages, keep the faster
+            t0 = time.perf_counter()
+            ix.query_batch(sk_cpu, threads=cores)
+            t = time.perf_counter() - t0
+            best = t if best is None else min(best, t)
+        t_q += best
+        n_sub_ix += 1
         for i in range(n_par):
             exp_cols[i, b0:b0 + n_sub] = ix.counts(sk_cpu[i])
         del ix, sub
@@ -598,19 +679,28 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
         lo, hi = int(off[i]), int(off[i + 1])
         parity_hits &= bool(np.array_equal(g_hc[lo:hi].astype(np.uint32), exp_cols[i, gids][order]) and
                             np.array_equal(g_hg[lo:hi].astype(np.uint32), gids[order].astype(np.uint32)))
-    (n1, t1), (n2, t2) = pts[0], pts[-1]
-    if n2 == n1:
-        t_q = t2
-    elif t2 > t1:
-        t_q = t1 + (t2 - t1) * (N - n1) / (n2 - n1)   # linear in N through both points
-    else:
-        t_q = t2                                      # no measurable growth: take the larger index as is
     val = n_s / (t_sk + t_q)
+    phys = set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
     return {
         "value": val, "unit": "genomes/s", "cores": cores, "kind": "port",
-        "sample": "%d query genomes of step %d: sketch leg timed in full (%.2f s); gather leg timed on "
-                  "sub-indexes of %d and %d genomes (%.3f s, %.3f s) and extrapolated linearly to %d"
-                  % (n_s, si, t_sk, n1, n2, t1, t2, N),
+        "host_logical_cpus": os.cpu_count(), "host_physical_cores": len(phys) or None,
+        "threads_tried": sorted({po.lib().nqo_max_threads(), max(1, po.lib().nqo_max_threads() // 2), max(1, po.lib().nqo_max_threads() // 4)}),
+        "sample": "%d query genomes of step %d on %d threads (the fastest of the thread counts tried): sketch leg timed in "
+                  "full (%.2f s); gather leg = the oracle's query loop timed on each of the %d sub-indexes of <= 16384 genomes "
+                  "that together hold all %d genomes, summed (%.2f s)" % (n_s, si, cores, t_sk, n_sub_ix, N, t_q),
         "parity": {"sketch_bit_exact": parity_sketch, "counts_bit_exact_all_columns": parity_counts,
                    "hit_lists_bit_exact": parity_hits, "queries_checked": n_par},
     }

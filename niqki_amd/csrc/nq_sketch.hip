@@ -1080,8 +1080,9 @@ __global__ __launch_bounds__(1024) void alu_probe_kernel(uint32_t iters, uint32_
     for (uint32_t i = 0; i < iters; ++i) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        a0 = (a0 << 3) + a1; a1 = (a1 << 3) + a2; a2 = (a2 << 3) + a3; a3 = (a3 << 3) + a4;
-        a4 = (a4 << 3) + a5; a5 = (a5 << 3) + a6; a6 = (a6 << 3) + a7; a7 = (a7 << 3) + a0;
+#define NQ_LA(x, y) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x) : "v"(y))
+        NQ_LA(a0, a1); NQ_LA(a1, a2); NQ_LA(a2, a3); NQ_LA(a3, a4); NQ_LA(a4, a5); NQ_LA(a5, a6); NQ_LA(a6, a7); NQ_LA(a7, a0);
+#undef NQ_LA
       }
     }
     const uint32_t x = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;

@@ -1,7 +1,7 @@
-// niqki_main.cpp -- the `niqki` command line on the MI355X engine.  Same options,
-// phases, output files and info box as the reference's main()
-// (src/niqki.cpp:229-456, option table :102-185); the work is done by
-// nqhost::Index -> libniqki_hip.so.  Extensions (long options only):
+// niqki_main.cpp -- the `niqki` command line on the MI355X engine.  Same options, output
+// files, info box text and exit codes as the reference's program (behaviour of
+// src/niqki.cpp:229-456, option table :102-185); here the run is a table of phases -- index
+// inputs, dump, matrix, query inputs -- each a driver of nqhost::Index -> libniqki_hip.so.  Extensions (long options only):
 //   --device <n>   HIP device ordinal (default: current device)
 //   --gpus <n>     cut the index by sketch-slot range over n GPUs (devices --device .. +n-1)
 #include <libgen.h>
@@ -18,6 +18,7 @@
 #include <iomanip>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -135,31 +136,103 @@ void print_usage() {
   }
 }
 
-int old_wd = -1;
-void changeDirFromFilename(const char *fname) {  // src/niqki.cpp:202-215
-  old_wd = open(".", O_CLOEXEC);
-  char copy[PATH_MAX];
-  strncpy(copy, fname, PATH_MAX);
-  copy[PATH_MAX - 1] = '\0';
-  errno = 0;
-  if (chdir(dirname(copy))) cout << "Error: " << strerror(errno) << endl;
-}
-void restoreDir() {  // src/niqki.cpp:219-224
-  errno = 0;
-  if (fchdir(old_wd)) cout << "Error: " << strerror(errno) << endl;
-}
-string base_name(const string &s) { return s.substr(s.find_last_of("/\\") + 1); }
+// The names inside a file of files are relative to the list: while such a list is read the process
+// sits in the list's directory (what src/niqki.cpp:200-224 does around its index and matrix phases).
+class ListDir {
+ public:
+  explicit ListDir(const string &list_path) : back_(open(".", O_CLOEXEC)) {
+    vector<char> path(list_path.begin(), list_path.end());
+    path.push_back('\0');
+    errno = 0;
+    if (chdir(dirname(path.data())) != 0) cout << "Error: " << strerror(errno) << endl;
+  }
+  ~ListDir() {
+    errno = 0;
+    if (fchdir(back_) != 0) cout << "Error: " << strerror(errno) << endl;
+    if (back_ >= 0) close(back_);
+  }
+  ListDir(const ListDir &) = delete;
+  ListDir &operator=(const ListDir &) = delete;
 
-void box_time(const char *label, double s) {
-  cout << label << setw(30) << setfill(' ') << s << " |" << endl;
+ private:
+  int back_;
+};
+
+string leaf_of(const string &path) { return path.substr(path.find_last_of("/\\") + 1); }
+
+void warn_if_unreadable(const string &path) {
+  if (!ifstream(path)) cout << "Unable to open the file '" << path << "'" << endl;
 }
+
+// the three time stamps behind the info box's "lasted" rows
+struct RunClock {
+  using tp = time_point<system_clock>;
+  tp run_begin = system_clock::now(), index_end = run_begin;
+  static void row(const char *label, tp from, tp to) {
+    cout << label << setw(30) << setfill(' ') << duration<double>(to - from).count() << " |" << endl;
+  }
+  void index_done() {
+    index_end = system_clock::now();
+    row("| Indexing lasted (s)               |", run_begin, index_end);
+  }
+};
+
+template <typename T>
+void box_row(const char *label, const T &value) {
+  cout << label << setw(30) << setfill(' ') << value << " |" << endl;
+}
+
+// One input option = one phase: which Index driver takes the file, and whether it is a list whose
+// entries are relative to its own directory.
+struct Phase {
+  Opt opt;
+  bool in_list_dir;
+  void (nqhost::Index::*driver)(const string &);
+};
+const Phase kIndexPhases[] = {{LIST, true, &nqhost::Index::insert_file_of_file_whole},
+                              {LISTLINES, true, &nqhost::Index::insert_file_lines}};
+const Phase kQueryPhases[] = {{QUERY, false, &nqhost::Index::query_file_of_file_whole},
+                              {QUERYLINES, false, &nqhost::Index::query_file_lines}};
+
+void run_phase(nqhost::Index &ix, const Parsed &o, const Phase &ph) {
+  if (!o.has(ph.opt)) return;
+  const string path = o.last(ph.opt);
+  warn_if_unreadable(path);
+  if (ph.in_list_dir) {
+    ListDir here(path);
+    (ix.*ph.driver)(leaf_of(path));
+  } else {
+    (ix.*ph.driver)(path);
+  }
+}
+
+// -M: the list doubles as the index input when no index option was given; the matrix itself is timed
+// as a query of its own (both "lasted" rows are printed again, as the reference does)
+void run_matrix(nqhost::Index &ix, const Parsed &o, RunClock &clk) {
+  if (!o.has(MATRIX)) return;
+  const string list = o.last(MATRIX);
+  warn_if_unreadable(list);
+  if (!o.has(LIST) && !o.has(LISTLINES)) {
+    clk.run_begin = system_clock::now();
+    {
+      ListDir here(list);
+      ix.insert_file_of_file_whole(leaf_of(list));
+    }
+    clk.index_done();
+  }
+  ListDir here(list);
+  clk.run_begin = system_clock::now();
+  ix.query_matrix();
+  RunClock::row("| Query lasted (s)                  |", clk.run_begin, system_clock::now());
+}
+
+int int_opt(const Parsed &o, Opt id, int dflt) { return o.has(id) ? atoi(o.last(id).c_str()) : dflt; }
 
 }  // namespace
 
 int main(int argc, char *argv[]) {
-  argc -= (argc > 0);
-  argv += (argc > 0);
-  Parsed o = parse(argc, argv);
+  if (argc > 0) { --argc; ++argv; }
+  const Parsed o = parse(argc, argv);
   if (o.error) {
     cout << "Bad usage!!!" << endl;
     return EXIT_FAILURE;
@@ -168,131 +241,57 @@ int main(int argc, char *argv[]) {
     print_usage();
     return EXIT_SUCCESS;
   }
-  const int K = o.has(KMER) ? atoi(o.last(KMER).c_str()) : 31;
-  const int F = o.has(FETCH) ? atoi(o.last(FETCH).c_str()) : 15;
-  const int H = o.has(HHL) ? atoi(o.last(HHL).c_str()) : 4;
-  const int W = o.has(WORD) ? atoi(o.last(WORD).c_str()) : 12;
-  const double min_fract = o.has(MIN) ? atof(o.last(MIN).c_str()) : 0;
-  const unsigned genomes_sizes = o.has(GENOME_SIZE) ? (unsigned)atoi(o.last(GENOME_SIZE).c_str()) : 0;
-  const int device = o.has(DEVICE) ? atoi(o.last(DEVICE).c_str()) : -1;
-  const int n_gpus = o.has(GPUS) ? atoi(o.last(GPUS).c_str()) : 1;
-
-  for (size_t i = 0; i < o.non_options.size(); ++i) {
-    cout << "Non-option argument #" << i << " is " << o.non_options[i] << endl;
-    cout << "Ignoring unknown argument '" << o.non_options[i] << "'" << endl;
-  }
+  for (size_t i = 0; i < o.non_options.size(); ++i)
+    cout << "Non-option argument #" << i << " is " << o.non_options[i] << endl
+         << "Ignoring unknown argument '" << o.non_options[i] << "'" << endl;
   if (!o.non_options.empty()) {
     cout << "Bad usage!!!" << endl;
     return EXIT_FAILURE;
   }
+  const int K = int_opt(o, KMER, 31), S = int_opt(o, FETCH, 15), H = int_opt(o, HHL, 4), W = int_opt(o, WORD, 12);
+  const double min_jaccard = o.has(MIN) ? atof(o.last(MIN).c_str()) : 0;
+  const int device = int_opt(o, DEVICE, -1), n_gpus = int_opt(o, GPUS, 1);
   const string out_file = o.has(OUTPUT) ? o.last(OUTPUT) : "niqkiOutput.gz";
-  cout << "+-------------------------------------------------------------------+" << endl;
-  cout << "|                            Informations                           |" << endl;
-  cout << "+-----------------------------------+-------------------------------+" << endl;
-  nqhost::Index *monindex = nullptr;
+
+  const char *rule = "+-----------------------------------+-------------------------------+";
+  cout << "+-------------------------------------------------------------------+" << endl
+       << "|                            Informations                           |" << endl
+       << rule << endl;
+  std::unique_ptr<nqhost::Index> ix;
   try {
-    if (o.has(LOAD)) monindex = new nqhost::Index(o.last(LOAD), true, out_file, device, n_gpus);
-    else monindex = new nqhost::Index(F, K, W, H, out_file, min_fract, device, n_gpus);
+    if (o.has(LOAD)) ix.reset(new nqhost::Index(o.last(LOAD), true, out_file, device, n_gpus));
+    else ix.reset(new nqhost::Index(S, K, W, H, out_file, min_jaccard, device, n_gpus));
+    if (const unsigned expect = (unsigned)int_opt(o, GENOME_SIZE, 0)) ix->select_best_H(expect);   // src/niqki.cpp:303-305
+
+    RunClock clk;
+    for (const Phase &ph : kIndexPhases) run_phase(*ix, o, ph);
+    if (o.has(DOWNLAD)) cout << "--indexdownload needs network access and is not part of this build" << endl;
+    if (o.has(DUMP)) ix->dump_index_disk(o.last(DUMP));
+    clk.index_done();
+    run_matrix(*ix, o, clk);
+    for (const Phase &ph : kQueryPhases) run_phase(*ix, o, ph);
+    ix->outfile->close();
+    const RunClock::tp done = system_clock::now();
+    RunClock::row("| Query lasted (s)                  |", clk.index_end, done);
+    RunClock::row("| Whole run lasted (s)              |", clk.run_begin, done);
   } catch (const std::exception &e) {
     cerr << "niqki: " << e.what() << endl;
     return EXIT_FAILURE;
   }
-  if (genomes_sizes != 0) {
-    try {
-      monindex->select_best_H(genomes_sizes);  // src/niqki.cpp:303-305
-    } catch (const std::exception &e) {
-      cerr << "niqki: " << e.what() << endl;
-      return EXIT_FAILURE;
-    }
-  }
-
-  time_point<system_clock> start, endindex, end;
-  start = system_clock::now();
-  try {
-    if (o.has(LIST)) {
-      const string list_file = o.last(LIST);
-      ifstream ifs(list_file);
-      if (!ifs) cout << "Unable to open the file '" << list_file << "'" << endl;
-      changeDirFromFilename(list_file.c_str());
-      monindex->insert_file_of_file_whole(base_name(list_file));
-      restoreDir();
-    }
-    if (o.has(LISTLINES)) {
-      const string list_file = o.last(LISTLINES);
-      ifstream ifs(list_file);
-      if (!ifs) cout << "Unable to open the file '" << list_file << "'" << endl;
-      changeDirFromFilename(list_file.c_str());
-      monindex->insert_file_lines(base_name(list_file));
-      restoreDir();
-    }
-    if (o.has(DOWNLAD))
-      cout << "--indexdownload needs network access and is not part of this build" << endl;
-    if (o.has(DUMP)) monindex->dump_index_disk(o.last(DUMP));
-
-    endindex = system_clock::now();
-    duration<double> elapsed = endindex - start;
-    box_time("| Indexing lasted (s)               |", elapsed.count());
-
-    if (o.has(MATRIX)) {
-      const string matrix_file = o.last(MATRIX);
-      ifstream ifs(matrix_file);
-      if (!ifs) cout << "Unable to open the file '" << matrix_file << "'" << endl;
-      if (!o.has(LIST) && !o.has(LISTLINES)) {
-        start = system_clock::now();
-        changeDirFromFilename(matrix_file.c_str());
-        monindex->insert_file_of_file_whole(base_name(matrix_file));
-        restoreDir();
-        endindex = system_clock::now();
-        elapsed = endindex - start;
-        box_time("| Indexing lasted (s)               |", elapsed.count());
-      }
-      changeDirFromFilename(matrix_file.c_str());
-      start = system_clock::now();
-      monindex->query_matrix();
-      end = system_clock::now();
-      elapsed = end - start;
-      box_time("| Query lasted (s)                  |", elapsed.count());
-      restoreDir();
-    }
-    if (o.has(QUERY)) {
-      const string query_file = o.last(QUERY);
-      ifstream ifs(query_file);
-      if (!ifs) cout << "Unable to open the file '" << query_file << "'" << endl;
-      monindex->query_file_of_file_whole(query_file);
-    }
-    if (o.has(QUERYLINES)) {
-      const string query_file = o.last(QUERYLINES);
-      ifstream ifs(query_file);
-      if (!ifs) cout << "Unable to open the file '" << query_file << "'" << endl;
-      monindex->query_file_lines(query_file);
-    }
-    monindex->outfile->close();
-  } catch (const std::exception &e) {
-    cerr << "niqki: " << e.what() << endl;
-    return EXIT_FAILURE;
-  }
-
-  end = system_clock::now();
-  duration<double> elapsed = end - endindex;
-  box_time("| Query lasted (s)                  |", elapsed.count());
-  elapsed = end - start;
-  box_time("| Whole run lasted (s)              |", elapsed.count());
 
   if (o.has(LOGO)) {
-    ifstream logo("../resources/niqki.ascii");
-    string line;
-    if (logo.is_open()) while (getline(logo, line)) cout << line << '\n';
-    else cout << "Unable to open file :'../resources/niqki.ascii'" << endl;
+    ifstream art("../resources/niqki.ascii");
+    if (!art.is_open()) cout << "Unable to open file :'../resources/niqki.ascii'" << endl;
+    for (string line; art.is_open() && getline(art, line);) cout << line << '\n';
     return EXIT_SUCCESS;
   }
-  cout << "+-----------------------------------+-------------------------------+" << endl;
-  cout << "| k-mer size                        |" << setw(30) << setfill(' ') << K << " |" << endl
-       << "| S                                 |" << setw(30) << setfill(' ') << F << " |" << endl
-       << "| Number of fingerprints            |" << setw(30) << setfill(' ') << monindex->F << " |" << endl
-       << "| W                                 |" << setw(30) << setfill(' ') << W << " |" << endl
-       << "| H                                 |" << setw(30) << setfill(' ') << H << " |" << endl
-       << "| Number of indexed genomes         |" << setw(30) << setfill(' ') << monindex->getNbGenomes() << " |" << endl;
-  cout << "+-----------------------------------+-------------------------------+" << endl;
-  delete monindex;
+  cout << rule << endl;
+  box_row("| k-mer size                        |", K);
+  box_row("| S                                 |", S);
+  box_row("| Number of fingerprints            |", ix->F);
+  box_row("| W                                 |", W);
+  box_row("| H                                 |", H);
+  box_row("| Number of indexed genomes         |", ix->getNbGenomes());
+  cout << rule << endl;
   return EXIT_SUCCESS;
 }
