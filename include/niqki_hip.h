@@ -352,6 +352,30 @@ int niqki_get_sketches(niqki_index *ix, uint32_t begin, uint32_t n,
 int niqki_query_gathered(niqki_index *ix, const int32_t *sketches, uint32_t nq,
                          uint64_t *gathered_per_query, int mem);
 
+/* The sparse exchange WITHOUT counter rows, step by step (NIQKI_MEM_DEVICE only; what a slot shard of
+ * a niqki_group runs -- exposed for tests and for timing one shard's compute):
+ *   niqki_query_survivors       gather over the handle's slots; per query the candidates (count >=
+ *                               cand_threshold: ids, as niqki_candidates_from_counts) and the survivors
+ *                               (count >= surv_threshold <= cand_threshold: surv[q*surv_cap + i] =
+ *                               {genome id, count} as two int32, n_surv[q] how many qualified).  No
+ *                               2N-byte counter row per query is written.
+ *   niqki_survivor_counts       counts[q*m + i] = the handle's count of genome ids[q*m + i] (-1: 0) for
+ *                               query q: from the survivor list, or -- an id that is not among them --
+ *                               counted exactly as the slots where the genome's stored sketch equals the
+ *                               query's (sketches: the same rows as given to niqki_query_survivors).
+ *   niqki_hits_from_candidates  the hits of nq queries from m candidate ids each and their (cross-shard)
+ *                               sums: distinct ids with a sum >= min_score, ordered as niqki_query's.
+ * m <= 4096, surv_cap <= 4096. */
+int niqki_query_survivors(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint32_t cand_threshold,
+                          uint32_t surv_threshold, uint32_t cand_cap, uint32_t surv_cap, int32_t *cand,
+                          int32_t *n_cand, int32_t *surv, int32_t *n_surv, int mem);
+int niqki_survivor_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq, const int32_t *ids, uint32_t m,
+                          const int32_t *surv, const int32_t *n_surv, uint32_t surv_cap, uint16_t *counts,
+                          int mem);
+int niqki_hits_from_candidates(niqki_index *ix, const int32_t *ids, const uint16_t *totals, uint32_t nq,
+                               uint32_t m, uint64_t *hit_off, uint32_t *hit_counts, uint32_t *hit_gids,
+                               uint64_t capacity, int mem);
+
 /* ---- one index over several GPUs: slot-range shards -----------------------------
  * No reference counterpart (the reference is one process on one host); this is how
  * Index::insert_sketch / Index::query_sketch (src/niqki_index.cpp:362-370, :633-687)
@@ -393,7 +417,9 @@ const char *niqki_group_last_error(const niqki_group *g);
 /* "exchange": 0 = choose (sparse when min_score >= 4 * world), 1 = sparse (candidate
  * genomes only), 2 = dense (reduce-scatter of whole hit vectors); "cand_cap": candidate
  * ids per query and rank of the sparse form, even, default 256 (a step whose lists
- * overflow is redone densely, never answered wrongly). */
+ * overflow is redone densely, never answered wrongly); "surv_cap": survivors (genomes with a
+ * partial count of at least half the candidate threshold) a shard keeps per query, default 1024,
+ * at most 4096. */
 int niqki_group_set_option(niqki_group *g, const char *key, int64_t value);
 /* "overflows" (sparse steps redone densely so far), "rccl" (1 = RCCL transport),
  * "transport" (0 = device copies inside one process, 1 = RCCL, 2 = ipc),

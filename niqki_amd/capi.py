@@ -84,6 +84,9 @@ ABI = [
     ("niqki_candidates_from_counts", _int, [_vp, _vp, _u32, _u64, _u32, _u32, _u32, _vp, _vp, _int]),
     ("niqki_query_counts_candidates", _int, [_vp, _vp, _u32, _vp, _u64, _u32, _u32, _vp, _vp, _int]),
     ("niqki_query", _int, [_vp, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_query_survivors", _int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _int]),
+    ("niqki_survivor_counts", _int, [_vp, _vp, _u32, _vp, _u32, _vp, _vp, _u32, _vp, _int]),
+    ("niqki_hits_from_candidates", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_query_sequences", _int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_stage_raw", _int, [_vp, C.POINTER(RawBatch), _int, C.POINTER(StageInfo), _vp]),
     ("niqki_staged_sketch", _int, [_vp, _vp, _int]),
@@ -499,6 +502,18 @@ class Engine:
     def query_counts_candidates_dev(self, sketches, nq, counts, stride, threshold, cap, cand, n_cand):
         self._ck(self.L.niqki_query_counts_candidates(self.h, _p(sketches), nq, _p(counts), stride, threshold, cap,
                                                       _p(cand), _p(n_cand), MEM_DEVICE))
+
+    def query_survivors_dev(self, sketches, nq, cand_thr, surv_thr, cand_cap, surv_cap, cand, n_cand, surv, n_surv):
+        self._ck(self.L.niqki_query_survivors(self.h, _p(sketches), nq, cand_thr, surv_thr, cand_cap, surv_cap, _p(cand),
+                                              _p(n_cand), _p(surv), _p(n_surv), MEM_DEVICE))
+
+    def survivor_counts_dev(self, sketches, nq, ids, m, surv, n_surv, surv_cap, counts):
+        self._ck(self.L.niqki_survivor_counts(self.h, _p(sketches), nq, _p(ids), m, _p(surv), _p(n_surv), surv_cap,
+                                              _p(counts), MEM_DEVICE))
+
+    def hits_from_candidates_dev(self, ids, totals, nq, m, hit_off, hc, hg, capacity):
+        self._ck(self.L.niqki_hits_from_candidates(self.h, _p(ids), _p(totals), nq, m, _p(hit_off), _p(hc), _p(hg),
+                                                   capacity, MEM_DEVICE))
 
     def query_dev(self, sketches, nq, hit_off, hc, hg, capacity):
         self._ck(self.L.niqki_query(self.h, _p(sketches), nq, _p(hit_off), _p(hc), _p(hg), capacity,

@@ -355,9 +355,13 @@ int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint
     return fail(ix, NIQKI_E_INVALID, "candidate lists: not on a paged or whole-range S = 16 handle; cand, n_cand and cap > 0 needed");
   if (ix->resident_bytes) return counts_paged(ix, sketches, q_stride, q_off, nq, counts, stride, counts2);
   if (two_planes(ix) && !counts2) return fail(ix, NIQKI_E_INVALID, "S = 16: counts reach 2^16, use niqki_query_counts32 (or the hit calls)");
+  if (!counts && !(co && co->surv)) return fail(ix, NIQKI_E_INVALID, "no counter rows: only together with survivor lists");
+  if (co && co->surv && (!co->surv_n || !co->surv_cap || co->surv_thr > co->thr))
+    return fail(ix, NIQKI_E_INVALID, "survivor lists need surv_n, surv_cap > 0 and surv_thr <= thr");
   if (co && nq) {
     NQ_HIP(ix, hipMemsetAsync(co->n, 0, (size_t)nq * 4, ix->stream));
     NQ_HIP(ix, hipMemsetAsync(co->cand, 0xFF, (size_t)nq * co->cap * 4, ix->stream));
+    if (co->surv) NQ_HIP(ix, hipMemsetAsync(co->surv_n, 0, (size_t)nq * 4, ix->stream));
   }
   return counts_resident(ix, sketches, q_stride, q_off, nq, counts, stride, false, counts2, co);
 }
@@ -367,7 +371,7 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
   int rc = ix->resident_bytes ? NIQKI_OK : build_if_needed(ix);
   if (rc) return rc;
   if (nq == 0) return NIQKI_OK;
-  if (stride < ix->built_n || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
+  if (counts && (stride < ix->built_n || (stride & 1))) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
   if ((uintptr_t)counts & 3) return fail(ix, NIQKI_E_INVALID, "counts must be 4-byte aligned (rows are written as packed u16 pairs)");
   if (ix->built_n == 0) return NIQKI_OK;
   if (ix->delta_n && !ix->resident_bytes) {  // the delta segment first (its columns are its own), then the main index below
@@ -459,8 +463,13 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
       NQ_HIP(ix, nq::launch_lookup(v, sketches + (size_t)q0 * q_stride, n, (uint32_t *)ix->ws_pre.p, ix->stream));
     if (fork) NQ_HIP(ix, hipStreamWaitEvent(ix->stream, ix->ev_join, 0));
     nq::CandOut c;
-    if (co) { c = *co; c.cand += (size_t)q0 * co->cap; c.n += q0; }
-    NQ_HIP(ix, nq::launch_gather(v, sketches + (size_t)q0 * q_stride, n, counts + (size_t)q0 * stride,
+    if (co) {
+      c = *co;
+      c.cand += (size_t)q0 * co->cap;
+      c.n += q0;
+      if (co->surv) { c.surv += (size_t)q0 * co->surv_cap; c.surv_n += q0; }
+    }
+    NQ_HIP(ix, nq::launch_gather(v, sketches + (size_t)q0 * q_stride, n, counts ? counts + (size_t)q0 * stride : nullptr,
                                  counts2 ? counts2 + (size_t)q0 * stride : nullptr, stride,
                                  pre ? (nq::Entry *)ix->ws_pre.p : (nq::Entry *)ix->ws_stash.p, order, ix->gather_variant,
                                  pre, ix->stream, c));

@@ -153,36 +153,173 @@ __global__ __launch_bounds__(256) void slice_unpack_kernel(const int16_t *in, ui
   for (uint32_t j = threadIdx.x; j < f_local; j += 256) out[(uint64_t)q * f_local + j] = src[j];
 }
 
-// A rank's candidates travel as one blob: nq lists of C ids, then the nq list sizes (one all-gather).
-__host__ __device__ inline uint64_t cand_blob_ints(uint32_t nq, uint32_t C) { return (uint64_t)nq * C + nq; }
+// A rank's candidates travel as one blob: nq lists of C ids, the nq list sizes, the nq sizes of its survivor
+// lists (one all-gather).
+__host__ __device__ inline uint64_t cand_blob_ints(uint32_t nq, uint32_t C) { return (uint64_t)nq * C + 2ull * nq; }
 
-// mine[q][g*C + c] = this shard's partial count of candidate c of rank g for query q (0 where the
-// list has no entry), as u16: the cross-shard sums stay <= F <= 2^15, so the ranks add them as packed
-// pairs in u32 words without a carry (half the bytes of the reduce-scatter); flag |= some list
-// overflowed its capacity
-// (blob: ints between two ranks' candidate blobs in cand_all, >= cand_blob_ints)
-__global__ __launch_bounds__(256) void cand_lookup_kernel(const uint16_t *counts, uint64_t stride, uint32_t nq, uint32_t G,
-                                                         uint32_t C, const int32_t *cand_all, uint64_t blob, uint16_t *mine,
-                                                         uint32_t *flag) {
-  const uint32_t q = blockIdx.x;
-  const uint16_t *row = counts + (uint64_t)q * stride;
-  for (uint32_t i = threadIdx.x; i < G * C; i += 256) {
-    const uint32_t g = i / C, c = i % C;
-    const int32_t id = cand_all[g * blob + (uint64_t)q * C + c];
-    mine[(uint64_t)q * G * C + i] = id >= 0 ? row[id] : (uint16_t)0;
+// ---- sparse exchange without counter rows ---------------------------------------------------------
+// The ids a query's ranks proposed, m per query: id(q, i) = p[(i / C) * blob + q * C + i % C]
+// (the all-gathered blobs: C ids per rank; a flat [nq][m] array: C = m).
+struct IdView {
+  const int32_t *p;
+  uint64_t blob;
+  uint32_t C;
+  __device__ int32_t at(uint32_t q, uint32_t i) const { return p[(uint64_t)(i / C) * blob + (uint64_t)q * C + i % C]; }
+};
+__device__ inline uint32_t id_hash(uint32_t id) { return (id * 2654435761u) >> 7; }
+constexpr uint32_t kSurvMax = 4096;       // survivors per query a lookup can index (LDS table of 2x)
+constexpr uint32_t kCandMax = 4096;       // ids per query cand_hits_kernel can order in LDS
+
+// mine[q][i] = this shard's partial count of id(q, i) (0 for -1): from the shard's survivor list of the
+// query (every genome with a partial count >= surv_thr, indexed here by an LDS hash table) or, for an id
+// that is not among them -- another rank's candidate that is weak here --, counted exactly as the slots
+// in which the genome's stored sketch equals the query's (the identity behind the matrix path, DESIGN.md
+// 4.6): f_local strided 2-byte reads per such id, rare by construction.  flag[0] |= a list overflowed.
+__global__ __launch_bounds__(256) void surv_lookup_kernel(const int2 *surv, const int32_t *surv_n, uint32_t SC, uint32_t T, uint32_t m,
+                                                         IdView ids, const int32_t *sk, uint32_t q_stride, uint32_t q_off,
+                                                         uint32_t f_local, const uint16_t *store, uint64_t store_cap, uint32_t R,
+                                                         uint16_t *mine, uint32_t *flag) {
+  extern __shared__ __align__(8) int lds_tab[];
+  int2 *tab = (int2 *)lds_tab;                  // T x {id, count}
+  uint32_t *missing = (uint32_t *)(tab + T);    // one bit per position i < m <= kCandMax
+  __shared__ uint32_t acc;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x, mw = (m + 31) / 32;
+  for (uint32_t i = tid; i < T; i += 256) tab[i] = make_int2(-1, 0);
+  for (uint32_t i = tid; i < mw; i += 256) missing[i] = 0;
+  __syncthreads();
+  const uint32_t ns_all = (uint32_t)surv_n[q], ns = ns_all < SC ? ns_all : SC;   // (an overflow is every rank's to see:
+  for (uint32_t i = tid; i < ns; i += 256) {                                     //  blob_overflow_kernel)
+    const int2 e = surv[(uint64_t)q * SC + i];
+    uint32_t h = id_hash((uint32_t)e.x) & (T - 1);
+    while (atomicCAS(&tab[h].x, -1, e.x) != -1) h = (h + 1) & (T - 1);   // (ids of one list are distinct)
+    tab[h].y = e.y;
   }
-  if (threadIdx.x < G && (uint32_t)cand_all[threadIdx.x * blob + (uint64_t)nq * C + q] > C) atomicOr(flag, 1u);
+  __syncthreads();
+  for (uint32_t i = tid; i < m; i += 256) {
+    const int32_t id = ids.at(q, i);
+    uint32_t c = 0;
+    if (id >= 0) {
+      uint32_t h = id_hash((uint32_t)id) & (T - 1);
+      bool found = false;
+      for (int2 e = tab[h]; e.x != -1; h = (h + 1) & (T - 1), e = tab[h])
+        if (e.x == id) { c = (uint32_t)e.y; found = true; break; }
+      if (!found) atomicOr(&missing[i >> 5], 1u << (i & 31));
+    }
+    mine[(uint64_t)q * m + i] = (uint16_t)c;
+  }
+  __syncthreads();
+  // ids this shard holds no survivor entry for: counted exactly from the sketch store, one after the other
+  const int32_t *row = sk + (uint64_t)q * q_stride + q_off;
+  for (uint32_t w = 0; w < mw; ++w) {
+    for (uint32_t bits = missing[w]; bits; bits &= bits - 1) {   // (uniform: every thread reads the same word)
+      const uint32_t i = w * 32 + (uint32_t)__builtin_ctz(bits);
+      const uint32_t id = (uint32_t)ids.at(q, i);
+      if (tid == 0) acc = 0;
+      __syncthreads();
+      uint32_t c = 0;
+      for (uint32_t s_ = tid; s_ < f_local; s_ += 256) {
+        const int32_t fp = row[s_];
+        c += (fp >= 0 && (uint32_t)fp < R && store[(uint64_t)s_ * store_cap + id] == (uint16_t)fp) ? 1u : 0u;
+      }
+      if (c) atomicAdd(&acc, c);
+      __syncthreads();
+      if (tid == 0) mine[(uint64_t)q * m + i] = (uint16_t)acc;
+      __syncthreads();
+    }
+  }
+  (void)flag;
 }
 
-// summed candidate counts into the (zeroed) counter rows of this rank's own queries
-__global__ __launch_bounds__(256) void cand_scatter_kernel(const uint16_t *tot, uint32_t per, uint32_t first_q, uint32_t nq,
-                                                          uint32_t G, uint32_t C, const int32_t *cand_all, uint64_t blob,
-                                                          uint16_t *red, uint64_t stride) {
-  const uint32_t ql = blockIdx.x, q = first_q + ql;
-  for (uint32_t i = threadIdx.x; i < G * C; i += 256) {
-    const uint32_t g = i / C, c = i % C;
-    const int32_t id = cand_all[g * blob + (uint64_t)q * C + c];
-    if (id >= 0) red[(uint64_t)ql * stride + id] = tot[(uint64_t)ql * G * C + i];  // duplicates write the same sum
+// The hits of one query from its candidates alone: ids id(first_q + ql, i) with summed counts tot[ql][i]
+// (the same id may appear under several ranks, with the same sum): distinct ids whose sum reaches min_score,
+// ordered like greater<pair<count, gid>> (src/niqki_index.cpp:685), as 64-bit keys count << 32 | gid.
+__global__ __launch_bounds__(256) void cand_hits_kernel(const uint16_t *tot, uint32_t first_q, uint32_t m, IdView ids, uint32_t min_score,
+                                                       uint32_t T, uint32_t P, unsigned long long *keys, uint32_t *n_out) {
+  extern __shared__ __align__(8) int lds_tab[];
+  unsigned long long *list = (unsigned long long *)lds_tab;   // P keys
+  int32_t *set = (int32_t *)(list + P);                        // T ids
+  __shared__ uint32_t cnt;
+  const uint32_t ql = blockIdx.x, q = first_q + ql, tid = threadIdx.x;
+  for (uint32_t i = tid; i < T; i += 256) set[i] = -1;
+  for (uint32_t i = tid; i < P; i += 256) list[i] = 0ull;
+  if (tid == 0) cnt = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < m; i += 256) {
+    const int32_t id = ids.at(q, i);
+    if (id < 0) continue;
+    uint32_t h = id_hash((uint32_t)id) & (T - 1);
+    for (;;) {
+      const int32_t prev = atomicCAS(&set[h], -1, id);
+      if (prev == -1) {   // first of its copies
+        const uint32_t c = tot[(uint64_t)ql * m + i];
+        if (c >= min_score) list[atomicAdd(&cnt, 1u)] = ((unsigned long long)c << 32) | (uint32_t)id;
+        break;
+      }
+      if (prev == id) break;
+      h = (h + 1) & (T - 1);
+    }
+  }
+  __syncthreads();
+  const uint32_t n = cnt;
+  // bitonic sort, descending (empty places hold 0 and end up last; a real key is never 0: count >= 1 unless
+  // min_score is 0, and then gid 0 with count 0 keeps its place among the n first by the write below)
+  for (uint32_t k = 2; k <= P; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = tid; i < P; i += 256) {
+        const uint32_t l = i ^ j;
+        if (l > i) {
+          const unsigned long long x = list[i], y = list[l];
+          const bool desc = (i & k) == 0;
+          if ((x < y) == desc) { list[i] = y; list[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  for (uint32_t i = tid; i < n; i += 256) keys[(uint64_t)ql * m + i] = list[i];
+  if (tid == 0) n_out[ql] = n;
+}
+
+// flag |= some rank's candidate or survivor list of some query holds more than its capacity
+__global__ __launch_bounds__(256) void blob_overflow_kernel(const int32_t *cand_all, uint64_t blob, uint32_t nq, uint32_t G, uint32_t C,
+                                                           uint32_t SC, uint32_t *flag) {
+  const uint32_t q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  bool over = false;
+  for (uint32_t g = 0; g < G; ++g) {
+    const int32_t *tail = cand_all + g * blob + (uint64_t)nq * C;
+    over |= (uint32_t)tail[q] > C || (uint32_t)tail[nq + q] > SC;
+  }
+  if (over) atomicOr(flag, 1u);
+}
+
+// hit_off[0..nq] = exclusive prefix of n (one workgroup)
+__global__ __launch_bounds__(1024) void cand_hits_scan_kernel(const uint32_t *n, uint32_t nq, unsigned long long *hit_off) {
+  __shared__ unsigned long long part[1024];
+  const uint32_t tid = threadIdx.x, per_t = (nq + 1023) / 1024;
+  unsigned long long s = 0;
+  for (uint32_t i = tid * per_t; i < (tid + 1) * per_t && i < nq; ++i) s += n[i];
+  part[tid] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    const unsigned long long v = tid >= d ? part[tid - d] : 0ull;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  unsigned long long run = tid ? part[tid - 1] : 0ull;
+  for (uint32_t i = tid * per_t; i < (tid + 1) * per_t && i < nq; ++i) { hit_off[i] = run; run += n[i]; }
+  if (tid == 1023) hit_off[nq] = part[1023];
+}
+__global__ __launch_bounds__(256) void cand_hits_write_kernel(const unsigned long long *keys, const uint32_t *n, uint32_t m,
+                                                             const unsigned long long *hit_off, uint32_t *hc, uint32_t *hg,
+                                                             unsigned long long capacity) {
+  const uint32_t ql = blockIdx.x;
+  const unsigned long long base = hit_off[ql];
+  for (uint32_t i = threadIdx.x; i < n[ql]; i += 256) {
+    if (base + i >= capacity) break;
+    const unsigned long long k = keys[(uint64_t)ql * m + i];
+    hc[base + i] = (uint32_t)(k >> 32);
+    hg[base + i] = (uint32_t)k;
   }
 }
 
@@ -239,10 +376,11 @@ struct niqki_group {
   std::vector<ncclComm_t> comm;      // per local rank (kRccl)
   int exchange = 0;                  // 0 = choose, 1 = sparse, 2 = dense reduce-scatter
   uint32_t cand_cap = 256;
+  uint32_t surv_cap = 1024;          // survivors (partial count >= half the candidate threshold) kept per query and shard
   uint64_t overflows = 0;            // sparse steps redone densely
   std::string err;
   struct Ws {
-    Buf send, recv, allsk, counts, cand, cand_all, mine, tot, red, flag, hitoff, hc, hg, stpad;
+    Buf send, recv, allsk, counts, cand, cand_all, mine, tot, red, flag, hitoff, hc, hg, stpad, surv, keys, nhit;
     hipEvent_t ev = nullptr;
   };
   std::vector<Ws> ws;
@@ -677,11 +815,12 @@ int prepare_batch(niqki_group *g, uint32_t per, uint32_t N, bool query, bool spa
   const uint64_t stride = NIQKI_ROW_STRIDE(N);
   size_t need[kIpcBufs] = {slice_bytes(per, (F + G - 1) / G) * G, 0, 0, 0};
   if (query) {
-    if (sparse) {
+    if (sparse) {   // no counter rows (they are made only if a batch has to be redone densely)
       need[1] = blob_bytes(nq_, C);
       need[2] = (size_t)nq_ * G * C * 2;
+    } else {
+      need[3] = std::max<size_t>((size_t)nq_ * stride * 2, 4);
     }
-    need[3] = std::max<size_t>((size_t)nq_ * stride * 2, 4);
   }
   return ipc_prepare(g, need);
 }
@@ -800,7 +939,7 @@ void niqki_group_destroy(niqki_group *g) {
   for (uint32_t l = 0; l < g->n_local && l < g->ws.size(); ++l) {
     auto &w = g->ws[l];   // (ipc_teardown has dropped the views of its arena)
     for (Buf *b : {&w.send, &w.recv, &w.allsk, &w.counts, &w.cand, &w.cand_all, &w.mine, &w.tot, &w.red,
-                   &w.flag, &w.hitoff, &w.hc, &w.hg, &w.stpad})
+                   &w.flag, &w.hitoff, &w.hc, &w.hg, &w.stpad, &w.surv, &w.keys, &w.nhit})
       if (b->p) (void)hipFree(b->p);
     if (w.ev) (void)hipEventDestroy(w.ev);
     if (l < g->comm.size() && g->comm[l]) (void)rccl().CommDestroy(g->comm[l]);
@@ -822,6 +961,11 @@ int niqki_group_set_option(niqki_group *g, const char *key, int64_t value) {
   if (!std::strcmp(key, "cand_cap")) {
     if (value < 2 || value > 65536 || (value & 1)) return gfail(g, NIQKI_E_INVALID, "cand_cap must be even, in 2..65536");
     g->cand_cap = (uint32_t)value;
+    return NIQKI_OK;
+  }
+  if (!std::strcmp(key, "surv_cap")) {
+    if (value < 2 || value > (int64_t)nq::kSurvMax) return gfail(g, NIQKI_E_INVALID, "surv_cap must be in 2..4096");
+    g->surv_cap = (uint32_t)value;
     return NIQKI_OK;
   }
   return gfail(g, NIQKI_E_INVALID, std::string("unknown group option ") + key);
@@ -858,6 +1002,64 @@ int niqki_group_insert(niqki_group *g, const int32_t *const *local_sketches, uin
 }
 
 namespace {
+
+uint32_t pow2_at_least(uint32_t x) {
+  uint32_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+// this shard's partial counts of the ids a query's ranks proposed (nq::surv_lookup_kernel)
+hipError_t launch_surv_lookup(niqki_index *ix, const int2 *surv, const int32_t *surv_n, uint32_t SC, uint32_t nq_, uint32_t m,
+                              const nq::IdView &ids, const int32_t *sk, uint32_t q_stride, uint32_t q_off, uint16_t *mine,
+                              uint32_t *flag) {
+  if (nq_ == 0 || m == 0) return hipSuccess;
+  const uint32_t T = pow2_at_least(2 * std::max(SC, 1u));
+  const size_t lds = (size_t)T * 8 + (size_t)((m + 31) / 32) * 4;
+  hipError_t e = hipFuncSetAttribute((const void *)nq::surv_lookup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(nq::surv_lookup_kernel, dim3(nq_), dim3(256), lds, ix->stream, surv, surv_n, SC, T, m, ids, sk, q_stride, q_off,
+                     ix->d.slot_end - ix->d.slot_begin, (const uint16_t *)ix->store, (uint64_t)ix->cap, ix->d.R, mine, flag);
+  return hipGetLastError();
+}
+
+// hits of `per` queries (first_q ..) from candidate ids and their summed counts; keys / nhit: scratch
+int hits_from_candidates(niqki_index *ix, const uint16_t *tot, uint32_t first_q, uint32_t per, uint32_t m, const nq::IdView &ids,
+                         uint32_t min_score, Buf &keys, Buf &nhit, unsigned long long *hit_off, uint32_t *hc, uint32_t *hg,
+                         uint64_t capacity) {
+  if (per == 0) return NIQKI_OK;
+  if (m > nq::kCandMax) return nqi::fail(ix, NIQKI_E_INVALID, "too many candidate ids per query");
+  int rc = nqi::ensure(ix, keys, std::max<size_t>((size_t)per * m * 8, 8));
+  if (!rc) rc = nqi::ensure(ix, nhit, (size_t)per * 4);
+  if (rc) return rc;
+  const uint32_t P = pow2_at_least(std::max(m, 2u)), T = 2 * P;
+  const size_t lds = (size_t)P * 8 + (size_t)T * 4;
+  NQ_HIP(ix, hipFuncSetAttribute((const void *)nq::cand_hits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  nqi::Span sp(ix, NIQKI_KC_HITS);
+  hipLaunchKernelGGL(nq::cand_hits_kernel, dim3(per), dim3(256), lds, ix->stream, tot, first_q, m, ids, min_score, T, P,
+                     (unsigned long long *)keys.p, (uint32_t *)nhit.p);
+  hipLaunchKernelGGL(nq::cand_hits_scan_kernel, dim3(1), dim3(1024), 0, ix->stream, (const uint32_t *)nhit.p, per, hit_off);
+  hipLaunchKernelGGL(nq::cand_hits_write_kernel, dim3(per), dim3(256), 0, ix->stream, (const unsigned long long *)keys.p,
+                     (const uint32_t *)nhit.p, m, (const unsigned long long *)hit_off, hc, hg, (unsigned long long)capacity);
+  NQ_HIP(ix, hipGetLastError());
+  return NIQKI_OK;
+}
+
+// 3 (dense form): counter rows of all queries over the local slots
+int gather_rows(niqki_group *g, uint32_t nq_, uint32_t N, uint64_t stride) {
+  int rc = pre_produce(g, &niqki_group::Ws::counts);
+  if (rc) return rc;
+  for (uint32_t l = 0; l < g->n_local; ++l) {
+    niqki_index *ix = g->sh[l];
+    NQ_GH(g, hipSetDevice(ix->device));
+    auto &w = g->ws[l];
+    NQ_G(g, l, nqi::ensure(ix, w.counts, std::max<size_t>((size_t)nq_ * stride * 2, 4)));
+    if (N == 0) NQ_GH(g, hipMemsetAsync(w.counts.p, 0, std::max<size_t>((size_t)nq_ * stride * 2, 4), ix->stream));
+    NQ_G(g, l, nqi::counts_dev(ix, (const int32_t *)w.allsk.p, ix->d.slot_end - ix->d.slot_begin, 0, nq_, (uint16_t *)w.counts.p,
+                               stride, nullptr, nullptr));
+  }
+  return NIQKI_OK;
+}
 
 // 4b + 5 of a batch whose partial hit vectors (ws.counts) are complete: dense reduce-scatter, threshold, order
 int finish_dense(niqki_group *g, uint32_t per, uint32_t N, uint64_t stride) {
@@ -919,45 +1121,40 @@ int niqki_group_query_begin(niqki_group *g, const int32_t *const *local_sketches
   const uint32_t min_score = g->sh[0]->d.min_score;
   bool sparse = g->exchange == 1 || (g->exchange == 0 && min_score >= 4 * G);
   if (min_score < G || N == 0) sparse = false;   // ceil(min_score / G) must be >= 1
+  if ((uint64_t)G * g->cand_cap > nq::kCandMax) sparse = false;   // (cand_hits_kernel orders a query's candidates in LDS)
   pd.sparse = sparse;
   int rc = prepare_batch(g, per, N, true, sparse);
   if (!rc) rc = exchange_slices(g, local_sketches, per);
   if (rc) { pd.active = false; return rc; }
-  const uint32_t C = g->cand_cap, thr = (min_score + G - 1) / G;
-  // 3. partial hit vectors of all queries over the local slots; for the sparse exchange the gather kernel
-  //    also leaves every query's candidates (partial count >= ceil(min_score / G))
-  if ((rc = pre_produce(g, &niqki_group::Ws::counts))) return rc;
-  if (sparse && (rc = pre_produce(g, &niqki_group::Ws::cand))) return rc;
-  for (uint32_t l = 0; l < g->n_local; ++l) {
-    niqki_index *ix = g->sh[l];
-    NQ_GH(g, hipSetDevice(ix->device));
-    auto &w = g->ws[l];
-    NQ_G(g, l, nqi::ensure(ix, w.counts, std::max<size_t>((size_t)nq * stride * 2, 4)));
-    if (N == 0) NQ_GH(g, hipMemsetAsync(w.counts.p, 0, std::max<size_t>((size_t)nq * stride * 2, 4), ix->stream));
-    nq::CandOut co;
-    if (sparse) {
-      NQ_G(g, l, nqi::ensure(ix, w.cand, blob_bytes(nq, C)));
-      co.cand = (int32_t *)w.cand.p;
-      co.n = (int32_t *)w.cand.p + (size_t)nq * C;
-      co.thr = thr;
-      co.cap = C;
-    }
-    NQ_G(g, l, nqi::counts_dev(ix, (const int32_t *)w.allsk.p, ix->d.slot_end - ix->d.slot_begin, 0, nq,
-                               (uint16_t *)w.counts.p, stride, nullptr, sparse ? &co : nullptr));
-  }
-  // 4. cross-shard sum, scattered by query
+  const uint32_t C = g->cand_cap, SC = g->surv_cap, thr = (min_score + G - 1) / G;
   if (sparse) {
+    // 3. gather over the local slots WITHOUT counter rows: what leaves the kernel is, per query, the candidates
+    //    (partial count >= ceil(min_score / G): their ids travel) and the survivors (partial count >= half of
+    //    that, with their counts: what the other ranks' candidates are looked up in)
     const size_t blob = blob_bytes(nq, C);
+    if ((rc = pre_produce(g, &niqki_group::Ws::cand))) return rc;
     for (uint32_t l = 0; l < g->n_local; ++l) {
       niqki_index *ix = g->sh[l];
       NQ_GH(g, hipSetDevice(ix->device));
       auto &w = g->ws[l];
+      NQ_G(g, l, nqi::ensure(ix, w.cand, blob));
+      NQ_G(g, l, nqi::ensure(ix, w.surv, (size_t)nq * SC * 8));
       NQ_G(g, l, nqi::ensure(ix, w.cand_all, (size_t)G * blob));
       NQ_G(g, l, nqi::ensure(ix, w.mine, (size_t)nq * G * C * 2));
       NQ_G(g, l, nqi::ensure(ix, w.tot, (size_t)per * G * C * 2));
-      NQ_G(g, l, nqi::ensure(ix, w.red, (size_t)per * stride * 2));
       NQ_G(g, l, nqi::ensure(ix, w.flag, 4));
+      nq::CandOut co;
+      co.cand = (int32_t *)w.cand.p;
+      co.n = (int32_t *)w.cand.p + (size_t)nq * C;
+      co.thr = thr;
+      co.cap = C;
+      co.surv = (int2 *)w.surv.p;
+      co.surv_n = co.n + nq;
+      co.surv_thr = std::max(1u, thr / 2);
+      co.surv_cap = SC;
+      NQ_G(g, l, nqi::counts_dev(ix, (const int32_t *)w.allsk.p, ix->d.slot_end - ix->d.slot_begin, 0, nq, nullptr, stride, nullptr, &co));
     }
+    // 4. the candidates of all ranks, my partial counts of them, their sums
     {
       nqi::Span sp(g->sh[0], NIQKI_KC_EXCHANGE);
       if ((rc = all_gather(g, &niqki_group::Ws::cand, &niqki_group::Ws::cand_all, blob))) return rc;
@@ -969,31 +1166,43 @@ int niqki_group_query_begin(niqki_group *g, const int32_t *const *local_sketches
       auto &w = g->ws[l];
       nqi::Span sp(ix, NIQKI_KC_EXCHANGE);
       NQ_GH(g, hipMemsetAsync(w.flag.p, 0, 4, ix->stream));
-      hipLaunchKernelGGL(nq::cand_lookup_kernel, dim3(nq), dim3(256), 0, ix->stream, (const uint16_t *)w.counts.p, stride, nq, G, C,
-                         (const int32_t *)w.cand_all.p, (uint64_t)(blob / 4), (uint16_t *)w.mine.p, (uint32_t *)w.flag.p);
+      const nq::IdView ids{(const int32_t *)w.cand_all.p, (uint64_t)(blob / 4), C};
+      NQ_GH(g, launch_surv_lookup(ix, (const int2 *)w.surv.p, (const int32_t *)w.cand.p + (size_t)nq * C + nq, SC, nq, G * C, ids,
+                                  (const int32_t *)w.allsk.p, ix->d.slot_end - ix->d.slot_begin, 0, (uint16_t *)w.mine.p,
+                                  (uint32_t *)w.flag.p));
+      // a candidate list of ANY rank that overflowed (same words on every rank: all decide alike)
+      hipLaunchKernelGGL(nq::blob_overflow_kernel, dim3((nq + 255) / 256), dim3(256), 0, ix->stream, (const int32_t *)w.cand_all.p,
+                         (uint64_t)(blob / 4), nq, G, C, SC, (uint32_t *)w.flag.p);
       NQ_GH(g, hipGetLastError());
     }
     {
       nqi::Span sp(g->sh[0], NIQKI_KC_EXCHANGE);
       if ((rc = reduce_scatter_u32(g, &niqki_group::Ws::mine, &niqki_group::Ws::tot, (size_t)per * G * C / 2))) return rc;
     }
-    // The overflow word stays on the device: the sparse result is scattered and thresholded right away, and
+    // 5. The overflow word stays on the device: the hits are made from the candidates' sums right away, and
     // query_end -- the one place the host waits -- redoes the batch densely in the (rare) case that a list
-    // overflowed.  Every rank saw the same all-gathered list sizes, so all ranks (and processes) decide alike.
+    // overflowed.
     for (uint32_t l = 0; l < g->n_local; ++l) {
       niqki_index *ix = g->sh[l];
       NQ_GH(g, hipSetDevice(ix->device));
       auto &w = g->ws[l];
-      nqi::Span sp(ix, NIQKI_KC_EXCHANGE);
-      NQ_GH(g, hipMemsetAsync(w.red.p, 0, (size_t)per * stride * 2, ix->stream));
-      hipLaunchKernelGGL(nq::cand_scatter_kernel, dim3(per), dim3(256), 0, ix->stream, (const uint16_t *)w.tot.p, per,
-                         (g->first + l) * per, nq, G, C, (const int32_t *)w.cand_all.p, (uint64_t)(blob / 4), (uint16_t *)w.red.p, stride);
-      NQ_GH(g, hipGetLastError());
+      unsigned long long *off = (unsigned long long *)pd.hit_off[l];
+      uint32_t *hc = pd.hit_counts[l], *hg = pd.hit_gids[l];
+      if (pd.host) {
+        NQ_G(g, l, nqi::ensure(ix, w.hitoff, (size_t)(per + 1) * 8));
+        NQ_G(g, l, nqi::ensure(ix, w.hc, (size_t)std::max<uint64_t>(capacity, 1) * 4));
+        NQ_G(g, l, nqi::ensure(ix, w.hg, (size_t)std::max<uint64_t>(capacity, 1) * 4));
+        off = (unsigned long long *)w.hitoff.p; hc = (uint32_t *)w.hc.p; hg = (uint32_t *)w.hg.p;
+      }
+      const nq::IdView ids{(const int32_t *)w.cand_all.p, (uint64_t)(blob / 4), C};
+      NQ_G(g, l, hits_from_candidates(ix, (const uint16_t *)w.tot.p, (g->first + l) * per, per, G * C, ids, min_score, w.keys, w.nhit,
+                                      off, hc, hg, capacity));
     }
-  } else if ((rc = finish_dense(g, per, N, stride))) {
-    return rc;
+  } else {
+    if ((rc = gather_rows(g, nq, N, stride))) return rc;
+    if ((rc = finish_dense(g, per, N, stride))) return rc;
+    if ((rc = run_hits(g, per, N, stride))) return rc;
   }
-  if ((rc = run_hits(g, per, N, stride))) return rc;
   // the two words query_end looks at, on their way to pinned memory behind everything above
   NQ_GH(g, hipSetDevice(g->sh[0]->device));
   g->host_flags[0] = g->host_flags[1] = 0;
@@ -1016,7 +1225,10 @@ int niqki_group_query_end(niqki_group *g) {
   if (g->host_flags[1]) return gfail(g, NIQKI_E_HIP, "a peer of the group did not answer in time (ipc transport)");
   int rc;
   if (pd.sparse && g->host_flags[0]) {
+    // a list overflowed on some rank: the batch again with counter rows (the sketch slices are still in ws.allsk)
     ++g->overflows;
+    if ((rc = prepare_batch(g, per, N, true, false))) return rc;
+    if ((rc = gather_rows(g, g->world * per, N, pd.stride))) return rc;
     if ((rc = finish_dense(g, per, N, pd.stride))) return rc;
     if ((rc = run_hits(g, per, N, pd.stride))) return rc;
   }
@@ -1046,6 +1258,48 @@ int niqki_group_query(niqki_group *g, const int32_t *const *local_sketches, uint
     return rc;
   }
   return niqki_group_query_end(g);
+}
+
+// ---- the row-free sparse exchange step by step (what a shard of a group runs; device memory only) ----
+int niqki_query_survivors(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint32_t cand_threshold, uint32_t surv_threshold,
+                          uint32_t cand_cap, uint32_t surv_cap, int32_t *cand, int32_t *n_cand, int32_t *surv, int32_t *n_surv,
+                          int mem) {
+  if (!ix || (nq && (!sketches || !cand || !n_cand || !surv || !n_surv)) || !cand_cap || !surv_cap) return NIQKI_E_INVALID;
+  if (mem != NIQKI_MEM_DEVICE) return nqi::fail(ix, NIQKI_E_INVALID, "niqki_query_survivors is device-memory only");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  nq::CandOut co;
+  co.cand = cand; co.n = n_cand; co.thr = cand_threshold; co.cap = cand_cap;
+  co.surv = (int2 *)surv; co.surv_n = n_surv; co.surv_thr = surv_threshold; co.surv_cap = surv_cap;
+  return nqi::counts_dev(ix, sketches, ix->d.F, ix->resident_bytes ? ix->full_begin : ix->d.slot_begin, nq, nullptr, 0, nullptr, &co);
+}
+
+int niqki_survivor_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq, const int32_t *ids, uint32_t m, const int32_t *surv,
+                          const int32_t *n_surv, uint32_t surv_cap, uint16_t *counts, int mem) {
+  if (!ix || (nq && m && (!sketches || !ids || !surv || !n_surv || !counts))) return NIQKI_E_INVALID;
+  if (mem != NIQKI_MEM_DEVICE) return nqi::fail(ix, NIQKI_E_INVALID, "niqki_survivor_counts is device-memory only");
+  if (ix->resident_bytes) return nqi::fail(ix, NIQKI_E_STATE, "not on a paged index (the sketch store is in host memory)");
+  if (m > nq::kCandMax || surv_cap > nq::kSurvMax || !surv_cap) return nqi::fail(ix, NIQKI_E_INVALID, "at most 4096 ids per query and 4096 survivors");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = nqi::ensure(ix, ix->ws_misc, 256);
+  if (rc) return rc;
+  const nq::IdView view{ids, 0, std::max(m, 1u)};
+  NQ_HIP(ix, launch_surv_lookup(ix, (const int2 *)surv, n_surv, surv_cap, nq, m, view, sketches, ix->d.F, ix->d.slot_begin, counts,
+                                (uint32_t *)ix->ws_misc.p));
+  return NIQKI_OK;
+}
+
+int niqki_hits_from_candidates(niqki_index *ix, const int32_t *ids, const uint16_t *totals, uint32_t nq, uint32_t m, uint64_t *hit_off,
+                               uint32_t *hit_counts, uint32_t *hit_gids, uint64_t capacity, int mem) {
+  if (!ix || !hit_off || (nq && m && (!ids || !totals))) return NIQKI_E_INVALID;
+  if (mem != NIQKI_MEM_DEVICE) return nqi::fail(ix, NIQKI_E_INVALID, "niqki_hits_from_candidates is device-memory only");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  if (nq == 0 || m == 0) {
+    NQ_HIP(ix, hipMemsetAsync(hit_off, 0, (size_t)(nq + 1) * 8, ix->stream));
+    return NIQKI_OK;
+  }
+  const nq::IdView view{ids, 0, m};
+  return hits_from_candidates(ix, totals, 0, nq, m, view, ix->d.min_score, ix->ws_tc, ix->ws_tg, (unsigned long long *)hit_off,
+                              hit_counts, hit_gids, capacity);
 }
 
 namespace {

@@ -133,6 +133,14 @@ struct CandOut {
   int32_t *cand = nullptr;
   int32_t *n = nullptr;
   uint32_t thr = 0, cap = 0;
+  // Survivors (the sparse exchange without counter rows): every genome whose count reaches surv_thr
+  // (<= thr) is appended as {genome id, count} to surv[q*surv_cap ..] (unordered, at most surv_cap kept)
+  // and surv_n[q] grows by how many qualified.  With survivors the launch may run WITHOUT a counter row
+  // (counts = nullptr): what another rank may ask about a genome that is not among them is answered from
+  // the sketch store instead (nq_group.hip).
+  int2 *surv = nullptr;
+  int32_t *surv_n = nullptr;
+  uint32_t surv_thr = 0, surv_cap = 0;
 };
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq,
                          uint16_t *counts, uint16_t *counts2, uint64_t stride, Entry *stash, const uint32_t *order,

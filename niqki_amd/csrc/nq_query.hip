@@ -580,10 +580,18 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
   Item *queue = (Item *)(cnt + (v.tile + 1) / 2 + (PAD ? kPadWords : 0u));  // behind the counters: kQueue items per wave
   uint32_t sink = 0;
   const bool want_cand = co.cand != nullptr;
+  const bool want_surv = co.surv != nullptr;
+  const uint32_t emit_thr = want_surv ? co.surv_thr : co.thr;   // surv_thr <= thr
   auto emit = [&](uint32_t c, uint32_t col) {   // col: column of the row = genome id - g_base
-    if (c >= co.thr) {   // rare: a global atomic per candidate (the LDS is full: kPadMaxTile)
-      const uint32_t i = atomicAdd((uint32_t *)&co.n[q], 1u);
-      if (i < co.cap) co.cand[(uint64_t)q * co.cap + i] = (int32_t)(v.g_base + col);
+    if (c >= emit_thr) {   // rare: a global atomic per entry (the LDS is full: kPadMaxTile)
+      if (want_surv) {
+        const uint32_t i = atomicAdd((uint32_t *)&co.surv_n[q], 1u);
+        if (i < co.surv_cap) co.surv[(uint64_t)q * co.surv_cap + i] = make_int2((int)(v.g_base + col), (int)c);
+      }
+      if (c >= co.thr) {
+        const uint32_t i = atomicAdd((uint32_t *)&co.n[q], 1u);
+        if (i < co.cap) co.cand[(uint64_t)q * co.cap + i] = (int32_t)(v.g_base + col);
+      }
     }
   };
   const uint32_t n_it_all = (v.f_local + 63) / 64, it_pass = kPassSlots / 64;
@@ -607,6 +615,16 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     if (MODE != 0) cnt[tid % n_words] ^= sink;
     __syncthreads();
     if (MODE == 7) continue;
+    if (plane == nullptr) {
+      // no counter row (survivor output only): the tile's counters are scanned where they are
+      for (uint32_t w = tid; w < n_words; w += BLOCK) {
+        const uint32_t c = cnt[w];
+        if ((c & 0xFFFFu) >= emit_thr) emit(c & 0xFFFFu, tile_gid(v, t, 2 * w));
+        if (2 * w + 1 < n_t && (c >> 16) >= emit_thr) emit(c >> 16, tile_gid(v, t, 2 * w + 1));
+      }
+      __syncthreads();
+      continue;
+    }
     uint16_t *row = plane + (uint64_t)q * stride + v.g_base;
     if (v.stripe > 1 && v.n_tiles > 1 && ((uintptr_t)row & 3u) == 0) {
       // tiles striped in blocks of an even number of genomes: local ids 2w, 2w + 1 are neighbours in
@@ -696,6 +714,8 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
   if (nq == 0 || v.n_tiles == 0) return hipSuccess;
   if (v.f_local > kPassSlots && (!counts2 || v.accumulate)) return hipErrorInvalidValue;
   if (co.cand && (v.accumulate || v.f_local > kPassSlots || !co.n)) return hipErrorInvalidValue;
+  if (co.surv && (!co.cand || !co.surv_n || co.surv_thr > co.thr || !co.surv_cap)) return hipErrorInvalidValue;
+  if (!counts && !co.surv) return hipErrorInvalidValue;
 #define NQ_GATHER_LDS(B) ((size_t)((v.tile + 1) / 2 + (v.padded ? kPadWords : 0u)) * 4 + (size_t)(B / 64) * kQueue * sizeof(Item))
   // with a locality order the grid is padded to whole groups on every XCD
   const uint32_t per_round = kXcds * kOrderGroup;

@@ -8,7 +8,7 @@ caller of it: torch.distributed only carries the 128-byte group id from rank 0 t
 
 torch.distributed's backend may be gloo (ranks that share a device, NIQKI_GROUP_TRANSPORT=ipc: the id
 then travels as a CPU tensor).  The same protocol written with torch collectives lives with the tests
-(tests/torch_exchange.py): the CPU suite runs it over gloo with an oracle-backed stand-in engine.
+(tests/torch_exchange.py): the CPU suite runs it over gloo with a stand-in engine.
 
 Rank r of G owns sketch slots [r*F/G, (r+1)*F/G) of EVERY indexed genome.  The hit
 count of a genome is a sum over slots, so a query step has exactly one exchange of partial results:

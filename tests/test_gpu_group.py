@@ -133,3 +133,80 @@ def test_rccl_world1_group(native, po):
         assert np.array_equal(hc[int(off[i]):int(off[i + 1])], got[i][0]) and np.array_equal(hg[int(off[i]):int(off[i + 1])], got[i][1])
     grp.close()
     e.close()
+
+
+def test_row_free_sparse_steps_vs_dense_counters(native):
+    """niqki_query_survivors / niqki_survivor_counts / niqki_hits_from_candidates -- the sparse exchange without
+    counter rows, step by step on a slot shard -- against the shard's dense counters (niqki_query_counts)."""
+    import torch
+    dev = torch.device("cuda")
+    S, W, N, NQ, MS = 10, 8, 3000, 37, 60
+    sk, q = make_data(S, W, N, NQ, 99)
+    F = 1 << S
+    for sb, se in ((0, F), (F // 4, F // 2)):                       # whole range, and one shard of four
+        e = native.Engine(K=31, S=S, W=W, H=3, min_score_value=MS, slot_begin=sb, slot_end=se)
+        e.set_stream(torch.cuda.current_stream().cuda_stream)
+        e.insert(sk)
+        dense = e.query_counts(q).astype(np.uint32)                 # [NQ][N]
+        thr, sthr, C, SC = (MS, MS // 2, 64, 512) if sb == 0 else (MS // 4, MS // 8, 64, 1024)
+        dq = torch.from_numpy(q).to(dev)
+        cand = torch.zeros((NQ, C), dtype=torch.int32, device=dev)
+        ncand = torch.zeros(NQ, dtype=torch.int32, device=dev)
+        surv = torch.zeros((NQ, SC, 2), dtype=torch.int32, device=dev)
+        nsurv = torch.zeros(NQ, dtype=torch.int32, device=dev)
+        e.query_survivors_dev(dq, NQ, thr, sthr, C, SC, cand, ncand, surv, nsurv)
+        e.synchronize()
+        h_cand, h_nc, h_surv, h_ns = cand.cpu().numpy(), ncand.cpu().numpy(), surv.cpu().numpy(), nsurv.cpu().numpy()
+        for i in range(NQ):
+            want_c = np.nonzero(dense[i] >= thr)[0]
+            want_s = np.nonzero(dense[i] >= sthr)[0]
+            assert h_nc[i] == len(want_c) and h_ns[i] == len(want_s), i
+            if len(want_c) <= C:
+                assert sorted(h_cand[i, :len(want_c)].tolist()) == want_c.tolist() and (h_cand[i, len(want_c):] == -1).all()
+            if len(want_s) <= SC:
+                got = h_surv[i, :len(want_s)]
+                order = np.argsort(got[:, 0])
+                assert np.array_equal(got[order, 0], want_s) and np.array_equal(got[order, 1].astype(np.uint32), dense[i, want_s])
+        assert (h_ns <= SC).all() and h_ns.max() > 0
+        # any ids -- survivors, genomes that are not (counted from the sketch store), -1, duplicates
+        rng = np.random.default_rng(3)
+        m = 96
+        ids = rng.integers(0, N, (NQ, m)).astype(np.int32)
+        for i in range(NQ):
+            k = min(int(h_ns[i]), SC, 40)
+            ids[i, :k] = h_surv[i, :k, 0]
+        ids[:, 50:54] = -1
+        ids[:, 60] = ids[:, 0]
+        d_ids = torch.from_numpy(ids).to(dev)
+        out = torch.zeros((NQ, m), dtype=torch.int16, device=dev)
+        e.survivor_counts_dev(dq, NQ, d_ids, m, surv, nsurv, SC, out)
+        e.synchronize()
+        got = out.cpu().numpy().view(np.uint16).astype(np.uint32)
+        exp = np.where(ids >= 0, np.take_along_axis(dense, np.maximum(ids, 0).astype(np.int64), axis=1), 0)
+        assert np.array_equal(got, exp)
+        # hits from candidates: every genome that reaches min_score is among the ids (plus weaker ones, -1s, duplicates)
+        m2 = 128
+        ids2 = np.full((NQ, m2), -1, np.int32)
+        for i in range(NQ):
+            strong = np.nonzero(dense[i] >= MS)[0][:100]
+            ids2[i, :len(strong)] = strong[::-1]
+            ids2[i, 100:110] = rng.integers(0, N, 10)
+            if len(strong):
+                ids2[i, 120] = strong[0]
+        tot = np.where(ids2 >= 0, np.take_along_axis(dense, np.maximum(ids2, 0).astype(np.int64), axis=1), 0).astype(np.uint16)
+        cap = NQ * m2
+        h_off = torch.zeros(NQ + 1, dtype=torch.int64, device=dev)
+        hc, hg = torch.zeros(cap, dtype=torch.int32, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
+        e.hits_from_candidates_dev(torch.from_numpy(ids2).to(dev), torch.from_numpy(tot.view(np.int16)).to(dev), NQ, m2, h_off, hc, hg, cap)
+        e.synchronize()
+        off, c_, g_ = h_off.cpu().numpy(), hc.cpu().numpy().astype(np.uint32), hg.cpu().numpy().astype(np.uint32)
+        n_hits = 0
+        for i in range(NQ):
+            gids = np.unique(ids2[i][ids2[i] >= 0])                 # distinct ids offered ...
+            gids = gids[dense[i, gids] >= MS]                       # ... whose sum reaches min_score
+            order = np.lexsort((-gids.astype(np.int64), -dense[i, gids].astype(np.int64)))
+            lo, hi = int(off[i]), int(off[i + 1])
+            assert np.array_equal(c_[lo:hi], dense[i, gids][order]) and np.array_equal(g_[lo:hi], gids[order].astype(np.uint32)), i
+            n_hits += hi - lo
+        assert n_hits > (20 if sb == 0 else 0)
+        e.close()
