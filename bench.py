@@ -279,7 +279,7 @@ def main():
     hc = torch.zeros(cap, dtype=torch.int32, device=dev)
     hg = torch.zeros(cap, dtype=torch.int32, device=dev)
     stride = niqki_amd.row_stride(N)
-    counts = None if use_dist else torch.zeros((nq_gather, stride), dtype=torch.int16, device=dev)
+    counts = None if (use_dist or emu) else torch.zeros((nq_gather, stride), dtype=torch.int16, device=dev)
     allsk = None
     if emu:
         # the other ranks' sketches of every batch, made once outside the timed region: in the real
@@ -292,8 +292,15 @@ def main():
                 eng.synth_dev(args.seed, dev_u32(fam), dev_u32(mem), dev_u32(rate), per, L, stride_b, tmp)
                 eng.sketch_dev(tmp, d_ro, per, allsk[bi, r * per:(r + 1) * per])
         del tmp
-        cand = torch.zeros((nq_all, 256), dtype=torch.int32, device=dev)
+        EC, ESC = 256, 1024                       # candidate / survivor capacities (the group's defaults)
+        cand = torch.zeros((nq_all, EC), dtype=torch.int32, device=dev)
         ncand = torch.zeros(nq_all, dtype=torch.int32, device=dev)
+        surv = torch.zeros((nq_all, ESC, 2), dtype=torch.int32, device=dev)
+        nsurv = torch.zeros(nq_all, dtype=torch.int32, device=dev)
+        # stand-in for the all-gathered candidate lists of the G ranks: this rank's own list G times
+        cand_all = torch.zeros((nq_all, G, EC), dtype=torch.int32, device=dev)
+        mine = torch.zeros((nq_all, G * EC), dtype=torch.int16, device=dev)
+        e_thr = -(-eng.min_score // G)
     eng.synchronize()
 
     # N > 1: batch i's exchange (slices, candidate lists, sums: the GPU mostly waits for its peers) runs
@@ -336,10 +343,13 @@ def main():
         if use_dist:
             sq.step(qsk[bi], hit_off[si], hc, hg, cap)
         elif emu:
-            # rank 0's compute of one step: its share sketched above, partial hit vectors of ALL
-            # queries over its slots, its candidate lists, threshold + order of its own rows
-            eng.query_counts_candidates_dev(allsk[bi], nq_all, counts, stride, -(-eng.min_score // G), 256, cand, ncand)
-            eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[si], hc, hg, cap)
+            # rank 0's compute of one step of the sparse exchange: its share sketched above; the gather of ALL queries
+            # over its slots leaves candidates and survivors, no counter rows; the (stand-in) candidate lists of all
+            # ranks are looked up in the survivors; the hits of its own queries come from the candidates' counts
+            eng.query_survivors_dev(allsk[bi], nq_all, e_thr, max(1, e_thr // 2), EC, ESC, cand, ncand, surv, nsurv)
+            cand_all.copy_(cand.unsqueeze(1).expand(nq_all, G, EC))
+            eng.survivor_counts_dev(allsk[bi], nq_all, cand_all, G * EC, surv, nsurv, ESC, mine)
+            eng.hits_from_candidates_dev(cand_all, mine, per, G * EC, hit_off[si], hc, hg, cap)
         else:
             eng.query_counts_dev(qsk[bi], per, counts, stride)
             eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[si], hc, hg, cap)
@@ -602,7 +612,10 @@ def main():
             out["shard_emulation"] = {
                 "shards": emu, "slots": [sb, se], "queries_sketched_per_step": per, "queries_gathered_per_step": nq_all,
                 "gather_ms_per_step": gather_ms / max(1, gather_launches), "roofline_frac": achieved / HBM_PEAK_GBS,
-                "counter_row_bytes_per_query": 2 * N, "counter_bytes_written_per_step": 2 * N * nq_all,
+                "counter_row_bytes_per_query": 0,
+                "counter_bytes_written_per_step": int(nsurv.sum().item()) * 8 + int(ncand.sum().item()) * 4 + 8 * nq_all,
+                "counter_bytes_written_per_step_with_rows": 2 * N * nq_all,
+                "survivors_per_query": float(nsurv.float().mean().item()), "candidates_per_query": float(ncand.float().mean().item()),
                 "sketch_ms_per_step": prof["sketch"][0] / max(1, args.steps), "hits_ms_per_step": prof["hits"][0] / max(1, args.steps),
                 "projected_genomes_per_s_if_exchange_is_free": nq_all / (dt / args.steps),
             }

@@ -139,8 +139,9 @@ int niqki_synchronize(niqki_index *ix);
  * sized so that the page's store rows + index stay within the value; a query batch walks the
  * pages and the gather kernel accumulates the hit counters, which are sums over slots.  Same
  * answers as a resident index.  Insert, the dump import (niqki_params.resident_mib), every query
- * call and niqki_get_sketches work on a paged handle; dump export, niqki_matrix_range,
- * niqki_query_gathered and groups do not (NIQKI_E_STATE)). */
+ * call, niqki_get_sketches, niqki_matrix_range (the stored sketches are read from the host store)
+ * and the dump export (page after page) work on a paged handle; niqki_query_gathered, the
+ * candidate / survivor calls and groups do not (NIQKI_E_STATE / NIQKI_E_INVALID)). */
 int niqki_set_option(niqki_index *ix, const char *key, int64_t value);
 
 /* Pre-sizes the sketch store for n_genomes (optional; the store grows). */

@@ -1375,10 +1375,23 @@ int niqki_matrix_range(niqki_index *ix, uint32_t begin, uint32_t end, uint16_t *
                        int mem) {
   if (!ix || begin > end || end > ix->n_genomes || (!counts && end > begin)) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
-  if (ix->resident_bytes) return fail(ix, NIQKI_E_STATE, "niqki_matrix_range is not available on a paged index (resident_bytes)");
-  int rc = build_if_needed(ix);
+  // A paged index keeps its sketch store in page-locked host memory: the stored sketches of a batch are read
+  // from there by the device (zero-copy, 2 bytes per cell), the counters then come from the paged walk.
+  int rc = ix->resident_bytes ? NIQKI_OK : build_if_needed(ix);
   if (rc) return rc;
-  if (stride < ix->built_n || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
+  const uint32_t n_all = ix->resident_bytes ? ix->n_genomes : ix->built_n;
+  if (stride < n_all || (stride & 1)) return fail(ix, NIQKI_E_INVALID, "stride must be even and >= genome count");
+  nq::Derived d_full = ix->d;
+  const uint16_t *store_dev = ix->store;
+  uint64_t store_cap = ix->cap;
+  if (ix->resident_bytes) {
+    d_full.slot_begin = ix->full_begin;
+    d_full.slot_end = ix->full_end;
+    void *dp = nullptr;
+    NQ_HIP(ix, hipHostGetDevicePointer(&dp, ix->host_store, 0));
+    store_dev = (const uint16_t *)dp;
+    store_cap = ix->host_cap;
+  }
   // The bucket co-occurrence count of (a, t) equals the hit count of genome a
   // for the stored sketch of t: both count the slots where the two sketches
   // hold the same valid fingerprint.  So the range is answered by the gather
@@ -1387,7 +1400,7 @@ int niqki_matrix_range(niqki_index *ix, uint32_t begin, uint32_t end, uint16_t *
   for (uint32_t t0 = begin; t0 < end; t0 += qb) {
     const uint32_t n = std::min(qb, end - t0);
     if ((rc = ensure(ix, ix->ws_misc, (size_t)n * ix->d.F * 4))) return rc;
-    NQ_HIP(ix, nq::launch_store_read(ix->d, ix->store, ix->cap, t0, n, (int32_t *)ix->ws_misc.p, ix->stream));
+    NQ_HIP(ix, nq::launch_store_read(d_full, store_dev, store_cap, t0, n, (int32_t *)ix->ws_misc.p, ix->stream));
     uint16_t *dst = counts + (size_t)(t0 - begin) * stride;
     if (mem == NIQKI_MEM_DEVICE) {
       uint16_t *c2 = nullptr;
@@ -1416,9 +1429,47 @@ int niqki_matrix_range(niqki_index *ix, uint32_t begin, uint32_t end, uint16_t *
 
 namespace {
 
-// slot_word (F+1 word positions, header excluded) computed on the device, copied to the host
+// the page of a paged index that holds slot s (relative to the handle's first slot): pages never straddle 2^15
+void page_of(const niqki_index *ix, uint32_t s, uint32_t &pb, uint32_t &pe) {
+  const uint32_t f_all = ix->full_end - ix->full_begin, f_page = page_slots(ix);
+  const uint32_t h0 = s / nq::kPassSlots * nq::kPassSlots, h1 = std::min(f_all, h0 + nq::kPassSlots);
+  pb = h0 + (s - h0) / f_page * f_page;
+  pe = std::min(h1, pb + f_page);
+}
+
+// slot_word (F+1 word positions, header excluded) computed on the device, copied to the host.
+// Paged index: page after page (each page's index is built for it), the positions chained on the host.
 int export_layout(niqki_index *ix, std::vector<uint64_t> &slot_word) {
-  if (ix->resident_bytes) return fail(ix, NIQKI_E_STATE, "dump export is not available on a paged index (resident_bytes)");
+  if (ix->resident_bytes) {
+    const uint32_t f_all = ix->full_end - ix->full_begin;
+    if (ix->pg_layout_n == ix->n_genomes && ix->pg_layout.size() == (size_t)f_all + 1) {   // (a dump asks slot group by slot group)
+      slot_word = ix->pg_layout;
+      return NIQKI_OK;
+    }
+    slot_word.assign((size_t)f_all + 1, 0);
+    if (ix->n_genomes == 0) {
+      for (uint32_t s = 0; s <= f_all; ++s) slot_word[s] = (uint64_t)s * ix->d.R;
+      return NIQKI_OK;
+    }
+    uint64_t base = 0;
+    std::vector<uint64_t> local;
+    for (uint32_t pb = 0, pe = 0; pb < f_all; pb = pe) {
+      page_of(ix, pb, pb, pe);
+      int rc = load_page(ix, pb, pe);
+      if (rc) return rc;
+      nq::IndexView v = view(ix);
+      local.assign((size_t)v.f_local + 1, 0);
+      if ((rc = ensure(ix, ix->ws_misc, (size_t)(v.f_local + 1) * 8))) return rc;
+      NQ_HIP(ix, nq::launch_export_layout(v, (unsigned long long *)ix->ws_misc.p, ix->stream));
+      NQ_HIP(ix, hipMemcpyAsync(local.data(), ix->ws_misc.p, (size_t)(v.f_local + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
+      NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+      for (uint32_t i = 0; i <= v.f_local; ++i) slot_word[pb + i] = base + local[i];
+      base += local[v.f_local];
+    }
+    ix->pg_layout = slot_word;
+    ix->pg_layout_n = ix->n_genomes;
+    return NIQKI_OK;
+  }
   int rc = build_single(ix);
   if (rc) return rc;
   nq::IndexView v = view(ix);
@@ -1436,9 +1487,30 @@ int export_layout(niqki_index *ix, std::vector<uint64_t> &slot_word) {
 
 // payload of slots [s0, s1) to host memory; slot_word device copy is in ws_misc (export_layout ran)
 int export_slots(niqki_index *ix, const std::vector<uint64_t> &slot_word, uint32_t s0, uint32_t s1, uint8_t *dst) {
-  nq::IndexView v = view(ix);
   const uint64_t words = slot_word[s1] - slot_word[s0];
   if (words == 0) return NIQKI_OK;
+  if (ix->resident_bytes) {
+    if (ix->n_genomes == 0) { std::memset(dst, 0, words * 4); return NIQKI_OK; }
+    // piece by piece of the pages that hold the slots; a page's word positions are made again when it comes in
+    for (uint32_t a = s0; a < s1;) {
+      uint32_t pb, pe;
+      page_of(ix, a, pb, pe);
+      const uint32_t b = std::min(s1, pe);
+      int rc = load_page(ix, pb, pe);
+      if (rc) return rc;
+      nq::IndexView v = view(ix);
+      if ((rc = ensure(ix, ix->ws_misc, (size_t)(v.f_local + 1) * 8))) return rc;
+      NQ_HIP(ix, nq::launch_export_layout(v, (unsigned long long *)ix->ws_misc.p, ix->stream));
+      const uint64_t w = slot_word[b] - slot_word[a];
+      if ((rc = ensure(ix, ix->ws_counts, std::max<uint64_t>(w, 1) * 4))) return rc;
+      NQ_HIP(ix, nq::launch_export(v, (const unsigned long long *)ix->ws_misc.p, (uint32_t *)ix->ws_counts.p, a - pb, b - pb, ix->stream));
+      NQ_HIP(ix, hipMemcpyAsync(dst + (slot_word[a] - slot_word[s0]) * 4, ix->ws_counts.p, w * 4, hipMemcpyDeviceToHost, ix->stream));
+      NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+      a = b;
+    }
+    return NIQKI_OK;
+  }
+  nq::IndexView v = view(ix);
   if (v.n_tiles == 0) { std::memset(dst, 0, words * 4); return NIQKI_OK; }
   int rc = ensure(ix, ix->ws_counts, words * 4);
   if (rc) return rc;
@@ -1469,7 +1541,8 @@ int niqki_export_dump_layout(niqki_index *ix, uint64_t *slot_bytes) {
 
 int niqki_export_dump_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end, uint8_t *buf,
                             uint64_t capacity, uint64_t *size) {
-  if (!ix || !size || slot_begin > slot_end || slot_end > ix->d.slot_end - ix->d.slot_begin) return NIQKI_E_INVALID;
+  if (!ix || !size || slot_begin > slot_end) return NIQKI_E_INVALID;
+  if (slot_end > (ix->resident_bytes ? ix->full_end - ix->full_begin : ix->d.slot_end - ix->d.slot_begin)) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
   std::vector<uint64_t> sw;
   int rc = export_layout(ix, sw);
@@ -1482,7 +1555,8 @@ int niqki_export_dump_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_
 
 int niqki_export_dump(niqki_index *ix, uint8_t *buf, uint64_t capacity, uint64_t *size) {
   if (!ix || !size) return NIQKI_E_INVALID;
-  if (ix->d.slot_begin != 0 || ix->d.slot_end != ix->d.F) return fail(ix, NIQKI_E_STATE, "export needs a whole-range handle");
+  if (first_slot(ix) != 0 || (ix->resident_bytes ? ix->full_end : ix->d.slot_end) != ix->d.F)
+    return fail(ix, NIQKI_E_STATE, "export needs a whole-range handle");
   NQ_HIP(ix, hipSetDevice(ix->device));
   std::vector<uint64_t> sw;
   int rc = export_layout(ix, sw);

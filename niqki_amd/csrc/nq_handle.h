@@ -47,6 +47,8 @@ struct niqki_index {
   uint32_t page_begin = 0, page_end = 0;   // slots (relative to full_begin) of the resident page; equal = none
   uint32_t page_n = 0;                     // genomes the resident page was built for
   nqi::Buf pg_store, pg_stage;
+  std::vector<uint64_t> pg_layout;      // dump word positions of all slots (export of a paged index), for pg_layout_n genomes
+  uint32_t pg_layout_n = 0xFFFFFFFFu;
 
   // inverted index
   uint32_t tile = 0, n_tiles = 0, built_n = 0, align_log2 = 0, padded = 0;

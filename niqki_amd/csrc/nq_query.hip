@@ -575,7 +575,8 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     q = order[i];
   }
   const uint32_t tid = threadIdx.x;
-  if (PAD && (uint32_t)(uintptr_t)(lds_u32 *)cnt != 0u) __builtin_trap();   // the padded walk addresses the counters from LDS address 0
+  // (PAD: the padded walk addresses the counters from LDS address 0 -- launch_gather checks that this
+  // instantiation has no static LDS in front of its dynamic block and otherwise launches the form without PAD)
   const int32_t *sk = NT < 0 ? nullptr : sketches + (uint64_t)q * v.q_stride + v.q_off;
   Item *queue = (Item *)(cnt + (v.tile + 1) / 2 + (PAD ? kPadWords : 0u));  // behind the counters: kQueue items per wave
   uint32_t sink = 0;
@@ -729,6 +730,16 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     if (e != hipSuccess) return e;                                                               \
     hipLaunchKernelGGL(k, grid, dim3(B), lds, stream, v, sketches, counts, counts2, stride, stash, order, nq, co); \
   } while (0)
+  // The padded walk (PAD = true) takes a counter's LDS address from the genome id alone: the kernel's dynamic
+  // LDS must start at LDS address 0, i.e. the instantiation must have no static LDS in front of it.  Asked of
+  // the runtime once per process; if a toolchain ever puts something there, the form with explicit lengths
+  // (any LDS base, any index layout) is launched instead.
+  static const bool pad_at_zero = [] {
+    hipFuncAttributes fa{};
+    return hipFuncGetAttributes(&fa, (const void *)gather_kernel<1024, 32, -1, 0, true>) == hipSuccess && fa.sharedSizeBytes == 0 &&
+           hipFuncGetAttributes(&fa, (const void *)gather_kernel<1024, 16, 2, 0, true>) == hipSuccess && fa.sharedSizeBytes == 0;
+  }();
+  const bool padded = v.padded && pad_at_zero;
 #define NQ_BY_TILES(B, U, ...)                                                                   \
   do {                                                                                           \
     if (pre) NQ_LAUNCH_GATHER(B, U, -1, ##__VA_ARGS__);                                           \
@@ -738,8 +749,8 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     else NQ_LAUNCH_GATHER(B, U, 1, ##__VA_ARGS__);                                               \
   } while (0)
   switch (variant) {
-    case 1: if (v.padded) NQ_BY_TILES(1024, 8, 0, true); else NQ_BY_TILES(1024, 8); break;
-    case 2: if (v.padded) NQ_BY_TILES(1024, 32, 0, true); else NQ_BY_TILES(1024, 32); break;
+    case 1: if (padded) NQ_BY_TILES(1024, 8, 0, true); else NQ_BY_TILES(1024, 8); break;
+    case 2: if (padded) NQ_BY_TILES(1024, 32, 0, true); else NQ_BY_TILES(1024, 32); break;
     case 3: NQ_BY_TILES(512, 16); break;
     case 4: NQ_BY_TILES(256, 16); break;
     case 5: NQ_BY_TILES(128, 16); break;
@@ -753,8 +764,8 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
       // small tiles (short-read indexes): counters of <= 24 KB leave room for several
       // workgroups per CU, and 4 waves per query then beat 16 (tools/bench_reads.py)
       if (v.tile <= 12288) NQ_BY_TILES(256, 16);
-      else if (v.padded && pre) NQ_BY_TILES(1024, 32, 0, true);   // without look-ups of its own the walk gains from 32 lines per round trip (8.42 against 8.6 ms)
-      else if (v.padded) NQ_BY_TILES(1024, 16, 0, true);   // padded index: mask-free bucket walk
+      else if (padded && pre) NQ_BY_TILES(1024, 32, 0, true);   // without look-ups of its own the walk gains from 32 lines per round trip (8.42 against 8.6 ms)
+      else if (padded) NQ_BY_TILES(1024, 16, 0, true);   // padded index: mask-free bucket walk
       else NQ_BY_TILES(1024, 16);
       break;
   }

@@ -247,9 +247,10 @@ void Index::make_shards(const niqki_params &p0, int device, int n_gpus, const ui
 }
 
 Index::Index(uint32_t ilF, uint32_t iK, uint32_t iW, uint32_t iH, const std::string &out_filename,
-             double min_fract, int device, int n_gpus) {
+             double min_fract, int device, int n_gpus, int resident_mib) {
   niqki_params p{};
   p.K = iK; p.S = ilF; p.W = iW; p.H = iH;
+  p.resident_mib = resident_mib > 0 ? (uint32_t)resident_mib : 0u;
   p.min_score = niqki_min_score(min_fract, ilF);
   make_shards(p, device, n_gpus, nullptr);
   if (n_gpus > 1) {
@@ -260,7 +261,8 @@ Index::Index(uint32_t ilF, uint32_t iK, uint32_t iW, uint32_t iH, const std::str
   outfile.reset(new GzWriter(out_filename));
 }
 
-Index::Index(const std::string &dump_file, bool pretty, const std::string &out_filename, int device, int n_gpus) {
+Index::Index(const std::string &dump_file, bool pretty, const std::string &out_filename, int device, int n_gpus,
+             int resident_mib) {
   pretty_printing = pretty;
   // The dump is streamed: header, then the buckets in groups of whole slots (the
   // payload of a 100k-genome index is 13.6 GB), then the names.
@@ -268,6 +270,7 @@ Index::Index(const std::string &dump_file, bool pretty, const std::string &out_f
   uint8_t hdr[24];
   if (in.read(hdr, 24) != 24) throw std::runtime_error("'" + dump_file + "' is not a niqki dump");
   niqki_params p{};
+  p.resident_mib = resident_mib > 0 ? (uint32_t)resident_mib : 0u;
   make_shards(p, device, n_gpus, hdr);   // every shard keeps its own slots of the stream
   niqki_params q{};
   niqki_get_params(h_, &q);

@@ -22,11 +22,13 @@ class Index {
   // n_gpus > 1 (the program's --gpus): the index is cut by sketch-slot range over devices
   // device .. device + n_gpus - 1 (niqki_group_*, RCCL inside libniqki_hip.so); the files of a
   // batch are dealt to the GPUs in order, every GPU frames and sketches its share
+  // resident_mib > 0 (the program's --resident-mib): a paged index -- the sketch store in page-locked host
+  // memory, the inverted index built for one page of slots at a time within that budget
   Index(uint32_t lF, uint32_t K, uint32_t W, uint32_t H, const std::string &out_filename, double min_fract,
-        int device = -1, int n_gpus = 1);
+        int device = -1, int n_gpus = 1, int resident_mib = 0);
   // Index(dump file, pretty, filename): src/niqki_index.cpp:63-102
   Index(const std::string &dump_file, bool pretty_printing, const std::string &out_filename, int device = -1,
-        int n_gpus = 1);
+        int n_gpus = 1, int resident_mib = 0);
   ~Index();
   Index(const Index &) = delete;
   Index &operator=(const Index &) = delete;

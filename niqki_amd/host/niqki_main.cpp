@@ -4,6 +4,7 @@
 // inputs, dump, matrix, query inputs -- each a driver of nqhost::Index -> libniqki_hip.so.  Extensions (long options only):
 //   --device <n>   HIP device ordinal (default: current device)
 //   --gpus <n>     cut the index by sketch-slot range over n GPUs (devices --device .. +n-1)
+//   --resident-mib <n>  paged index: sketch store in host memory, n MiB of device memory for one page of slots
 #include <libgen.h>
 #include <limits.h>
 #include <unistd.h>
@@ -30,7 +31,7 @@ using namespace std::chrono;
 namespace {
 
 enum Opt { LIST, QUERY, LISTLINES, QUERYLINES, KMER, FETCH, OUTPUT, MIN, PRETTY, MATRIX, WORD, GENOME_SIZE, HHL,
-           DUMP, LOAD, DOWNLAD, LOGO, HELP, DEVICE, GPUS, N_OPT };
+           DUMP, LOAD, DOWNLAD, LOGO, HELP, DEVICE, GPUS, RESIDENT, N_OPT };
 enum ArgKind { NONE, NONEMPTY, NUMERIC };
 
 // Same order as the reference's descriptor table: a short option character
@@ -58,6 +59,7 @@ const Desc kDesc[] = {
     {HELP, "h", "help", NONE, "  --help, -h                    Print usage and exit."},
     {DEVICE, "", "device", NUMERIC, "  --device <int>                HIP device ordinal."},
     {GPUS, "", "gpus", NUMERIC, "  --gpus <int>                  Number of GPUs the index is sharded over (1)."},
+    {RESIDENT, "", "resident-mib", NUMERIC, "  --resident-mib <int>          Device memory budget of a paged index in MiB (0: everything resident)."},
 };
 
 struct Parsed {
@@ -250,7 +252,7 @@ int main(int argc, char *argv[]) {
   }
   const int K = int_opt(o, KMER, 31), S = int_opt(o, FETCH, 15), H = int_opt(o, HHL, 4), W = int_opt(o, WORD, 12);
   const double min_jaccard = o.has(MIN) ? atof(o.last(MIN).c_str()) : 0;
-  const int device = int_opt(o, DEVICE, -1), n_gpus = int_opt(o, GPUS, 1);
+  const int device = int_opt(o, DEVICE, -1), n_gpus = int_opt(o, GPUS, 1), resident_mib = int_opt(o, RESIDENT, 0);
   const string out_file = o.has(OUTPUT) ? o.last(OUTPUT) : "niqkiOutput.gz";
 
   const char *rule = "+-----------------------------------+-------------------------------+";
@@ -259,8 +261,8 @@ int main(int argc, char *argv[]) {
        << rule << endl;
   std::unique_ptr<nqhost::Index> ix;
   try {
-    if (o.has(LOAD)) ix.reset(new nqhost::Index(o.last(LOAD), true, out_file, device, n_gpus));
-    else ix.reset(new nqhost::Index(S, K, W, H, out_file, min_jaccard, device, n_gpus));
+    if (o.has(LOAD)) ix.reset(new nqhost::Index(o.last(LOAD), true, out_file, device, n_gpus, resident_mib));
+    else ix.reset(new nqhost::Index(S, K, W, H, out_file, min_jaccard, device, n_gpus, resident_mib));
     if (const unsigned expect = (unsigned)int_opt(o, GENOME_SIZE, 0)) ix->select_best_H(expect);   // src/niqki.cpp:303-305
 
     RunClock clk;

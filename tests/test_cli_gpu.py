@@ -256,3 +256,15 @@ def test_sketch_size_16(workdir):
     run(workdir, ["-M", "fof.txt", "-S", "16", "-W", "8", "-J", "0.1", "-O", "s16_matrix.gz"])
     assert_same_text(gunzip(workdir / "s16_matrix.gz").decode(), exp["matrix"])
     assert "syn00.fa\t0\t0.970917" in exp["matrix"]
+
+
+def test_paged_index_matrix_and_dump(workdir, gold):
+    """--resident-mib: the index paged through 1 MiB of device memory (several pages of slots at S = 10): the
+    matrix text, the hits and the dump bytes are those of the reference's CLI (src/niqki_index.cpp:570-628, :42-59)."""
+    _, meta = gold
+    run(workdir, ["-M", "fof.txt", "-S", "10", "-O", "matrix_pg.gz", "--resident-mib", "1"])
+    assert_same_text(gunzip(workdir / "matrix_pg.gz").decode(), meta["cli"]["matrix"])
+    run(workdir, ["-I", "fof.txt", "-Q", "fof.txt", "-S", "10", "-J", "0.1", "-O", "hits_pg.gz", "-D", "idx_pg.dump", "--resident-mib", "1"])
+    assert_same_text(gunzip(workdir / "hits_pg.gz").decode(), meta["cli"]["hits"])
+    raw = gunzip(workdir / "idx_pg.dump")
+    assert len(raw) == meta["cli"]["dump_len"] and hashlib.md5(raw).hexdigest() == meta["cli"]["dump_md5"]
