@@ -61,8 +61,9 @@ typedef struct niqki_index niqki_index; /* opaque */
  * Supported: 1<=K<=31 (K=32 is UB in the reference, :28-29), 1<=S<=16,
  * H<=W<=15, S+W<=30.  S = 16 is the reference's lF>15 branch (uint32 counters, :668-682): a
  * count can reach 2^16, so the u16 counter calls (niqki_query_counts, niqki_hits_from_counts)
- * and groups refuse it; niqki_query* / niqki_staged_query / niqki_query_counts32 are exact (also
- * on a paged handle, whose pages add up per half of the slots)
+ * refuse it on a whole-range handle; niqki_query* / niqki_staged_query / niqki_query_counts32 are
+ * exact (also on a paged handle, whose pages add up per half of the slots), and so are groups of
+ * two or more shards (a shard counts at most 2^15 slots, the cross-shard sums travel as u32)
  * and niqki_matrix_range wraps like the reference's uint16 matrix counters (:572). */
 typedef struct niqki_params {
   uint32_t K;          /* k-mer length */
@@ -410,7 +411,7 @@ void niqki_group_slot_range(uint32_t rank, uint32_t world, uint32_t S, uint32_t 
                             uint32_t *slot_end);
 int niqki_group_new_id(uint8_t id[NIQKI_GROUP_ID_BYTES]);
 /* The shards must agree in K, S, W, min_score and genome count and own the slot ranges
- * of their ranks.  On failure niqki_last_error(shards[0]) says why. */
+ * of their ranks (S = 16: at least two shards).  On failure niqki_last_error(shards[0]) says why. */
 int niqki_group_create(niqki_index *const *shards, uint32_t n_local, uint32_t first_rank,
                        uint32_t world, const uint8_t *id, niqki_group **out);
 void niqki_group_destroy(niqki_group *g); /* the shard handles stay the caller's */

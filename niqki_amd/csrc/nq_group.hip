@@ -175,10 +175,12 @@ constexpr uint32_t kCandMax = 4096;       // ids per query cand_hits_kernel can 
 // that is not among them -- another rank's candidate that is weak here --, counted exactly as the slots
 // in which the genome's stored sketch equals the query's (the identity behind the matrix path, DESIGN.md
 // 4.6): f_local strided 2-byte reads per such id, rare by construction.  flag[0] |= a list overflowed.
+// CT: uint16_t, or uint32_t where the cross-shard sums can pass 2^16 - 1 (S = 16)
+template <typename CT>
 __global__ __launch_bounds__(256) void surv_lookup_kernel(const int2 *surv, const int32_t *surv_n, uint32_t SC, uint32_t T, uint32_t m,
                                                          IdView ids, const int32_t *sk, uint32_t q_stride, uint32_t q_off,
                                                          uint32_t f_local, const uint16_t *store, uint64_t store_cap, uint32_t R,
-                                                         uint16_t *mine, uint32_t *flag) {
+                                                         CT *mine, uint32_t *flag) {
   extern __shared__ __align__(8) int lds_tab[];
   int2 *tab = (int2 *)lds_tab;                  // T x {id, count}
   uint32_t *missing = (uint32_t *)(tab + T);    // one bit per position i < m <= kCandMax
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void surv_lookup_kernel(const int2 *surv, cons
         if (e.x == id) { c = (uint32_t)e.y; found = true; break; }
       if (!found) atomicOr(&missing[i >> 5], 1u << (i & 31));
     }
-    mine[(uint64_t)q * m + i] = (uint16_t)c;
+    mine[(uint64_t)q * m + i] = (CT)c;
   }
   __syncthreads();
   // ids this shard holds no survivor entry for: counted exactly from the sketch store, one after the other
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(256) void surv_lookup_kernel(const int2 *surv, cons
       }
       if (c) atomicAdd(&acc, c);
       __syncthreads();
-      if (tid == 0) mine[(uint64_t)q * m + i] = (uint16_t)acc;
+      if (tid == 0) mine[(uint64_t)q * m + i] = (CT)acc;
       __syncthreads();
     }
   }
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(256) void surv_lookup_kernel(const int2 *surv, cons
 // The hits of one query from its candidates alone: ids id(first_q + ql, i) with summed counts tot[ql][i]
 // (the same id may appear under several ranks, with the same sum): distinct ids whose sum reaches min_score,
 // ordered like greater<pair<count, gid>> (src/niqki_index.cpp:685), as 64-bit keys count << 32 | gid.
-__global__ __launch_bounds__(256) void cand_hits_kernel(const uint16_t *tot, uint32_t first_q, uint32_t m, IdView ids, uint32_t min_score,
+template <typename CT>
+__global__ __launch_bounds__(256) void cand_hits_kernel(const CT *tot, uint32_t first_q, uint32_t m, IdView ids, uint32_t min_score,
                                                        uint32_t T, uint32_t P, unsigned long long *keys, uint32_t *n_out) {
   extern __shared__ __align__(8) int lds_tab[];
   unsigned long long *list = (unsigned long long *)lds_tab;   // P keys
@@ -277,6 +280,21 @@ __global__ __launch_bounds__(256) void cand_hits_kernel(const uint16_t *tot, uin
     }
   for (uint32_t i = tid; i < n; i += 256) keys[(uint64_t)ql * m + i] = list[i];
   if (tid == 0) n_out[ql] = n;
+}
+
+// S = 16 groups, dense exchange: a shard's counters (<= 2^15 each) as u32 words for the sum, and the sums
+// (<= 2^16) back as two u16 planes lo = min(sum, 2^15), hi = sum - lo for the hit kernels' 32-bit form
+__global__ __launch_bounds__(256) void widen_rows_kernel(const uint16_t *in, uint64_t n, uint32_t *out) {
+  const uint64_t step = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += step) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void split_sums_kernel(const uint32_t *in, uint64_t n, uint16_t *lo, uint16_t *hi) {
+  const uint64_t step = (uint64_t)gridDim.x * 256;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += step) {
+    const uint32_t v = in[i], l = v < 32768u ? v : 32768u;
+    lo[i] = (uint16_t)l;
+    hi[i] = (uint16_t)(v - l);
+  }
 }
 
 // flag |= some rank's candidate or survivor list of some query holds more than its capacity
@@ -378,9 +396,10 @@ struct niqki_group {
   uint32_t cand_cap = 256;
   uint32_t surv_cap = 1024;          // survivors (partial count >= half the candidate threshold) kept per query and shard
   uint64_t overflows = 0;            // sparse steps redone densely
+  bool wide = false;                 // S = 16: cross-shard sums reach 2^16, they travel and add up as u32
   std::string err;
   struct Ws {
-    Buf send, recv, allsk, counts, cand, cand_all, mine, tot, red, flag, hitoff, hc, hg, stpad, surv, keys, nhit;
+    Buf send, recv, allsk, counts, cand, cand_all, mine, tot, red, flag, hitoff, hc, hg, stpad, surv, keys, nhit, rows16, sum32;
     hipEvent_t ev = nullptr;
   };
   std::vector<Ws> ws;
@@ -815,11 +834,12 @@ int prepare_batch(niqki_group *g, uint32_t per, uint32_t N, bool query, bool spa
   const uint64_t stride = NIQKI_ROW_STRIDE(N);
   size_t need[kIpcBufs] = {slice_bytes(per, (F + G - 1) / G) * G, 0, 0, 0};
   if (query) {
+    const size_t cw = g->wide ? 4 : 2;   // bytes per exchanged count
     if (sparse) {   // no counter rows (they are made only if a batch has to be redone densely)
       need[1] = blob_bytes(nq_, C);
-      need[2] = (size_t)nq_ * G * C * 2;
+      need[2] = (size_t)nq_ * G * C * cw;
     } else {
-      need[3] = std::max<size_t>((size_t)nq_ * stride * 2, 4);
+      need[3] = std::max<size_t>((size_t)nq_ * stride * cw, 4);
     }
   }
   return ipc_prepare(g, need);
@@ -859,6 +879,7 @@ int niqki_group_create(niqki_index *const *shards, uint32_t n_local, uint32_t fi
   niqki_group *g = new (std::nothrow) niqki_group();
   if (!g) return NIQKI_E_NOMEM;
   g->world = world; g->n_local = n_local; g->first = first_rank;
+  g->wide = shards[0] && shards[0]->d.S > 15;
   g->sh.assign(shards, shards + n_local);
   g->ws.resize(n_local);
   auto bail = [&](int code, const std::string &why) {
@@ -877,7 +898,8 @@ int niqki_group_create(niqki_index *const *shards, uint32_t n_local, uint32_t fi
       return bail(NIQKI_E_INVALID, "shard " + std::to_string(first_rank + l) + " must own slots [" + std::to_string(b) + ", " +
                                        std::to_string(e) + ") (niqki_group_slot_range)");
     if (ix->resident_bytes) return bail(NIQKI_E_INVALID, "a paged index (resident_bytes) cannot be a shard of a group");
-    if (ix->d.S > 15) return bail(NIQKI_E_INVALID, "groups need S <= 15 (the exchange sums u16 counters)");
+    if (ix->d.S > 15 && world < 2)
+      return bail(NIQKI_E_INVALID, "an S = 16 group needs at least two shards (a shard counts at most 2^15 slots in u16)");
     if (ix->d.K != shards[0]->d.K || ix->d.W != shards[0]->d.W || ix->d.min_score != shards[0]->d.min_score ||
         ix->n_genomes != shards[0]->n_genomes)
       return bail(NIQKI_E_INVALID, "the shards of a group must agree in K, W, min_score and genome count");
@@ -939,7 +961,7 @@ void niqki_group_destroy(niqki_group *g) {
   for (uint32_t l = 0; l < g->n_local && l < g->ws.size(); ++l) {
     auto &w = g->ws[l];   // (ipc_teardown has dropped the views of its arena)
     for (Buf *b : {&w.send, &w.recv, &w.allsk, &w.counts, &w.cand, &w.cand_all, &w.mine, &w.tot, &w.red,
-                   &w.flag, &w.hitoff, &w.hc, &w.hg, &w.stpad, &w.surv, &w.keys, &w.nhit})
+                   &w.flag, &w.hitoff, &w.hc, &w.hg, &w.stpad, &w.surv, &w.keys, &w.nhit, &w.rows16, &w.sum32})
       if (b->p) (void)hipFree(b->p);
     if (w.ev) (void)hipEventDestroy(w.ev);
     if (l < g->comm.size() && g->comm[l]) (void)rccl().CommDestroy(g->comm[l]);
@@ -1010,23 +1032,32 @@ uint32_t pow2_at_least(uint32_t x) {
 }
 
 // this shard's partial counts of the ids a query's ranks proposed (nq::surv_lookup_kernel)
+// (wide: `mine` holds uint32_t values)
 hipError_t launch_surv_lookup(niqki_index *ix, const int2 *surv, const int32_t *surv_n, uint32_t SC, uint32_t nq_, uint32_t m,
-                              const nq::IdView &ids, const int32_t *sk, uint32_t q_stride, uint32_t q_off, uint16_t *mine,
-                              uint32_t *flag) {
+                              const nq::IdView &ids, const int32_t *sk, uint32_t q_stride, uint32_t q_off, void *mine,
+                              uint32_t *flag, bool wide = false) {
   if (nq_ == 0 || m == 0) return hipSuccess;
   const uint32_t T = pow2_at_least(2 * std::max(SC, 1u));
   const size_t lds = (size_t)T * 8 + (size_t)((m + 31) / 32) * 4;
-  hipError_t e = hipFuncSetAttribute((const void *)nq::surv_lookup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(nq::surv_lookup_kernel, dim3(nq_), dim3(256), lds, ix->stream, surv, surv_n, SC, T, m, ids, sk, q_stride, q_off,
-                     ix->d.slot_end - ix->d.slot_begin, (const uint16_t *)ix->store, (uint64_t)ix->cap, ix->d.R, mine, flag);
+  const uint32_t f_local = ix->d.slot_end - ix->d.slot_begin;
+  if (wide) {
+    hipError_t e = hipFuncSetAttribute((const void *)nq::surv_lookup_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nq::surv_lookup_kernel<uint32_t>, dim3(nq_), dim3(256), lds, ix->stream, surv, surv_n, SC, T, m, ids, sk, q_stride,
+                       q_off, f_local, (const uint16_t *)ix->store, (uint64_t)ix->cap, ix->d.R, (uint32_t *)mine, flag);
+  } else {
+    hipError_t e = hipFuncSetAttribute((const void *)nq::surv_lookup_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(nq::surv_lookup_kernel<uint16_t>, dim3(nq_), dim3(256), lds, ix->stream, surv, surv_n, SC, T, m, ids, sk, q_stride,
+                       q_off, f_local, (const uint16_t *)ix->store, (uint64_t)ix->cap, ix->d.R, (uint16_t *)mine, flag);
+  }
   return hipGetLastError();
 }
 
 // hits of `per` queries (first_q ..) from candidate ids and their summed counts; keys / nhit: scratch
-int hits_from_candidates(niqki_index *ix, const uint16_t *tot, uint32_t first_q, uint32_t per, uint32_t m, const nq::IdView &ids,
+int hits_from_candidates(niqki_index *ix, const void *tot, uint32_t first_q, uint32_t per, uint32_t m, const nq::IdView &ids,
                          uint32_t min_score, Buf &keys, Buf &nhit, unsigned long long *hit_off, uint32_t *hc, uint32_t *hg,
-                         uint64_t capacity) {
+                         uint64_t capacity, bool wide = false) {
   if (per == 0) return NIQKI_OK;
   if (m > nq::kCandMax) return nqi::fail(ix, NIQKI_E_INVALID, "too many candidate ids per query");
   int rc = nqi::ensure(ix, keys, std::max<size_t>((size_t)per * m * 8, 8));
@@ -1034,10 +1065,16 @@ int hits_from_candidates(niqki_index *ix, const uint16_t *tot, uint32_t first_q,
   if (rc) return rc;
   const uint32_t P = pow2_at_least(std::max(m, 2u)), T = 2 * P;
   const size_t lds = (size_t)P * 8 + (size_t)T * 4;
-  NQ_HIP(ix, hipFuncSetAttribute((const void *)nq::cand_hits_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   nqi::Span sp(ix, NIQKI_KC_HITS);
-  hipLaunchKernelGGL(nq::cand_hits_kernel, dim3(per), dim3(256), lds, ix->stream, tot, first_q, m, ids, min_score, T, P,
-                     (unsigned long long *)keys.p, (uint32_t *)nhit.p);
+  if (wide) {
+    NQ_HIP(ix, hipFuncSetAttribute((const void *)nq::cand_hits_kernel<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(nq::cand_hits_kernel<uint32_t>, dim3(per), dim3(256), lds, ix->stream, (const uint32_t *)tot, first_q, m, ids,
+                       min_score, T, P, (unsigned long long *)keys.p, (uint32_t *)nhit.p);
+  } else {
+    NQ_HIP(ix, hipFuncSetAttribute((const void *)nq::cand_hits_kernel<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(nq::cand_hits_kernel<uint16_t>, dim3(per), dim3(256), lds, ix->stream, (const uint16_t *)tot, first_q, m, ids,
+                       min_score, T, P, (unsigned long long *)keys.p, (uint32_t *)nhit.p);
+  }
   hipLaunchKernelGGL(nq::cand_hits_scan_kernel, dim3(1), dim3(1024), 0, ix->stream, (const uint32_t *)nhit.p, per, hit_off);
   hipLaunchKernelGGL(nq::cand_hits_write_kernel, dim3(per), dim3(256), 0, ix->stream, (const unsigned long long *)keys.p,
                      (const uint32_t *)nhit.p, m, (const unsigned long long *)hit_off, hc, hg, (unsigned long long)capacity);
@@ -1053,10 +1090,18 @@ int gather_rows(niqki_group *g, uint32_t nq_, uint32_t N, uint64_t stride) {
     niqki_index *ix = g->sh[l];
     NQ_GH(g, hipSetDevice(ix->device));
     auto &w = g->ws[l];
-    NQ_G(g, l, nqi::ensure(ix, w.counts, std::max<size_t>((size_t)nq_ * stride * 2, 4)));
-    if (N == 0) NQ_GH(g, hipMemsetAsync(w.counts.p, 0, std::max<size_t>((size_t)nq_ * stride * 2, 4), ix->stream));
-    NQ_G(g, l, nqi::counts_dev(ix, (const int32_t *)w.allsk.p, ix->d.slot_end - ix->d.slot_begin, 0, nq_, (uint16_t *)w.counts.p,
+    const size_t cells = std::max<size_t>((size_t)nq_ * stride, 2);
+    NQ_G(g, l, nqi::ensure(ix, w.counts, cells * (g->wide ? 4 : 2)));
+    Buf &rows = g->wide ? w.rows16 : w.counts;   // S = 16: u16 rows of the shard first, widened for the sum
+    if (g->wide) NQ_G(g, l, nqi::ensure(ix, w.rows16, cells * 2));
+    if (N == 0) NQ_GH(g, hipMemsetAsync(rows.p, 0, cells * 2, ix->stream));
+    NQ_G(g, l, nqi::counts_dev(ix, (const int32_t *)w.allsk.p, ix->d.slot_end - ix->d.slot_begin, 0, nq_, (uint16_t *)rows.p,
                                stride, nullptr, nullptr));
+    if (g->wide) {
+      hipLaunchKernelGGL(nq::widen_rows_kernel, dim3(4096), dim3(256), 0, ix->stream, (const uint16_t *)w.rows16.p,
+                         (uint64_t)nq_ * stride, (uint32_t *)w.counts.p);
+      NQ_GH(g, hipGetLastError());
+    }
   }
   return NIQKI_OK;
 }
@@ -1064,12 +1109,24 @@ int gather_rows(niqki_group *g, uint32_t nq_, uint32_t N, uint64_t stride) {
 // 4b + 5 of a batch whose partial hit vectors (ws.counts) are complete: dense reduce-scatter, threshold, order
 int finish_dense(niqki_group *g, uint32_t per, uint32_t N, uint64_t stride) {
   int rc;
+  const size_t cells = std::max<size_t>((size_t)per * stride, 2);
   for (uint32_t l = 0; l < g->n_local; ++l) {
     NQ_GH(g, hipSetDevice(g->sh[l]->device));
-    NQ_G(g, l, nqi::ensure(g->sh[l], g->ws[l].red, std::max<size_t>((size_t)per * stride * 2, 4)));
+    NQ_G(g, l, nqi::ensure(g->sh[l], g->ws[l].red, cells * 2 * (g->wide ? 2 : 1)));   // (S = 16: two planes)
+    if (g->wide) NQ_G(g, l, nqi::ensure(g->sh[l], g->ws[l].sum32, cells * 4));
   }
   nqi::Span sp(g->sh[0], NIQKI_KC_EXCHANGE);
-  if ((rc = reduce_scatter_u32(g, &niqki_group::Ws::counts, &niqki_group::Ws::red, (size_t)per * (stride / 2)))) return rc;
+  if (!g->wide) return reduce_scatter_u32(g, &niqki_group::Ws::counts, &niqki_group::Ws::red, (size_t)per * (stride / 2));
+  if ((rc = reduce_scatter_u32(g, &niqki_group::Ws::counts, &niqki_group::Ws::sum32, (size_t)per * stride))) return rc;
+  for (uint32_t l = 0; l < g->n_local; ++l) {
+    niqki_index *ix = g->sh[l];
+    NQ_GH(g, hipSetDevice(ix->device));
+    auto &w = g->ws[l];
+    hipLaunchKernelGGL(nq::split_sums_kernel, dim3(4096), dim3(256), 0, ix->stream, (const uint32_t *)w.sum32.p, (uint64_t)per * stride,
+                       (uint16_t *)w.red.p, (uint16_t *)w.red.p + cells);
+    NQ_GH(g, hipGetLastError());
+  }
+  (void)N;
   return NIQKI_OK;
 }
 
@@ -1081,16 +1138,17 @@ int run_hits(niqki_group *g, uint32_t per, uint32_t N, uint64_t stride) {
     niqki_index *ix = g->sh[l];
     NQ_GH(g, hipSetDevice(ix->device));
     auto &w = g->ws[l];
+    const uint16_t *plane2 = g->wide ? (const uint16_t *)w.red.p + std::max<size_t>((size_t)per * stride, 2) : nullptr;
     if (!pd.host) {
       NQ_G(g, l, nqi::hits_dev(ix, (const uint16_t *)w.red.p, per, stride, 0, N, (unsigned long long *)pd.hit_off[l], pd.hit_counts[l],
-                               pd.hit_gids[l], pd.capacity, false, nullptr));
+                               pd.hit_gids[l], pd.capacity, false, nullptr, plane2));
       continue;
     }
     NQ_G(g, l, nqi::ensure(ix, w.hitoff, (size_t)(per + 1) * 8));
     NQ_G(g, l, nqi::ensure(ix, w.hc, (size_t)std::max<uint64_t>(pd.capacity, 1) * 4));
     NQ_G(g, l, nqi::ensure(ix, w.hg, (size_t)std::max<uint64_t>(pd.capacity, 1) * 4));
     NQ_G(g, l, nqi::hits_dev(ix, (const uint16_t *)w.red.p, per, stride, 0, N, (unsigned long long *)w.hitoff.p, (uint32_t *)w.hc.p,
-                             (uint32_t *)w.hg.p, pd.capacity, false, nullptr));
+                             (uint32_t *)w.hg.p, pd.capacity, false, nullptr, plane2));
   }
   return NIQKI_OK;
 }
@@ -1140,8 +1198,8 @@ int niqki_group_query_begin(niqki_group *g, const int32_t *const *local_sketches
       NQ_G(g, l, nqi::ensure(ix, w.cand, blob));
       NQ_G(g, l, nqi::ensure(ix, w.surv, (size_t)nq * SC * 8));
       NQ_G(g, l, nqi::ensure(ix, w.cand_all, (size_t)G * blob));
-      NQ_G(g, l, nqi::ensure(ix, w.mine, (size_t)nq * G * C * 2));
-      NQ_G(g, l, nqi::ensure(ix, w.tot, (size_t)per * G * C * 2));
+      NQ_G(g, l, nqi::ensure(ix, w.mine, (size_t)nq * G * C * (g->wide ? 4 : 2)));
+      NQ_G(g, l, nqi::ensure(ix, w.tot, (size_t)per * G * C * (g->wide ? 4 : 2)));
       NQ_G(g, l, nqi::ensure(ix, w.flag, 4));
       nq::CandOut co;
       co.cand = (int32_t *)w.cand.p;
@@ -1168,8 +1226,8 @@ int niqki_group_query_begin(niqki_group *g, const int32_t *const *local_sketches
       NQ_GH(g, hipMemsetAsync(w.flag.p, 0, 4, ix->stream));
       const nq::IdView ids{(const int32_t *)w.cand_all.p, (uint64_t)(blob / 4), C};
       NQ_GH(g, launch_surv_lookup(ix, (const int2 *)w.surv.p, (const int32_t *)w.cand.p + (size_t)nq * C + nq, SC, nq, G * C, ids,
-                                  (const int32_t *)w.allsk.p, ix->d.slot_end - ix->d.slot_begin, 0, (uint16_t *)w.mine.p,
-                                  (uint32_t *)w.flag.p));
+                                  (const int32_t *)w.allsk.p, ix->d.slot_end - ix->d.slot_begin, 0, w.mine.p,
+                                  (uint32_t *)w.flag.p, g->wide));
       // a candidate list of ANY rank that overflowed (same words on every rank: all decide alike)
       hipLaunchKernelGGL(nq::blob_overflow_kernel, dim3((nq + 255) / 256), dim3(256), 0, ix->stream, (const int32_t *)w.cand_all.p,
                          (uint64_t)(blob / 4), nq, G, C, SC, (uint32_t *)w.flag.p);
@@ -1177,7 +1235,7 @@ int niqki_group_query_begin(niqki_group *g, const int32_t *const *local_sketches
     }
     {
       nqi::Span sp(g->sh[0], NIQKI_KC_EXCHANGE);
-      if ((rc = reduce_scatter_u32(g, &niqki_group::Ws::mine, &niqki_group::Ws::tot, (size_t)per * G * C / 2))) return rc;
+      if ((rc = reduce_scatter_u32(g, &niqki_group::Ws::mine, &niqki_group::Ws::tot, g->wide ? (size_t)per * G * C : (size_t)per * G * C / 2))) return rc;
     }
     // 5. The overflow word stays on the device: the hits are made from the candidates' sums right away, and
     // query_end -- the one place the host waits -- redoes the batch densely in the (rare) case that a list
@@ -1195,8 +1253,8 @@ int niqki_group_query_begin(niqki_group *g, const int32_t *const *local_sketches
         off = (unsigned long long *)w.hitoff.p; hc = (uint32_t *)w.hc.p; hg = (uint32_t *)w.hg.p;
       }
       const nq::IdView ids{(const int32_t *)w.cand_all.p, (uint64_t)(blob / 4), C};
-      NQ_G(g, l, hits_from_candidates(ix, (const uint16_t *)w.tot.p, (g->first + l) * per, per, G * C, ids, min_score, w.keys, w.nhit,
-                                      off, hc, hg, capacity));
+      NQ_G(g, l, hits_from_candidates(ix, w.tot.p, (g->first + l) * per, per, G * C, ids, min_score, w.keys, w.nhit, off, hc, hg,
+                                      capacity, g->wide));
     }
   } else {
     if ((rc = gather_rows(g, nq, N, stride))) return rc;

@@ -268,3 +268,14 @@ def test_paged_index_matrix_and_dump(workdir, gold):
     assert_same_text(gunzip(workdir / "hits_pg.gz").decode(), meta["cli"]["hits"])
     raw = gunzip(workdir / "idx_pg.dump")
     assert len(raw) == meta["cli"]["dump_len"] and hashlib.md5(raw).hexdigest() == meta["cli"]["dump_md5"]
+
+
+def test_sketch_size_16_sharded(workdir, monkeypatch):
+    """`niqki --gpus 2 -S 16`: every shard counts 2^15 slots, the sums reach 2^16 (u32 in the exchange)."""
+    import json
+    monkeypatch.setenv("NIQKI_SHARDS_ON_ONE_DEVICE", "1")
+    exp = json.load(open(os.path.join(GOLD, "reference_s16.json")))["cli_s16"]
+    run(workdir, ["--gpus", "2", "-I", "fof.txt", "-Q", "fof.txt", "-S", "16", "-W", "8", "-J", "0.1", "-O", "s16g_hits.gz"])
+    assert_same_text(gunzip(workdir / "s16g_hits.gz").decode(), exp["hits"])
+    run(workdir, ["--gpus", "2", "-M", "fof.txt", "-S", "16", "-W", "8", "-J", "0.1", "-O", "s16g_matrix.gz"])
+    assert_same_text(gunzip(workdir / "s16g_matrix.gz").decode(), exp["matrix"])

@@ -113,3 +113,54 @@ def test_s16_many_genomes_two_tiles_and_device_path(native, po):
     assert np.array_equal(c32[0].astype(np.int64), ix.counts(q[0]))
     pg.close()
     e.close()
+
+
+@pytest.mark.parametrize("world,exchange", [(2, "sparse"), (2, "dense"), (4, "sparse"), (4, "overflow")])
+def test_s16_slot_shards_equal_the_whole_index(native, d5, world, exchange):
+    """S = 16 over slot shards (niqki_group_*): a shard counts at most 2^15 slots in u16, the cross-shard sums
+    reach 2^16 and travel as u32 -- candidates' sums in the sparse exchange, widened counter rows in the dense
+    one (two planes for the hit kernels).  Golden D5's hit lists, counts of 2^16 included."""
+    import torch
+    vec, m, seed = d5
+    dev = torch.device("cuda")
+    S, F = m["S"], 1 << m["S"]
+    sk = vec["D5_sketches"].astype(np.int32)
+    qsk = vec["D5_qsketches"].astype(np.int32)
+    engines = []
+    for r in range(world):
+        b, e_ = native.group_slot_range(r, world, S)
+        sh = native.Engine(K=m["K"], S=S, W=m["W"], H=m["H"], J=m["J"], slot_begin=b, slot_end=e_)
+        sh.set_stream(torch.cuda.current_stream().cuda_stream)
+        engines.append(sh)
+    grp = native.Group(engines)
+    grp.set_option("exchange", 2 if exchange == "dense" else 1)
+    if exchange == "overflow":
+        grp.set_option("cand_cap", 2)
+    n = sk.shape[0]
+    per_i = -(-n // world)
+    pad = np.full((world * per_i, F), -1, np.int32)
+    pad[:n] = sk
+    grp.insert_dev([torch.from_numpy(pad[r * per_i:(r + 1) * per_i].copy()).to(dev) for r in range(world)], per_i, n)
+    nq = qsk.shape[0]
+    per = -(-nq // world)
+    padq = np.full((world * per, F), -1, np.int32)
+    padq[:nq] = qsk
+    res = grp.query([torch.from_numpy(padq[r * per:(r + 1) * per].copy()).to(dev) for r in range(world)], per)
+    off, hc, hg = vec["D5_hit_off"], vec["D5_hit_counts"], vec["D5_hit_gids"]
+    seen_full = 0
+    for q in range(nq):
+        r, j = divmod(q, per)
+        o, c, g_ = res[r]
+        lo, hi = int(off[q]), int(off[q + 1])
+        assert np.array_equal(c[int(o[j]):int(o[j + 1])], hc[lo:hi]) and np.array_equal(g_[int(o[j]):int(o[j + 1])], hg[lo:hi]), (world, exchange, q)
+        seen_full += int((c[int(o[j]):int(o[j + 1])] == 1 << 16).sum())
+    assert seen_full >= 1
+    assert (grp.stat("overflows") >= 1) == (exchange == "overflow")
+    grp.close()
+    for sh in engines:
+        sh.close()
+    # one shard cannot hold 2^16 slots in u16 counters
+    whole = native.Engine(K=m["K"], S=S, W=m["W"], H=m["H"], J=m["J"])
+    with pytest.raises(native.NiqkiError):
+        native.Group([whole])
+    whole.close()
