@@ -904,7 +904,14 @@ int niqki_build(niqki_index *ix) {
   }
   ix->delta_n = 0;   // one index over everything inserted so far
   int rc = build_range(ix, 0, ix->n_genomes);
-  if (rc == NIQKI_OK) ix->built_n = ix->n_genomes;
+  if (rc == NIQKI_OK) {
+    ix->built_n = ix->n_genomes;
+    // the delta segment's buffers are not needed until genomes arrive again: give their memory back
+    auto &a = ix->alt;
+    for (void *p : {(void *)a.entries, (void *)a.gids, (void *)a.tile_base, (void *)a.slot_units, (void *)a.ptab})
+      if (p) (void)hipFree(p);
+    a = niqki_index::Seg();
+  }
   return rc;
 }
 
@@ -945,6 +952,17 @@ int build_range(niqki_index *ix, uint32_t g_base, uint32_t N) {
     have = want;
     return NIQKI_OK;
   };
+  // Nothing of the segment counts as built until the fill has gone through: an error on the way (out of
+  // memory: grow() has freed the old buffer by then) must not leave seg_n naming ids that do not exist --
+  // build_if_needed would take such a segment for a main index and put a delta on top of it.
+  struct Uncommitted {
+    niqki_index *ix;
+    bool ok = false;
+    ~Uncommitted() {
+      if (!ok) { ix->seg_n = 0; ix->built = false; }
+    }
+  } commit{ix};
+  ix->built = false;
   int rc;
   if ((rc = grow((void **)&ix->entries, ix->entries_bytes, (size_t)f_local * ix->d.R * n_tiles * sizeof(nq::Entry)))) return rc;
   if ((rc = grow((void **)&ix->slot_units, ix->slot_units_bytes, (size_t)n_tiles * (f_local + 1) * 4))) return rc;
@@ -963,7 +981,7 @@ int build_range(niqki_index *ix, uint32_t g_base, uint32_t N) {
     while (B > 1 && ((N + B - 1) / B + n_tiles - 1) / n_tiles * B > tile) B /= 2;
     ix->stripe = B;
   }
-  if (n_tiles == 0) { ix->built = true; return NIQKI_OK; }
+  if (n_tiles == 0) { commit.ok = true; ix->built = true; return NIQKI_OK; }
   {
     Span sp(ix, NIQKI_KC_BUILD);
     NQ_HIP(ix, nq::launch_build_sizes(view(ix), ix->slot_units, ix->tile_base, ix->stream));
@@ -985,6 +1003,7 @@ int build_range(niqki_index *ix, uint32_t g_base, uint32_t N) {
     Span sp(ix, NIQKI_KC_BUILD);
     NQ_HIP(ix, nq::launch_build_fill(view(ix), ix->entries, ix->gids, ix->stream));
   }
+  commit.ok = true;
   ix->built = true;
   return NIQKI_OK;
 }

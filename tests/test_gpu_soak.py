@@ -1,7 +1,8 @@
 """GPU: randomized cross-check of the query path's launch forms on mid-sized random indexes: counter
 tiles (size, ranges / stripes of 1 .. 64 genomes), table look-ups inside the gather kernel or by the
 pre-pass (random look-ups / streamed rows), locality order on or off, genomes added after a build
-(delta segment), candidates picked inside the gather kernel -- all against one plain engine and
+(rebuild, or -- main index of >= 4096 genomes -- the delta segment, asserted), candidates picked inside
+the gather kernel -- all against one plain engine and
 against the oracle.  NIQKI_FUZZ_SCALE=k runs k times as many seeds."""
 import os
 
@@ -20,10 +21,14 @@ def test_launch_forms_agree(native, po, seed, monkeypatch):
     W = int(rng.choice([6, 11, 12]))
     F = 1 << S
     n = int(rng.integers(100, 3000))
+    n_late = int(rng.choice([0, 0, 37]))
+    if n_late and seed % 2:
+        n = int(rng.integers(4096 + n_late, 5200))      # a main index of >= 4096 genomes: the late ones get a DELTA segment
     tile = int(rng.choice([0, 64, 192, 256, 1024]))
+    if n >= 4096 and tile == 64:
+        tile = 192                                       # (the dump merges at most 64 tiles)
     stripe = int(rng.choice([0, 1, 2, 8, 32, 64]))
     nq = int(rng.choice([7, 70, 600, 1100, 2100]))
-    n_late = int(rng.choice([0, 0, 37]))
     fam = rng.integers(0, 1 << W, (6, F)).astype(np.int32)
     sk = fam[(np.arange(n) // int(rng.integers(5, 90))) % 6].copy()
     noise = rng.random((n, F)) < 0.3
@@ -55,6 +60,8 @@ def test_launch_forms_agree(native, po, seed, monkeypatch):
     plain.close()
     e = engine(tile, stripe, int(rng.choice([-1, 0, 1])), int(rng.choice([0, 2])))
     cnt, hits = e.query_counts(q), e.query(q)
+    # genomes that arrived after a query on a main index of >= 4096: indexed by the delta segment, not a rebuild
+    assert e.stat("delta_genomes") == (n_late if (n_late and n - n_late >= 4096) else 0), (seed, n, n_late)
     assert np.array_equal(cnt, ref_cnt), (seed, S, W, n, tile, stripe, nq, n_late)
     assert all(np.array_equal(a, b) for a, b in zip(hits, ref_hits)), seed
     # candidates from inside the gather kernel = the counters' threshold
