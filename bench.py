@@ -465,21 +465,7 @@ def main():
             pass
 
     # ---- what a streaming copy reaches on this device, now (the practical HBM ceiling beside the 8 TB/s spec) ----
-    copy_gbs = None
-    if rank == 0:
-        n_copy = 1 << 30
-        src_c = torch.zeros(n_copy // 4, dtype=torch.float32, device=dev)
-        dst_c = torch.empty(n_copy // 4, dtype=torch.float32, device=dev)
-        dst_c.copy_(src_c)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(8):
-            dst_c.copy_(src_c)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 8 * 2.0 * n_copy / (e0.elapsed_time(e1) * 1e-3) / 1e9      # bytes read + bytes written
-        del src_c, dst_c
+    copy_gbs = eng.measure_alu(4) / 1e9 if rank == 0 else None
 
     # ---- sketch kernel against integer-ALU ceilings measured now, on this device ----
     kmers = args.steps * per * max(L - K, 0)
@@ -508,25 +494,48 @@ def main():
         if not args.no_cpu:
             cpu = cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, (K, S, W, H, J))
         # ---- the same steps with the hits copied back to the host (SURVEY.md 8d "end-to-end incl. D2H of hits") ----
+        # as a caller would: two sets of hit buffers, step i+1 runs while a copy stream brings step i's
+        # hit_off and then exactly its hits into page-locked memory
         if rank == 0 and world == 1 and not emu:
-            h_off = torch.empty(per + 1, dtype=torch.int64).pin_memory()
+            hcs, hgs = [hc, torch.zeros_like(hc)], [hg, torch.zeros_like(hg)]
+            h_off = [torch.empty(per + 1, dtype=torch.int64).pin_memory() for _ in range(2)]
             h_hc = torch.empty(cap, dtype=torch.int32).pin_memory()
             h_hg = torch.empty(cap, dtype=torch.int32).pin_memory()
-            n_d2h = min(5, args.steps)
+            cstream = torch.cuda.Stream(device=dev)
+            done = [torch.cuda.Event() for _ in range(2)]
+            n_d2h = min(8, args.steps)
+            nh_tot = 0
+
+            def fetch(k, si):     # hits of step si (buffer set k) to the host, on the copy stream
+                nonlocal nh_tot
+                with torch.cuda.stream(cstream):
+                    cstream.wait_event(done[k])
+                    h_off[k].copy_(hit_off[si], non_blocking=True)
+                    cstream.synchronize()                 # the sizes first ...
+                    nh = int(h_off[k][per])
+                    h_hc[:nh].copy_(hcs[k][:nh], non_blocking=True)      # ... then exactly the hits
+                    h_hg[:nh].copy_(hgs[k][:nh], non_blocking=True)
+                    cstream.synchronize()
+                nh_tot += nh
             torch.cuda.synchronize()
             td = time.perf_counter()
-            for si in range(args.warmup, args.warmup + n_d2h):
-                step(si)
-                h_off.copy_(hit_off[si], non_blocking=True)
-                torch.cuda.synchronize()                     # the sizes first, then exactly the hits
-                nh = int(h_off[per])
-                h_hc[:nh].copy_(hc[:nh], non_blocking=True)
-                h_hg[:nh].copy_(hg[:nh], non_blocking=True)
-                torch.cuda.synchronize()
+            for j, si in enumerate(range(args.warmup, args.warmup + n_d2h)):
+                k = j % 2
+                bi = si % n_batches
+                eng.sketch_dev(qseq[bi * per * stride_b:], d_ro, per, qsk[bi])
+                eng.query_counts_dev(qsk[bi], per, counts, stride)
+                eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[si], hcs[k], hgs[k], cap)
+                done[k].record(torch.cuda.current_stream())
+                if j:
+                    fetch(1 - k, si - 1)                  # while step si runs
+            fetch((n_d2h - 1) % 2, args.warmup + n_d2h - 1)
+            torch.cuda.synchronize()
             td = time.perf_counter() - td
             d2h = {"value": n_d2h * per / td, "unit": "genomes/s", "ms_per_step": td / n_d2h * 1e3, "steps": n_d2h,
-                   "hit_bytes_per_step": 8 * (per + 1) + 8 * nh,
-                   "note": "the timed step followed by the copy of hit_off, hit_counts and hit_gids into page-locked host memory"}
+                   "hit_bytes_per_step": 8 * (per + 1) + 8 * nh_tot // n_d2h,
+                   "note": "the timed step with hit_off, hit_counts and hit_gids copied into page-locked host memory by a copy "
+                           "stream while the next step runs (two sets of hit buffers)"}
+            del hcs, hgs
 
         if not args.no_extra:
             del counts
@@ -929,6 +938,27 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
         "cpu_oracle": cpu4,
     }
     e.close()
+
+    # ---- the `niqki` host program on FILES: FASTA bytes in the page cache -> hits in a gz ----
+    # (tools/bench_cli.py in child processes: whole-file mode, plain and gzip level 1 inputs; rates from the
+    # program's own phase clocks, its start-up reported beside them)
+    import subprocess
+    cli = {}
+    for tag, n_files, gz in (("plain_fasta", 128, False), ("gzip_fasta", 32, True)):
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_cli.py"), "--genomes", str(n_files), "--len", str(L),
+               "--dir", os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "niqki_bench_cli_%d" % os.getpid())]
+        if gz:
+            cmd.append("--gz")
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            j = json.loads(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else None
+        except (OSError, ValueError, IndexError, subprocess.SubprocessError):
+            j = None
+        if j:
+            cli[tag] = {"files": n_files, "index_genomes_per_s": j["index_genomes_per_s"], "query_genomes_per_s": j["query_genomes_per_s"],
+                        "index_file_GBps": j["index_fasta_GBps"], "process_startup_s": j["startup_s"]}
+    out["cli_files"] = {"workload": "niqki -I fof -Q fof -J 0.1 on 5 Mbp FASTA files (70 columns) in the page cache, whole-file mode",
+                        **cli} if cli else None
     return out
 
 

@@ -514,8 +514,9 @@ int niqki_synth_reads(niqki_index *ix, uint64_t seed, const uint32_t *family, co
  * fraction of one): what = 0 independent 32-bit adds, 1 = 32-bit multiplies, 2 = the sketch
  * kernel's per-k-mer arithmetic alone (K = 31 roll + canonical choice + filter hash; no LDS,
  * memory or compaction), 3 = three-operand integer instructions (v_lshl_add_u32: the issue class of
- * every gfx950 vector opcode except add / sub / and / or / xor / mov / shift-right).
- * *rate = adds / multiplies / k-mers / instructions per second over ~ms milliseconds. */
+ * every gfx950 vector opcode except add / sub / and / or / xor / mov / shift-right), 4 = a streaming
+ * copy of 1 GiB (bytes read + written per second: the HBM rate a plain kernel reaches).
+ * *rate = adds / multiplies / k-mers / instructions / bytes per second over ~ms milliseconds. */
 int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate);
 
 #ifdef __cplusplus

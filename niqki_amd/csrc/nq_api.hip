@@ -1812,8 +1812,33 @@ int niqki_synth_reads(niqki_index *ix, uint64_t seed, const uint32_t *family, co
 }
 
 int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate) {
-  if (!ix || !rate || what < 0 || what > 3 || !(ms > 0)) return NIQKI_E_INVALID;
+  if (!ix || !rate || what < 0 || what > 4 || !(ms > 0)) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
+  if (what == 4) {   // streaming copy of 1 GiB: bytes read + bytes written per second
+    const uint64_t bytes = 1ull << 30;
+    void *a_ = nullptr, *b_ = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipMalloc(&a_, bytes);
+    if (e == hipSuccess) e = hipMalloc(&b_, bytes);
+    if (e == hipSuccess) e = hipMemsetAsync(a_, 1, bytes, ix->stream);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = nq::launch_copy_probe(a_, b_, bytes, ix->stream);
+    const int reps = 8;
+    if (e == hipSuccess) e = hipEventRecord(e0, ix->stream);
+    for (int r = 0; r < reps && e == hipSuccess; ++r) e = nq::launch_copy_probe(a_, b_, bytes, ix->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, ix->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float f = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&f, e0, e1);
+    if (a_) (void)hipFree(a_);
+    if (b_) (void)hipFree(b_);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(ix, e == hipErrorOutOfMemory ? NIQKI_E_NOMEM : NIQKI_E_HIP, std::string("copy probe: ") + hipGetErrorString(e));
+    *rate = f > 0 ? 2.0 * reps * (double)bytes / (f * 1e-3) : 0.0;
+    return NIQKI_OK;
+  }
   int rc = ensure(ix, ix->ws_misc, 256);
   if (rc) return rc;
   hipEvent_t a = nullptr, b = nullptr;

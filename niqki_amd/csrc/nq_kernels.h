@@ -230,5 +230,7 @@ hipError_t launch_synth_reads(uint64_t seed, const uint32_t *family, const uint3
 // LDS, memory or compaction; 3: v_lshl_add_u32 (the issue class of most vector opcodes).
 // *units = adds / multiplies / k-mers / instructions executed; timed by the caller.
 hipError_t launch_alu_probe(int what, uint32_t iters, uint32_t *sink, uint64_t *units, hipStream_t stream);
+// dst[0, bytes) = src[0, bytes) by a plain grid-stride kernel (bytes a multiple of 16)
+hipError_t launch_copy_probe(const void *src, void *dst, uint64_t bytes, hipStream_t stream);
 
 }  // namespace nq

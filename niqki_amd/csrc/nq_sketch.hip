@@ -1101,6 +1101,27 @@ __global__ __launch_bounds__(1024) void alu_probe_kernel(uint32_t iters, uint32_
   }
 }
 
+// streaming copy: the HBM rate a kernel reaches on this device (the practical ceiling beside the spec peak).
+// Four 16-byte nontemporal loads in flight per thread, one workgroup per 16 KB: the fastest of the forms in
+// tools/ubench_copy.hip (6.2 TB/s; a plain one-load loop 4.8, hipMemcpyAsync 4.7).
+typedef unsigned int copy_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy_probe_kernel(const copy_u4 *src, copy_u4 *dst, uint64_t n) {
+  const uint64_t step = (uint64_t)gridDim.x * 1024;
+  for (uint64_t i = (uint64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += step) {
+    copy_u4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * 256 < n) v[u] = __builtin_nontemporal_load(src + i + u * 256);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i + u * 256 < n) __builtin_nontemporal_store(v[u], dst + i + u * 256);
+  }
+}
+hipError_t launch_copy_probe(const void *src, void *dst, uint64_t bytes, hipStream_t stream) {
+  hipLaunchKernelGGL(copy_probe_kernel, dim3(32768), dim3(256), 0, stream, (const copy_u4 *)src, (copy_u4 *)dst, bytes / 16);
+  return hipGetLastError();
+}
+
 hipError_t launch_alu_probe(int what, uint32_t iters, uint32_t *sink, uint64_t *units, hipStream_t stream) {
   const uint32_t blocks = 256 * 4;  // four 1024-thread workgroups per CU: 16 waves per SIMD-quartet, as the sketch kernel
   const uint64_t threads = (uint64_t)blocks * 1024;
