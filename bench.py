@@ -473,9 +473,9 @@ def main():
     alu = None
     if rank == 0:
         adds, muls, arith, vop3 = eng.measure_alu(0), eng.measure_alu(1), eng.measure_alu(2), eng.measure_alu(3)
-        # 28.9 vector instructions per k-mer (profiles/r03_sketch_sq_counters.txt: SQ_INSTS_VALU over the k-mers of
-        # the launch) at the issue rate of a three-operand integer instruction, the class of 21 of them
-        valu_per_kmer = 28.9
+        # 27.8 vector instructions per k-mer (profiles/r03_sketch_sq_counters.txt: SQ_INSTS_VALU over the k-mers of
+        # the launch) at the issue rate of a three-operand integer instruction, the class of 20 of them
+        valu_per_kmer = 27.8
         alu = {"add_lane_ops_per_s": adds, "mul_lane_ops_per_s": muls, "vop3_lane_ops_per_s": vop3,
                "arithmetic_only_kmers_per_s": arith,
                "alu_frac": sk_rate / arith if arith else None,

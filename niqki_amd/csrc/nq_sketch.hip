@@ -366,8 +366,14 @@ __device__ __forceinline__ void candidate_update(uint64_t canon, const Derived &
   const uint32_t uh = mix_round_hi(ulo, uhi, (uint32_t)kUnrevMul, (uint32_t)(kUnrevMul >> 32));
   mix_round(lo, hi, (uint32_t)kRevMul, (uint32_t)(kRevMul >> 32));
   mix_round(lo, hi, (uint32_t)kRevMul, (uint32_t)(kRevMul >> 32));
-  const uint64_t h = ((uint64_t)hi << 32) | (lo ^ hi);
-  uint32_t fp = fingerprint(h, d.M, d.mask_m, d.max_rem);
+  // get_fingerprint (:277-287) of h = hi : lo ^ hi.  A candidate's high word is below 2^29 and, but for one
+  // hash in 2^29, not 0: its leading zeros are those of the high word (one v_ffbh); the rare zero high word
+  // takes the general form for the whole wave.
+  const uint32_t hl = lo ^ hi;
+  uint32_t lz = (uint32_t)__builtin_clz(hi);
+  if (__builtin_expect(__any(hi == 0u), 0)) lz = clz64(((uint64_t)hi << 32) | hl);
+  const uint32_t rem = lz < d.max_rem ? d.max_rem - lz : 0u;
+  uint32_t fp = (hl & d.mask_m) + (rem << d.M);
   fp = live ? fp : kEmpty32;  // a min with "empty" changes nothing
   const uint32_t cell = (uh >> (30u - d.S)) & ~3u;   // byte offset of the slot's cell
   __hip_atomic_fetch_min((lds_u32_t *)(uintptr_t)(lds0 + kCellOff + cell), fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -449,7 +455,27 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
       // them, :255-273) and their complements (rcb, :240-250); every later
       // position carries the codes of the rolling tables.
       uint64_t fw = 0, rc = 0;
-      {
+      if (FAST && __all(i0 >= Km1)) {
+        // no lane of the wave starts inside a record's first K-1 positions (all chunks but a record's
+        // first): the 30 steps are plain rolling updates from the 8-byte code table, 4 instructions each
+        ByteStream ws;
+        ws.open(base + i0);
+        uint64_t ew[32];
+        {
+          uint64_t e16[16];
+          lut64_16(ws.next16(), lds0, e16);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) ew[j] = e16[j];
+          lut64_16(ws.next16(), lds0, e16);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) ew[16 + j] = e16[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 30; ++j) {
+          fw = shl2_64(fw) | (uint32_t)ew[j];
+          rc = shr2_64(rc) | (ew[j] & 0xFFFFFFFF00000000ULL);
+        }
+      } else {
         uint32_t ok = 1;
         if (i0 < Km1) {
           ByteStream ps;
@@ -1043,7 +1069,11 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   } else if (avg_len < (1u << 21)) {
     if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 8, 31); else NQ_LAUNCH_SKETCH(1024, 8, 0);
   } else {
+#ifdef NQ_SK_BLOCK
+    NQ_LAUNCH_SKETCH(NQ_SK_BLOCK, 32, 31);
+#else
     if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 32, 31); else NQ_LAUNCH_SKETCH(1024, 32, 0);
+#endif
   }
 #undef NQ_LAUNCH_SKETCH
   return hipGetLastError();

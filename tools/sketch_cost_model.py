@@ -107,12 +107,16 @@ def main():
     print("%-26s %6d %8.2f %10.1f   (every opcode at its own measured cost)" % ("total per step", nv, nv / 16.0, a / 16.0))
     print("%-26s %6s %8s %10.1f   (every opcode at %.2f: the add / xor / or class does not keep its 2.4-cycle rate between other opcodes)"
           % ("", "", "", b / 16.0, uniform))
-    # the drain behind the loop: the block with ds_min_u32 ... offset:2320 reached from the loop
-    drains = [i for i, l in enumerate(k) if "ds_min_u32" in l and "offset:2320" in l and i > end]
-    if drains:
-        d0 = drains[0]
-        s0 = max(i for i in range(d0) if re.match(r"^(\.LBB\S+):", k[i]) or "; %bb." in k[i])
-        dr = ops_of(k[s0:d0 + 1])
+    # the drain behind the loop: where the loop's first "stack holds 64" branch goes, up to its ds_min_u32
+    tgt = None
+    for i in range(start, end + 1):
+        m = re.match(r"\s+s_cbranch_scc0\s+(\.LBB\S+)", k[i])
+        if m and labels.get(m.group(1), 0) > end:
+            tgt = labels[m.group(1)]
+            break
+    if tgt is not None:
+        d0 = next(i for i in range(tgt, len(k)) if "ds_min_u32" in k[i])
+        dr = ops_of(k[tgt:d0 + 1])
         drows, da, db = price(dr, cost, uniform)
         dn = sum(n for _, (n, _, _) in drows.items())
         print("\n# candidate drain (64 candidates: slot hash, fingerprint, ds_min), once per 8 steps at T = 3")
