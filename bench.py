@@ -944,7 +944,7 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
     # program's own phase clocks, its start-up reported beside them)
     import subprocess
     cli = {}
-    for tag, n_files, gz in (("plain_fasta", 128, False), ("gzip_fasta", 32, True)):
+    for tag, n_files, gz in (("plain_fasta", 512, False), ("gzip_fasta", 64, True)):
         cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_cli.py"), "--genomes", str(n_files), "--len", str(L),
                "--dir", os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "niqki_bench_cli_%d" % os.getpid())]
         if gz:
@@ -956,7 +956,8 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
             j = None
         if j:
             cli[tag] = {"files": n_files, "index_genomes_per_s": j["index_genomes_per_s"], "query_genomes_per_s": j["query_genomes_per_s"],
-                        "index_file_GBps": j["index_fasta_GBps"], "process_startup_s": j["startup_s"]}
+                        "index_file_GBps": j["index_fasta_GBps"], "process_startup_s": j["startup_s"],
+                        "query_phase_split_s": j.get("query_phase_split_s"), "query_host_to_device_copy_GBps": j.get("query_copy_GBps")}
     out["cli_files"] = {"workload": "niqki -I fof -Q fof -J 0.1 on 5 Mbp FASTA files (70 columns) in the page cache, whole-file mode",
                         **cli} if cli else None
     return out

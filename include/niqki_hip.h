@@ -285,6 +285,14 @@ typedef struct niqki_stage_info {
  * header line of each entry (names are the header lines, :395-400). */
 int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *batch, int mem_space,
                     niqki_stage_info *info, uint64_t *entry_hdr);
+/* Starts the host-to-device copy of the NEXT batch's file bytes (file_ptr form, whole mode) on a
+ * copy stream of the handle and returns without waiting: the copy runs beside the kernels of the
+ * batch staged now (the read loops of :461-500 / :523-540 with the transfer of file i+1 under the
+ * work on file i).  The next niqki_stage_raw(NIQKI_MEM_HOST) whose batch names the same file_ptr[]
+ * and file_off[] takes these bytes instead of copying; any other niqki_stage_raw drops them.  The
+ * caller keeps the host bytes valid until that call returns (page-locked memory, or the copy is
+ * not asynchronous). */
+int niqki_stage_raw_prefetch(niqki_index *ix, const niqki_raw_batch *batch);
 /* compute_sketch of every staged entry (n_entry x 2^S int32). */
 int niqki_staged_sketch(niqki_index *ix, int32_t *sketches, int mem_space);
 /* ... + insert_sketch: ids follow the entries (:396-401, :479-490). */

@@ -89,6 +89,7 @@ ABI = [
     ("niqki_hits_from_candidates", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_query_sequences", _int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_stage_raw", _int, [_vp, C.POINTER(RawBatch), _int, C.POINTER(StageInfo), _vp]),
+    ("niqki_stage_raw_prefetch", _int, [_vp, C.POINTER(RawBatch)]),
     ("niqki_staged_sketch", _int, [_vp, _vp, _int]),
     ("niqki_staged_insert", _int, [_vp]),
     ("niqki_staged_query", _int, [_vp, _vp, _vp, _vp, _u64, _int]),
@@ -349,10 +350,13 @@ class Engine:
             self.h, _p(seqs), _p(off), nq, None, nq, _p(ho), _p(hc), _p(hg), c, MEM_HOST), nq, cap)
 
     # -- raw file bytes, framed on the GPU (niqki_stage_raw and friends)
-    def stage_raw(self, files, types=None, lines=False, final=True, max_entries=16384, scattered=False):
+    def stage_raw(self, files, types=None, lines=False, final=True, max_entries=16384, scattered=False, prefetch=None):
         """files: list of bytes-like (the gunzipped content of each file).  Returns
         (StageInfo, entry_hdr) -- entry_hdr: raw offset of each entry's header line (lines mode).
-        scattered: hand the files over as separate buffers (file_ptr) instead of one."""
+        scattered: hand the files over as separate buffers (file_ptr) instead of one.
+        prefetch (with scattered): "this" = niqki_stage_raw_prefetch of this very batch first,
+        "only" = just the prefetch, nothing staged (the buffers stay alive on the object), "take" =
+        stage the batch of the last "only" call from those very buffers."""
         blobs = [np.frombuffer(bytes(f), dtype=np.uint8) for f in files]
         off = np.zeros(len(blobs) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([b.size for b in blobs], dtype=np.uint64)
@@ -361,13 +365,20 @@ class Engine:
         if ty.size == 0:
             ty = np.zeros(1, np.uint8)
         ptrs = None
-        if scattered:
+        if prefetch == "take":      # the buffers an earlier prefetch="only" call handed over
+            keep, ptrs, off, ty = self._pre_keep
+        elif scattered:
             keep = [np.ascontiguousarray(x).copy() for x in blobs]
             ptrs = (C.c_void_p * max(len(keep), 1))(*[k.ctypes.data for k in keep])
         b = RawBatch(None if scattered or not raw.size else _p(raw), C.cast(ptrs, C.c_void_p) if scattered else None,
                      _p(off), _p(ty), len(blobs), int(bool(lines)), int(bool(final)), max_entries)
         info = StageInfo()
         hdr = np.zeros(max(max_entries, 1), dtype=np.uint64)
+        if prefetch in ("this", "only"):
+            self._ck(self.L.niqki_stage_raw_prefetch(self.h, C.byref(b)))
+            if prefetch == "only":
+                self._pre_keep = (keep, ptrs, off, ty)
+                return None, None
         self._ck(self.L.niqki_stage_raw(self.h, C.byref(b), MEM_HOST, C.byref(info), _p(hdr) if lines else None))
         self._staged = info
         return info, hdr[:info.n_entry] if lines else None

@@ -705,7 +705,7 @@ void niqki_destroy(niqki_index *ix) {
   (void)hipStreamSynchronize(ix->stream);
   for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
                  &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash,
-                 &ix->ws_raw, &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
+                 &ix->ws_raw, &ix->ws_raw2, &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
                  &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order, &ix->ws_pre})
     if (b->p) (void)hipFree(b->p);
   for (Buf *b : {&ix->pg_store, &ix->pg_stage})
@@ -722,6 +722,8 @@ void niqki_destroy(niqki_index *ix) {
   for (auto &s : ix->spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
   for (auto e : ix->ev_pool) (void)hipEventDestroy(e);
   if (ix->aux_stream) { (void)hipStreamSynchronize(ix->aux_stream); (void)hipStreamDestroy(ix->aux_stream); }
+  if (ix->copy_stream) { (void)hipStreamSynchronize(ix->copy_stream); (void)hipStreamDestroy(ix->copy_stream); }
+  if (ix->ev_copy) (void)hipEventDestroy(ix->ev_copy);
   if (ix->ev_fork) (void)hipEventDestroy(ix->ev_fork);
   if (ix->ev_join) (void)hipEventDestroy(ix->ev_join);
   if (ix->own_stream) (void)hipStreamDestroy(ix->stream);
@@ -1187,6 +1189,34 @@ int niqki_get_sketches(niqki_index *ix, uint32_t begin, uint32_t n, int32_t *ske
   return NIQKI_OK;
 }
 
+int niqki_stage_raw_prefetch(niqki_index *ix, const niqki_raw_batch *b) {
+  if (!ix || !b) return NIQKI_E_INVALID;
+  if (!b->file_ptr || !b->file_off) return fail(ix, NIQKI_E_INVALID, "a prefetch takes the file_ptr form of a host batch");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  if (!ix->copy_stream) {
+    NQ_HIP(ix, hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
+    NQ_HIP(ix, hipEventCreateWithFlags(&ix->ev_copy, hipEventDisableTiming));
+  }
+  if (ix->pre.valid) NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream));  // an unused one: its host bytes may go away now
+  ix->pre.valid = false;
+  const uint32_t nf = b->n_files;
+  if (nf == 0) return NIQKI_OK;
+  for (uint32_t f = 0; f < nf; ++f)
+    if (b->file_off[f + 1] < b->file_off[f]) return fail(ix, NIQKI_E_INVALID, "file_off must be non-decreasing");
+  const uint64_t T = b->file_off[nf];
+  int rc = ensure(ix, ix->ws_raw2, (size_t)T + 2 * NIQKI_SEQ_PAD);
+  if (rc) return rc;
+  for (uint32_t f = 0; f < nf; ++f) {
+    const uint64_t n = b->file_off[f + 1] - b->file_off[f];
+    if (n) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_raw2.p + b->file_off[f], b->file_ptr[f], n, hipMemcpyHostToDevice, ix->copy_stream));
+  }
+  NQ_HIP(ix, hipEventRecord(ix->ev_copy, ix->copy_stream));
+  ix->pre.ptr.assign(b->file_ptr, b->file_ptr + nf);
+  ix->pre.off.assign(b->file_off, b->file_off + nf + 1);
+  ix->pre.valid = true;
+  return NIQKI_OK;
+}
+
 int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_stage_info *info,
                     uint64_t *entry_hdr) {
   if (!ix || !b || !info) return NIQKI_E_INVALID;
@@ -1220,7 +1250,22 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   h_first[nf] = (uint32_t)chunks;
   int rc;
   const uint8_t *d_raw = b->raw;
-  if (mem == NIQKI_MEM_HOST) {
+  bool prefetched = false;
+  if (ix->pre.valid) {  // bytes a niqki_stage_raw_prefetch put on their way: this batch's, or dropped
+    prefetched = mem == NIQKI_MEM_HOST && b->file_ptr && nf == ix->pre.ptr.size() &&
+                 std::equal(ix->pre.ptr.begin(), ix->pre.ptr.end(), b->file_ptr) &&
+                 std::equal(ix->pre.off.begin(), ix->pre.off.end(), b->file_off);
+    ix->pre.valid = false;
+    if (prefetched) {
+      std::swap(ix->ws_raw, ix->ws_raw2);
+      NQ_HIP(ix, hipStreamWaitEvent(ix->stream, ix->ev_copy, 0));
+      d_raw = (const uint8_t *)ix->ws_raw.p;
+    } else {
+      NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream));
+    }
+  }
+  if (prefetched) {
+  } else if (mem == NIQKI_MEM_HOST) {
     if ((rc = ensure(ix, ix->ws_raw, (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
     if (b->file_ptr) {
       for (uint32_t f = 0; f < nf; ++f) {

@@ -101,6 +101,15 @@ struct niqki_index {
     uint64_t seq_bytes = 0;
     const uint32_t *entry_rec = nullptr;  // device, n_entry+1
   } staged;
+  // niqki_stage_raw_prefetch: the next batch's file bytes on their way into ws_raw2 on copy_stream
+  nqi::Buf ws_raw2;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_copy = nullptr;
+  struct {
+    bool valid = false;
+    std::vector<const uint8_t *> ptr;
+    std::vector<uint64_t> off;
+  } pre;
 
   bool prof = false;
   double prof_ms[NIQKI_KC_COUNT] = {0};

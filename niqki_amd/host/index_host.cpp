@@ -365,53 +365,54 @@ static void rank_share(size_t n, size_t per, size_t r, size_t &lo, size_t &hi) {
   hi = std::min(n, lo + per);
 }
 
-void Index::stage_batch(Batch &b) {
-  if (grp_) {
-    const size_t n = b.files.size(), per = per_rank(n);
-    for (size_t r = 0; r < sh_.size(); ++r) {
-      size_t lo, hi;
-      rank_share(n, per, r, lo, hi);
-      if (lo == hi) continue;
-      std::vector<const uint8_t *> ptr(hi - lo);
-      std::vector<uint64_t> off(hi - lo + 1, 0);
-      std::vector<uint8_t> type(hi - lo);
-      for (size_t i = lo; i < hi; ++i) {
-        ptr[i - lo] = b.files[i]->buf.p;
-        off[i - lo + 1] = off[i - lo] + b.files[i]->buf.size;
-        type[i - lo] = (uint8_t)data_type(b.names[i]);
-      }
-      niqki_raw_batch rb{};
-      rb.file_ptr = ptr.data();
-      rb.file_off = off.data();
-      rb.file_type = type.data();
-      rb.n_files = (uint32_t)(hi - lo);
-      niqki_stage_info info{};
-      const int rc = niqki_stage_raw(sh_[r], &rb, NIQKI_MEM_HOST, &info, nullptr);
-      if (rc) throw std::runtime_error(std::string("niqki_stage_raw: ") + niqki_status_string(rc) + " (" + niqki_last_error(sh_[r]) + ")");
+// prefetch: only start the batch's host-to-device copy (niqki_stage_raw_prefetch); the stage_batch call
+// that follows for the same batch takes those bytes
+void Index::stage_batch(Batch &b, bool prefetch) {
+  auto stage = [&](niqki_index *h, size_t lo, size_t hi) {
+    std::vector<const uint8_t *> ptr(hi - lo);
+    std::vector<uint64_t> off(hi - lo + 1, 0);
+    std::vector<uint8_t> type(hi - lo);
+    for (size_t i = lo; i < hi; ++i) {
+      ptr[i - lo] = b.files[i]->buf.p;
+      off[i - lo + 1] = off[i - lo] + b.files[i]->buf.size;
+      type[i - lo] = (uint8_t)data_type(b.names[i]);
     }
+    niqki_raw_batch rb{};
+    rb.file_ptr = ptr.data();
+    rb.file_off = off.data();
+    rb.file_type = type.data();
+    rb.n_files = (uint32_t)(hi - lo);
+    niqki_stage_info info{};
+    const int rc = prefetch ? niqki_stage_raw_prefetch(h, &rb) : niqki_stage_raw(h, &rb, NIQKI_MEM_HOST, &info, nullptr);
+    if (rc) throw std::runtime_error(std::string("niqki_stage_raw: ") + niqki_status_string(rc) + " (" + niqki_last_error(h) + ")");
+  };
+  if (!grp_) {
+    stage(h_, 0, b.files.size());
     return;
   }
-  const size_t n = b.files.size();
-  std::vector<const uint8_t *> ptr(n);
-  std::vector<uint64_t> off(n + 1, 0);
-  std::vector<uint8_t> type(n);
-  for (size_t i = 0; i < n; ++i) {
-    ptr[i] = b.files[i]->buf.p;
-    off[i + 1] = off[i] + b.files[i]->buf.size;
-    type[i] = (uint8_t)data_type(b.names[i]);
+  const size_t n = b.files.size(), per = per_rank(n);
+  for (size_t r = 0; r < sh_.size(); ++r) {
+    size_t lo, hi;
+    rank_share(n, per, r, lo, hi);
+    if (lo < hi) stage(sh_[r], lo, hi);
   }
-  niqki_raw_batch rb{};
-  rb.file_ptr = ptr.data();
-  rb.file_off = off.data();
-  rb.file_type = type.data();
-  rb.n_files = (uint32_t)n;
-  niqki_stage_info info{};
-  check(niqki_stage_raw(h_, &rb, NIQKI_MEM_HOST, &info, nullptr), "niqki_stage_raw");
 }
 
+namespace {
+struct Lap {  // adds the time since construction (or the last lap) to an accumulator
+  using clk = std::chrono::steady_clock;
+  clk::time_point t = clk::now();
+  void to(double &acc) {
+    const auto n = clk::now();
+    acc += std::chrono::duration<double>(n - t).count();
+    t = n;
+  }
+};
+}  // namespace
+
+// the staged batch of b's files: sketched and inserted
 void Index::flush_insert(Batch &b) {
-  if (b.files.empty()) return;
-  stage_batch(b);
+  Lap lap;
   if (grp_) {
     const size_t n = b.files.size(), per = per_rank(n);
     std::vector<uint32_t> n_entry(sh_.size());
@@ -425,6 +426,7 @@ void Index::flush_insert(Batch &b) {
     check(niqki_staged_insert(h_), "niqki_staged_insert");
   }
   for (auto &nm : b.names) filenames.push_back(nm);
+  lap.to(t_dev_);
 }
 
 // hits of the entries staged on the shards, rank after rank = entry order
@@ -488,16 +490,9 @@ void Index::write_hits(const Hits &h) {
   }
 }
 
-void Index::output_staged(const std::vector<std::string> &names) {
-  Hits h;
-  h.names = names;
-  query_staged(names.size(), h);
-  write_hits(h);
-}
-
+// ... sketched, queried and written out
 void Index::flush_query(Batch &b) {
-  if (b.files.empty()) return;
-  stage_batch(b);
+  Lap lap;
   if (grp_) {
     const size_t n = b.files.size(), per = per_rank(n);
     std::vector<uint32_t> n_entry(sh_.size());
@@ -509,44 +504,63 @@ void Index::flush_query(Batch &b) {
     Hits h;
     h.names = b.names;
     group_query_staged((uint32_t)per, n_entry, h);
+    lap.to(t_dev_);
     write_hits(h);
+    lap.to(t_out_);
     return;
   }
-  output_staged(b.names);
+  Hits h;
+  h.names = b.names;
+  query_staged(b.names.size(), h);
+  lap.to(t_dev_);
+  write_hits(h);
+  lap.to(t_out_);
 }
 
+// The files of `paths` in batches: reader threads fill page-locked buffers ahead, the bytes of batch i+1 cross
+// to the device (copy stream) while batch i is sketched, inserted or queried and its output written.
 void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*flush)(Batch &)) {
   using clk = std::chrono::steady_clock;
   const bool timing = std::getenv("NIQKI_HOST_TIMING") != nullptr;  // where the wall time goes, on stderr
   double t_wait = 0, t_gpu = 0;
+  t_stage_ = t_dev_ = t_out_ = 0;
   const auto t_begin = clk::now();
   OrderedFileReader rd(paths, host_threads(), kReaderBufs);
-  Batch b;
-  auto done = [&] {
-    const auto t0 = clk::now();
-    (this->*flush)(b);
-    t_gpu += std::chrono::duration<double>(clk::now() - t0).count();
-    for (auto *f : b.files) rd.release(f);
-    b.files.clear();
-    b.names.clear();
-    b.bytes = 0;
-  };
   size_t i = 0;
-  for (;;) {
+  auto assemble = [&](Batch &b) {
     const auto t0 = clk::now();
-    auto *f = rd.next();
+    while (b.files.size() < kWholeBatchFiles && b.bytes < kWholeBatchBytes) {
+      auto *f = rd.next();
+      if (!f) break;
+      b.files.push_back(f);
+      b.names.push_back(paths[i++]);
+      b.bytes += f->buf.size;
+    }
     t_wait += std::chrono::duration<double>(clk::now() - t0).count();
-    if (!f) break;
-    b.files.push_back(f);
-    b.names.push_back(paths[i++]);
-    b.bytes += f->buf.size;
-    if (b.files.size() >= kWholeBatchFiles || b.bytes >= kWholeBatchBytes) done();
+  };
+  Batch cur, nxt;
+  assemble(cur);
+  if (!cur.files.empty()) stage_batch(cur, true);
+  while (!cur.files.empty()) {
+    auto t0 = clk::now();
+    Lap lap;
+    stage_batch(cur, false);
+    lap.to(t_stage_);
+    t_gpu += std::chrono::duration<double>(clk::now() - t0).count();
+    assemble(nxt);
+    t0 = clk::now();
+    if (!nxt.files.empty()) stage_batch(nxt, true);
+    (this->*flush)(cur);
+    t_gpu += std::chrono::duration<double>(clk::now() - t0).count();
+    for (auto *f : cur.files) rd.release(f);
+    cur = std::move(nxt);
+    nxt = Batch();
   }
-  done();
   if (timing)
     std::cerr << "[niqki timing] " << paths.size() << " files: total "
               << std::chrono::duration<double>(clk::now() - t_begin).count() << " s, waiting for file bytes " << t_wait
-              << " s, GPU calls (copy + frame + sketch + insert/query + output) " << t_gpu << " s" << std::endl;
+              << " s, GPU calls (copy + frame + sketch + insert/query + output) " << t_gpu << " s (copy + frame "
+              << t_stage_ << ", sketch + insert/query " << t_dev_ << ", output " << t_out_ << ")" << std::endl;
 }
 
 void Index::insert_file_of_file_whole(const std::string &filestr) {

@@ -60,7 +60,7 @@ class Index {
 
  private:
   struct Batch;
-  void stage_batch(Batch &b);
+  void stage_batch(Batch &b, bool prefetch);
   void flush_insert(Batch &b);
   void flush_query(Batch &b);
   void for_each_batch(const std::vector<std::string> &paths, void (Index::*flush)(Batch &));
@@ -71,7 +71,6 @@ class Index {
   };
   void query_staged(size_t n, Hits &h);
   void write_hits(const Hits &h);
-  void output_staged(const std::vector<std::string> &names);
   void stream_lines(const std::string &filestr, bool insert);
   void check(int rc, const char *what) const;
   void check_group(int rc, const char *what) const;
@@ -82,6 +81,7 @@ class Index {
   niqki_index *h_ = nullptr;            // shard 0 (the only one with one GPU)
   std::vector<niqki_index *> sh_;       // all shards, rank order
   niqki_group *grp_ = nullptr;          // null with one GPU
+  double t_stage_ = 0, t_dev_ = 0, t_out_ = 0;  // NIQKI_HOST_TIMING: copy + frame / sketch + insert or query / output text
 };
 
 }  // namespace nqhost

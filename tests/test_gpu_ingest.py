@@ -258,3 +258,44 @@ def test_stage_errors(native):
     assert info.n_entry == 0 and info.n_rec == 0
     assert e.staged_sketch().shape == (0, 256)
     e.close()
+
+
+def test_prefetched_batches_equal_plain_staging(native, po):
+    """niqki_stage_raw_prefetch: the bytes of the next batch travel on the copy stream while the staged
+    batch is worked on; taken by the matching niqki_stage_raw, dropped by any other; sketches unchanged."""
+    rng = np.random.default_rng(16)
+    batches = []
+    for b in range(4):
+        n = int(rng.integers(3, 9))
+        batches.append([b">f%d_%d\n" % (b, i) + b"\n".join(
+            s[a:a + 70] for s in [rand_seq(rng, int(rng.integers(2_000, 60_000)))] for a in range(0, len(s), 70)) + b"\n"
+            for i in range(n)])
+    ref = native.Engine(K=31, S=10, W=12, H=4, J=0.05)
+    want = []
+    for files in batches:
+        ref.stage_raw(files, None)
+        want.append(ref.staged_sketch())
+    e = native.Engine(K=31, S=10, W=12, H=4, J=0.05)
+    # the host program's sequence: stage(i) takes prefetch(i), prefetch(i+1) runs beside the work on i
+    info, _ = e.stage_raw(batches[0], None, scattered=True, prefetch="this")
+    assert info.n_entry == len(batches[0])
+    for i in range(4):
+        if i:
+            info, _ = e.stage_raw(batches[i], None, scattered=True, prefetch="take")
+            assert info.n_entry == len(batches[i])
+        if i + 1 < 4:
+            e.stage_raw(batches[i + 1], None, scattered=True, prefetch="only")
+        assert np.array_equal(e.staged_sketch(), want[i]), i
+        e.staged_insert()
+    assert e.n_genomes == sum(len(b) for b in batches)
+    # a prefetch nobody takes: a different batch is staged by copy, the next prefetch replaces an unused one
+    e.stage_raw(batches[2], None, scattered=True, prefetch="only")
+    e.stage_raw(batches[1], None, scattered=True)
+    assert np.array_equal(e.staged_sketch(), want[1])
+    e.stage_raw(batches[0], None, scattered=True, prefetch="only")
+    e.stage_raw(batches[3], None, scattered=True, prefetch="only")
+    e.stage_raw(batches[3], None)                       # contiguous form: not the prefetched pointers
+    assert np.array_equal(e.staged_sketch(), want[3])
+    e.stage_raw([], None, scattered=True, prefetch="this")
+    e.close()
+    ref.close()

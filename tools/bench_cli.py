@@ -69,6 +69,7 @@ def main():
             # the program's own phase clocks: "[niqki timing] N files: total T s, ..." / "... lines mode: N entries in T s"
             phases[tag] = [float(x.split(" s")[0]) for line in r.stderr.splitlines() if line.startswith("[niqki timing]")
                            for x in [line.split("total ")[-1] if "total " in line else line.split(" in ")[-1]]]
+            res.setdefault("timing_lines", {})[tag] = [l for l in r.stderr.splitlines() if l.startswith("[niqki timing]")]
             if r.returncode != 0:
                 print(r.stdout[-2000:], r.stderr[-2000:], file=sys.stderr)
                 raise SystemExit(1)
@@ -86,6 +87,14 @@ def main():
         res["index_genomes_per_s"] = round(args.genomes / t_index, 1)
         res["index_fasta_GBps"] = round(raw_bytes / t_index / 1e9, 3)
         res["query_genomes_per_s"] = round(args.genomes / t_query, 1)
+        # the query phase's own split: "(copy + frame X, sketch + insert/query Y, output Z)"
+        import re
+        m = re.search(r"\(copy \+ frame ([0-9.e+-]+), sketch \+ insert/query ([0-9.e+-]+), output ([0-9.e+-]+)\)",
+                      res["timing_lines"]["index_query"][1])
+        if m:
+            cp, dv, ou = (float(x) for x in m.groups())
+            res["query_phase_split_s"] = {"copy_and_frame": cp, "sketch_and_query": dv, "output": ou}
+            res["query_copy_GBps"] = round(raw_bytes / cp / 1e9, 1) if cp > 0 else None
         if args.reads:
             rng = np.random.default_rng(3)
             src = niqki_amd.synth_genome_host(11, 0, 0, 0, args.len)
