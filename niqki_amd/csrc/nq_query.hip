@@ -48,49 +48,178 @@ struct Item {
 };
 constexpr uint32_t kQueue = 256;  // items per wave-private LDS work queue
 
-// Walks 64 chunks held one per lane (pos, len <= 64): all lanes read consecutive
-// u16 ids of one chunk, UNROLL chunks per round trip, two rounds in flight (the
-// loads of round r+1 are issued before the LDS atomics of round r; unconditional
-// loads, lanes past a chunk's end read what follows it and are masked).
+// Walks chunks handed over 64 at a time, one per lane (pos, len <= 64): all lanes read consecutive u16 ids
+// of one chunk, UNROLL chunks per round trip.  The rounds form one continuous pipeline over all the batches
+// of a tile: while the ids of one round are counted (LDS atomics) the loads of the next are in flight, and
+// the last round of a batch stays in flight while the wave cuts the next buckets into chunks -- a wave never
+// runs dry between batches (unconditional loads; lanes past a chunk's end read what follows it and are masked).
 // PAD (padded index, IndexView::padded): every chunk is a whole 128-byte line whose positions past
 // the bucket's end hold padding ids (a dummy counter word per position), so all 64 lanes count
 // what they read and the lengths are not needed here.
-template <int UNROLL, int MODE, bool PAD = false>
-__device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t pos, uint32_t len,
-                                       uint32_t lane, uint32_t *cnt, uint32_t &sink) {
+// buf: the tile's ids are addressed through a buffer descriptor (`rs`: base gl, the tile's bytes) with the
+// chunk's byte offset in an SGPR -- one v_readlane and one s_lshl per line (with plain pointers the compiler
+// forms every line's 64-bit lane address with a VALU add).  Needs the tile's ids within 4 GB; walk_tile checks.
+template <int UNROLL, int MODE, bool PAD>
+struct LineWalk {
+  static_assert(UNROLL == 8 || UNROLL == 16 || UNROLL == 32, "rounds per batch must be even");
+  const uint16_t *gl;
+  __amdgpu_buffer_rsrc_t rs;
+  bool buf;
+  uint32_t a, lane;
+  uint32_t *cnt;
   uint32_t ga[UNROLL], gb[UNROLL];
-  auto fetch = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
+  uint32_t carry_len = 0;   // lengths of the batch whose last round is in flight in ga
+  bool have = false;        // wave-uniform: ga holds a round in flight
+
+  __device__ __forceinline__ void fetch(uint32_t (&g)[UNROLL], uint32_t pos, uint32_t j0) {
+    if (buf) {
+      // eight offsets, then eight loads: an SGPR written by the scalar unit needs a few wait states before a
+      // buffer load may take it as its offset, and the other seven fill them
+      constexpr int GRP = 8;
+#pragma unroll
+      for (int u0 = 0; u0 < UNROLL; u0 += GRP) {
+        uint32_t off[GRP];
+#pragma unroll
+        for (int k = 0; k < GRP; ++k) off[k] = __builtin_amdgcn_readlane(pos, j0 + u0 + k) << (a + 1);
+#pragma unroll
+        for (int k = 0; k < GRP; ++k) {
+          asm volatile("" : "+s"(off[k]));   // keep the order: all offsets of the group first
+          g[u0 + k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2u, off[k], 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const uint32_t b = __builtin_amdgcn_readlane(pos, j0 + u);
       g[u] = (gl + ((uint64_t)b << a))[lane];
     }
-  };
-  auto apply = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
+  }
+  __device__ __forceinline__ void apply(uint32_t (&g)[UNROLL], uint32_t len, uint32_t j0, uint32_t &sink) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       if (PAD && (MODE == 0 || MODE == 7)) {
-        // word g >> 1, increment 1 << 16 * (g & 1) (the shifter takes the low 5 bits of g << 4).  The
-        // counters start at LDS address 0 (gather_kernel checks), so the word's byte offset IS its LDS
-        // address: 4 VALU per line for address and increment instead of 6.
-        lds_u32 *w = (lds_u32 *)(uintptr_t)((g[u] << 1) & 0x3FFFCu);
-        __hip_atomic_fetch_add(w, 1u << ((g[u] << 4) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // word g >> 1, increment 1 << 16 * (g & 1).  The counters start at LDS address 0 (gather_kernel
+        // checks), so the word's byte offset IS its LDS address.  Written with the opcodes that issue in
+        // 2.4 cycles on gfx950 (and, add) where there is a choice, one full-rate mad for the increment
+        // (profiles/r03_opcode_costs.txt): 11.5 cycles per line instead of 17.2 for shift, and, shift, shift.
+        uint32_t even, addr, odd, inc;
+        asm("v_and_b32 %0, 0xfffe, %1" : "=v"(even) : "v"(g[u]));
+        asm("v_add_u32 %0, %1, %1" : "=v"(addr) : "v"(even));
+        asm("v_and_b32 %0, 1, %1" : "=v"(odd) : "v"(g[u]));
+        asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc) : "v"(odd), "s"(0xFFFFu));
+        __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         continue;
       }
       const uint32_t l = __builtin_amdgcn_readlane(len, j0 + u);
       if (MODE == 1) { if (lane < l) sink ^= g[u]; }
       else bump_if(cnt, g[u], lane < l, lane);
     }
-  };
-  fetch(0, ga);
-#pragma unroll
-  for (uint32_t j0 = 0; j0 < 64; j0 += 2 * UNROLL) {
-    fetch(j0 + UNROLL, gb);
-    apply(j0, ga);
-    if (j0 + 2 * UNROLL < 64) fetch(j0 + 2 * UNROLL, ga);
-    apply(j0 + UNROLL, gb);
   }
-}
+  // 64 chunks, one per lane
+  __device__ __forceinline__ void batch(uint32_t pos, uint32_t len, uint32_t &sink) {
+    constexpr int R = 64 / UNROLL;
+#pragma unroll
+    for (int r = 0; r < R; r += 2) {
+      fetch(gb, pos, r * UNROLL);
+      if (r) apply(ga, len, (r - 1) * UNROLL, sink);
+      else if (have) apply(ga, carry_len, 64 - UNROLL, sink);
+      fetch(ga, pos, (r + 1) * UNROLL);
+      apply(gb, len, r * UNROLL, sink);
+    }
+    carry_len = len;
+    have = true;
+  }
+  __device__ __forceinline__ void finish(uint32_t &sink) {
+    if (have) apply(ga, carry_len, 64 - UNROLL, sink);
+    have = false;
+  }
+};
+
+// The padded walk's form (PAD, 64-id lines): ONE load instruction fetches TWO lines -- lanes 0..31 read
+// the 32 dwords of one chunk's line, lanes 32..63 those of the next chunk's -- and every lane counts the two
+// ids of its dword.  The CU's texture-address unit takes a wave-wide load every ~7.7 cycles whatever its
+// width (tools/ubench_lines.hip: 271 loads per microsecond and CU from L2, ushort or dword), so at one
+// line per instruction the walk was bound by load issue (31 SIMD cycles per line) before HBM; the lanes
+// take their chunk's position straight from the wave's LDS queue (one ds_read_b32 per load, its queue
+// slot in the instruction's offset field) instead of a v_readlane + s_lshl per line.  Per line now:
+// 0.5 load, 0.5 LDS read, ~5 vector ALU ops, 1 LDS atomic per lane and id (2 per load).
+// CARRY: the last round of a batch stays in flight while the wave cuts the next buckets into chunks.
+template <int UNROLL, bool CARRY>
+struct PairWalk {
+  static_assert(UNROLL == 16 || UNROLL == 32, "a round is UNROLL lines = UNROLL / 2 loads; two or four rounds per batch");
+  static constexpr int L = UNROLL / 2;   // loads per round
+  const uint8_t *lane_base;              // tile's ids + this lane's dword within a line
+  uint32_t half;                         // lane >> 5: which chunk of a pair this lane reads
+  uint32_t ga[L], gb[L];
+  bool have = false;                     // wave-uniform: ga holds a round in flight (CARRY)
+
+  __device__ __forceinline__ void init(const uint16_t *gl, uint32_t lane) {
+    lane_base = (const uint8_t *)gl + (lane & 31u) * 4u;
+    half = lane >> 5;
+  }
+  // loads of the chunks [j0, j0 + UNROLL) of the batch whose items start at `items` (LDS, this wave's queue)
+  __device__ __forceinline__ void fetch(uint32_t (&g)[L], const Item *items, uint32_t j0) {
+    const Item *mine = items + half;
+    uint32_t pos[L];   // line index within the tile (align_log2 = 6); all LDS reads first, one wait for them
+#pragma unroll
+    for (int k = 0; k < L; ++k) pos[k] = mine[j0 + 2 * k].pos;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      uint64_t addr;   // lane_base + 128 * pos in one vector op
+      asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(addr) : "v"(pos[k]), "s"(128u), "v"((uint64_t)lane_base) : "vcc");
+      g[k] = *(const __attribute__((address_space(1))) uint32_t *)addr;   // (global_load, not flat)
+    }
+  }
+  __device__ __forceinline__ void apply(uint32_t (&g)[L]) {
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      // per id: word g >> 1, increment 1 << 16 * (g & 1); the counters start at LDS address 0, so the word's
+      // byte offset IS its LDS address.  and / add issue in 2.8 cycles on gfx950, the mad in 4.4
+      // (profiles/r03_opcode_costs.txt).
+      uint32_t even, addr, odd, inc, hi;
+      asm("v_and_b32 %0, 0xfffe, %1" : "=v"(even) : "v"(g[k]));
+      asm("v_add_u32 %0, %1, %1" : "=v"(addr) : "v"(even));
+      asm("v_and_b32 %0, 1, %1" : "=v"(odd) : "v"(g[k]));
+      asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc) : "v"(odd), "s"(0xFFFFu));
+      __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm("v_lshrrev_b32 %0, 16, %1" : "=v"(hi) : "v"(g[k]));
+      asm("v_and_b32 %0, 0xfffe, %1" : "=v"(even) : "v"(hi));
+      asm("v_add_u32 %0, %1, %1" : "=v"(addr) : "v"(even));
+      asm("v_and_b32 %0, 1, %1" : "=v"(odd) : "v"(hi));
+      asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc) : "v"(odd), "s"(0xFFFFu));
+      __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  // 64 chunks: items[0 .. 64) of the wave's queue
+  __device__ __forceinline__ void batch(const Item *items) {
+    constexpr int R = 64 / UNROLL;
+    if (!CARRY) fetch(ga, items, 0);
+#pragma unroll
+    for (int r = 0; r < R; r += 2) {
+      if (CARRY) {
+        fetch(gb, items, r * UNROLL);
+        if (r || have) apply(ga);
+        fetch(ga, items, (r + 1) * UNROLL);
+        apply(gb);
+      } else {
+        fetch(gb, items, (r + 1) * UNROLL);
+        apply(ga);
+        if (r + 2 < R) fetch(ga, items, (r + 2) * UNROLL);
+        apply(gb);
+      }
+    }
+    if (CARRY) have = true;
+  }
+  __device__ __forceinline__ void finish() {
+    if (CARRY && have) apply(ga);
+    have = false;
+  }
+};
+#ifndef NQ_PAIR_CARRY
+#define NQ_PAIR_CARRY 0
+#endif
 
 // One pass of a workgroup over all slots of one tile.
 //   STASH_OUT: the lookup fetched the entries of NT tiles at once; tile 0 is
@@ -110,7 +239,8 @@ __device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t 
 template <int BLOCK, int UNROLL, int NT, bool STASH_OUT, bool STASH_IN, int MODE, bool PRE = false, bool PAD = false>
 __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk, uint32_t q, uint32_t t,
                                           uint32_t *cnt, Item *queue, Entry *stash, uint32_t &sink,
-                                          uint32_t it_lo, uint32_t n_it, const uint32_t *pre = nullptr) {
+                                          uint32_t it_lo, uint32_t n_it, const uint32_t *pre = nullptr,
+                                          Entry *ahead = nullptr) {
   // slots [64 * it_lo, min(64 * n_it, f_local)): one pass of the kernel
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   constexpr uint32_t NW = BLOCK / 64;
@@ -122,6 +252,15 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
   const uint32_t *my_units = v.slot_units + (uint64_t)t * (v.f_local + 1);
   Item *wq = queue + wave * kQueue;
   uint32_t q_head = 0, q_count = 0;  // wave-uniform
+  // the tile's ids (+ the line a walk may read past them) as a buffer, when 32-bit byte offsets reach all of it
+  const uint64_t tile_bytes = (v.tile_base[t + 1] - v.tile_base[t]) * 2 + 256;
+  const bool buf = tile_bytes < (1ull << 32);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)gl, 0, buf ? (int)(uint32_t)tile_bytes : 0, 0x00020000);
+  constexpr bool PAIR = PAD && MODE == 0 && (UNROLL == 16 || UNROLL == 32);
+  LineWalk<UNROLL, MODE, PAD> lw;
+  lw.gl = gl; lw.rs = rs; lw.buf = buf; lw.a = a; lw.lane = lane; lw.cnt = cnt;
+  PairWalk<PAIR ? UNROLL : 32, NQ_PAIR_CARRY != 0> pw;
+  pw.init(gl, lane);
 
   struct Look { Entry e[NE]; };
   auto slot_ok = [&](uint32_t it) -> bool { return it < n_it && it * 64 + lane < v.f_local; };
@@ -154,10 +293,19 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
   };
   auto drain = [&]() {
     while (q_count >= 64) {
+      if constexpr (PAIR) {
+        pw.batch(wq + q_head);             // (q_head is a multiple of 64: a batch never wraps; a wave's LDS traffic is in order)
+        q_head = (q_head + 64) & (kQueue - 1);
+        q_count -= 64;
+        continue;
+      }
       const Item x = wq[(q_head + lane) & (kQueue - 1)];
       q_head = (q_head + 64) & (kQueue - 1);
       q_count -= 64;
-      walk64<UNROLL, MODE, PAD>(gl, a, x.pos, x.len, lane, cnt, sink);
+      lw.batch(x.pos, x.len, sink);
+#ifdef NQ_GATHER_CLOCK
+      ++sink;   // batches of 64 lines this wave walked
+#endif
     }
   };
 
@@ -167,9 +315,28 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
   int32_t fp0 = load_fp(it);
   int32_t fp1 = load_fp(it + NW);
   int32_t fp2 = load_fp(it + 2 * NW);
-  Look cur = lookup(it, fp0);
+  Look cur, nxt;
+  if (PRE && ahead) {
+    // `ahead`: this wave's first two look-ups of the tile, issued during the walk of the tile before
+    // (a slot shard has only a few iterations per tile: nothing else hides their latency); the ones of
+    // the next tile are put on their way now
+    cur.e[0] = ahead[0];
+    nxt.e[0] = ahead[1];
+    if (t + 1 < v.n_tiles) {
+      const uint32_t *np = my_pre + v.f_local, *nu = my_units + (v.f_local + 1);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        uint32_t s = (it + k * NW) * 64 + lane;
+        if (s >= v.f_local) s = v.f_local - 1;
+        const uint32_t w = np[s];
+        ahead[k] = Entry{nu[s] + (w >> 16), w & 0xFFFFu};
+      }
+    }
+  } else {
+    cur = lookup(it, fp0);
+    nxt = lookup(it + NW, fp1);
+  }
   bool cur_ok = valid_of(it, fp0);
-  Look nxt = lookup(it + NW, fp1);
   bool nxt_ok = valid_of(it + NW, fp1);
 
   for (; it < n_it; it += NW) {
@@ -217,10 +384,16 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
     nxt_ok = nxt2_ok;
   }
   if (q_count) {  // the last partial batch; "no chunk" = the tile's spare line of padding ids
-    Item x = wq[(q_head + lane) & (kQueue - 1)];
-    if (lane >= q_count) x = Item{PAD ? my_units[v.f_local] : 0u, 0u};
-    walk64<UNROLL, MODE, PAD>(gl, a, x.pos, x.len, lane, cnt, sink);
+    if constexpr (PAIR) {
+      if (lane >= q_count) wq[q_head + lane] = Item{my_units[v.f_local], 0u};
+      pw.batch(wq + q_head);
+    } else {
+      Item x = wq[(q_head + lane) & (kQueue - 1)];
+      if (lane >= q_count) x = Item{PAD ? my_units[v.f_local] : 0u, 0u};
+      lw.batch(x.pos, x.len, sink);
+    }
   }
+  if constexpr (PAIR) pw.finish(); else lw.finish(sink);
 }
 
 // ---- slot-major look-up pre-pass ---------------------------------------------------------
@@ -556,8 +729,20 @@ __global__ __launch_bounds__(1024) void order_kernel(const uint32_t *keys, uint3
   for (uint32_t i = tid; i < nq; i += 1024) order[i] = a[i] & 0xFFFu;
 }
 
+#ifdef NQ_GATHER_CLOCK   // measurement builds only (tools/gather_clock.py): per-workgroup phase times
+__device__ unsigned long long *g_gclk;
+extern "C" int nq_debug_gather_clock(unsigned long long *buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gclk), &buf, sizeof(buf)); }
+#define NQ_GCLK(k) do { if (threadIdx.x == 0 && g_gclk) g_gclk[(uint64_t)blockIdx.x * 64 + (k)] = wall_clock64(); } while (0)
+#define NQ_GCLK_WAVE(k) do { if ((threadIdx.x & 63u) == 0 && g_gclk) g_gclk[(uint64_t)blockIdx.x * 64 + (k) + (threadIdx.x >> 6)] = wall_clock64(); } while (0)
+#else
+#define NQ_GCLK(k)
+#define NQ_GCLK_WAVE(k)
+#endif
+
 // One workgroup per query; the genome tiles are walked one after another with
 // the tile's hit counters (packed u16 pairs) in LDS.
+// Its barriers order LDS traffic only (lds_barrier): threads never read each other's global writes here,
+// and the look-ups already on their way for the next tile must not be waited for.
 // NT = -1: every tile's entries come from the look-up pre-pass (`stash` then holds its packed words)
 template <int BLOCK, int UNROLL, int NT, int MODE = 0, bool PAD = false>
 __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_t *sketches,
@@ -575,6 +760,15 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     q = order[i];
   }
   const uint32_t tid = threadIdx.x;
+  NQ_GCLK(0);
+#ifdef NQ_GATHER_CLOCK
+  if (tid == 0 && g_gclk) {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_gclk[(uint64_t)blockIdx.x * 64 + 15] = ((uint64_t)xcc << 32) | hw;
+  }
+#endif
   // (PAD: the padded walk addresses the counters from LDS address 0 -- launch_gather checks that this
   // instantiation has no static LDS in front of its dynamic block and otherwise launches the form without PAD)
   const int32_t *sk = NT < 0 ? nullptr : sketches + (uint64_t)q * v.q_stride + v.q_off;
@@ -583,14 +777,24 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
   const bool want_cand = co.cand != nullptr;
   const bool want_surv = co.surv != nullptr;
   const uint32_t emit_thr = want_surv ? co.surv_thr : co.thr;   // surv_thr <= thr
+  // List lengths of this query: only this workgroup appends to them during the launch, so they are counted
+  // in LDS (same-address global atomics serialise in L2: ~45 entries per tile cost 5 us) and written back once.
+  // The two words are wave 0's queue head, idle between two walks (the LDS is full: kPadMaxTile): thread 0
+  // parks the running totals there before the barrier that ends a walk and takes them back after the scan.
+  uint32_t *lds_n = (uint32_t *)queue;
+  uint32_t n_surv = 0, n_cand = 0;
+  if (want_cand && tid == 0) {
+    n_cand = (uint32_t)co.n[q];
+    if (want_surv) n_surv = (uint32_t)co.surv_n[q];
+  }
   auto emit = [&](uint32_t c, uint32_t col) {   // col: column of the row = genome id - g_base
-    if (c >= emit_thr) {   // rare: a global atomic per entry (the LDS is full: kPadMaxTile)
+    if (c >= emit_thr) {
       if (want_surv) {
-        const uint32_t i = atomicAdd((uint32_t *)&co.surv_n[q], 1u);
+        const uint32_t i = atomicAdd(&lds_n[0], 1u);
         if (i < co.surv_cap) co.surv[(uint64_t)q * co.surv_cap + i] = make_int2((int)(v.g_base + col), (int)c);
       }
       if (c >= co.thr) {
-        const uint32_t i = atomicAdd((uint32_t *)&co.n[q], 1u);
+        const uint32_t i = atomicAdd(&lds_n[1], 1u);
         if (i < co.cap) co.cand[(uint64_t)q * co.cap + i] = (int32_t)(v.g_base + col);
       }
     }
@@ -599,14 +803,32 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
   for (uint32_t it_lo = 0; it_lo < n_it_all; it_lo += it_pass) {   // one pass unless f_local > 2^15 (S = 16)
   const uint32_t n_it = it_lo + it_pass < n_it_all ? it_lo + it_pass : n_it_all;
   uint16_t *plane = it_lo ? counts2 : counts;
+  Entry ahead[2];
+  if constexpr (NT < 0) {   // the first tile's first look-ups (walk_tile keeps `ahead` one tile ahead from here on)
+    const uint32_t *p0 = (const uint32_t *)stash + (uint64_t)q * v.n_tiles * v.f_local;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      uint32_t s = (it_lo + (tid >> 6) + k * (BLOCK / 64)) * 64 + (tid & 63u);
+      if (s >= v.f_local) s = v.f_local - 1;
+      const uint32_t w = p0[s];
+      ahead[k] = Entry{v.slot_units[s] + (w >> 16), w & 0xFFFFu};
+    }
+  }
+  bool zeroed = false;   // the scan of the tile before left this tile's counters at zero
   for (uint32_t t = 0; t < v.n_tiles; ++t) {
     const uint32_t n_t = tile_count(v, t);
     const uint32_t n_words = (n_t + 1) / 2;
-    for (uint32_t i = tid; i < n_words; i += BLOCK) cnt[i] = 0;
-    __syncthreads();
+    if (!zeroed) {
+      uint4 *c4 = (uint4 *)cnt;   // (the dynamic LDS block is 16-byte aligned)
+      for (uint32_t i = tid; i < n_words / 4; i += BLOCK) c4[i] = make_uint4(0, 0, 0, 0);
+      for (uint32_t i = (n_words & ~3u) + tid; i < n_words; i += BLOCK) cnt[i] = 0;
+      lds_barrier();
+    }
+    zeroed = false;
+    NQ_GCLK(1 + 4 * (t & 1));
     if constexpr (MODE == 8) {
     } else if constexpr (NT < 0) {
-      walk_tile<BLOCK, UNROLL, 1, false, false, MODE, true, PAD>(v, sk, q, t, cnt, queue, nullptr, sink, it_lo, n_it, (const uint32_t *)stash);
+      walk_tile<BLOCK, UNROLL, 1, false, false, MODE, true, PAD>(v, sk, q, t, cnt, queue, nullptr, sink, it_lo, n_it, (const uint32_t *)stash, ahead);
     } else if constexpr (NT >= 2) {
       if (t == 0) walk_tile<BLOCK, UNROLL, NT, true, false, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink, it_lo, n_it);
       else walk_tile<BLOCK, UNROLL, NT, false, true, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink, it_lo, n_it);
@@ -614,16 +836,52 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
       walk_tile<BLOCK, UNROLL, 1, false, false, MODE, false, PAD>(v, sk, q, t, cnt, queue, stash, sink, it_lo, n_it);
     }
     if (MODE != 0) cnt[tid % n_words] ^= sink;
-    __syncthreads();
+    if (want_cand && tid == 0) { lds_n[0] = n_surv; lds_n[1] = n_cand; }
+    NQ_GCLK_WAVE(16 + 16 * (t & 1));
+#ifdef NQ_GATHER_CLOCK
+    if ((tid & 63u) == 0 && g_gclk && t == 1) g_gclk[(uint64_t)blockIdx.x * 64 + 48 + (tid >> 6)] = sink;
+#endif
+    NQ_GCLK(2 + 4 * (t & 1));
+    lds_barrier();
+    NQ_GCLK(3 + 4 * (t & 1));
     if (MODE == 7) continue;
     if (plane == nullptr) {
       // no counter row (survivor output only): the tile's counters are scanned where they are
-      for (uint32_t w = tid; w < n_words; w += BLOCK) {
-        const uint32_t c = cnt[w];
+      // ... and left at zero for the next tile (whose counters are no more than this one's)
+      zeroed = t + 1 < v.n_tiles && tile_count(v, t + 1) <= n_t;
+      // 16 bytes per LDS access, four accesses in flight per thread; a quad whose OR-ed halves stay under
+      // the threshold holds no survivor
+      uint4 *c4 = (uint4 *)cnt;
+      const uint32_t n_quads = n_words / 4;
+      auto word = [&](uint32_t c, uint32_t w) {
         if ((c & 0xFFFFu) >= emit_thr) emit(c & 0xFFFFu, tile_gid(v, t, 2 * w));
         if (2 * w + 1 < n_t && (c >> 16) >= emit_thr) emit(c >> 16, tile_gid(v, t, 2 * w + 1));
+      };
+      for (uint32_t k0 = tid; k0 < n_quads; k0 += 4 * BLOCK) {
+        uint4 c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t k = k0 + j * BLOCK;
+          c[j] = k < n_quads ? c4[k] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t k = k0 + j * BLOCK;
+          if (zeroed && k < n_quads) c4[k] = make_uint4(0, 0, 0, 0);
+          const uint32_t o = c[j].x | c[j].y | c[j].z | c[j].w;
+          if ((o & 0xFFFFu) >= emit_thr || (o >> 16) >= emit_thr) {
+            word(c[j].x, 4 * k); word(c[j].y, 4 * k + 1); word(c[j].z, 4 * k + 2); word(c[j].w, 4 * k + 3);
+          }
+        }
       }
-      __syncthreads();
+      for (uint32_t w = 4 * n_quads + tid; w < n_words; w += BLOCK) {
+        const uint32_t c = cnt[w];
+        if (zeroed) cnt[w] = 0;
+        word(c, w);
+      }
+      lds_barrier();
+      if (tid == 0) { n_surv = lds_n[0]; n_cand = lds_n[1]; }
+      NQ_GCLK(4 + 4 * (t & 1));
       continue;
     }
     uint16_t *row = plane + (uint64_t)q * stride + v.g_base;
@@ -686,8 +944,13 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
         if (want_cand) emit(c, g0 + n_t - 1);
       }
     }
-    __syncthreads();
+    lds_barrier();
+    if (want_cand && tid == 0) { n_surv = lds_n[0]; n_cand = lds_n[1]; }
   }
+  }
+  if (want_cand && tid == 0) {
+    co.n[q] = (int32_t)n_cand;
+    if (want_surv) co.surv_n[q] = (int32_t)n_surv;
   }
 }
 
@@ -704,7 +967,7 @@ hipError_t launch_order(const IndexView &v, const int32_t *sketches, uint32_t nq
 
 bool gather_variant_valid(int variant) {
 #ifdef NQ_ABLATION
-  if (variant == 11 || variant == 16 || variant == 17 || variant == 18) return true;
+  if (variant == 11 || variant == 12 || variant == 16 || variant == 17 || variant == 18) return true;
 #endif
   return variant >= 0 && variant <= 5;
 }
@@ -756,6 +1019,7 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     case 5: NQ_BY_TILES(128, 16); break;
 #ifdef NQ_ABLATION  // measurement builds only (make ABLATION=1): these variants return wrong counters
     case 11: NQ_BY_TILES(1024, 16, 1); break;
+    case 12: NQ_BY_TILES(1024, 32, 1, true); break;
     case 16: NQ_BY_TILES(1024, 16, 6); break;
     case 17: NQ_BY_TILES(1024, 16, 7, true); break;
     case 18: NQ_BY_TILES(1024, 16, 8, true); break;
