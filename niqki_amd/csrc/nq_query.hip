@@ -48,93 +48,39 @@ struct Item {
 };
 constexpr uint32_t kQueue = 256;  // items per wave-private LDS work queue
 
-// Walks chunks handed over 64 at a time, one per lane (pos, len <= 64): all lanes read consecutive u16 ids
-// of one chunk, UNROLL chunks per round trip.  The rounds form one continuous pipeline over all the batches
-// of a tile: while the ids of one round are counted (LDS atomics) the loads of the next are in flight, and
-// the last round of a batch stays in flight while the wave cuts the next buckets into chunks -- a wave never
-// runs dry between batches (unconditional loads; lanes past a chunk's end read what follows it and are masked).
-// PAD (padded index, IndexView::padded): every chunk is a whole 128-byte line whose positions past
-// the bucket's end hold padding ids (a dummy counter word per position), so all 64 lanes count
-// what they read and the lengths are not needed here.
-// buf: the tile's ids are addressed through a buffer descriptor (`rs`: base gl, the tile's bytes) with the
-// chunk's byte offset in an SGPR -- one v_readlane and one s_lshl per line (with plain pointers the compiler
-// forms every line's 64-bit lane address with a VALU add).  Needs the tile's ids within 4 GB; walk_tile checks.
-template <int UNROLL, int MODE, bool PAD>
-struct LineWalk {
-  static_assert(UNROLL == 8 || UNROLL == 16 || UNROLL == 32, "rounds per batch must be even");
-  const uint16_t *gl;
-  __amdgpu_buffer_rsrc_t rs;
-  bool buf;
-  uint32_t a, lane;
-  uint32_t *cnt;
+// Walks 64 chunks held one per lane (pos, len <= 64): all lanes read consecutive
+// u16 ids of one chunk, UNROLL chunks per round trip, two rounds in flight (the
+// loads of round r+1 are issued before the LDS atomics of round r; unconditional
+// loads, lanes past a chunk's end read what follows it and are masked).
+// The form of indexes that are not padded (and of the measurement modes); padded ones take PairWalk below.
+template <int UNROLL, int MODE>
+__device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t pos, uint32_t len,
+                                       uint32_t lane, uint32_t *cnt, uint32_t &sink) {
   uint32_t ga[UNROLL], gb[UNROLL];
-  uint32_t carry_len = 0;   // lengths of the batch whose last round is in flight in ga
-  bool have = false;        // wave-uniform: ga holds a round in flight
-
-  __device__ __forceinline__ void fetch(uint32_t (&g)[UNROLL], uint32_t pos, uint32_t j0) {
-    if (buf) {
-      // eight offsets, then eight loads: an SGPR written by the scalar unit needs a few wait states before a
-      // buffer load may take it as its offset, and the other seven fill them
-      constexpr int GRP = 8;
-#pragma unroll
-      for (int u0 = 0; u0 < UNROLL; u0 += GRP) {
-        uint32_t off[GRP];
-#pragma unroll
-        for (int k = 0; k < GRP; ++k) off[k] = __builtin_amdgcn_readlane(pos, j0 + u0 + k) << (a + 1);
-#pragma unroll
-        for (int k = 0; k < GRP; ++k) {
-          asm volatile("" : "+s"(off[k]));   // keep the order: all offsets of the group first
-          g[u0 + k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, lane * 2u, off[k], 0);
-        }
-      }
-      return;
-    }
+  auto fetch = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const uint32_t b = __builtin_amdgcn_readlane(pos, j0 + u);
       g[u] = (gl + ((uint64_t)b << a))[lane];
     }
-  }
-  __device__ __forceinline__ void apply(uint32_t (&g)[UNROLL], uint32_t len, uint32_t j0, uint32_t &sink) {
+  };
+  auto apply = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      if (PAD && (MODE == 0 || MODE == 7)) {
-        // word g >> 1, increment 1 << 16 * (g & 1).  The counters start at LDS address 0 (gather_kernel
-        // checks), so the word's byte offset IS its LDS address.  Written with the opcodes that issue in
-        // 2.4 cycles on gfx950 (and, add) where there is a choice, one full-rate mad for the increment
-        // (profiles/r03_opcode_costs.txt): 11.5 cycles per line instead of 17.2 for shift, and, shift, shift.
-        uint32_t even, addr, odd, inc;
-        asm("v_and_b32 %0, 0xfffe, %1" : "=v"(even) : "v"(g[u]));
-        asm("v_add_u32 %0, %1, %1" : "=v"(addr) : "v"(even));
-        asm("v_and_b32 %0, 1, %1" : "=v"(odd) : "v"(g[u]));
-        asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc) : "v"(odd), "s"(0xFFFFu));
-        __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        continue;
-      }
       const uint32_t l = __builtin_amdgcn_readlane(len, j0 + u);
       if (MODE == 1) { if (lane < l) sink ^= g[u]; }
       else bump_if(cnt, g[u], lane < l, lane);
     }
-  }
-  // 64 chunks, one per lane
-  __device__ __forceinline__ void batch(uint32_t pos, uint32_t len, uint32_t &sink) {
-    constexpr int R = 64 / UNROLL;
+  };
+  fetch(0, ga);
 #pragma unroll
-    for (int r = 0; r < R; r += 2) {
-      fetch(gb, pos, r * UNROLL);
-      if (r) apply(ga, len, (r - 1) * UNROLL, sink);
-      else if (have) apply(ga, carry_len, 64 - UNROLL, sink);
-      fetch(ga, pos, (r + 1) * UNROLL);
-      apply(gb, len, r * UNROLL, sink);
-    }
-    carry_len = len;
-    have = true;
+  for (uint32_t j0 = 0; j0 < 64; j0 += 2 * UNROLL) {
+    fetch(j0 + UNROLL, gb);
+    apply(j0, ga);
+    if (j0 + 2 * UNROLL < 64) fetch(j0 + 2 * UNROLL, ga);
+    apply(j0 + UNROLL, gb);
   }
-  __device__ __forceinline__ void finish(uint32_t &sink) {
-    if (have) apply(ga, carry_len, 64 - UNROLL, sink);
-    have = false;
-  }
-};
+}
 
 // The padded walk's form (PAD, 64-id lines): ONE load instruction fetches TWO lines -- lanes 0..31 read
 // the 32 dwords of one chunk's line, lanes 32..63 those of the next chunk's -- and every lane counts the two
@@ -144,15 +90,13 @@ struct LineWalk {
 // take their chunk's position straight from the wave's LDS queue (one ds_read_b32 per load, its queue
 // slot in the instruction's offset field) instead of a v_readlane + s_lshl per line.  Per line now:
 // 0.5 load, 0.5 LDS read, ~5 vector ALU ops, 1 LDS atomic per lane and id (2 per load).
-// CARRY: the last round of a batch stays in flight while the wave cuts the next buckets into chunks.
-template <int UNROLL, bool CARRY>
+template <int UNROLL>
 struct PairWalk {
   static_assert(UNROLL == 16 || UNROLL == 32, "a round is UNROLL lines = UNROLL / 2 loads; two or four rounds per batch");
   static constexpr int L = UNROLL / 2;   // loads per round
   const uint8_t *lane_base;              // tile's ids + this lane's dword within a line
   uint32_t half;                         // lane >> 5: which chunk of a pair this lane reads
   uint32_t ga[L], gb[L];
-  bool have = false;                     // wave-uniform: ga holds a round in flight (CARRY)
 
   __device__ __forceinline__ void init(const uint16_t *gl, uint32_t lane) {
     lane_base = (const uint8_t *)gl + (lane & 31u) * 4u;
@@ -192,34 +136,20 @@ struct PairWalk {
       __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
-  // 64 chunks: items[0 .. 64) of the wave's queue
+  // 64 chunks: items[0 .. 64) of the wave's queue; all their lines in flight before the first id is counted
+  // (keeping a round in flight across batches, over the cutting of the next buckets, gained nothing: measured)
   __device__ __forceinline__ void batch(const Item *items) {
     constexpr int R = 64 / UNROLL;
-    if (!CARRY) fetch(ga, items, 0);
+    fetch(ga, items, 0);
 #pragma unroll
     for (int r = 0; r < R; r += 2) {
-      if (CARRY) {
-        fetch(gb, items, r * UNROLL);
-        if (r || have) apply(ga);
-        fetch(ga, items, (r + 1) * UNROLL);
-        apply(gb);
-      } else {
-        fetch(gb, items, (r + 1) * UNROLL);
-        apply(ga);
-        if (r + 2 < R) fetch(ga, items, (r + 2) * UNROLL);
-        apply(gb);
-      }
+      fetch(gb, items, (r + 1) * UNROLL);
+      apply(ga);
+      if (r + 2 < R) fetch(ga, items, (r + 2) * UNROLL);
+      apply(gb);
     }
-    if (CARRY) have = true;
-  }
-  __device__ __forceinline__ void finish() {
-    if (CARRY && have) apply(ga);
-    have = false;
   }
 };
-#ifndef NQ_PAIR_CARRY
-#define NQ_PAIR_CARRY 0
-#endif
 
 // One pass of a workgroup over all slots of one tile.
 //   STASH_OUT: the lookup fetched the entries of NT tiles at once; tile 0 is
@@ -252,14 +182,9 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
   const uint32_t *my_units = v.slot_units + (uint64_t)t * (v.f_local + 1);
   Item *wq = queue + wave * kQueue;
   uint32_t q_head = 0, q_count = 0;  // wave-uniform
-  // the tile's ids (+ the line a walk may read past them) as a buffer, when 32-bit byte offsets reach all of it
-  const uint64_t tile_bytes = (v.tile_base[t + 1] - v.tile_base[t]) * 2 + 256;
-  const bool buf = tile_bytes < (1ull << 32);
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)gl, 0, buf ? (int)(uint32_t)tile_bytes : 0, 0x00020000);
   constexpr bool PAIR = PAD && MODE == 0 && (UNROLL == 16 || UNROLL == 32);
-  LineWalk<UNROLL, MODE, PAD> lw;
-  lw.gl = gl; lw.rs = rs; lw.buf = buf; lw.a = a; lw.lane = lane; lw.cnt = cnt;
-  PairWalk<PAIR ? UNROLL : 32, NQ_PAIR_CARRY != 0> pw;
+  uint32_t prio_turn = wave >> 2;   // the four waves of a SIMD take turns at the issue arbiter's top priority (PAIR)
+  PairWalk<PAIR ? UNROLL : 32> pw;
   pw.init(gl, lane);
 
   struct Look { Entry e[NE]; };
@@ -294,6 +219,13 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
   auto drain = [&]() {
     while (q_count >= 64) {
       if constexpr (PAIR) {
+        // the issue arbiter serves the oldest wave of a SIMD first: left alone, the four waves of a SIMD finish
+        // a tile 3 us apart (18 / 20 / 23 / 26 us) and the youngest runs the last stretch alone
+        prio_turn = (prio_turn + 1) & 3;
+        if (prio_turn == 0) __builtin_amdgcn_s_setprio(0);
+        else if (prio_turn == 1) __builtin_amdgcn_s_setprio(1);
+        else if (prio_turn == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
         pw.batch(wq + q_head);             // (q_head is a multiple of 64: a batch never wraps; a wave's LDS traffic is in order)
         q_head = (q_head + 64) & (kQueue - 1);
         q_count -= 64;
@@ -302,7 +234,7 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
       const Item x = wq[(q_head + lane) & (kQueue - 1)];
       q_head = (q_head + 64) & (kQueue - 1);
       q_count -= 64;
-      lw.batch(x.pos, x.len, sink);
+      walk64<UNROLL, MODE>(gl, a, x.pos, x.len, lane, cnt, sink);
 #ifdef NQ_GATHER_CLOCK
       ++sink;   // batches of 64 lines this wave walked
 #endif
@@ -390,10 +322,9 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
     } else {
       Item x = wq[(q_head + lane) & (kQueue - 1)];
       if (lane >= q_count) x = Item{PAD ? my_units[v.f_local] : 0u, 0u};
-      lw.batch(x.pos, x.len, sink);
+      walk64<UNROLL, MODE>(gl, a, x.pos, x.len, lane, cnt, sink);
     }
   }
-  if constexpr (PAIR) pw.finish(); else lw.finish(sink);
 }
 
 // ---- slot-major look-up pre-pass ---------------------------------------------------------
@@ -799,6 +730,39 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
       }
     }
   };
+  uint32_t t_emit = 0;   // the tile being scanned / written out
+  // The eight counters of a quad (words 4k .. 4k+3 of tile t) at once: ONE LDS atomic per list claims the places
+  // of all its entries, then the lane stores them.  (Survivors come in runs -- the genomes of a family sit next
+  // to each other -- and one atomic per entry made a lane with eight of them wait eight LDS round trips.)
+  auto emit_quad = [&](const uint4 &c, uint32_t k, uint32_t n_t) {
+    const uint32_t o = c.x | c.y | c.z | c.w;
+    if ((o & 0xFFFFu) < emit_thr && (o >> 16) < emit_thr) return;   // no half of the quad can reach the threshold
+    const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+    uint32_t ms = 0, mc = 0;   // halves that go to the survivor / candidate list
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t h = (i & 1) ? cw[i >> 1] >> 16 : cw[i >> 1] & 0xFFFFu;
+      const bool in = 8 * k + i < n_t;
+      ms |= (uint32_t)(in && h >= emit_thr) << i;
+      mc |= (uint32_t)(in && h >= co.thr) << i;
+    }
+    uint32_t bs = 0, bc = 0;
+    if (want_surv && ms) bs = atomicAdd(&lds_n[0], (uint32_t)__builtin_popcount(ms));
+    if (mc) bc = atomicAdd(&lds_n[1], (uint32_t)__builtin_popcount(mc));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t h = (i & 1) ? cw[i >> 1] >> 16 : cw[i >> 1] & 0xFFFFu;
+      const uint32_t gid = v.g_base + tile_gid(v, t_emit, 8 * k + i);
+      if (want_surv && (ms >> i & 1u)) {
+        if (bs < co.surv_cap) co.surv[(uint64_t)q * co.surv_cap + bs] = make_int2((int)gid, (int)h);
+        ++bs;
+      }
+      if (mc >> i & 1u) {
+        if (bc < co.cap) co.cand[(uint64_t)q * co.cap + bc] = (int32_t)gid;
+        ++bc;
+      }
+    }
+  };
   const uint32_t n_it_all = (v.f_local + 63) / 64, it_pass = kPassSlots / 64;
   for (uint32_t it_lo = 0; it_lo < n_it_all; it_lo += it_pass) {   // one pass unless f_local > 2^15 (S = 16)
   const uint32_t n_it = it_lo + it_pass < n_it_all ? it_lo + it_pass : n_it_all;
@@ -818,6 +782,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
   for (uint32_t t = 0; t < v.n_tiles; ++t) {
     const uint32_t n_t = tile_count(v, t);
     const uint32_t n_words = (n_t + 1) / 2;
+    t_emit = t;
     if (!zeroed) {
       uint4 *c4 = (uint4 *)cnt;   // (the dynamic LDS block is 16-byte aligned)
       for (uint32_t i = tid; i < n_words / 4; i += BLOCK) c4[i] = make_uint4(0, 0, 0, 0);
@@ -868,10 +833,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
         for (int j = 0; j < 4; ++j) {
           const uint32_t k = k0 + j * BLOCK;
           if (zeroed && k < n_quads) c4[k] = make_uint4(0, 0, 0, 0);
-          const uint32_t o = c[j].x | c[j].y | c[j].z | c[j].w;
-          if ((o & 0xFFFFu) >= emit_thr || (o >> 16) >= emit_thr) {
-            word(c[j].x, 4 * k); word(c[j].y, 4 * k + 1); word(c[j].z, 4 * k + 2); word(c[j].w, 4 * k + 3);
-          }
+          emit_quad(c[j], k, n_t);
         }
       }
       for (uint32_t w = 4 * n_quads + tid; w < n_words; w += BLOCK) {
@@ -895,11 +857,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
         const uint32_t col = tile_gid(v, t, 8 * k);
         const uint4 c = *(const uint4 *)(cnt + 4 * k);
         *(uint4 *)(row + col) = c;
-        if (want_cand) {
-          const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { emit(cw[j] & 0xFFFFu, col + 2 * j); emit(cw[j] >> 16, col + 2 * j + 1); }
-        }
+        if (want_cand) emit_quad(c, k, n_t);
       }
       for (uint32_t w = 4 * quads + tid; w < n_words; w += BLOCK) {
         const uint32_t col = tile_gid(v, t, 2 * w), c = cnt[w];
