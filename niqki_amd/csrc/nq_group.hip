@@ -115,6 +115,7 @@ struct IpcRank {
 };
 struct IpcShared {
   std::atomic<uint32_t> init, bar_count, bar_gen, abort;
+  std::atomic<uint32_t> export_lock;   // one rank at a time allocates and exports its arena
   IpcRank r[kMaxWorld];
 };
 // sequence words of a rank (device memory, mapped by every peer): ready[b] = uses of buffer b whose data
@@ -492,6 +493,8 @@ int ipc_buf_index(Buf niqki_group::Ws::*m) {
   return -1;
 }
 
+int ipc_export_alloc(niqki_group *g, size_t bytes, void **out, hipIpcMemHandle_t *h, uint64_t *off);
+
 int ipc_setup(niqki_group *g, const uint8_t *id) {
   auto &ic = g->ipc;
   niqki_index *ix = g->sh[0];
@@ -527,17 +530,15 @@ int ipc_setup(niqki_group *g, const uint8_t *id) {
     }
   // my sequence words
   NQ_GH(g, hipSetDevice(ix->device));
-  NQ_GH(g, hipMalloc((void **)&ic.flags, kFlagWords * 4));
-  NQ_GH(g, hipMemset(ic.flags, 0, kFlagWords * 4));
-  NQ_GH(g, hipDeviceSynchronize());
   IpcRank &me = ic.shm->r[g->first];
   {
-    void *base = nullptr;
-    size_t sz = 0;
-    NQ_GH(g, hipMemGetAddressRange((hipDeviceptr_t *)&base, &sz, (hipDeviceptr_t)ic.flags));
-    NQ_GH(g, hipIpcGetMemHandle(&me.flags, base));
-    me.flags_off = (uint64_t)((char *)ic.flags - (char *)base);
+    void *fl = nullptr;
+    const int rc = ipc_export_alloc(g, kFlagWords * 4, &fl, &me.flags, &me.flags_off);
+    if (rc) return rc;
+    ic.flags = (uint32_t *)fl;
   }
+  NQ_GH(g, hipMemset(ic.flags, 0, kFlagWords * 4));
+  NQ_GH(g, hipDeviceSynchronize());
   me.device = ix->device;
   int rc = ipc_barrier(g);
   if (rc) return rc;
@@ -568,6 +569,46 @@ void ipc_teardown(niqki_group *g) {
   if (g->first == 0) shm_unlink(ic.name.c_str());   // (no-op once setup has finished)
   munmap(ic.shm, sizeof(IpcShared));
   ic.shm = nullptr;
+}
+
+// Device memory of `bytes` that peers can map: *h names the allocation it lies in, *off its place there
+// (hipMalloc may carve a pointer out of a larger block, whose base is what hipIpcGetMemHandle takes).
+// Exporting a fresh allocation now and then fails with "invalid argument" when two processes of one GPU do it
+// at the same moment (seen once in four runs of two ranks on one MI355X, on the rank that came second): the
+// ranks take turns, and a failed export is tried again on a new allocation.
+int ipc_export_alloc(niqki_group *g, size_t bytes, void **out, hipIpcMemHandle_t *h, uint64_t *off) {
+  auto &ic = g->ipc;
+  const double t0 = now_s();
+  uint32_t unlocked = 0;
+  while (!ic.shm->export_lock.compare_exchange_weak(unlocked, 1u, std::memory_order_acquire)) {
+    unlocked = 0;
+    if (now_s() - t0 > kIpcHostTimeout) return gfail(g, NIQKI_E_STATE, "a peer never released the group's export lock");
+    usleep(50);
+  }
+  void *p = nullptr, *base = nullptr;
+  size_t sz = 0;
+  hipError_t e = hipSuccess;
+  for (int attempt = 0; attempt < 6; ++attempt) {
+    if (p) { (void)hipFree(p); p = nullptr; usleep(2000u << attempt); }
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { p = nullptr; break; }
+    e = hipMemGetAddressRange((hipDeviceptr_t *)&base, &sz, (hipDeviceptr_t)p);
+    if (e != hipSuccess) break;
+    e = hipIpcGetMemHandle(h, base);
+    if (e == hipSuccess) break;
+    (void)hipGetLastError();
+  }
+  ic.shm->export_lock.store(0u, std::memory_order_release);
+  if (e != hipSuccess) {
+    char msg[256];
+    std::snprintf(msg, sizeof msg, "exchange memory for peers (%zu bytes at %p, allocation %p of %zu bytes): %s", bytes, p, base, sz,
+                  hipGetErrorString(e));
+    if (p) (void)hipFree(p);
+    return gfail(g, NIQKI_E_HIP, msg);
+  }
+  *out = p;
+  *off = (uint64_t)((char *)p - (char *)base);
+  return NIQKI_OK;
 }
 
 // The exchange buffers of this batch, sized BEFORE any of them is used: every rank takes the same
@@ -604,13 +645,10 @@ int ipc_prepare(niqki_group *g, const size_t need[kIpcBufs]) {
   }
   if (ic.arena.p) NQ_GH(g, hipFree(ic.arena.p));
   ic.arena = Buf();
-  NQ_GH(g, hipMalloc(&ic.arena.p, std::max<size_t>(total, 256)));
+  void *arena = nullptr;
+  if ((rc = ipc_export_alloc(g, std::max<size_t>(total, 256), &arena, &me.arena, &me.arena_off))) return rc;
+  ic.arena.p = arena;
   ic.arena.n = std::max<size_t>(total, 256);
-  void *base = nullptr;
-  size_t sz = 0;
-  NQ_GH(g, hipMemGetAddressRange((hipDeviceptr_t *)&base, &sz, (hipDeviceptr_t)ic.arena.p));
-  NQ_GH(g, hipIpcGetMemHandle(&me.arena, base));
-  me.arena_off = (uint64_t)((char *)ic.arena.p - (char *)base);
   for (uint32_t b = 0; b < kIpcBufs; ++b) {
     Buf &buf = w.*kIpcBufMember[b];
     buf.p = size[b] ? (char *)ic.arena.p + off[b] : nullptr;

@@ -235,9 +235,6 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
       q_head = (q_head + 64) & (kQueue - 1);
       q_count -= 64;
       walk64<UNROLL, MODE>(gl, a, x.pos, x.len, lane, cnt, sink);
-#ifdef NQ_GATHER_CLOCK
-      ++sink;   // batches of 64 lines this wave walked
-#endif
     }
   };
 
@@ -803,9 +800,6 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     if (MODE != 0) cnt[tid % n_words] ^= sink;
     if (want_cand && tid == 0) { lds_n[0] = n_surv; lds_n[1] = n_cand; }
     NQ_GCLK_WAVE(16 + 16 * (t & 1));
-#ifdef NQ_GATHER_CLOCK
-    if ((tid & 63u) == 0 && g_gclk && t == 1) g_gclk[(uint64_t)blockIdx.x * 64 + 48 + (tid >> 6)] = sink;
-#endif
     NQ_GCLK(2 + 4 * (t & 1));
     lds_barrier();
     NQ_GCLK(3 + 4 * (t & 1));

@@ -42,12 +42,6 @@ for k, base in ((0, 16), (1, 32)):
     print("  walk%d per wave: first done %6.2f us, median %6.2f, last %6.2f (mean over workgroups); wave 0 %6.2f" % (
         k, srt[:, 0].mean(), srt[:, 8].mean(), srt[:, 15].mean(), w[:, 0].mean()))
     print("    by wave index: " + " ".join("%.1f" % x for x in w.mean(axis=0)))
-if last == 8:
-    nb = a[:, 48:64].astype(np.float64)     # batches of 64 lines per wave over both tiles
-    print("  batches of 64 lines per wave (both tiles): mean %.2f, per-workgroup max/mean %.3f, by wave index: %s" % (
-        nb.mean(), (nb.max(axis=1) / nb.mean(axis=1)).mean(), " ".join("%.1f" % x for x in nb.mean(axis=0))))
-    w1 = a[:, 32:48].astype(np.float64) / 100.0 - t[:, [5]]
-    print("  correlation (walk1 end, batches) over waves: %.3f" % np.corrcoef(w1.ravel(), nb.ravel())[0, 1])
 tot = t[:, last] - t[:, 0]
 print("  workgroup      mean %7.2f us" % tot.mean())
 cu = a[:, 15].astype(np.uint64) & np.uint64(0xFFFFFFFF0000FF00)     # XCC id, SE / SH / CU id of HW_ID

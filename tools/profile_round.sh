@@ -26,6 +26,14 @@ timeout -k 10 600 python3 bench.py --shard-of 8 --no-cpu > gpurun_out/${TAG}_sha
 timeout -k 10 600 python3 bench.py --shard-of 8 --batch 32768 --ring 2 --steps 5 --warmup 2 --no-cpu --no-extra > gpurun_out/${TAG}_shard_of_8_weak.json 2> gpurun_out/${TAG}_shard_of_8_weak.err || exit 1
 timeout -k 10 600 python3 tools/bench_group_local.py --steps 3 > gpurun_out/${TAG}_group_local_8_shards.json 2> gpurun_out/${TAG}_group_local.err || exit 1
 NIQKI_FORCE_DIST=1 timeout -k 10 600 python3 bench.py --no-cpu --no-extra > gpurun_out/${TAG}_force_dist_world1.json 2> gpurun_out/${TAG}_force_dist_world1.err || exit 1
+# the walk's access pattern alone, and which instruction kinds issue side by side (built by hand into tools/bin/)
+[ -x tools/bin/ubench_lines ] && timeout -k 10 60 tools/bin/ubench_lines > gpurun_out/${TAG}_ubench_lines.txt 2>&1
+[ -x tools/bin/ubench_mix ] && timeout -k 10 60 stdbuf -oL tools/bin/ubench_mix > gpurun_out/${TAG}_ubench_mix.txt 2>&1
+# LAST (it rebuilds the library of this scratch copy with clock reads in the gather kernel): phase clocks of a gather workgroup
+touch niqki_amd/csrc/nq_query.hip && make -C niqki_amd/csrc HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DNQ_GATHER_CLOCK" > gpurun_out/${TAG}_clock_build.log 2>&1 && {
+  timeout -k 10 300 python3 tools/gather_clock.py --shard-of 8 --no-cpu --no-extra --steps 3 2>&1 | grep -v "^{\|amdgpu.ids" > gpurun_out/${TAG}_gather_phase_clocks_shard_of_8.txt
+  timeout -k 10 300 python3 tools/gather_clock.py --no-cpu --no-extra --steps 3 2>&1 | grep -v "^{\|amdgpu.ids" > gpurun_out/${TAG}_gather_phase_clocks_whole_range.txt
+}
 cd $R; head -14 gpurun_out/${TAG}_bench_kernel_trace_summary.txt | cut -c1-170
 python3 -c "
 import json
