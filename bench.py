@@ -496,7 +496,7 @@ def main():
         # ---- the same steps with the hits copied back to the host (SURVEY.md 8d "end-to-end incl. D2H of hits") ----
         # as a caller would: two sets of hit buffers, step i+1 runs while a copy stream brings step i's
         # hit_off and then exactly its hits into page-locked memory
-        if rank == 0 and world == 1 and not emu:
+        if counts is not None:     # (the group path of NIQKI_FORCE_DIST keeps no counter rows)
             hcs, hgs = [hc, torch.zeros_like(hc)], [hg, torch.zeros_like(hg)]
             h_off = [torch.empty(per + 1, dtype=torch.int64).pin_memory() for _ in range(2)]
             h_hc = torch.empty(cap, dtype=torch.int32).pin_memory()
@@ -597,7 +597,12 @@ def main():
                 "real_frac": (traffic / (gather_ms / max(1, gather_launches) * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and gather_ms) else None,
                 "copy_gbs": copy_gbs,
                 "copy_ceiling_frac": (traffic / (gather_ms / max(1, gather_launches) * 1e-3) / 1e9 / copy_gbs) if (traffic and gather_ms and copy_gbs) else None,
-                "frac_box_to_box": "0.87-0.91 over the boxes of this pool (DESIGN.md 4.4)",
+                "frac_box_to_box": "0.99-1.01 over the boxes of this pool (DESIGN.md 4.4)",
+                "note": ("achieved counts the ALGORITHMIC bytes of SURVEY.md 8d (4 bytes per id as the reference stores them, "
+                         "bucket lines that neighbouring queries share counted for each); the layout moves 2-byte ids and the "
+                         "XCD's L2 serves shared lines, so frac can pass 1 -- real_frac is what HBM really moved (PMC)"
+                         + ("; with the next batch's sketch kernel beside the exchange the gather kernel shares the device, "
+                            "its duration here is not a roofline figure (see the --no-overlap run)" if (use_dist and overlap) else "")),
                 "algorithmic_bytes_per_launch": alg_bytes / max(1, gather_launches),
                 "layout_min_bytes_per_launch": layout_min / max(1, gather_launches),
                 "launches": gather_launches, "avg_launch_ms": gather_ms / max(1, gather_launches),
@@ -957,7 +962,7 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
         if j:
             cli[tag] = {"files": n_files, "index_genomes_per_s": j["index_genomes_per_s"], "query_genomes_per_s": j["query_genomes_per_s"],
                         "index_file_GBps": j["index_fasta_GBps"], "process_startup_s": j["startup_s"],
-                        "query_phase_split_s": j.get("query_phase_split_s"), "query_host_to_device_copy_GBps": j.get("query_copy_GBps")}
+                        "query_phase_split_s": j.get("query_phase_split_s")}
     out["cli_files"] = {"workload": "niqki -I fof -Q fof -J 0.1 on 5 Mbp FASTA files (70 columns) in the page cache, whole-file mode",
                         **cli} if cli else None
     return out

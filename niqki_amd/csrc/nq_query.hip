@@ -898,6 +898,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     }
     lds_barrier();
     if (want_cand && tid == 0) { n_surv = lds_n[0]; n_cand = lds_n[1]; }
+    NQ_GCLK(4 + 4 * (t & 1));
   }
   }
   if (want_cand && tid == 0) {

@@ -93,8 +93,8 @@ def main():
                       res["timing_lines"]["index_query"][1])
         if m:
             cp, dv, ou = (float(x) for x in m.groups())
+            # (copy_and_frame: what the main thread still waits for -- the copy of batch i+1 runs under batch i)
             res["query_phase_split_s"] = {"copy_and_frame": cp, "sketch_and_query": dv, "output": ou}
-            res["query_copy_GBps"] = round(raw_bytes / cp / 1e9, 1) if cp > 0 else None
         if args.reads:
             rng = np.random.default_rng(3)
             src = niqki_amd.synth_genome_host(11, 0, 0, 0, args.len)
