@@ -114,6 +114,18 @@ def test_gzip_inputs_and_many_files(workdir, gold):
         for name, val in gh:
             base = name.split("_", 1)[1][:-3]
             assert eh[base] == val
+    # ... and as the QUERY list: three batches through the host program's copy / compute pipeline (the bytes of
+    # batch i+1 cross to the device under batch i's kernels), every copy answers like its original
+    run(workdir, ["-I", "fof.txt", "-Q", "big.txt", "-S", "10", "-J", "0.1", "-O", "bigq.gz"])
+    got = gunzip(workdir / "bigq.gz").decode().splitlines()
+    assert len(got) == len(big) == 300
+    by_name = {e.split(" ")[0]: e.split(" ", 1)[1] if " " in e else "" for e in exp}
+    for g, dst in zip(got, big):
+        qname, rest = (g.split(" ", 1) + [""])[:2]
+        assert qname == dst + ":" or qname.startswith(dst), (qname, dst)
+        orig = dst.split("_", 1)[1][:-3]
+        key = next(k for k in by_name if k.startswith(orig))
+        assert rest == by_name[key], dst
 
 
 @pytest.mark.parametrize("fmt", ["fa", "fq"])
