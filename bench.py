@@ -195,6 +195,10 @@ def main():
     n_dev = max(1, torch.cuda.device_count())
     shared = world > n_dev
     transport = args.transport if args.transport != "auto" else ("ipc" if shared else "rccl")
+    # (rehearsal of the fall-back below on a one-GPU box: the rccl group "fails" before RCCL is touched)
+    inject = os.environ.get("NIQKI_BENCH_INJECT_RCCL_FAILURE") == "1" and args.transport == "auto"
+    if inject:
+        transport = "rccl"
     if transport == "ipc":
         os.environ["NIQKI_GROUP_TRANSPORT"] = "ipc"
     else:
@@ -233,7 +237,56 @@ def main():
     def rec_offsets(n):
         return torch.from_numpy((np.arange(n + 1, dtype=np.int64) * stride_b)).to(dev)
 
-    sq = ShardedQuery(eng, N, F, dev, exchange=args.exchange, cand_cap=256) if use_dist else None
+    # The exchange transport is chosen once for all ranks.  "auto" on distinct devices means RCCL; should its
+    # group not come up, or its first exchange (round 0 of the index build, before anything is inserted) raise,
+    # on ANY rank, all ranks agree (one all_reduce over torch.distributed) to go on with the library's ipc
+    # transport -- peers' exchange buffers mapped over xGMI -- instead of losing the run.
+    def make_group(tr):
+        if tr == "rccl" and inject:
+            raise RuntimeError("injected failure (NIQKI_BENCH_INJECT_RCCL_FAILURE)")
+        if tr == "ipc":
+            os.environ["NIQKI_GROUP_TRANSPORT"] = "ipc"
+        else:
+            os.environ.pop("NIQKI_GROUP_TRANSPORT", None)
+        return ShardedQuery(eng, N, F, dev, exchange=args.exchange, cand_cap=256)
+
+    def all_ok(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if on_gloo else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    can_fall_back = use_dist and world > 1 and args.transport == "auto" and transport == "rccl"
+    transport_note = None
+
+    def guarded(what, fn):
+        """fn() on every rank; False when it raised somewhere and the ranks agreed to fall back"""
+        nonlocal sq, transport, transport_note
+        err = None
+        try:
+            fn()
+        except Exception as e:      # noqa: BLE001 -- whatever the transport raised: decided collectively below
+            err = e
+        if all_ok(err is None):
+            return True
+        if not can_fall_back or transport != "rccl":
+            raise err if err is not None else RuntimeError("%s failed on another rank" % what)
+        log("[rank %d] %s failed over rccl (%s): all ranks fall back to the ipc transport" % (rank, what, err))
+        transport_note = "rccl: %s failed (%s); ipc used instead" % (what, str(err)[:200] if err else "on another rank")
+        if sq is not None:
+            try:
+                sq.close()
+            except Exception:       # noqa: BLE001
+                pass
+        transport = "ipc"
+        sq = make_group("ipc")
+        return False
+
+    sq = None
+    if use_dist:
+        def _mk():
+            nonlocal sq
+            sq = make_group(transport)
+        guarded("group creation", _mk)
 
     # ---- index build (not timed): synth -> sketch -> (slice exchange) -> insert ----
     t0 = time.time()
@@ -251,7 +304,15 @@ def main():
             eng.synth_dev(args.seed, dev_u32(fam), dev_u32(mem), dev_u32(rate), n, L, stride_b, seqbuf)
             eng.sketch_dev(seqbuf, ro_full if n == GB else rec_offsets(n), n, skbuf)
         if use_dist:
-            sq.insert(skbuf, max(0, min(world * GB, N - r * world * GB)))
+            n_round = max(0, min(world * GB, N - r * world * GB))
+            if r == 0 and can_fall_back:
+                def _first():
+                    sq.insert(skbuf, n_round)
+                    eng.synchronize()
+                if not guarded("the first slice exchange", _first):
+                    sq.insert(skbuf, n_round)      # nothing was inserted: again over ipc
+            else:
+                sq.insert(skbuf, n_round)
         elif n:
             eng.insert_dev(skbuf, n)
     eng.build()
@@ -579,6 +640,7 @@ def main():
                                 % (world, sq.exchange, sq.transport, ", next batch sketched beside the exchange" if overlap else "")) if use_dist
                 else ("1 GPU as rank 0 of a %d-way slot shard" % emu if emu else "1 GPU"),
                 "transport": sq.transport if use_dist else None,
+                "transport_note": transport_note,
                 "ranks_share_devices": bool(shared) if use_dist else None,
                 "exchange_redone_densely": sq.overflows if use_dist else 0,
                 "exchange_bytes_per_rank_per_step": xbytes,
