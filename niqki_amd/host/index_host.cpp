@@ -4,6 +4,7 @@
 // Biogetline), sketching, counting and sorting all happen on the GPU.
 #include "index_host.h"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -14,6 +15,7 @@
 #include <mutex>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -21,6 +23,7 @@
 #include <memory>
 #include <stdexcept>
 #include <thread>
+#include <vector>
 
 #include "seqio.h"
 
@@ -73,6 +76,67 @@ struct PinnedBuf {
   }
 };
 
+// libdeflate (its whole-buffer gzip decoder runs 2-3 x zlib's inflate) when the system has the library;
+// loaded once, by name -- no header is needed for the three entry points used.
+struct FastInflate {
+  void *(*alloc)() = nullptr;
+  void (*release)(void *) = nullptr;
+  // 0 = ok, 1 = bad data, 2 = short output, 3 = insufficient space
+  int (*gzip_ex)(void *, const void *, size_t, void *, size_t, size_t *, size_t *) = nullptr;
+  FastInflate() {
+    if (std::getenv("NIQKI_HOST_ZLIB_ONLY")) return;
+    void *lib = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!lib) return;
+    alloc = (void *(*)())dlsym(lib, "libdeflate_alloc_decompressor");
+    release = (void (*)(void *))dlsym(lib, "libdeflate_free_decompressor");
+    gzip_ex = (int (*)(void *, const void *, size_t, void *, size_t, size_t *, size_t *))dlsym(lib, "libdeflate_gzip_decompress_ex");
+    if (!alloc || !release || !gzip_ex) alloc = nullptr;
+  }
+  bool usable() const { return alloc != nullptr; }
+};
+const FastInflate &fast_inflate() {
+  static const FastInflate f;
+  return f;
+}
+
+// A whole regular gzip file (all its members) through libdeflate.  false = leave it to zlib (no library, not a
+// plain well-formed file: zlib then decides what a damaged or truncated stream yields, as before).
+bool gunzip_whole(int fd, size_t file_bytes, PinnedBuf &out) {
+  const FastInflate &fi = fast_inflate();
+  if (!fi.usable() || file_bytes < 18 || file_bytes > (size_t(1) << 31)) return false;
+  thread_local std::vector<uint8_t> in;
+  thread_local struct Dec {
+    void *d = nullptr;
+    ~Dec() { if (d) fast_inflate().release(d); }
+  } dec;
+  if (!dec.d && !(dec.d = fi.alloc())) return false;
+  in.resize(file_bytes);
+  size_t got = 0;
+  while (got < file_bytes) {
+    const ssize_t n = pread(fd, in.data() + got, file_bytes - got, (off_t)got);
+    if (n <= 0) return false;
+    got += (size_t)n;
+  }
+  // the last member's size (mod 2^32) closes the file: exact for the usual one-member file
+  const uint32_t isize = (uint32_t)in[file_bytes - 4] | (uint32_t)in[file_bytes - 3] << 8 | (uint32_t)in[file_bytes - 2] << 16 |
+                         (uint32_t)in[file_bytes - 1] << 24;
+  out.size = 0;
+  out.reserve(std::max<size_t>((size_t)isize + 64, size_t(1) << 20));
+  size_t at = 0;
+  while (at + 18 <= file_bytes && in[at] == 0x1F && in[at + 1] == 0x8B) {
+    size_t used = 0, made = 0;
+    const int r = fi.gzip_ex(dec.d, in.data() + at, file_bytes - at, out.p + out.size, out.cap - out.size, &used, &made);
+    if (r == 3) {   // the member needs more room: again from its start
+      out.reserve(std::max(out.cap * 2, out.size + 4 * (file_bytes - at)));
+      continue;
+    }
+    if (r != 0 || used == 0) return false;
+    at += used;
+    out.size += made;
+  }
+  return at > 0;   // (bytes behind the last member are ignored, as zlib's gzread does)
+}
+
 // Whole content of a file, gunzipped when it starts with the gzip magic (the
 // reference's zstr::ifstream auto-detects the same way, src/zstr.hpp:190-203).
 void read_file_bytes(const std::string &path, PinnedBuf &out) {
@@ -84,6 +148,8 @@ void read_file_bytes(const std::string &path, PinnedBuf &out) {
   unsigned char magic[2] = {0, 0};
   const ssize_t m = pread(fd, magic, 2, 0);
   if (m == 2 && magic[0] == 0x1F && magic[1] == 0x8B) {
+    if (S_ISREG(st.st_mode) && gunzip_whole(fd, (size_t)st.st_size, out)) { ::close(fd); return; }
+    out.size = 0;
     gzFile g = gzdopen(fd, "rb");  // owns fd from here
     if (!g) { ::close(fd); throw std::runtime_error("cannot open '" + path + "'"); }
     gzbuffer(g, 1 << 20);
