@@ -1069,11 +1069,7 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   } else if (avg_len < (1u << 21)) {
     if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 8, 31); else NQ_LAUNCH_SKETCH(1024, 8, 0);
   } else {
-#ifdef NQ_SK_BLOCK
-    NQ_LAUNCH_SKETCH(NQ_SK_BLOCK, 32, 31);
-#else
     if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 32, 31); else NQ_LAUNCH_SKETCH(1024, 32, 0);
-#endif
   }
 #undef NQ_LAUNCH_SKETCH
   return hipGetLastError();
