@@ -494,6 +494,16 @@ int ipc_buf_index(Buf niqki_group::Ws::*m) {
 }
 
 int ipc_export_alloc(niqki_group *g, size_t bytes, void **out, hipIpcMemHandle_t *h, uint64_t *off);
+// a peer's exported allocation into this process (a few tries: the same transient failure as on the export side)
+hipError_t ipc_open(void **q, const hipIpcMemHandle_t &h) {
+  hipError_t e = hipSuccess;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    if (attempt) { (void)hipGetLastError(); usleep(2000u << attempt); }
+    e = hipIpcOpenMemHandle(q, h, hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) break;
+  }
+  return e;
+}
 
 int ipc_setup(niqki_group *g, const uint8_t *id) {
   auto &ic = g->ipc;
@@ -545,7 +555,7 @@ int ipc_setup(niqki_group *g, const uint8_t *id) {
   for (uint32_t s = 0; s < g->world; ++s) {
     if (s == g->first) { ic.peer_flags[s] = ic.flags; continue; }
     void *q = nullptr;
-    NQ_GH(g, hipIpcOpenMemHandle(&q, ic.shm->r[s].flags, hipIpcMemLazyEnablePeerAccess));
+    NQ_GH(g, ipc_open(&q, ic.shm->r[s].flags));
     ic.peer_flags_base[s] = q;
     ic.peer_flags[s] = (uint32_t *)((char *)q + ic.shm->r[s].flags_off);
   }
@@ -662,7 +672,7 @@ int ipc_prepare(niqki_group *g, const size_t need[kIpcBufs]) {
     if (s == g->first) continue;
     const IpcRank &pr = ic.shm->r[s];
     void *q = nullptr;
-    NQ_GH(g, hipIpcOpenMemHandle(&q, pr.arena, hipIpcMemLazyEnablePeerAccess));
+    NQ_GH(g, ipc_open(&q, pr.arena));
     ic.peer_base[s] = q;
     ic.peer_gen[s] = pr.gen;
     for (uint32_t b = 0; b < kIpcBufs; ++b) ic.peer_buf[s][b] = (char *)q + pr.arena_off + pr.buf_off[b];
