@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--transport", default=os.environ.get("NIQKI_GROUP_TRANSPORT", "auto"),
                     help="exchange transport for N > 1: auto (rccl; ipc when the ranks share devices) | rccl | ipc "
                          "(direct peer access through HIP IPC handles, include/niqki_hip.h)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="N = 1: sketch batch i+1 on a second handle's stream beside batch i's gather and hits kernels "
+                         "(+4 %% genomes/s; the kernels then share the CUs and the gather launch time is no roofline figure)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: do not run the next batch's sketch kernel beside the exchange of the current one")
     ap.add_argument("--verify", action="store_true",
@@ -367,7 +370,8 @@ def main():
     # N > 1: batch i's exchange (slices, candidate lists, sums: the GPU mostly waits for its peers) runs
     # beside batch i+1's sketch kernel: a second handle sketches on a side stream, niqki_group_query_begin
     # returns without waiting, niqki_group_query_end is the step's one host wait.
-    overlap = use_dist and not args.no_overlap
+    pipeline = args.pipeline and not use_dist and not emu
+    overlap = (use_dist and not args.no_overlap) or pipeline
     if overlap:
         sk_eng = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev)
         side = torch.cuda.Stream(device=dev)
@@ -395,10 +399,15 @@ def main():
         if overlap:
             sketch_ahead(si)                       # (only the first step finds its batch not sketched yet)
             torch.cuda.current_stream().wait_event(ev_sk[bi])
-            sq.begin(qsk[bi], hit_off[si], hc, hg, cap)
+            if use_dist:
+                sq.begin(qsk[bi], hit_off[si], hc, hg, cap)
+            else:
+                eng.query_counts_dev(qsk[bi], per, counts, stride)
+                eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[si], hc, hg, cap)
             ev_used[bi].record(torch.cuda.current_stream())
             sketch_ahead(si + 1)
-            sq.end()
+            if use_dist:
+                sq.end()
             return
         eng.sketch_dev(qseq[bi * per * stride_b:], d_ro, per, qsk[bi])
         if use_dist:
@@ -664,7 +673,7 @@ def main():
                          "bucket lines that neighbouring queries share counted for each); the layout moves 2-byte ids and the "
                          "XCD's L2 serves shared lines, so frac can pass 1 -- real_frac is what HBM really moved (PMC)"
                          + ("; with the next batch's sketch kernel beside the exchange the gather kernel shares the device, "
-                            "its duration here is not a roofline figure (see the --no-overlap run)" if (use_dist and overlap) else "")),
+                            "its duration here is not a roofline figure (see the --no-overlap run)" if overlap else "")),
                 "algorithmic_bytes_per_launch": alg_bytes / max(1, gather_launches),
                 "layout_min_bytes_per_launch": layout_min / max(1, gather_launches),
                 "launches": gather_launches, "avg_launch_ms": gather_ms / max(1, gather_launches),
