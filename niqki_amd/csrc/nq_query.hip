@@ -166,6 +166,9 @@ struct PairWalk {
 //   PRE      : entries come from the slot-major look-up pre-pass (lookup_kernel below): one
 //              packed word per (query, tile, slot) = bucket start relative to the slot's first
 //              unit << 16 | length, read coalesced; no table access in this kernel at all.
+//   PAD      : padded index (whole-line chunks): batches go through PairWalk (two lines per load), and the four
+//              waves of a SIMD take turns at the top issue priority; otherwise walk64 with explicit lengths.
+//   ahead    : (PRE) this wave's first two look-ups of the tile, issued a tile earlier by the caller / this function.
 template <int BLOCK, int UNROLL, int NT, bool STASH_OUT, bool STASH_IN, int MODE, bool PRE = false, bool PAD = false>
 __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk, uint32_t q, uint32_t t,
                                           uint32_t *cnt, Item *queue, Entry *stash, uint32_t &sink,
