@@ -124,6 +124,11 @@ def test_gzip_inputs_and_many_files(workdir, gold):
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, NIQKI_HOST_ZLIB_ONLY="1"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert gunzip(workdir / "big_zlib.gz") == gunzip(workdir / "big.gz")
+    # three shards, each staging (and prefetching) its share of every batch: the same text
+    r = subprocess.run([BIN, "--gpus", "3", "-I", "big.txt", "-Q", "fof.txt", "-S", "10", "-J", "0.1", "-O", "big_mg.gz"], cwd=workdir,
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, NIQKI_SHARDS_ON_ONE_DEVICE="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert gunzip(workdir / "big_mg.gz") == gunzip(workdir / "big.gz")
     # ... and as the QUERY list: three batches through the host program's copy / compute pipeline (the bytes of
     # batch i+1 cross to the device under batch i's kernels), every copy answers like its original
     run(workdir, ["-I", "fof.txt", "-Q", "big.txt", "-S", "10", "-J", "0.1", "-O", "bigq.gz"])
