@@ -66,10 +66,14 @@ def query_spec(q, n_fam):
     return fam, mem, rate
 
 
-def measure_traffic(args):
-    """HBM bytes per gather launch (gather kernel + look-up pre-pass + locality probe) from rocprofv3 PMC
-    passes of a short run of this same command: 2 x FETCH_SIZE (gfx950 tallies 128-byte requests at 64
-    bytes, MI355X_MICROARCH.md) + WRITE_SIZE, both in KB.  None if anything goes wrong."""
+def measure_counters(args):
+    """Hardware counters of a short run of this same command under rocprofv3 (one --pmc pass per counter, no
+    trace flags, child processes started before this process touches the GPU):
+      * HBM-side bytes per gather launch (gather kernel + look-up pre-pass + locality probe):
+        2 x FETCH_SIZE (gfx950 tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md) + WRITE_SIZE, in KB;
+      * vector instructions per k-mer of the sketch kernel: SQ_INSTS_VALU (wave instructions, all XCDs)
+        x 64 lanes over the k-mers its launches of that run rolled.
+    None if anything goes wrong."""
     import csv
     import glob
     import re
@@ -86,12 +90,14 @@ def measure_traffic(args):
         return None
     kb = {}
     launches = None
+    valu = None
+    c_steps, c_warm = 2, 1
     t0 = time.time()
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         out = tempfile.mkdtemp(prefix="niqki_pmc_", dir="/tmp")
         try:
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "2", "--warmup", "1",
+                   os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", str(c_steps), "--warmup", str(c_warm),
                    "--genomes", str(args.genomes), "--batch", str(args.batch), "--len", str(args.len),
                    "--family", str(args.family), "--seed", str(args.seed), "--ring", str(args.ring)]
             env = dict(os.environ, TMPDIR="/tmp")
@@ -109,14 +115,28 @@ def measure_traffic(args):
                 return None
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if rc != 0 or not files:
+                if counter == "SQ_INSTS_VALU":
+                    break                  # (the traffic passes stand on their own)
                 return None
-            total, n_gather = 0.0, 0
+            total, n_gather, v_sum, v_n = 0.0, 0, 0.0, 0
             with open(files[0], newline="") as f:
                 for row in csv.DictReader(f):
                     name = row.get("Kernel_Name", "")
-                    if row.get("Counter_Name") == counter and rx.search(name):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    if counter == "SQ_INSTS_VALU":
+                        if "sketch_kernel<" in name:
+                            v_sum += float(row["Counter_Value"])
+                            v_n += 1
+                    elif rx.search(name):
                         total += float(row["Counter_Value"])
                         n_gather += "gather_kernel<" in name
+            if counter == "SQ_INSTS_VALU":
+                # every sketch launch of the child: the index build (all genomes) and its warm-up + timed query batches
+                kmers = (args.genomes + (c_steps + c_warm) * args.batch) * max(args.len - 31, 0)
+                if v_n and kmers:
+                    valu = {"valu_per_kmer": v_sum * 64.0 / kmers, "launches": v_n}
+                continue
             if n_gather == 0:
                 return None
             kb[counter] = total / n_gather
@@ -125,12 +145,62 @@ def measure_traffic(args):
             return None
         finally:
             shutil.rmtree(out, ignore_errors=True)
-    log("[bench] HBM traffic of the gather path: FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB per launch (%d launches, %.0f s)"
-        % (kb["FETCH_SIZE"], kb["WRITE_SIZE"], launches, time.time() - t0))
+    log("[bench] HBM traffic of the gather path: FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB per launch (%d launches); sketch kernel %s "
+        "vector instructions per k-mer (%.0f s)" % (kb["FETCH_SIZE"], kb["WRITE_SIZE"], launches,
+                                                    ("%.2f" % valu["valu_per_kmer"]) if valu else "n/a", time.time() - t0))
     return {"bytes_per_launch": (2 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024,
+            "fetch_kb": kb["FETCH_SIZE"], "write_kb": kb["WRITE_SIZE"],
+            "valu": valu,
             "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over %d launches of this same command, run by "
                       "bench.py before its timed run: 2 x FETCH_SIZE (gfx950) + WRITE_SIZE of gather_kernel, the look-up "
                       "pre-pass and the locality probe" % launches}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this same command under
+    torch.distributed.run as a CHILD process (a session of its own, killed as a group on a time-out), relay
+    its stdout -- the one JSON line of rank 0 -- and return its exit code.  Called before this process has
+    imported torch or made any HIP call: a process that has initialised the GPU must not be replaced or
+    forked into a launcher on this pool."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL and the ipc transport need on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    limit = float(os.environ.get("NIQKI_BENCH_LAUNCH_TIMEOUT", "3000"))
+    log("[bench] --gpus %d without a launcher: starting %s" % (n, " ".join(cmd[1:10]) + " ..."))
+    pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    try:
+        out, _ = pr.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        pr.wait()
+        log("[bench] the %d ranks did not finish within %.0f s: killed" % (n, limit))
+        return 124
+    except KeyboardInterrupt:
+        try:
+            os.killpg(pr.pid, signal.SIGTERM)
+        except OSError:
+            pass
+        pr.wait()
+        return 130
+    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    elif pr.returncode == 0:
+        log("[bench] the ranks exited 0 without a JSON line")
+        return 1
+    return pr.returncode
 
 
 def main():
@@ -155,19 +225,34 @@ def main():
                     help="do not measure the gather path's HBM traffic with rocprofv3 --pmc passes before the run "
                          "(roofline.traffic then comes from profiles/gather_traffic.json)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-legs", action="store_true",
+                    help="only the index build, the warm-up and the K timed steps: no end_to_end_d2h / pipelined_step legs, no "
+                         "ALU probes, no CPU baseline, no extra workloads (the command tools/profile_round.sh traces, so that a "
+                         "kernel's figures in profiles/ are those of the timed launches)")
     ap.add_argument("--transport", default=os.environ.get("NIQKI_GROUP_TRANSPORT", "auto"),
                     help="exchange transport for N > 1: auto (rccl; ipc when the ranks share devices) | rccl | ipc "
                          "(direct peer access through HIP IPC handles, include/niqki_hip.h)")
+    ap.add_argument("--devices", type=int, default=0,
+                    help="N > 1: deal the ranks over the first D devices only (0 = all visible ones); with fewer devices than "
+                         "ranks the ranks share them over the ipc transport (config.ranks_share_devices)")
     ap.add_argument("--pipeline", action="store_true",
                     help="N = 1: sketch batch i+1 on a second handle's stream beside batch i's gather and hits kernels "
                          "(+4 %% genomes/s; the kernels then share the CUs and the gather launch time is no roofline figure)")
+    ap.add_argument("--priority-streams", action="store_true",
+                    help="with --pipeline: the query handle on a stream at the top of the device's stream priority range, the "
+                         "sketch handle at the bottom (option stream_priority of the C ABI)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: do not run the next batch's sketch kernel beside the exchange of the current one")
     ap.add_argument("--verify", action="store_true",
                     help="N > 1, small indexes: every rank checks the hit lists of its last step against a whole-range handle")
     args = ap.parse_args()
     if args.pmc_child:
+        args.no_legs = True
+    if args.no_legs:
         args.no_cpu = args.no_extra = args.no_pmc = True
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: this process becomes one (it has not touched the GPU, torch is not imported)
+        sys.exit(launch_ranks(args.gpus))
 
     # HBM bytes per launch of the gather path, measured now: two rocprofv3 --pmc passes (FETCH_SIZE,
     # WRITE_SIZE: passes of their own, no trace flags) over a 3-launch run of this same command, as
@@ -175,7 +260,7 @@ def main():
     live_traffic = None
     if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.shard_of and not args.no_cpu
             and not args.no_extra and not args.no_pmc and os.environ.get("NIQKI_BENCH_PMC", "1") != "0"):
-        live_traffic = measure_traffic(args)
+        live_traffic = measure_counters(args)
 
     # Only the JSON line may reach stdout: libraries (RCCL prints a version banner)
     # get stderr for the whole run, the result is written to the saved descriptor.
@@ -191,11 +276,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if world != args.gpus:
+        log("warning: --gpus %d but WORLD_SIZE %d: the launcher's world size counts" % (args.gpus, world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # (before the first HIP call of this process)
     # ranks that share a device (more ranks than GPUs: a one-GPU box rehearsing N > 1): RCCL refuses that,
     # the library's ipc transport does not; torch.distributed then runs over gloo
     n_dev = max(1, torch.cuda.device_count())
+    if args.devices > 0:
+        n_dev = min(n_dev, args.devices)
     shared = world > n_dev
     transport = args.transport if args.transport != "auto" else ("ipc" if shared else "rccl")
     # (rehearsal of the fall-back below on a one-GPU box: the rccl group "fails" before RCCL is touched)
@@ -230,7 +318,11 @@ def main():
     G = emu if emu else world                  # shards the index is cut into
     sb, se = niqki_amd.group_slot_range(0 if emu else rank, G, S)
     eng = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev, slot_begin=sb, slot_end=se)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    if args.pipeline and args.priority_streams:
+        eng.set_option("stream_priority", 1)
+        torch.cuda.set_stream(torch.cuda.ExternalStream(eng.get_stream(), device=dev))   # torch's current stream IS the handle's
+    else:
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_option("record_len_hint", L)
     stride_b = L  # records are stored back to back; NIQKI_SEQ_PAD bytes follow the last one
 
@@ -374,8 +466,12 @@ def main():
     overlap = (use_dist and not args.no_overlap) or pipeline
     if overlap:
         sk_eng = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev)
-        side = torch.cuda.Stream(device=dev)
-        sk_eng.set_stream(side.cuda_stream)
+        if args.pipeline and args.priority_streams:
+            sk_eng.set_option("stream_priority", -1)
+            side = torch.cuda.ExternalStream(sk_eng.get_stream(), device=dev)
+        else:
+            side = torch.cuda.Stream(device=dev)
+            sk_eng.set_stream(side.cuda_stream)
         sk_eng.set_option("record_len_hint", L)
         ev_sk = [torch.cuda.Event() for _ in range(n_batches)]      # sketches of ring slot b are complete
         ev_used = [torch.cuda.Event() for _ in range(n_batches)]    # ... have been consumed by their batch
@@ -555,33 +651,39 @@ def main():
             pass
 
     # ---- what a streaming copy reaches on this device, now (the practical HBM ceiling beside the 8 TB/s spec) ----
-    copy_gbs = eng.measure_alu(4) / 1e9 if rank == 0 else None
+    copy_gbs = eng.measure_alu(4) / 1e9 if (rank == 0 and not args.no_legs) else None
 
     # ---- sketch kernel against integer-ALU ceilings measured now, on this device ----
     kmers = args.steps * per * max(L - K, 0)
     sk_rate = kmers / (prof["sketch"][0] * 1e-3) if prof["sketch"][0] else 0.0
     alu = None
-    if rank == 0:
+    if rank == 0 and not args.no_legs:
         adds, muls, arith, vop3 = eng.measure_alu(0), eng.measure_alu(1), eng.measure_alu(2), eng.measure_alu(3)
-        # 27.8 vector instructions per k-mer (profiles/r03_sketch_sq_counters.txt: SQ_INSTS_VALU over the k-mers of
-        # the launch) at the issue rate of a three-operand integer instruction, the class of 20 of them
-        valu_per_kmer = 27.8
+        # vector instructions per k-mer: counted in this run (SQ_INSTS_VALU pass of measure_counters) or, where the
+        # run took no counter passes, the committed figure of the same kernel
+        if live_traffic is not None and live_traffic.get("valu"):
+            valu_per_kmer = live_traffic["valu"]["valu_per_kmer"]
+            valu_source = ("SQ_INSTS_VALU x 64 over the k-mers of the %d sketch launches of a rocprofv3 --pmc pass of this "
+                           "same command, run by bench.py before its timed run" % live_traffic["valu"]["launches"])
+        else:
+            valu_per_kmer = 27.8
+            valu_source = "profiles/r03_sketch_sq_counters.txt (not measured in this run)"
         alu = {"add_lane_ops_per_s": adds, "mul_lane_ops_per_s": muls, "vop3_lane_ops_per_s": vop3,
                "arithmetic_only_kmers_per_s": arith,
                "alu_frac": sk_rate / arith if arith else None,
-               "valu_per_kmer": valu_per_kmer,
+               "valu_per_kmer": valu_per_kmer, "valu_per_kmer_source": valu_source,
                "issue_frac": sk_rate * valu_per_kmer / vop3 if vop3 else None,
                "note": "alu_frac = sketch kernel k-mers/s over the rate of its per-k-mer arithmetic alone (roll, canonical "
                        "choice, filter hash; no LDS table, compaction, candidates or memory); issue_frac = its vector "
-                       "instructions per second (k-mers/s x valu_per_kmer, counted with SQ_INSTS_VALU) over the measured "
-                       "issue rate of v_lshl_add_u32, which every vector opcode but add/and/or/xor/mov shares on gfx950 "
-                       "(profiles/r03_opcode_costs.txt); all rates measured in this run"}
+                       "instructions per second (k-mers/s x valu_per_kmer) over the measured issue rate of v_lshl_add_u32, "
+                       "which every vector opcode but add/and/or/xor/mov shares on gfx950 (profiles/r03_opcode_costs.txt); "
+                       "the four ALU rates are measured in this run, valu_per_kmer as valu_per_kmer_source says"}
 
     cpu = None
     extra = None
     d2h = None
     pipelined = None
-    if rank == 0 and world == 1 and not emu:
+    if rank == 0 and world == 1 and not emu and not args.no_legs:
         if not args.no_cpu:
             cpu = cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, (K, S, W, H, J))
         # ---- the same steps with the hits copied back to the host (SURVEY.md 8d "end-to-end incl. D2H of hits") ----
@@ -629,40 +731,61 @@ def main():
             del hcs, hgs
 
         # ---- the same steps with batch i+1 sketched beside batch i's gather (what --pipeline times as the line) ----
+        # twice: both handles on streams of the default priority, then the query handle on a stream at the top of
+        # the device's priority range and the sketch handle at the bottom (option "stream_priority"): the pre-pass,
+        # probe / order, gather and hit kernels are then dispatched ahead of waiting sketch workgroups
         if counts is not None and not pipeline:
-            sk2 = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev)
-            side2 = torch.cuda.Stream(device=dev)
-            sk2.set_stream(side2.cuda_stream)
-            sk2.set_option("record_len_hint", L)
             n_pl = min(10, args.steps)
-            e_sk = [torch.cuda.Event() for _ in range(n_batches)]
-            e_used = [torch.cuda.Event() for _ in range(n_batches)]
-            main = torch.cuda.current_stream()
 
-            def ahead(j):
-                bj = j % n_batches
-                with torch.cuda.stream(side2):
+            def pipelined_leg(prio):
+                sk2 = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev)
+                sk2.set_option("record_len_hint", L)
+                if prio:
+                    eng.set_option("stream_priority", 1)
+                    sk2.set_option("stream_priority", -1)
+                    main = torch.cuda.ExternalStream(eng.get_stream(), device=dev)
+                    side2 = torch.cuda.ExternalStream(sk2.get_stream(), device=dev)
+                else:
+                    main = torch.cuda.current_stream()
+                    side2 = torch.cuda.Stream(device=dev)
+                    sk2.set_stream(side2.cuda_stream)
+                e_sk = [torch.cuda.Event() for _ in range(n_batches)]
+                e_used = [torch.cuda.Event() for _ in range(n_batches)]
+
+                def ahead(j):
+                    bj = j % n_batches
                     if j >= n_batches:
                         side2.wait_event(e_used[bj])
                     sk2.sketch_dev(qseq[bj * per * stride_b:], d_ro, per, qsk[bj])
                     e_sk[bj].record(side2)
-            ahead(0)
-            torch.cuda.synchronize()
-            tp = time.perf_counter()
-            for j in range(n_pl):
-                bj = j % n_batches
-                main.wait_event(e_sk[bj])
-                eng.query_counts_dev(qsk[bj], per, counts, stride)
-                eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[args.warmup + j], hc, hg, cap)
-                e_used[bj].record(main)
-                ahead(j + 1)             # (one sketch per step inside the timed region; the last one is for a step beyond it)
-            torch.cuda.synchronize()
-            tp = time.perf_counter() - tp
+                torch.cuda.synchronize()
+                ahead(0)
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                for j in range(n_pl):
+                    bj = j % n_batches
+                    main.wait_event(e_sk[bj])
+                    eng.query_counts_dev(qsk[bj], per, counts, stride)
+                    eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[args.warmup + j], hc, hg, cap)
+                    e_used[bj].record(main)
+                    ahead(j + 1)             # (one sketch per step inside the timed region; the last one is for a step beyond it)
+                torch.cuda.synchronize()
+                tp = time.perf_counter() - tp
+                sk2.close()
+                if prio:                     # back onto torch's current stream for what follows
+                    eng.synchronize()
+                    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+                return tp
+            tp0 = pipelined_leg(False)
+            tp1 = pipelined_leg(True)
+            tp = min(tp0, tp1)
             pipelined = {"value": n_pl * per / tp, "unit": "genomes/s", "ms_per_step": tp / n_pl * 1e3, "steps": n_pl,
+                         "ms_per_step_default_priority": tp0 / n_pl * 1e3, "ms_per_step_priority_streams": tp1 / n_pl * 1e3,
+                         "floor_ms_if_kernels_could_share_cus": max(prof["sketch"][0], prof["gather"][0] + prof["hits"][0]) / max(1, args.steps),
                          "note": "batch i+1 sketched on a second handle's stream beside batch i's gather and hits kernels "
-                                 "(bench.py --pipeline makes this the timed line); the kernels then share the CUs, so the "
-                                 "reported line keeps them one after the other and its roofline figure clean"}
-            sk2.close()
+                                 "(bench.py --pipeline makes this the timed line); value = the faster of the two stream set-ups. "
+                                 "The two kernels cannot share a CU (128 KB of LDS each) and each keeps its CUs busy (the gather "
+                                 "launch on half of the CUs takes twice as long, DESIGN.md 4.4), so the overlap only fills the tails"}
 
         if not args.no_extra:
             del counts
@@ -707,36 +830,15 @@ def main():
                 else ("1 GPU as rank 0 of a %d-way slot shard" % emu if emu else "1 GPU"),
                 "transport": sq.transport if use_dist else None,
                 "transport_note": transport_note,
-                "ranks_share_devices": bool(shared) if use_dist else None,
+                "ranks_share_devices": bool(shared) if use_dist else None, "devices_visible": n_dev,
                 "exchange_redone_densely": sq.overflows if use_dist else 0,
                 "exchange_bytes_per_rank_per_step": xbytes,
                 "exchange_avg_gbs_per_rank": (xbytes / (dt / args.steps) / 1e9) if xbytes else None,
                 "tile_genomes": eng.tile_genomes(), "index_build_s": round(t_index, 2),
                 "hits_per_query": total_hits / max(1, args.steps * per), "hit_overflow": overflow,
             },
-            "roofline": {
-                "kernel": "nq::gather_kernel (gather-histogram, rank 0's slot shard) incl. its look-up pre-pass and probe / order passes",
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": traffic_source,
-                # what the memory system really moved per launch over the launch time: against the spec peak and
-                # against the copy this run measured (frac above counts SURVEY's 4-byte ids, the layout stores 2)
-                "real_gbs": (traffic / (gather_ms / max(1, gather_launches) * 1e-3) / 1e9) if (traffic and gather_ms) else None,
-                "real_frac": (traffic / (gather_ms / max(1, gather_launches) * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and gather_ms) else None,
-                "copy_gbs": copy_gbs,
-                "copy_ceiling_frac": (traffic / (gather_ms / max(1, gather_launches) * 1e-3) / 1e9 / copy_gbs) if (traffic and gather_ms and copy_gbs) else None,
-                "frac_box_to_box": "0.99-1.01 over the boxes of this pool (DESIGN.md 4.4)",
-                "note": ("achieved counts the ALGORITHMIC bytes of SURVEY.md 8d (4 bytes per id as the reference stores them, "
-                         "bucket lines that neighbouring queries share counted for each); the layout moves 2-byte ids and the "
-                         "XCD's L2 serves shared lines, so frac can pass 1 -- real_frac is what HBM really moved (PMC)"
-                         + ("; with the next batch's sketch kernel beside the gather the two share the CUs, "
-                            "the gather launch time here is not a roofline figure" if pipeline else "")),
-                "algorithmic_bytes_per_launch": alg_bytes / max(1, gather_launches),
-                "layout_min_bytes_per_launch": layout_min / max(1, gather_launches),
-                "launches": gather_launches, "avg_launch_ms": gather_ms / max(1, gather_launches),
-                "measured_in": roofline_from or "the timed steps",
-                "gathered_ids_per_query": T / max(1, n_q_local),
-            },
+            "roofline": roofline_record(achieved, traffic, traffic_source, live_traffic, gather_ms, gather_launches, alg_bytes, layout_min,
+                                        copy_gbs, roofline_from, T, n_q_local, pipeline),
             "kernels": {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items()},
             # the sketch kernel is integer-ALU bound (4 64-bit multiplies per k-mer):
             # its rate in k-mers, the HBM bytes it needs (1 byte per base + the sketch) and the ALU ceilings
@@ -755,7 +857,8 @@ def main():
             out["metric"] += " (one GPU as rank 0 of %d slot shards, compute only)" % emu
             out["shard_emulation"] = {
                 "shards": emu, "slots": [sb, se], "queries_sketched_per_step": per, "queries_gathered_per_step": nq_all,
-                "gather_ms_per_step": gather_ms / max(1, gather_launches), "roofline_frac": achieved / HBM_PEAK_GBS,
+                "gather_ms_per_step": gather_ms / max(1, gather_launches), "roofline_frac_algorithmic": achieved / HBM_PEAK_GBS,
+                "roofline_frac_layout_min": layout_min / max(1, gather_launches) / (gather_ms / max(1, gather_launches) * 1e-3) / 1e9 / HBM_PEAK_GBS if gather_ms else None,
                 "counter_row_bytes_per_query": 0,
                 "counter_bytes_written_per_step": int(nsurv.sum().item()) * 8 + int(ncand.sum().item()) * 4 + 8 * nq_all,
                 "counter_bytes_written_per_step_with_rows": 2 * N * nq_all,
@@ -777,6 +880,90 @@ def main():
         dist.destroy_process_group()
 
 
+def roofline_record(achieved_alg, traffic, traffic_source, live, gather_ms, launches, alg_bytes, layout_min, copy_gbs, measured_in,
+                    T, n_q_local, pipeline):
+    """The `roofline` object of the line.  `frac` is what the memory system moved (PMC counters, per launch) over the
+    launch time over the spec peak -- at most 1 by construction; without a counter measurement for this shape, the bytes
+    the layout cannot avoid stand in (a lower bound of the traffic).  SURVEY.md 8(d)'s algorithmic figure (4-byte ids,
+    every query's lines counted for itself) is `achieved` / `frac_algorithmic`: the layout stores 2-byte ids and an
+    XCD's L2 serves lines that neighbouring queries share, so that one can pass 1."""
+    n = max(1, launches)
+    t_launch = gather_ms / n * 1e-3
+    alg_l, lay_l = alg_bytes / n, layout_min / n
+    real_gbs = traffic / t_launch / 1e9 if (traffic and t_launch) else None
+    lay_gbs = lay_l / t_launch / 1e9 if t_launch else None
+    basis_gbs = real_gbs if real_gbs is not None else lay_gbs
+    rec = {
+        "kernel": "nq::gather_kernel (gather-histogram, rank 0's slot shard) incl. its look-up pre-pass and probe / order passes",
+        "bound": "hbm", "achieved": achieved_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": (basis_gbs / HBM_PEAK_GBS) if basis_gbs else None,
+        "frac_basis": ("traffic: (2 x FETCH_SIZE + WRITE_SIZE) per launch / avg_launch_ms / peak" if real_gbs is not None
+                       else "layout_min_bytes_per_launch / avg_launch_ms / peak (no counter measurement for this shape in this run: "
+                            "a lower bound of the bytes moved)"),
+        "achieved_measured": real_gbs,
+        "frac_algorithmic": achieved_alg / HBM_PEAK_GBS,
+        "frac_layout_min": (lay_gbs / HBM_PEAK_GBS) if lay_gbs else None,
+        "traffic": traffic, "traffic_source": traffic_source,
+        "traffic_over_layout_min": (traffic / lay_l) if (traffic and lay_l) else None,
+        "traffic_fetch_kb": live["fetch_kb"] if live else None, "traffic_write_kb": live["write_kb"] if live else None,
+        "copy_gbs": copy_gbs,
+        "copy_ceiling_frac": (real_gbs / copy_gbs) if (real_gbs and copy_gbs) else None,
+        "note": ("achieved / frac_algorithmic count the ALGORITHMIC bytes of SURVEY.md 8d (4 bytes per id as the reference stores "
+                 "them, bucket lines that neighbouring queries share counted for each): the layout moves 2-byte ids and an XCD's "
+                 "L2 serves shared lines, so that figure can pass 1.  frac is the counter traffic; FETCH_SIZE counts requests that "
+                 "leave the L2, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM section), so frac is an UPPER bound of the "
+                 "HBM-proper fraction.  traffic_over_layout_min: bytes moved over the bytes this layout cannot avoid (half-empty "
+                 "128-byte bucket lines are the difference)"
+                 + ("; with the next batch's sketch kernel beside the gather the two share the CUs, the gather launch time here "
+                    "is not a roofline figure" if pipeline else "")),
+        "algorithmic_bytes_per_launch": alg_l,
+        "layout_min_bytes_per_launch": lay_l,
+        "launches": launches, "avg_launch_ms": gather_ms / n,
+        "measured_in": measured_in or "the timed steps",
+        "gathered_ids_per_query": T / max(1, n_q_local),
+    }
+    return rec
+
+
+def host_cpu_info():
+    """What this process may use of the host: logical CPUs, physical cores, the affinity mask and the cgroup's CPU
+    quota (a container is often handed a share of the node: more threads than that only take turns)."""
+    phys = set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count()
+    return {"logical_cpus": os.cpu_count(), "physical_cores": len(phys) or None, "affinity_cpus": aff,
+            "cgroup_cpu_quota": quota}
+
+
 def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, prm):
     """The oracle (port of the reference CPU path) on this host, on a bounded
     sample of the same workload; also the in-run parity check (sketches, dense counters and the
@@ -784,20 +971,29 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
     from oracle import pyoracle as po
     K, S, W, H, J = prm
     p = po.make_params(K, S, W, H, J)
-    cores = po.lib().nqo_max_threads()
-    n_s = int(min(per, max(8, 2 * cores)))
+    host = host_cpu_info()
+    omp_max = po.lib().nqo_max_threads()
+    phys = host["physical_cores"] or omp_max
+    # thread counts: the physical cores and the logical CPUs (what the host has), the cgroup quota if there is one
+    # (what this process gets), and halvings in between: the scaling table says which of them is the limit
+    cand = {omp_max, min(omp_max, phys), max(1, min(omp_max, phys) // 2), max(1, min(omp_max, phys) // 4)}
+    if host["cgroup_cpu_quota"]:
+        qn = max(1, int(round(host["cgroup_cpu_quota"])))
+        cand |= {min(omp_max, qn), min(omp_max, 2 * qn)}
+    cand = sorted(cand, reverse=True)
+    n_s = int(min(per, max(8, 2 * min(omp_max, phys))))
     si = args.warmup + args.steps - 1  # the last timed step: its hits are what hc / hg still hold
     bi = si % qsk.shape[0]
     seqs = qseq[bi * per * stride_b: bi * per * stride_b + n_s * stride_b].cpu().numpy()
     rec = np.stack([seqs[i * stride_b:i * stride_b + L] for i in range(n_s)])
     rec_off = (np.arange(n_s + 1) * L).astype(np.uint64)
-    # the host may hand this process fewer CPUs than it has threads: time the sketch leg
-    # at a few thread counts and keep the fastest (that count is what `cores` reports)
-    t_sk, sk_cpu, best_threads = None, None, cores
-    for th in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
+    # sketch leg at every thread count (each pass sketches all n_s genomes: a few seconds together)
+    t_sk, sk_cpu, best_threads, sk_table = None, None, cand[0], {}
+    for th in cand:
         t0 = time.perf_counter()
         out = po.sketch_batch(p, rec.reshape(-1), rec_off, threads=th)
         t = time.perf_counter() - t0
+        sk_table[th] = n_s / t
         if t_sk is None or t < t_sk:
             t_sk, sk_cpu, best_threads = t, out, th
     cores = best_threads
@@ -805,19 +1001,31 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
     parity_sketch = bool(np.array_equal(sk_cpu, sk_gpu))
     # gather leg: the oracle's query loop timed on EVERY sub-index of <= 16384 genomes the index is cut into
     # (the seven of them hold all 100 000 genomes: their sum is the whole-index figure, nothing extrapolated);
+    # the sub-index' arrays are first touched by the threads that gather from them (nqo_index_spread);
     # parity over ALL columns from the same seven sub-indexes
     n_par = min(n_s, 8)
     exp_cols = np.zeros((n_par, N), np.uint32)
     cnt = eng.query_counts(sk_gpu[:n_par])
-    t_q, n_sub_ix = 0.0, 0
+    t_q, n_sub_ix, q_table, q_threads = 0.0, 0, {}, cores
     for b0 in range(0, N, 16384):
         n_sub = min(16384, N - b0)
         sub = eng.get_sketches(b0, n_sub)
         ix = po.Index(p, sub)
+        if b0 == 0:
+            # the first sub-index picks the thread count of the gather leg (random 4-byte reads: memory bound,
+            # its best count need not be the sketch leg's)
+            for th in cand:
+                ix.spread(th)
+                ix.query_batch(sk_cpu, threads=th)
+                t0 = time.perf_counter()
+                ix.query_batch(sk_cpu, threads=th)
+                q_table[th] = n_s / (time.perf_counter() - t0)
+            q_threads = max(q_table, key=q_table.get)
+        ix.spread(q_threads)
         best = None
         for _ in range(2):        # first pass warms the pages, keep the faster
             t0 = time.perf_counter()
-            ix.query_batch(sk_cpu, threads=cores)
+            ix.query_batch(sk_cpu, threads=q_threads)
             t = time.perf_counter() - t0
             best = t if best is None else min(best, t)
         t_q += best
@@ -837,27 +1045,69 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
         parity_hits &= bool(np.array_equal(g_hc[lo:hi].astype(np.uint32), exp_cols[i, gids][order]) and
                             np.array_equal(g_hg[lo:hi].astype(np.uint32), gids[order].astype(np.uint32)))
     val = n_s / (t_sk + t_q)
-    phys = set()
-    try:
-        pid = cid = None
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("physical id"):
-                pid = line.split(":")[1].strip()
-            elif line.startswith("core id"):
-                cid = line.split(":")[1].strip()
-            elif not line.strip():
-                if pid is not None and cid is not None:
-                    phys.add((pid, cid))
-                pid = cid = None
-    except OSError:
-        pass
+
+    # ---- the REAL reference's own code beside the port, where oracle/_ref travelled with the repo: its
+    # compute_sketch (src/niqki_index.cpp:335-358) on a few of the same genomes, and its insert_sketch + query_sketch
+    # (:362-370, :633-687; vector<gid>[2^27] buckets) on a 2048-genome sub-index, each on ONE thread next to the port
+    # on one thread -- same work, so the ratio says what the port's flat arrays change
+    ref = None
+    if po.have_ref():
+        try:
+            n_r, n_ri, n_rq = 4, 2048, 16
+            t0 = time.perf_counter()
+            r = po.Ref(K=K, S=S, W=W, H=H, J=J, out_path="/tmp/niqki_bench_ref_%d.gz" % os.getpid())
+            t_ctor = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            r_sk = [r.compute_sketch(rec[i]) for i in range(n_r)]
+            t_ref_sk = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            po.sketch_batch(p, rec[:n_r].reshape(-1), rec_off[:n_r + 1], threads=1)
+            t_port_sk = time.perf_counter() - t0
+            sub = eng.get_sketches(0, n_ri)
+            t0 = time.perf_counter()
+            for g in range(n_ri):
+                r.insert(sub[g])
+            t_ref_ins = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            ixr = po.Index(p, sub)
+            t_port_ins = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            r_hits = [r.query(sk_cpu[i]) for i in range(n_rq)]
+            t_ref_q = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            p_hits = [ixr.query(sk_cpu[i]) for i in range(n_rq)]
+            t_port_q = time.perf_counter() - t0
+            same = all(np.array_equal(r_sk[i], sk_cpu[i]) for i in range(n_r)) and \
+                all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(r_hits, p_hits))
+            r.close()
+            try:
+                os.remove("/tmp/niqki_bench_ref_%d.gz" % os.getpid())
+            except OSError:
+                pass
+            del ixr, sub
+            ref = {"kind": "reference", "threads": 1, "constructor_s": t_ctor,
+                   "sketch_genomes_per_s": n_r / t_ref_sk, "port_sketch_genomes_per_s": n_r / t_port_sk,
+                   "insert_genomes_per_s": n_ri / t_ref_ins, "port_index_build_genomes_per_s": n_ri / t_port_ins,
+                   "query_per_s_on_%d_genomes" % n_ri: n_rq / t_ref_q, "port_query_per_s_on_%d_genomes" % n_ri: n_rq / t_port_q,
+                   "reference_equals_port": bool(same),
+                   "sample": "the reference's own Index class (oracle/_ref/libniqki_ref.so, built from /root/reference/src by "
+                             "oracle/Makefile): compute_sketch on %d query genomes; insert_sketch of %d indexed genomes; query_sketch "
+                             "of %d queries against them -- one thread, the port timed on the same work beside it" % (n_r, n_ri, n_rq)}
+        except Exception as e:      # noqa: BLE001 -- a baseline beside the baseline: never the run's failure
+            ref = {"error": str(e)[:200]}
     return {
         "value": val, "unit": "genomes/s", "cores": cores, "kind": "port",
-        "host_logical_cpus": os.cpu_count(), "host_physical_cores": len(phys) or None,
-        "threads_tried": sorted({po.lib().nqo_max_threads(), max(1, po.lib().nqo_max_threads() // 2), max(1, po.lib().nqo_max_threads() // 4)}),
-        "sample": "%d query genomes of step %d on %d threads (the fastest of the thread counts tried): sketch leg timed in "
-                  "full (%.2f s); gather leg = the oracle's query loop timed on each of the %d sub-indexes of <= 16384 genomes "
-                  "that together hold all %d genomes, summed (%.2f s)" % (n_s, si, cores, t_sk, n_sub_ix, N, t_q),
+        "host_logical_cpus": host["logical_cpus"], "host_physical_cores": host["physical_cores"],
+        "host_affinity_cpus": host["affinity_cpus"], "host_cgroup_cpu_quota": host["cgroup_cpu_quota"],
+        "threads_tried": cand,
+        "sketch_genomes_per_s_by_threads": {str(k): v for k, v in sorted(sk_table.items())},
+        "gather_queries_per_s_by_threads_first_sub_index": {str(k): v for k, v in sorted(q_table.items())},
+        "gather_threads": q_threads,
+        "sample": "%d query genomes of step %d: sketch leg timed in full on %d threads (the fastest of the thread counts tried, "
+                  "%.2f s); gather leg = the oracle's query loop on %d threads (its own fastest) timed on each of the %d sub-indexes of "
+                  "<= 16384 genomes that together hold all %d genomes, summed (%.2f s); the index arrays first touched by the "
+                  "gathering threads" % (n_s, si, cores, t_sk, q_threads, n_sub_ix, N, t_q),
+        "reference_sample": ref,
         "parity": {"sketch_bit_exact": parity_sketch, "counts_bit_exact_all_columns": parity_counts,
                    "hit_lists_bit_exact": parity_hits, "queries_checked": n_par},
     }
@@ -944,8 +1194,31 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
                    "queries_checked": len(range(0, N1, 16))},
         "cpu_oracle": cpu1,
     }
-    del ix, seq, sk
+    del ix
     e.close()
+
+    # ---- -K other than 31 (src/niqki.cpp:260): the sketch kernel's rate at K = 21 on the same bytes ----
+    p21 = po.make_params(21, S, W, H, J)
+    e21 = niqki_amd.Engine(K=21, S=S, W=W, H=4, J=0.1, device=dev.index)
+    e21.set_stream(torch.cuda.current_stream().cuda_stream)
+    e21.set_option("record_len_hint", L)
+    e21.sketch_dev(seq, ro, N1, sk)
+    t21 = timed(lambda: e21.sketch_dev(seq, ro, N1, sk), e21, reps=2)
+    e31 = engine(S, W)
+    sk31 = torch.empty_like(sk)
+    e31.sketch_dev(seq, ro, N1, sk31)
+    t31 = timed(lambda: e31.sketch_dev(seq, ro, N1, sk31), e31, reps=2)
+    sk21h = sk[:2].cpu().numpy()
+    par21 = all(np.array_equal(sk21h[i], po.compute_sketch(p21, seq[i * L:(i + 1) * L].cpu().numpy())) for i in range(2))
+    out["sketch_k21"] = {
+        "workload": "the sketch kernel alone on 1000 synthetic %d bp genomes, K = 21 beside K = 31 (S=15 W=12)" % L,
+        "k21_gkmers_per_s": N1 * (L - 21) / t21 / 1e9, "k31_gkmers_per_s": N1 * (L - 31) / t31 / 1e9,
+        "k21_over_k31": (N1 * (L - 21) / t21) / (N1 * (L - 31) / t31),
+        "parity": {"sketch_bit_exact": bool(par21), "sketches_checked": 2},
+    }
+    e21.close()
+    e31.close()
+    del sk31, seq, sk
 
     # ---- matrix path: all-vs-all of a 10k-genome index (query_range / query_matrix) ----
     NM, GB = 10_000, 250
@@ -1049,6 +1322,9 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
     p4.min_score = min_score
     rskh = rsk[:64].cpu().numpy()
     par_sk = all(np.array_equal(rskh[i], po.compute_sketch(p4, rd[i])) for i in range(64))
+    # densification passes of these reads (the oracle's loop is the reference's: src/niqki_index.cpp:313-331)
+    passes = [po.densify(p4, po.sketch_accumulate(p4, rd[i]))[1] for i in range(64)]
+    passes_per_read = float(np.mean([x for x in passes if x > 0])) if any(x > 0 for x in passes) else 0.0
     ix4 = po.Index(p4, e.get_sketches(0, N4))
     off, c_, g_ = rho.cpu().numpy(), rhc.cpu().numpy(), rhg.cpu().numpy()
     par_hits = all(hits_equal(off, c_, g_, i, ix4.counts(rskh[i]), min_score) for i in range(64))
@@ -1062,12 +1338,43 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
         ix4.query_batch(skc, threads=th)
         cpu4 = {"reads_per_s": n_c / (time.perf_counter() - t0), "threads": th, "kind": "port",
                 "sample": "%d reads: sketch (densification dominated, src/niqki_index.cpp:313-331) + query" % n_c}
+    # ceilings of the two big kernels of this workload, measured / computed now:
+    #  * sketch: its time is the densification passes (one LDS round trip each at 8 wavefronts per CU); the ceiling is
+    #    the rate of those passes with nothing but their LDS traffic and exit test (niqki_measure_alu(5))
+    #  * gather: HBM -- per read its sketch in (4F), its counter row out (2N) and the table entries and bucket ids
+    #    of the look-ups the per-slot class mask lets through (measured: T ids + their entries)
+    pass_rate = e.measure_alu(5)
+    sk_s = kprof["sketch"] * 1e-3
+    sk_pass_rate = NR * passes_per_read / sk_s if sk_s else 0.0
+    T4 = float(e.gathered_dev(rsk, RB).sum()) / RB        # ids gathered per read (last batch)
+    g_bytes = NR * (4 * F4 + 2 * N4 + 4 * T4 + 8 * T4)
+    g_s = kprof["gather"] * 1e-3
+    h_bytes = NR * (2 * N4) + 8 * float(th_.sum())
+    h_s = kprof["hits"] * 1e-3
+    ceilings = {
+        "sketch": {"bound": "lds round trips of the densification passes", "passes_per_read": passes_per_read,
+                   "achieved_passes_per_s": sk_pass_rate, "peak_passes_per_s": pass_rate,
+                   "frac": sk_pass_rate / pass_rate if pass_rate else None,
+                   "note": "peak = niqki_measure_alu(5): the pass loop of the short-read kernel (8 one-wave workgroups per CU, two "
+                           "proposals + two read-backs per lane and pass) with nothing but its LDS traffic and exit test, measured "
+                           "in this run; achieved = reads/s of the sketch kernel x the passes the oracle's serial loop takes for "
+                           "64 of these reads (k-mer hashing and the entry list are inside the kernel's time, outside the peak)"},
+        "gather": {"bound": "hbm", "algorithmic_bytes_per_read": 4 * F4 + 2 * N4 + 12 * T4, "gathered_ids_per_read": T4,
+                   "achieved": g_bytes / g_s / 1e9 if g_s else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": g_bytes / g_s / 1e9 / HBM_PEAK_GBS if g_s else None,
+                   "class_mask": int(e.stat("class_mask")),
+                   "note": "per read: its 2^S-cell sketch in, its 2N-byte counter row out, and the entries and ids of the buckets "
+                           "it touches; with the per-slot class mask the 2^S table look-ups of a read are not memory traffic any more"},
+        "hits": {"bound": "hbm", "achieved": h_bytes / h_s / 1e9 if h_s else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": h_bytes / h_s / 1e9 / HBM_PEAK_GBS if h_s else None},
+    }
     out["configs4_reads_vs_10k_index"] = {
         "workload": "%d distinct 150-base reads (1 %% substitutions, generated on the device) against a 10000-genome index, "
                     "K=31 S=12 W=10, one sketch per read, batches of %d resident in HBM" % (NR, RB),
         "reads_per_s": NR / t_reads, "seconds": t_reads, "min_score": min_score, "J_equivalent": min_score / F4,
         "hits_total": int(th_.sum()), "hits_per_read": float(th_.sum()) / NR, "hit_overflow": bool((th_ > rcap).any()),
         "kernel_ms": {k_: round(v, 1) for k_, v in kprof.items()},
+        "ceilings": ceilings,
         "parity": {"device_reads_equal_host_generator": bool(np.array_equal(rd, host_rd)), "sketch_bit_exact": bool(par_sk),
                    "hit_lists_bit_exact": bool(par_hits), "reads_checked": 64},
         "cpu_oracle": cpu4,

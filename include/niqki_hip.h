@@ -142,7 +142,11 @@ int niqki_synchronize(niqki_index *ix);
  * answers as a resident index.  Insert, the dump import (niqki_params.resident_mib), every query
  * call, niqki_get_sketches, niqki_matrix_range (the stored sketches are read from the host store)
  * and the dump export (page after page) work on a paged handle; niqki_query_gathered, the
- * candidate / survivor calls and groups do not (NIQKI_E_STATE / NIQKI_E_INVALID)). */
+ * candidate / survivor calls and groups do not (NIQKI_E_STATE / NIQKI_E_INVALID)),
+ * "stream_priority" (1 / 0 / -1: the handle gets a stream of its own, made at the top / default / bottom of
+ * the device's stream priority range -- also after niqki_set_stream, whose stream stays the caller's --, so
+ * that e.g. a query handle's short kernels are dispatched ahead of another handle's long sketch kernel;
+ * niqki_get_stream returns it). */
 int niqki_set_option(niqki_index *ix, const char *key, int64_t value);
 
 /* Pre-sizes the sketch store for n_genomes (optional; the store grows). */
@@ -433,7 +437,10 @@ const char *niqki_group_last_error(const niqki_group *g);
 int niqki_group_set_option(niqki_group *g, const char *key, int64_t value);
 /* "overflows" (sparse steps redone densely so far), "rccl" (1 = RCCL transport),
  * "transport" (0 = device copies inside one process, 1 = RCCL, 2 = ipc),
- * "sparse" (1 = the sparse exchange is selected). */
+ * "sparse" (1 = the sparse exchange is selected), "ipc_words_kind" (ipc transport: where this rank's
+ * sequence words live -- 1 = fine-grained device memory mapped by the peers, 2 = the processes' shared block
+ * page-locked and mapped into every device, 0 = plain device memory), "ipc_arena_fine" (1 = its exchange
+ * buffers are fine-grained device memory). */
 int niqki_group_get_stat(const niqki_group *g, const char *key, uint64_t *value);
 /* Index::insert_sketch for a batch of world * per sketches of which rank r holds rows
  * [r*per, (r+1)*per) (local_sketches[i]: per x 2^S int32, device memory); the first
@@ -492,7 +499,11 @@ enum niqki_kernel_class {
  * slots per page; 1 / all slots unless the index is paged), "delta_genomes" (genomes indexed by
  * the delta segment, see option "incremental_build"), "last_gather_form" (launch form the last
  * counter call used: bit 0 look-up pre-pass, bit 1 its streamed-rows kernel, bit 2 locality
- * order). */
+ * order), "class_mask" (1 = the built index carries its per-slot class mask: single-tile
+ * indexes; the gather kernel then looks up only fingerprints whose sixteenth of the
+ * fingerprint range holds a bucket in their slot -- a short read against a genome index
+ * skips nearly all of its 2^S table look-ups; results are unaffected; NIQKI_HMASK=0 in the
+ * environment builds indexes without it). */
 int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value);
 int niqki_profile_enable(niqki_index *ix, int on);
 int niqki_profile_reset(niqki_index *ix);
@@ -523,8 +534,11 @@ int niqki_synth_reads(niqki_index *ix, uint64_t seed, const uint32_t *family, co
  * kernel's per-k-mer arithmetic alone (K = 31 roll + canonical choice + filter hash; no LDS,
  * memory or compaction), 3 = three-operand integer instructions (v_lshl_add_u32: the issue class of
  * every gfx950 vector opcode except add / sub / and / or / xor / mov / shift-right), 4 = a streaming
- * copy of 1 GiB (bytes read + written per second: the HBM rate a plain kernel reaches).
- * *rate = adds / multiplies / k-mers / instructions / bytes per second over ~ms milliseconds. */
+ * copy of 1 GiB (bytes read + written per second: the HBM rate a plain kernel reaches), 5 = the
+ * densification passes of the short-read sketch kernel with nothing but their LDS traffic and exit
+ * test (one wavefront per sketch, 8 per CU, two proposals + two read-backs per lane and pass: the
+ * LDS round-trip ceiling of src/niqki_index.cpp:313-331 on this device).
+ * *rate = adds / multiplies / k-mers / instructions / bytes / passes per second over ~ms milliseconds. */
 int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate);
 
 #ifdef __cplusplus

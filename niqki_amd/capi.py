@@ -226,6 +226,10 @@ class Engine:
     def set_stream(self, stream_ptr):
         self._ck(self.L.niqki_set_stream(self.h, stream_ptr))
 
+    def get_stream(self):
+        """The hipStream_t the handle enqueues on (an int, for torch.cuda.ExternalStream)."""
+        return int(self.L.niqki_get_stream(self.h) or 0)
+
     def synchronize(self):
         self._ck(self.L.niqki_synchronize(self.h))
 

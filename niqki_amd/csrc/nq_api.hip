@@ -144,6 +144,8 @@ nq::IndexView view(const niqki_index *ix) {
   v.tile_base = ix->tile_base;
   v.slot_units = ix->slot_units;
   v.ptab = ix->ptab_ok ? ix->ptab : nullptr;
+  v.hmask = ix->hmask_ok ? ix->hmask : nullptr;
+  v.hmask_shift = ix->d.W > 4 ? ix->d.W - 4 : 0;
   return v;
 }
 
@@ -251,6 +253,7 @@ void swap_segment(niqki_index *ix) {
   std::swap(ix->g_base, a.g_base); std::swap(ix->align_log2, a.align_log2);
   std::swap(ix->padded, a.padded); std::swap(ix->stripe, a.stripe);
   std::swap(ix->ptab, a.ptab); std::swap(ix->ptab_bytes, a.ptab_bytes); std::swap(ix->ptab_ok, a.ptab_ok);
+  std::swap(ix->hmask, a.hmask); std::swap(ix->hmask_bytes, a.hmask_bytes); std::swap(ix->hmask_ok, a.hmask_ok);
 }
 
 int build_range(niqki_index *ix, uint32_t g_base, uint32_t N);
@@ -446,7 +449,8 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
     const bool fork = ordered && n >= 64 && pre;   // probe + order beside the pre-pass (both only read the sketches)
     if (fork) {
       if (!ix->aux_stream) {
-        NQ_HIP(ix, hipStreamCreateWithFlags(&ix->aux_stream, hipStreamNonBlocking));
+        if (ix->stream_prio_set) NQ_HIP(ix, hipStreamCreateWithPriority(&ix->aux_stream, hipStreamNonBlocking, ix->stream_prio));
+        else NQ_HIP(ix, hipStreamCreateWithFlags(&ix->aux_stream, hipStreamNonBlocking));
         NQ_HIP(ix, hipEventCreateWithFlags(&ix->ev_fork, hipEventDisableTiming));
         NQ_HIP(ix, hipEventCreateWithFlags(&ix->ev_join, hipEventDisableTiming));
       }
@@ -713,7 +717,7 @@ void niqki_destroy(niqki_index *ix) {
   if (ix->store && !ix->resident_bytes) (void)hipFree(ix->store);
   if (ix->host_store) (void)hipHostFree(ix->host_store);
   for (void *p : {(void *)ix->alt.entries, (void *)ix->alt.gids, (void *)ix->alt.tile_base, (void *)ix->alt.slot_units,
-                  (void *)ix->alt.ptab, (void *)ix->ptab})
+                  (void *)ix->alt.ptab, (void *)ix->ptab, (void *)ix->alt.hmask, (void *)ix->hmask})
     if (p) (void)hipFree(p);
   if (ix->entries) (void)hipFree(ix->entries);
   if (ix->gids) (void)hipFree(ix->gids);
@@ -797,6 +801,29 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
     return NIQKI_OK;
   }
   if (!std::strcmp(key, "record_len_hint")) { ix->record_len_hint = (uint64_t)value; return NIQKI_OK; }
+  if (!std::strcmp(key, "stream_priority")) {
+    // a stream of the handle's own (and its side stream) made anew, at the top (1), default (0) or bottom (-1) of the
+    // device's priority range: the hardware scheduler hands free CUs to the queue of higher priority first
+    if (value < -1 || value > 1) return fail(ix, NIQKI_E_INVALID, "stream_priority: 1 = high, 0 = default, -1 = low");
+    NQ_HIP(ix, hipSetDevice(ix->device));
+    int least = 0, greatest = 0;   // (numerically: greatest priority = the smallest value)
+    NQ_HIP(ix, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int prio = value > 0 ? greatest : (value < 0 ? least : 0);
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    hipStream_t s = nullptr;
+    NQ_HIP(ix, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio));
+    if (ix->own_stream) (void)hipStreamDestroy(ix->stream);   // (a caller's stream, niqki_set_stream, is the caller's to keep)
+    ix->stream = s;
+    ix->own_stream = true;
+    if (ix->aux_stream) {
+      NQ_HIP(ix, hipStreamSynchronize(ix->aux_stream));
+      (void)hipStreamDestroy(ix->aux_stream);
+      ix->aux_stream = nullptr;
+    }
+    ix->stream_prio = prio;
+    ix->stream_prio_set = true;
+    return NIQKI_OK;
+  }
   if (!std::strcmp(key, "min_score")) { ix->p.min_score = ix->d.min_score = (uint32_t)value; return NIQKI_OK; }
   return fail(ix, NIQKI_E_INVALID, std::string("unknown option ") + key);
 }
@@ -910,7 +937,7 @@ int niqki_build(niqki_index *ix) {
     ix->built_n = ix->n_genomes;
     // the delta segment's buffers are not needed until genomes arrive again: give their memory back
     auto &a = ix->alt;
-    for (void *p : {(void *)a.entries, (void *)a.gids, (void *)a.tile_base, (void *)a.slot_units, (void *)a.ptab})
+    for (void *p : {(void *)a.entries, (void *)a.gids, (void *)a.tile_base, (void *)a.slot_units, (void *)a.ptab, (void *)a.hmask})
       if (p) (void)hipFree(p);
     a = niqki_index::Seg();
   }
@@ -972,6 +999,7 @@ int build_range(niqki_index *ix, uint32_t g_base, uint32_t N) {
   ix->tile = tile;
   ix->n_tiles = n_tiles;
   ix->ptab_ok = false;
+  ix->hmask_ok = false;
   ix->seg_n = N;
   ix->g_base = g_base;
   ix->align_log2 = (uint32_t)al;
@@ -1004,6 +1032,17 @@ int build_range(niqki_index *ix, uint32_t g_base, uint32_t N) {
   {
     Span sp(ix, NIQKI_KC_BUILD);
     NQ_HIP(ix, nq::launch_build_fill(view(ix), ix->entries, ix->gids, ix->stream));
+  }
+  // single-tile indexes: the per-slot class mask the gather kernel's own look-ups test first (IndexView::hmask;
+  // NIQKI_HMASK=0 leaves it out).  One more pass over the table: 32 MB at S = 12 W = 10.
+  {
+    const char *hv = std::getenv("NIQKI_HMASK");
+    if (n_tiles == 1 && !(hv && hv[0] == '0')) {
+      if ((rc = grow((void **)&ix->hmask, ix->hmask_bytes, (size_t)f_local * 2))) return rc;
+      Span sp(ix, NIQKI_KC_BUILD);
+      NQ_HIP(ix, nq::launch_hmask(view(ix), ix->hmask, ix->stream));
+      ix->hmask_ok = true;
+    }
   }
   commit.ok = true;
   ix->built = true;
@@ -1789,6 +1828,7 @@ int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value) {
   if (!std::strcmp(key, "index_bytes")) { *value = ix->built ? (uint64_t)ix->entries_bytes + ix->gids_bytes + ix->ptab_bytes + ix->alt.entries_bytes + ix->alt.gids_bytes + ix->alt.ptab_bytes : 0; return NIQKI_OK; }
   if (!std::strcmp(key, "delta_genomes")) { *value = ix->delta_n; return NIQKI_OK; }
   if (!std::strcmp(key, "tiles")) { *value = ix->n_tiles; return NIQKI_OK; }
+  if (!std::strcmp(key, "class_mask")) { *value = (ix->built && ix->hmask_ok) ? 1 : 0; return NIQKI_OK; }
   if (!std::strcmp(key, "last_gather_form")) { *value = ix->last_form; return NIQKI_OK; }
   if (!std::strcmp(key, "page_slots")) { *value = ix->resident_bytes ? page_slots(ix) : f_all; return NIQKI_OK; }
   if (!std::strcmp(key, "pages")) {
@@ -1857,7 +1897,7 @@ int niqki_synth_reads(niqki_index *ix, uint64_t seed, const uint32_t *family, co
 }
 
 int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate) {
-  if (!ix || !rate || what < 0 || what > 4 || !(ms > 0)) return NIQKI_E_INVALID;
+  if (!ix || !rate || what < 0 || what > 5 || !(ms > 0)) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
   if (what == 4) {   // streaming copy of 1 GiB: bytes read + bytes written per second
     const uint64_t bytes = 1ull << 30;

@@ -112,15 +112,26 @@ struct IpcRank {
   uint64_t buf_off[kIpcBufs];         // ... buffer i at arena + buf_off[i]
   uint64_t gen;                       // bumped when `arena` names a new allocation
   int32_t device;
+  uint32_t words_kind;                // where the rank's sequence words live (kWords*)
+  uint32_t arena_fine;                // 1 = the arena is fine-grained device memory
+  char pci[32];                       // the rank's device (hipDeviceGetPCIBusId): peers check that they can reach it
 };
+// Memory kinds of a rank's sequence words.  A peer GPU polls them from a RUNNING kernel, so they must be
+// coherent at system scope by contract, not by observed behaviour: fine-grained device memory (what RCCL keeps
+// its own flags in), or -- where that cannot be made or exported -- words in the POSIX shared block itself,
+// page-locked and mapped into every process (hipHostRegister: host-coherent).  Plain hipMalloc memory
+// (coarse-grained: coherent across devices only at kernel boundaries) is the last resort and is reported.
+constexpr uint32_t kWordsCoarse = 0, kWordsFine = 1, kWordsHost = 2;
+constexpr uint32_t kFlagWordsMax = 64;
 struct IpcShared {
   std::atomic<uint32_t> init, bar_count, bar_gen, abort;
   std::atomic<uint32_t> export_lock;   // one rank at a time allocates and exports its arena
   IpcRank r[kMaxWorld];
+  alignas(256) uint32_t host_words[kMaxWorld][kFlagWordsMax];   // kWordsHost: rank r's sequence words
 };
 // sequence words of a rank (device memory, mapped by every peer): ready[b] = uses of buffer b whose data
 // is complete, done[b] = uses whose data this rank has finished reading from ALL peers, err = a wait timed out
-constexpr uint32_t kFlagReady = 0, kFlagDone = kIpcBufs, kFlagErr = 2 * kIpcBufs, kFlagWords = 64;
+constexpr uint32_t kFlagReady = 0, kFlagDone = kIpcBufs, kFlagErr = 2 * kIpcBufs, kFlagWords = kFlagWordsMax;
 
 }  // namespace
 
@@ -416,6 +427,10 @@ struct niqki_group {
     uint64_t peer_gen[kMaxWorld] = {};
     Buf arena;                                 // my exchange buffers (ws.send / cand / mine / counts are views of it)
     bool ready = false;                        // ipc_setup went through: peers exist and wait in barriers
+    uint32_t words_kind = kWordsCoarse;        // where MY sequence words live
+    bool arena_fine = false;                   // my arena is fine-grained device memory
+    bool shm_registered = false;               // the shared block is page-locked and mapped for this device
+    uint32_t (*host_words_dev)[kFlagWordsMax] = nullptr;   // device view of IpcShared::host_words
     uint32_t seq[kIpcBufs] = {};               // uses of each exchange buffer so far
   } ipc;
   // a query batch between niqki_group_query_begin and _end
@@ -493,7 +508,24 @@ int ipc_buf_index(Buf niqki_group::Ws::*m) {
   return -1;
 }
 
-int ipc_export_alloc(niqki_group *g, size_t bytes, void **out, hipIpcMemHandle_t *h, uint64_t *off);
+int ipc_export_alloc(niqki_group *g, size_t bytes, bool fine, void **out, hipIpcMemHandle_t *h, uint64_t *off);
+bool env_is(const char *name, const char *value) {
+  const char *e = std::getenv(name);
+  return e && !std::strcmp(e, value);
+}
+// the shared block page-locked and mapped for my device (kWordsHost words of any rank are read through it)
+int ipc_register_block(niqki_group *g) {
+  auto &ic = g->ipc;
+  if (ic.shm_registered) return NIQKI_OK;
+  NQ_GH(g, hipSetDevice(g->sh[0]->device));
+  NQ_GH(g, hipHostRegister(ic.shm, sizeof(IpcShared), hipHostRegisterMapped | hipHostRegisterPortable));
+  void *d = nullptr;
+  hipError_t e = hipHostGetDevicePointer(&d, ic.shm->host_words, 0);
+  if (e != hipSuccess) { (void)hipHostUnregister(ic.shm); return gfail(g, NIQKI_E_HIP, std::string("hipHostGetDevicePointer(shared block): ") + hipGetErrorString(e)); }
+  ic.host_words_dev = (uint32_t (*)[kFlagWordsMax])d;
+  ic.shm_registered = true;
+  return NIQKI_OK;
+}
 // a peer's exported allocation into this process (a few tries: the same transient failure as on the export side)
 hipError_t ipc_open(void **q, const hipIpcMemHandle_t &h) {
   hipError_t e = hipSuccess;
@@ -538,26 +570,62 @@ int ipc_setup(niqki_group *g, const uint8_t *id) {
       if (now_s() - t0 > kIpcHostTimeout) return gfail(g, NIQKI_E_STATE, "the group's shared block was never initialised");
       usleep(50);
     }
-  // my sequence words
+  // my sequence words: fine-grained device memory that peers map (NIQKI_IPC_WORDS=host / coarse force the other kinds)
   NQ_GH(g, hipSetDevice(ix->device));
   IpcRank &me = ic.shm->r[g->first];
-  {
+  auto give_up = [&](int code, const std::string &why) {   // the peers sit in a barrier: let them leave at once
+    ic.shm->abort.store(1, std::memory_order_relaxed);
+    return gfail(g, code, why);
+  };
+  int rc = NIQKI_OK;
+  ic.words_kind = env_is("NIQKI_IPC_WORDS", "host") ? kWordsHost : env_is("NIQKI_IPC_WORDS", "coarse") ? kWordsCoarse : kWordsFine;
+  if (ic.words_kind != kWordsHost) {
     void *fl = nullptr;
-    const int rc = ipc_export_alloc(g, kFlagWords * 4, &fl, &me.flags, &me.flags_off);
-    if (rc) return rc;
-    ic.flags = (uint32_t *)fl;
+    rc = ipc_export_alloc(g, kFlagWords * 4, ic.words_kind == kWordsFine, &fl, &me.flags, &me.flags_off);
+    if (rc && ic.words_kind == kWordsFine) { ic.words_kind = kWordsHost; rc = NIQKI_OK; }   // cannot be made or exported here
+    else if (rc) return give_up(rc, g->err);
+    else ic.flags = (uint32_t *)fl;
   }
-  NQ_GH(g, hipMemset(ic.flags, 0, kFlagWords * 4));
-  NQ_GH(g, hipDeviceSynchronize());
+  if (ic.words_kind == kWordsHost) {
+    if ((rc = ipc_register_block(g))) return give_up(rc, g->err);
+    ic.flags = ic.host_words_dev[g->first];
+    std::memset(ic.shm->host_words[g->first], 0, sizeof ic.shm->host_words[g->first]);
+  } else {
+    NQ_GH(g, hipMemset(ic.flags, 0, kFlagWords * 4));
+    NQ_GH(g, hipDeviceSynchronize());
+  }
+  me.words_kind = ic.words_kind;
   me.device = ix->device;
-  int rc = ipc_barrier(g);
-  if (rc) return rc;
+  std::memset(me.pci, 0, sizeof me.pci);
+  if (hipDeviceGetPCIBusId(me.pci, (int)sizeof me.pci - 1, ix->device) != hipSuccess) { (void)hipGetLastError(); me.pci[0] = 0; }
+  if ((rc = ipc_barrier(g))) return rc;
   for (uint32_t s = 0; s < g->world; ++s) {
     if (s == g->first) { ic.peer_flags[s] = ic.flags; continue; }
+    const IpcRank &pr = ic.shm->r[s];
+    // a peer on another device must be reachable from mine (xGMI / PCIe peer access): say so now rather than
+    // through a wait kernel's 30 s time-out.  (A peer whose device this process cannot see is left to the mapping.)
+    if (pr.pci[0] && me.pci[0] && std::strcmp(pr.pci, me.pci) != 0) {
+      int peer_dev = -1, can = 1;
+      if (hipDeviceGetByPCIBusId(&peer_dev, pr.pci) == hipSuccess && peer_dev >= 0) {
+        if (hipDeviceCanAccessPeer(&can, ix->device, peer_dev) != hipSuccess) { (void)hipGetLastError(); can = 1; }
+      } else {
+        (void)hipGetLastError();
+      }
+      if (!can)
+        return give_up(NIQKI_E_STATE, "ipc transport: device " + std::string(me.pci) + " (rank " + std::to_string(g->first) +
+                                          ") has no peer access to device " + pr.pci + " (rank " + std::to_string(s) +
+                                          "): use the rccl transport (NIQKI_GROUP_TRANSPORT=rccl)");
+    }
+    if (pr.words_kind == kWordsHost) {
+      if ((rc = ipc_register_block(g))) return give_up(rc, g->err);
+      ic.peer_flags[s] = ic.host_words_dev[s];
+      continue;
+    }
     void *q = nullptr;
-    NQ_GH(g, ipc_open(&q, ic.shm->r[s].flags));
+    const hipError_t e = ipc_open(&q, pr.flags);
+    if (e != hipSuccess) return give_up(NIQKI_E_HIP, std::string("hipIpcOpenMemHandle(sequence words of rank ") + std::to_string(s) + "): " + hipGetErrorString(e));
     ic.peer_flags_base[s] = q;
-    ic.peer_flags[s] = (uint32_t *)((char *)q + ic.shm->r[s].flags_off);
+    ic.peer_flags[s] = (uint32_t *)((char *)q + pr.flags_off);
   }
   if ((rc = ipc_barrier(g))) return rc;
   if (g->first == 0) shm_unlink(name);   // everybody has it mapped: the name can go
@@ -573,7 +641,9 @@ void ipc_teardown(niqki_group *g) {
     if (ic.peer_base[s]) (void)hipIpcCloseMemHandle(ic.peer_base[s]);
     if (ic.peer_flags_base[s]) (void)hipIpcCloseMemHandle(ic.peer_flags_base[s]);
   }
-  if (ic.flags) (void)hipFree(ic.flags);
+  if (ic.flags && ic.words_kind != kWordsHost) (void)hipFree(ic.flags);
+  ic.flags = nullptr;
+  if (ic.shm_registered) { (void)hipHostUnregister(ic.shm); ic.shm_registered = false; }
   if (ic.arena.p) (void)hipFree(ic.arena.p);
   for (uint32_t b = 0; b < kIpcBufs; ++b) g->ws[0].*kIpcBufMember[b] = Buf();   // (views of the arena)
   if (g->first == 0) shm_unlink(ic.name.c_str());   // (no-op once setup has finished)
@@ -586,7 +656,8 @@ void ipc_teardown(niqki_group *g) {
 // Exporting a fresh allocation now and then fails with "invalid argument" when two processes of one GPU do it
 // at the same moment (seen once in four runs of two ranks on one MI355X, on the rank that came second): the
 // ranks take turns, and a failed export is tried again on a new allocation.
-int ipc_export_alloc(niqki_group *g, size_t bytes, void **out, hipIpcMemHandle_t *h, uint64_t *off) {
+// fine: fine-grained device memory (hipExtMallocWithFlags), coherent at system scope while kernels run.
+int ipc_export_alloc(niqki_group *g, size_t bytes, bool fine, void **out, hipIpcMemHandle_t *h, uint64_t *off) {
   auto &ic = g->ipc;
   const double t0 = now_s();
   uint32_t unlocked = 0;
@@ -600,7 +671,7 @@ int ipc_export_alloc(niqki_group *g, size_t bytes, void **out, hipIpcMemHandle_t
   hipError_t e = hipSuccess;
   for (int attempt = 0; attempt < 6; ++attempt) {
     if (p) { (void)hipFree(p); p = nullptr; usleep(2000u << attempt); }
-    e = hipMalloc(&p, bytes);
+    e = fine ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) : hipMalloc(&p, bytes);
     if (e != hipSuccess) { p = nullptr; break; }
     e = hipMemGetAddressRange((hipDeviceptr_t *)&base, &sz, (hipDeviceptr_t)p);
     if (e != hipSuccess) break;
@@ -611,8 +682,9 @@ int ipc_export_alloc(niqki_group *g, size_t bytes, void **out, hipIpcMemHandle_t
   ic.shm->export_lock.store(0u, std::memory_order_release);
   if (e != hipSuccess) {
     char msg[256];
-    std::snprintf(msg, sizeof msg, "exchange memory for peers (%zu bytes at %p, allocation %p of %zu bytes): %s", bytes, p, base, sz,
-                  hipGetErrorString(e));
+    (void)hipGetLastError();
+    std::snprintf(msg, sizeof msg, "%s exchange memory for peers (%zu bytes at %p, allocation %p of %zu bytes): %s",
+                  fine ? "fine-grained" : "device", bytes, p, base, sz, hipGetErrorString(e));
     if (p) (void)hipFree(p);
     return gfail(g, NIQKI_E_HIP, msg);
   }
@@ -656,7 +728,15 @@ int ipc_prepare(niqki_group *g, const size_t need[kIpcBufs]) {
   if (ic.arena.p) NQ_GH(g, hipFree(ic.arena.p));
   ic.arena = Buf();
   void *arena = nullptr;
-  if ((rc = ipc_export_alloc(g, std::max<size_t>(total, 256), &arena, &me.arena, &me.arena_off))) return rc;
+  // fine-grained like the words (peers read it while my later kernels run); plain device memory where that fails
+  const bool want_fine = !env_is("NIQKI_IPC_ARENA", "coarse");
+  rc = want_fine ? ipc_export_alloc(g, std::max<size_t>(total, 256), true, &arena, &me.arena, &me.arena_off) : NIQKI_E_HIP;
+  ic.arena_fine = rc == NIQKI_OK;
+  if (rc && (rc = ipc_export_alloc(g, std::max<size_t>(total, 256), false, &arena, &me.arena, &me.arena_off))) {
+    ic.shm->abort.store(1, std::memory_order_relaxed);
+    return rc;
+  }
+  me.arena_fine = ic.arena_fine ? 1u : 0u;
   ic.arena.p = arena;
   ic.arena.n = std::max<size_t>(total, 256);
   for (uint32_t b = 0; b < kIpcBufs; ++b) {
@@ -1046,6 +1126,8 @@ int niqki_group_get_stat(const niqki_group *g, const char *key, uint64_t *value)
   if (!std::strcmp(key, "overflows")) { *value = g->overflows; return NIQKI_OK; }
   if (!std::strcmp(key, "rccl")) { *value = g->transport == niqki_group::kRccl ? 1 : 0; return NIQKI_OK; }
   if (!std::strcmp(key, "transport")) { *value = (uint64_t)g->transport; return NIQKI_OK; }   // 0 local, 1 rccl, 2 ipc
+  if (!std::strcmp(key, "ipc_words_kind")) { *value = g->ipc.words_kind; return NIQKI_OK; }   // 0 coarse, 1 fine-grained, 2 host block
+  if (!std::strcmp(key, "ipc_arena_fine")) { *value = g->ipc.arena_fine ? 1 : 0; return NIQKI_OK; }
   if (!std::strcmp(key, "sparse")) {
     const uint32_t ms = g->sh[0]->d.min_score;
     *value = (g->exchange == 1 || (g->exchange == 0 && ms >= 4 * g->world)) ? 1 : 0;

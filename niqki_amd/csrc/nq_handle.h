@@ -28,6 +28,8 @@ struct niqki_index {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  bool stream_prio_set = false;   // option "stream_priority": the own stream (and the side stream) were made with stream_prio
+  int stream_prio = 0;
   std::string err;
 
   // sketch store, u16 [f_local][cap]
@@ -60,6 +62,9 @@ struct niqki_index {
   uint32_t *ptab = nullptr;        // packed copy of `entries` for the look-up pre-pass (made at its first launch)
   size_t ptab_bytes = 0;
   bool ptab_ok = false;
+  uint16_t *hmask = nullptr;       // per slot: which sixteenths of the fingerprint range hold a bucket (IndexView::hmask)
+  size_t hmask_bytes = 0;
+  bool hmask_ok = false;
   uint32_t stripe = 0;             // tiles are dealt round-robin
   int stripe_opt = 32;             // option: block size of the stripes when there are several tiles (0 = ranges)
   int bucket_align = -1;           // option: log2 ids per bucket alignment unit, -1 = choose
@@ -75,9 +80,10 @@ struct niqki_index {
     uint64_t *tile_base = nullptr;
     uint32_t *slot_units = nullptr;
     uint32_t *ptab = nullptr;   // packed copy of `entries` for the look-up pre-pass (made at its first launch)
-    size_t entries_bytes = 0, gids_bytes = 0, tile_base_bytes = 0, slot_units_bytes = 0, ptab_bytes = 0;
+    uint16_t *hmask = nullptr;
+    size_t entries_bytes = 0, gids_bytes = 0, tile_base_bytes = 0, slot_units_bytes = 0, ptab_bytes = 0, hmask_bytes = 0;
     uint32_t tile = 0, n_tiles = 0, seg_n = 0, g_base = 0, align_log2 = 0, padded = 0, stripe = 0;
-    bool ptab_ok = false;
+    bool ptab_ok = false, hmask_ok = false;
   } alt;
   uint32_t seg_n = 0;      // genomes of the current segment
   uint32_t g_base = 0;     // its first genome

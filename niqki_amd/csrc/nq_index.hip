@@ -225,6 +225,28 @@ hipError_t launch_build_fill(const IndexView &v, Entry *entries, uint16_t *gids,
   return hipGetLastError();
 }
 
+// hmask[s] (IndexView::hmask) from the finished table: one wave per slot ORs the classes of its non-empty buckets
+__global__ __launch_bounds__(256) void hmask_kernel(IndexView v, uint16_t *hmask) {
+  const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (s >= v.f_local) return;
+  const uint32_t R = v.d.R;
+  uint32_t m = 0;
+  for (uint32_t fp = lane; fp < R; fp += 64) {
+    const Entry *e = v.entries + ((uint64_t)s * R + fp) * v.n_tiles;
+    uint32_t len = 0;
+    for (uint32_t t = 0; t < v.n_tiles; ++t) len |= e[t].len;
+    if (len) m |= 1u << (fp >> v.hmask_shift);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m |= (uint32_t)__shfl_xor((int)m, o, 64);
+  if (lane == 0) hmask[s] = (uint16_t)m;
+}
+hipError_t launch_hmask(const IndexView &v, uint16_t *hmask, hipStream_t stream) {
+  if (v.f_local == 0) return hipSuccess;
+  hipLaunchKernelGGL(hmask_kernel, dim3((v.f_local + 3) / 4), dim3(256), 0, stream, v, hmask);
+  return hipGetLastError();
+}
+
 // padded layout: position p of every 128-byte line holds id tile + 2p until the fill overwrites it
 __global__ __launch_bounds__(256) void pad_fill_kernel(uint4 *gids, uint64_t n_vec, uint32_t tile) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;

@@ -69,7 +69,15 @@ struct IndexView {
   const uint64_t *tile_base;   // n_tiles+1 (in ids), device
   const uint32_t *slot_units;  // n_tiles x (f_local+1): units before slot s of tile t
   const uint32_t *ptab = nullptr;   // [F_local][R][n_tiles] (start - first unit of the slot) << 16 | len, or nullptr
+  // Single-tile indexes: bit c of hmask[s] = some bucket (s, fp) with fp >> hmask_shift == c is not empty
+  // (hmask_shift = max(W - 4, 0): sixteen classes of the fingerprint range; with the regular H = 4 form a class
+  // is a HyperLogLog part).  The gather kernel's own look-up tests it before it touches the table: a short
+  // read's fingerprints (few leading zeros) fall into classes no indexed genome's minimum ever has, so a read
+  // against a genome index skips ~99 % of its 2^S random table lines.  nullptr = no mask (look everything up).
+  const uint16_t *hmask = nullptr;
+  uint32_t hmask_shift = 0;
 };
+hipError_t launch_hmask(const IndexView &v, uint16_t *hmask, hipStream_t stream);
 
 // genomes of tile t / global id of its i-th genome
 NQ_HD uint32_t tile_count(const IndexView &v, uint32_t t) {

@@ -191,11 +191,23 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
   pw.init(gl, lane);
 
   struct Look { Entry e[NE]; };
+  // HM: a single-tile index with its per-slot class mask (IndexView::hmask): a fingerprint whose class holds no
+  // bucket in its slot is turned into "no fingerprint" (-1) as it is loaded -- it is never looked up, the table
+  // line is never requested.  (The mask word rides with the fingerprint: same slot, same pipeline stage.)
+  constexpr bool HM_FORM = NE == 1 && NT == 1 && !STASH_IN && !PRE;
+  const uint16_t *hm = HM_FORM ? v.hmask : nullptr;
   auto slot_ok = [&](uint32_t it) -> bool { return it < n_it && it * 64 + lane < v.f_local; };
   auto load_fp = [&](uint32_t it) -> int32_t {
     if (STASH_IN || PRE) return 0;
-    const uint32_t s = it * 64 + lane;
-    return sk[s < v.f_local ? s : v.f_local - 1];
+    uint32_t s = it * 64 + lane;
+    s = s < v.f_local ? s : v.f_local - 1;
+    int32_t fp = sk[s];
+    if (HM_FORM && hm) {   // (uniform)
+      const uint32_t m = hm[s];
+      const bool in = fp >= 0 && (uint32_t)fp < R && ((m >> ((uint32_t)fp >> v.hmask_shift)) & 1u);
+      fp = in ? fp : -1;
+    }
+    return fp;
   };
   auto valid_of = [&](uint32_t it, int32_t fp) -> bool {
     if (STASH_IN || PRE) return slot_ok(it);
@@ -214,8 +226,14 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
     } else {
       const bool ok = fp >= 0 && (uint32_t)fp < R;
       const Entry *p = v.entries + ((uint64_t)s * R + (ok ? (uint32_t)fp : 0u)) * v.n_tiles + (STASH_OUT ? 0u : t);
+      if (HM_FORM && hm) {
+        // masked form: only the lanes that still hold a fingerprint request their table line (few of a read's)
+        L.e[0] = Entry{0u, 0u};
+        if (ok) L.e[0] = p[0];
+      } else {
 #pragma unroll
-      for (int k = 0; k < NE; ++k) L.e[k] = p[k];
+        for (int k = 0; k < NE; ++k) L.e[k] = p[k];
+      }
     }
     return L;
   };
@@ -286,6 +304,7 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
       }
     }
     if (MODE == 6) { sink += pos ^ rem; cur = nxt; cur_ok = nxt_ok; nxt = nxt2; nxt_ok = nxt2_ok; continue; }
+    if (HM_FORM && !__any(rem != 0)) { cur = nxt; cur_ok = nxt_ok; nxt = nxt2; nxt_ok = nxt2_ok; continue; }   // 64 slots without a bucket
     // cut the 64 buckets into chunks of <= 64 ids, at most 3 per lane and round
     // (q_count < 64 here, so at most 63 + 192 items are ever queued)
     do {

@@ -279,6 +279,7 @@ __device__ __forceinline__ uint32_t rev64_hi_mad(uint64_t canon) {
   return mix_round_hi(lo, hi, (uint32_t)kRevMul, (uint32_t)(kRevMul >> 32));
 }
 
+constexpr uint32_t kFastKMin = 17;   // smallest K of the fast filtered path: 2K - 2 >= 32
 constexpr uint32_t kStack = 192;  // candidate k-mers per wave-private stack: < 64 left by a drain + two steps of <= 64
 
 // Candidate store of one step: lanes whose hash word hh is below thr push canon onto the wave's stack
@@ -397,7 +398,15 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t Km1 = d.K - 1u;
   const uint32_t rc_shift = 2u * d.K - 2u;
-  constexpr bool FAST = FILTER && KFIX == 31 && !HALF && ZERO;   // 8-byte code table, mad chains, S <= 15
+  // 8-byte code table, mad chains, S <= 15.  K = 31 is a compile-time specialisation; the KFIX = 0 kernel takes
+  // the same path for any K in 17..31 (kFastKMin: the rc code of a table entry must sit in its high word): the
+  // shifts by 2 are immediates whatever K, only the table's contents, the mask of the forward word's high half
+  // and the position the warm-up starts at depend on K.
+  constexpr bool FAST = FILTER && !HALF && ZERO && (KFIX == 31 || KFIX == 0);
+  const bool fast_k = KFIX == 31 || (d.K >= kFastKMin && d.K <= 31u);
+  const uint32_t mask_hi = KFIX == 31 ? 0x3FFFFFFFu : __builtin_amdgcn_readfirstlane((uint32_t)(d.kmer_mask >> 32));
+  const uint64_t fw_mask = ((uint64_t)mask_hi << 32) | 0xFFFFFFFFull;
+  const uint32_t warm_back = KFIX == 31 ? 0u : 31u - d.K;   // the 30 warm-up steps start this many bases before the chunk
   constexpr uint32_t lds0 = 0;
   uint64_t *stack = stack_base + (tid >> 6) * kStack;
   // LDS byte address of the stack's bottom / top (wave-uniform: scalar registers)
@@ -455,11 +464,13 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
       // them, :255-273) and their complements (rcb, :240-250); every later
       // position carries the codes of the rolling tables.
       uint64_t fw = 0, rc = 0;
-      if (FAST && __all(i0 >= Km1)) {
+      if (FAST && fast_k && __all(i0 >= Km1 + warm_back)) {
         // no lane of the wave starts inside a record's first K-1 positions (all chunks but a record's
-        // first): the 30 steps are plain rolling updates from the 8-byte code table, 4 instructions each
+        // first): the 30 steps are plain rolling updates from the 8-byte code table, 4 instructions each.
+        // (K < 31: 30 steps all the same, from 31 - K bases further back -- the forward word is masked below,
+        // the reverse word's older codes leave at the bottom.)
         ByteStream ws;
-        ws.open(base + i0);
+        ws.open(base + i0 - warm_back);
         uint64_t ew[32];
         {
           uint64_t e16[16];
@@ -475,6 +486,7 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
           fw = shl2_64(fw) | (uint32_t)ew[j];
           rc = shr2_64(rc) | (ew[j] & 0xFFFFFFFF00000000ULL);
         }
+        if (KFIX != 31) fw &= fw_mask;   // (K = 31: 30 steps from zero stay below 2^60)
       } else {
         uint32_t ok = 1;
         if (i0 < Km1) {
@@ -514,7 +526,7 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
       // Per 16-byte group the 16 table look-ups are issued together and one group
       // ahead of their use (LDS answers in order, so they return before the LDS
       // traffic of the group in between).
-      if (FAST && __all(cnt == CHUNK)) {
+      if (FAST && fast_k && __all(cnt == CHUNK)) {
         // Every lane of the wave has a full chunk: no per-step liveness at all.  Group g's 16 bytes sit
         // in the five dwords at qa + 4g at byte phase sh; they are loaded a group ahead, and the eight
         // table entries of a half group are reloaded into their own registers as soon as the half is
@@ -537,7 +549,7 @@ __device__ void roll_records(const SketchArgs &a, uint32_t entry, uint32_t part,
         auto step = [&](uint64_t ent, bool check) {
           // :225-229 and :233-236 with the entry's pre-placed codes
           fw = shl2_64(fw);
-          fw = (fw | (uint32_t)ent) & ((1ULL << 62) - 1ULL);
+          fw = (fw | (uint32_t)ent) & fw_mask;   // (only the high word's `and` is an instruction)
           rc = shr2_64(rc) | (ent & 0xFFFFFFFF00000000ULL);
           const uint64_t canon = fw < rc ? fw : rc;   // :345
           push_candidates(rev64_hi_mad(canon), thr, canon, top);
@@ -644,7 +656,8 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
   for (uint32_t i = tid; i < 256; i += BLOCK) {
     const uint32_t e = code_entry(i);
     lut[i] = (uint8_t)e;
-    lut64[i] = make_uint2(e & 3u, ((e >> 2) & 3u) << 28);
+    // rc code at bit 2K - 2 of the reverse word = bit 2K - 34 of the entry's high word (K >= 17; else unused)
+    lut64[i] = make_uint2(e & 3u, d.K >= kFastKMin ? ((e >> 2) & 3u) << (2u * d.K - 34u) : 0u);
   }
   if (a.accumulate) {
     const uint32_t *src = (const uint32_t *)a.sketches + (uint64_t)entry * d.F + (uint64_t)half * Fc;
@@ -1148,7 +1161,52 @@ hipError_t launch_copy_probe(const void *src, void *dst, uint64_t bytes, hipStre
   return hipGetLastError();
 }
 
+// The short-read kernel's densification passes with nothing but their LDS traffic and exit test: one wavefront per
+// workgroup with the 150-base kernel's LDS footprint (the F = 4096 cells + entry list + code tile: 8 workgroups per
+// CU), two register entries per lane (a 150-base read has ~120 occupied cells), per pass two ds_min_u32 proposals
+// to pseudo-random cells, their read-backs behind them in issue order, a ballot + popcount and the advance of the
+// targets -- densify_wave_entries<2> without winner writes.  The rate of these passes is the ceiling the passes of
+// sketch_reads_kernel are measured against (LDS round-trip latency at 8 waves per CU).
+__global__ __launch_bounds__(64) void lds_pass_probe_kernel(uint32_t iters, uint32_t *sink) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  const uint32_t F = 4096, Fm = F - 1u, lane = threadIdx.x;
+  for (uint32_t i = lane; i < F; i += 64) smem[i] = kEmpty32;
+  __syncthreads();
+  uint32_t T[2], B[2], mk[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const uint32_t v = (blockIdx.x * 131u + lane * 2u + (uint32_t)k) * 2654435761u;
+    T[k] = (uint32_t)unrev64(v);
+    B[k] = (uint32_t)rev64(v) | 1u;
+    mk[k] = 0x80000000u | ((lane * 2u + (uint32_t)k) & Fm);
+  }
+  uint32_t tot = 0;
+  for (uint32_t it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) atomicMin(&smem[T[k] & Fm], mk[k]);
+    wave_lds_order();
+    uint32_t back[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) back[k] = smem[T[k] & Fm];
+    wave_lds_order();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      tot += (uint32_t)__popcll(__ballot(back[k] == mk[k]));
+      T[k] += B[k];
+    }
+    if (tot == 0xFFFFFFFFu) break;   // (the exit test of a pass; never taken)
+  }
+  if (tot == 0x12345u) sink[0] = tot;
+}
+
 hipError_t launch_alu_probe(int what, uint32_t iters, uint32_t *sink, uint64_t *units, hipStream_t stream) {
+  if (what == 5) {
+    const uint32_t blocks = 256 * 8 * 4;   // four rounds of 8 one-wave workgroups per CU
+    const size_t lds = 4096 * 4 + 2 * kReadMaxEntries * 4 + kReadTile + 256;   // sketch_reads_lds_bytes at S = 12
+    hipLaunchKernelGGL(lds_pass_probe_kernel, dim3(blocks), dim3(64), lds, stream, iters * 16, sink);
+    *units = (uint64_t)blocks * iters * 16;
+    return hipGetLastError();
+  }
   const uint32_t blocks = 256 * 4;  // four 1024-thread workgroups per CU: 16 waves per SIMD-quartet, as the sketch kernel
   const uint64_t threads = (uint64_t)blocks * 1024;
   if (what == 0) { hipLaunchKernelGGL(alu_probe_kernel<0>, dim3(blocks), dim3(1024), 0, stream, iters, sink); *units = threads * iters * 64; }

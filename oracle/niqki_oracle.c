@@ -443,6 +443,35 @@ uint64_t nqo_query_batch(const nqo_index *ix, const int32_t *sketches,
   return total;
 }
 
+/* CPU baseline only: the CSR arrays again, first touched by `threads` threads in equal static parts, so that on a
+ * multi-socket host the pages are spread over the memory of all the threads that will gather from them
+ * (the index is built by one thread: everything would otherwise sit on that thread's node). */
+void nqo_index_spread(nqo_index *ix, int threads) {
+  const uint64_t nb = ix->n_buckets + 1, tot = ix->offsets[ix->n_buckets];
+  uint64_t *no = (uint64_t *)malloc(nb * sizeof(uint64_t));
+  uint32_t *ng = (uint32_t *)malloc((tot ? tot : 1) * sizeof(uint32_t));
+  if (!no || !ng) { free(no); free(ng); return; }
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel num_threads(threads)
+#endif
+  {
+#ifdef _OPENMP
+#pragma omp for schedule(static) nowait
+#endif
+    for (int64_t i = 0; i < (int64_t)nb; ++i) no[i] = ix->offsets[i];
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int64_t i = 0; i < (int64_t)tot; ++i) ng[i] = ix->gids[i];
+  }
+  free(ix->offsets);
+  free(ix->gids);
+  ix->offsets = no;
+  ix->gids = ng;
+  (void)threads;
+}
+
 uint64_t nqo_fnv1a64(const void *data, uint64_t len) {
   const uint8_t *p = (const uint8_t *)data;
   uint64_t h = 0xcbf29ce484222325ULL;

@@ -145,6 +145,9 @@ uint64_t nqo_query_batch(const nqo_index *ix, const int32_t *sketches,
 
 int nqo_max_threads(void);
 
+/* CPU baseline: re-places the index' arrays so that `threads` threads first touch equal parts (NUMA). */
+void nqo_index_spread(nqo_index *ix, int threads);
+
 /* 64-bit FNV-1a over a byte range (used for golden checksums). */
 uint64_t nqo_fnv1a64(const void *data, uint64_t len);
 

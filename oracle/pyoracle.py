@@ -89,6 +89,8 @@ def lib():
         L.nqo_query_batch.restype = C.c_uint64
         L.nqo_query_batch.argtypes = [C.POINTER(_Index), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
         L.nqo_max_threads.restype = C.c_int
+        L.nqo_index_spread.restype = None
+        L.nqo_index_spread.argtypes = [C.POINTER(_Index), C.c_int]
         L.nqo_fnv1a64.restype = C.c_uint64
         L.nqo_fnv1a64.argtypes = [C.c_void_p, C.c_uint64]
         _lib = L
@@ -224,6 +226,10 @@ class Index:
         hg = np.empty(self.n, dtype=np.uint32)
         nh = self._L.nqo_hits_from_counts(_ptr(c), self.n, ms, _ptr(hc), _ptr(hg), self.n)
         return hc[:nh].copy(), hg[:nh].copy()
+
+    def spread(self, threads=0):
+        """CPU baseline: the CSR arrays first touched by `threads` threads in equal parts (NUMA placement)."""
+        self._L.nqo_index_spread(self._h, threads)
 
     def query_batch(self, sketches, threads=0):
         sk = np.ascontiguousarray(sketches, dtype=np.int32)

@@ -4,8 +4,9 @@
 // reference source.  oracle/Makefile compiles it together with the reference's
 // own src/niqki_index.cpp and src/genome.cpp, taken where they lie under
 // /root/reference, into oracle/_ref/libniqki_ref.so (git-ignored).  It exists
-// so that oracle/make_goldens.py and tests/test_oracle_vs_ref.py can pin the
-// C restatement (niqki_oracle.c) against the reference's actual outputs.
+// so that oracle/make_goldens*.py and tests/test_oracle_golden.py can pin the
+// C restatement (niqki_oracle.c) against the reference's actual outputs, and so that
+// bench.py's cpu_baseline leg can time the reference's own code beside the port.
 // Nothing here is reachable from the product library.
 //
 // Every member of the reference's Index class is public

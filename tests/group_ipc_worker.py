@@ -1,5 +1,6 @@
-"""One rank of a multi-process slot-sharded group (tests/test_gpu_group_ipc.py starts `world` of these as
-fresh processes): NIQKI_GROUP_TRANSPORT=ipc, all ranks on device 0.
+"""One rank of a multi-process slot-sharded group (tests/test_gpu_group_ipc.py and tests/test_gpu_multi_device.py
+start `world` of these as fresh processes).  NIQKI_TEST_TRANSPORT = ipc (default) | rccl; NIQKI_TEST_DEVICES = number
+of devices the ranks are dealt over (default 1: all ranks on device 0, which only the ipc transport allows).
 
     python tests/group_ipc_worker.py <rank> <world> <group id hex> <npz in> <npz out> <exchange> <cand_cap>
 
@@ -20,18 +21,28 @@ def main():
     gid = np.frombuffer(bytes.fromhex(sys.argv[3]), dtype=np.uint8).copy()
     d = np.load(sys.argv[4])
     out_path, exchange, cand_cap = sys.argv[5], sys.argv[6], int(sys.argv[7])
-    os.environ["NIQKI_GROUP_TRANSPORT"] = "ipc"
+    transport = os.environ.get("NIQKI_TEST_TRANSPORT", "ipc")
+    if transport == "ipc":
+        os.environ["NIQKI_GROUP_TRANSPORT"] = "ipc"
+    else:
+        os.environ.pop("NIQKI_GROUP_TRANSPORT", None)
     import torch
     import niqki_amd
-    dev = torch.device("cuda", 0)
+    di = rank % max(1, int(os.environ.get("NIQKI_TEST_DEVICES", "1")))
+    torch.cuda.set_device(di)
+    dev = torch.device("cuda", di)
     sk, q = d["sk"], d["q"]
     S, W, MS = int(d["S"]), int(d["W"]), int(d["min_score"])
     F = 1 << S
     b, e = niqki_amd.group_slot_range(rank, world, S)
-    eng = niqki_amd.Engine(K=31, S=S, W=W, H=3, min_score_value=MS, slot_begin=b, slot_end=e, device=0)
+    eng = niqki_amd.Engine(K=31, S=S, W=W, H=3, min_score_value=MS, slot_begin=b, slot_end=e, device=di)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     grp = niqki_amd.Group([eng], first_rank=rank, world=world, group_id=gid)
-    assert grp.stat("transport") == 2
+    assert grp.stat("transport") == {"ipc": 2, "rccl": 1}[transport]
+    words_kind = grp.stat("ipc_words_kind") if transport == "ipc" else -1
+    want = os.environ.get("NIQKI_IPC_WORDS")
+    if transport == "ipc" and want in ("host", "coarse"):
+        assert words_kind == {"host": 2, "coarse": 0}[want]
     grp.set_option("exchange", {"sparse": 1, "dense": 2}[exchange])
     grp.set_option("cand_cap", cand_cap)
     ins_per = 41
@@ -59,7 +70,8 @@ def main():
     grp.query_end()
     eng.synchronize()
     np.savez(out_path, off=off, hc=hc, hg=hg, off2=d_off.cpu().numpy(), hc2=d_hc.cpu().numpy()[:int(off[per])],
-             hg2=d_hg.cpu().numpy()[:int(off[per])], overflows=grp.stat("overflows"), per=per)
+             hg2=d_hg.cpu().numpy()[:int(off[per])], overflows=grp.stat("overflows"), per=per, words_kind=words_kind,
+             arena_fine=grp.stat("ipc_arena_fine") if transport == "ipc" else -1, device=di)
     grp.close()
     eng.close()
 

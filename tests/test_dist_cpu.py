@@ -140,3 +140,23 @@ def test_slot_ranges_partition_the_sketch():
             assert cuts[0][0] == 0 and cuts[-1][1] == F
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
     assert padded_batch(10, 4) == 3
+
+
+def test_bench_launcher_starts_ranks_and_relays_their_exit_code(tmp_path):
+    """`python bench.py --gpus 2` without WORLD_SIZE: the process becomes a launcher BEFORE it imports torch or touches
+    a GPU -- it starts two ranks of itself under torch.distributed.run as a child and hands on their exit code.  Here
+    (no GPU) the ranks fail at their first device call: non-zero exit, no JSON line, and the launcher's own message."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NIQKI_BENCH_LAUNCH_TIMEOUT"] = "240"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--genomes", "500", "--steps", "1", "--warmup", "1",
+                        "--batch", "64", "--no-legs"], env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = r.stderr.decode(errors="replace")
+    assert "--gpus 2 without a launcher" in err and "torch.distributed.run" in err and "--nproc-per-node 2" in err
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode not in (0, 124) and not r.stdout.strip()
+    else:
+        assert r.returncode == 0 and r.stdout.decode().count("\n") == 1

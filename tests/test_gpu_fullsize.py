@@ -231,3 +231,19 @@ def test_config4_eight_slot_shards_at_full_size(native, big):
     grp.close()
     for sh in shards:
         sh.close()
+
+
+@pytest.mark.parametrize("Kx", [21, 27])
+def test_full_size_sketches_other_k(native, po, Kx):
+    """5 Mbp genomes of the bench's generator at -K 21 / 27 (src/niqki.cpp:260, src/niqki_index.cpp:225-236), S = 15
+    W = 12: the fast filtered loop with a run-time K, against the oracle on the same bytes."""
+    p = po.make_params(Kx, S, W, H, J)
+    e = native.Engine(K=Kx, S=S, W=W, H=H, J=J)
+    n_fam = N // FAMILY
+    gids = (0, 1, 99)
+    spec = [bench.genome_spec(np.array([g]), n_fam, FAMILY) for g in gids]
+    seqs = [native.synth_genome_host(SEED, int(f[0]), int(m[0]), int(r[0]), L) for f, m, r in spec]
+    sk = e.sketch(seqs)
+    for i in range(len(gids)):
+        assert np.array_equal(sk[i], po.compute_sketch(p, seqs[i])), (Kx, gids[i])
+    e.close()

@@ -17,11 +17,27 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_world(tmp_path, native, world, sk, q, S, W, MS, exchange, cand_cap):
-    gid = native.group_new_id()   # (the rccl form is fine too: 128 opaque bytes)
+def run_world(tmp_path, native, world, sk, q, S, W, MS, exchange, cand_cap, transport="ipc", devices=1, words=None):
+    """`world` fresh processes, one rank each, dealt over `devices` devices (tests/group_ipc_worker.py)"""
+    env = dict(os.environ, NIQKI_TEST_TRANSPORT=transport, NIQKI_TEST_DEVICES=str(devices))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (exported on this pool already: dmabuf IPC is what its driver supports)
+    if transport == "ipc":
+        env["NIQKI_GROUP_TRANSPORT"] = "ipc"
+    else:
+        env.pop("NIQKI_GROUP_TRANSPORT", None)
+    if words:
+        env["NIQKI_IPC_WORDS"] = words
+    if transport == "ipc":
+        gid = native.group_new_id()
+    else:   # an ncclUniqueId: made without NIQKI_GROUP_TRANSPORT=ipc in the environment
+        old = os.environ.pop("NIQKI_GROUP_TRANSPORT", None)
+        try:
+            gid = native.group_new_id()
+        finally:
+            if old is not None:
+                os.environ["NIQKI_GROUP_TRANSPORT"] = old
     inp = tmp_path / "in.npz"
     np.savez(inp, sk=sk, q=q, S=S, W=W, min_score=MS)
-    env = dict(os.environ, NIQKI_GROUP_TRANSPORT="ipc", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = []
     for r in range(world):
         out = tmp_path / ("out%d.npz" % r)
@@ -41,11 +57,9 @@ def run_world(tmp_path, native, world, sk, q, S, W, MS, exchange, cand_cap):
     return res
 
 
-@pytest.mark.parametrize("world,exchange,cand_cap", [(2, "sparse", 256), (2, "dense", 256), (3, "sparse", 2)])
-def test_one_process_per_rank_on_one_gpu(tmp_path, native, po, world, exchange, cand_cap):
-    S, W, N, NQ, MS = 9, 8, 1500, 23, 40
-    sk, q = make_data(S, W, N, NQ, 31 + world)
-    res = run_world(tmp_path, native, world, sk, q, S, W, MS, exchange, cand_cap)
+def check_world(res, native, po, sk, q, S, W, MS, world, exchange, cand_cap):
+    """every rank's hit lists = the whole-range handle's = the oracle's"""
+    NQ = q.shape[0]
     whole = native.Engine(K=31, S=S, W=W, H=3, min_score_value=MS)
     whole.insert(sk)
     w_off, w_hc, w_hg = whole.query(q)
@@ -72,17 +86,47 @@ def test_one_process_per_rank_on_one_gpu(tmp_path, native, po, world, exchange, 
     whole.close()
 
 
+# (words: where the sequence words a peer's running kernel polls live -- fine-grained device memory by default,
+# the processes' shared block page-locked into every device where that cannot be made)
+@pytest.mark.parametrize("world,exchange,cand_cap,words", [(2, "sparse", 256, None), (2, "dense", 256, "host"), (3, "sparse", 2, None),
+                                                           (2, "sparse", 256, "coarse")])
+def test_one_process_per_rank_on_one_gpu(tmp_path, native, po, world, exchange, cand_cap, words):
+    S, W, N, NQ, MS = 9, 8, 1500, 23, 40
+    sk, q = make_data(S, W, N, NQ, 31 + world)
+    res = run_world(tmp_path, native, world, sk, q, S, W, MS, exchange, cand_cap, words=words)
+    check_world(res, native, po, sk, q, S, W, MS, world, exchange, cand_cap)
+    if words is None:    # the default: coherent by contract -- fine-grained device memory, or the host block where that failed
+        assert all(int(d["words_kind"]) in (1, 2) for d in res)
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """bench.py --gpus 2 as the driver launches it (torch.distributed.run), both ranks on the one GPU:
     gloo carries bench.py's own barrier, the library's ipc transport the exchange; the run checks its
     answers against a whole-range handle itself (--verify)."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genomes", "2000", "--steps", "2", "--warmup", "1",
-           "--batch", "256", "--no-cpu", "--no-extra", "--verify"]
+           "--batch", "256", "--no-cpu", "--no-extra", "--verify", "--devices", "1"]
     r = subprocess.run(cmd, env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
     line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["value"] > 0
+    assert j["config"]["transport"] == "ipc" and j["verify"]["hit_lists_equal_whole_range_handle"] is True
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher in the command and no WORLD_SIZE in the environment: the
+    process starts two ranks of itself under torch.distributed.run as a child (before it touches the GPU),
+    relays rank 0's one JSON line and exits with the child's code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--genomes", "2000", "--steps", "2", "--warmup", "1",
+           "--batch", "256", "--no-cpu", "--no-extra", "--verify", "--devices", "1"]
+    r = subprocess.run(cmd, env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                      # ONE JSON line on stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["ranks_share_devices"] is True
     assert j["config"]["transport"] == "ipc" and j["verify"]["hit_lists_equal_whole_range_handle"] is True

@@ -361,6 +361,35 @@ def test_candidate_filter_is_exact(native, po, mode, monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("K", [17, 21, 25, 27, 30, 16, 9])
+@pytest.mark.parametrize("mode", ["1", "3"])
+def test_filtered_long_record_path_other_k(native, po, K, mode, monkeypatch):
+    """-K other than 31 on long records (src/niqki_index.cpp:28-29,225-236; src/niqki.cpp:260): K in 17..31 takes
+    the fast filtered loop of the K = 31 kernel (table entries, forward mask and warm-up start depend on K), K <= 16
+    the generic one.  Long single records, a record with dirty bytes, several records per sketch, a record cut over
+    several workgroups -- all against the oracle."""
+    monkeypatch.setenv("NIQKI_SKETCH_FILTER", mode)
+    p = po.make_params(K, 10, 12, 4, 0.0)
+    e = native.Engine(K=K, S=10, W=12, H=4)
+    g = [native.synth_genome_host(13, 3, k, 150 * k, L) for k, L in ((0, 400_000), (1, 70_001), (2, 20_003))]
+    g[1] = g[1].copy()
+    g[1][5000:5100] = ord("N")
+    g[1][40_000:40_007] = np.frombuffer(b"acgtnRY", np.uint8)
+    g[2] = g[2].copy()
+    g[2][:3] = np.frombuffer(b"acN", np.uint8)     # a dirty prefix: str2numstrand zeroes all K-1 digits (:255-273)
+    sk = e.sketch(g)
+    for i in range(3):
+        assert np.array_equal(sk[i], po.compute_sketch(p, g[i])), (K, mode, i)
+    sk2 = e.sketch([g[0][:200_000], g[0][200_000:], g[2]], entry_rec=np.array([0, 2, 3], np.uint32))
+    acc = np.full(1024, -1, np.int32)
+    po.sketch_accumulate(p, g[0][:200_000], acc)
+    po.sketch_accumulate(p, g[0][200_000:], acc)
+    assert np.array_equal(sk2[0], po.densify(p, acc)[0])
+    big = native.synth_genome_host(13, 9, 0, 0, 2_500_000)
+    assert np.array_equal(e.sketch([big])[0], po.compute_sketch(p, big))
+    e.close()
+
+
 def test_config2_index_and_self_query_1k_genomes(native):
     """BASELINE configs[1]: 1k synthetic 5 Mbp genomes, index + self query,
     K=31 S=15 W=12 -- too big for the oracle, checked through properties:

@@ -16,7 +16,7 @@ NR, RL, SEED = 65_536, 150, 20261003 + 3
 CHECK = np.r_[0:32, 30_000:30_032, NR - 32:NR]      # reads compared with the oracle
 
 
-def test_config5_reads_vs_10k_index(native, po):
+def test_config5_reads_vs_10k_index(native, po, monkeypatch):
     import torch
     dev = torch.device("cuda")
     t32 = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).to(torch.int32).to(dev)  # noqa: E731
@@ -85,4 +85,17 @@ def test_config5_reads_vs_10k_index(native, po):
         if hi > lo:
             assert int(src_g[i]) // 100 in set((hg[lo:hi] // 100).tolist()) or cols[src_g[i]] < min_score
     assert n_hit_reads >= len(CHECK) // 4
+    # the per-slot class mask (single-tile index) was in use ...
+    assert e.stat("class_mask") == 1
+    # ... and an index built without it answers the same bytes (the mask only skips look-ups of empty buckets)
+    monkeypatch.setenv("NIQKI_HMASK", "0")
+    e.set_option("tile_genomes", 0)        # (forces a rebuild)
+    e.build()
+    assert e.stat("class_mask") == 0
+    d_off2 = torch.zeros(NR + 1, dtype=torch.int64, device=dev)
+    d_hc2, d_hg2 = torch.zeros(cap, dtype=torch.int32, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
+    e.query_sequences_dev(reads, rro, NR, d_off2, d_hc2, d_hg2, cap)
+    e.synchronize()
+    nh = int(off[NR])
+    assert torch.equal(d_off2, d_off) and torch.equal(d_hc2[:nh], d_hc[:nh]) and torch.equal(d_hg2[:nh], d_hg[:nh])
     e.close()

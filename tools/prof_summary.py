@@ -16,19 +16,18 @@ def short(name):
 
 def main(d):
     for path in sorted(glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)):
-        agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+        durs = defaultdict(list)
         with open(path) as f:
             for r in csv.DictReader(f):
-                dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-                a = agg[short(r["Kernel_Name"])]
-                a[0] += 1
-                a[1] += dur
-                a[2] = min(a[2], dur)
-                a[3] = max(a[3], dur)
+                durs[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
         print("== kernel trace:", os.path.relpath(path, d))
-        print("%-92s %8s %14s %12s %12s %12s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us"))
-        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-            print("%-92s %8d %14.1f %12.1f %12.1f %12.1f" % (k, a[0], a[1], a[1] / a[0], a[2], a[3]))
+        print("%-92s %8s %14s %12s %12s %12s %12s %12s" % ("kernel", "calls", "total_us", "avg_us", "median_us", "p90_us", "min_us", "max_us"))
+        for k, v in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
+            v.sort()
+            n = len(v)
+            med = v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+            p90 = v[min(n - 1, int(0.9 * (n - 1) + 0.5))]
+            print("%-92s %8d %14.1f %12.1f %12.1f %12.1f %12.1f %12.1f" % (k, n, sum(v), sum(v) / n, med, p90, v[0], v[-1]))
     for path in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
         with open(path) as f:

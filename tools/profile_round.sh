@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile (run on the GPU box from the repo root):  tools/profile_round.sh r03
 # 1) the default bench line (with cpu_baseline and extra workloads)
-# 2) rocprofv3 --kernel-trace --stats of the same command (without the CPU legs)
+# 2) rocprofv3 --kernel-trace --stats of the timed steps alone (bench.py --no-legs), and of the pipelined mode
 # 3) separate --pmc passes (no tracing flags) for HBM traffic and the SQ counters of the query
 #    path's kernels (tools/pmc_bench.sh: FETCH_SIZE, WRITE_SIZE, TCC_EA0_RDREQ[_128B], SQ_*;
 #    MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled)
@@ -11,15 +11,25 @@ TAG=${1:-r03}
 cd $R; mkdir -p gpurun_out
 timeout -k 10 900 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err || { tail -5 gpurun_out/${TAG}_bench_n1.err; exit 1; }
 cd /tmp; export TMPDIR=/tmp
-rm -rf /tmp/kt; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-cpu --no-extra > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> /tmp/kt.log || { tail -5 /tmp/kt.log; exit 1; }
+# the traced command runs ONLY the index build, the warm-up and the timed steps (--no-legs): a kernel's median in the
+# summary is the median of the launches roofline.avg_launch_ms averages
+rm -rf /tmp/kt; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-legs --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> /tmp/kt.log || { tail -5 /tmp/kt.log; exit 1; }
 cd $R
 python3 tools/prof_summary.py /tmp/kt > gpurun_out/${TAG}_bench_kernel_trace_summary.txt
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_bench_rocprofv3_kernel_stats.csv
+# separately labelled: the pipelined mode (next batch sketched beside the gather), default and priority streams --
+# the gather-path kernels share the CUs with the sketch kernel there, their times are no roofline figures
+cd /tmp
+for pm in "" "--priority-streams"; do
+  rm -rf /tmp/ktp; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktp -- python3 $R/bench.py --no-legs --pipeline $pm --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_pipelined${pm}.json 2> /tmp/ktp.log || { tail -5 /tmp/ktp.log; exit 1; }
+  python3 $R/tools/prof_summary.py /tmp/ktp > $R/gpurun_out/${TAG}_pipelined${pm}_kernel_trace_summary.txt
+done
+cd $R
 bash tools/pmc_bench.sh ${TAG}_default --no-extra || exit 1
-# two processes on this one GPU, as the driver launches N > 1: gloo for bench.py's own barrier, the library's ipc transport
+# two processes on this one GPU (bench.py --gpus 2 starts its own ranks when no launcher did): gloo for bench.py's own barrier, the library's ipc transport
 # for the exchange; with and without the next batch's sketch kernel beside the exchange
 for ov in "" "--no-overlap"; do
-  timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 9 --warmup 2 --no-cpu --no-extra $ov > gpurun_out/${TAG}_bench_n2_ipc_one_gpu${ov}.json 2> gpurun_out/${TAG}_bench_n2.err || { tail -5 gpurun_out/${TAG}_bench_n2.err; exit 1; }
+  timeout -k 10 600 python3 bench.py --gpus 2 --steps 9 --warmup 2 --no-cpu --no-extra $ov > gpurun_out/${TAG}_bench_n2_ipc_one_gpu${ov}.json 2> gpurun_out/${TAG}_bench_n2.err || { tail -5 gpurun_out/${TAG}_bench_n2.err; exit 1; }
 done
 timeout -k 10 600 python3 bench.py --shard-of 8 --no-cpu > gpurun_out/${TAG}_shard_of_8.json 2> gpurun_out/${TAG}_shard_of_8.err || exit 1
 # the weak-scaling shape of --gpus 8 on rank 0 (every rank brings 4096 queries), and all 8 ranks of the group on this one GPU
@@ -38,6 +48,6 @@ cd $R; head -14 gpurun_out/${TAG}_bench_kernel_trace_summary.txt | cut -c1-170
 python3 -c "
 import json
 j=json.load(open('gpurun_out/${TAG}_bench_n1.json'))
-print('value %.0f ms/step %.2f gather %.3f frac %.3f' % (j['value'], j['ms_per_step'], j['roofline']['avg_launch_ms'], j['roofline']['frac']))
+print('value %.0f ms/step %.2f gather %.3f frac %.3f (algorithmic %.3f, layout min %.3f)' % (j['value'], j['ms_per_step'], j['roofline']['avg_launch_ms'], j['roofline']['frac'], j['roofline']['frac_algorithmic'], j['roofline']['frac_layout_min']))
 print(json.dumps(j['cpu_baseline']))
 print(json.dumps(j['sketch_kernel']))"
