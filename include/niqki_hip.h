@@ -15,7 +15,9 @@
  * signatures are plain C: opaque handle, pointers and sizes, int status.
  * No exceptions cross the boundary.  Calls on one handle must be serialised by
  * the caller (one handle per GPU; the reference's const query methods map to
- * batched calls here, not to concurrent ones).
+ * batched calls here, not to concurrent ones) -- except the niqki_*_shared entry
+ * points, which any number of host threads may call on one handle at the same time
+ * (the reference's `omp parallel` record loops, kept as they are).
  *
  * Memory spaces: every array argument of a call lives in the space named by
  * the call's `mem` argument -- NIQKI_MEM_HOST (pageable or pinned host memory;
@@ -234,6 +236,32 @@ int niqki_candidates_from_counts(niqki_index *ix, const uint16_t *counts, uint32
 int niqki_query_counts_candidates(niqki_index *ix, const int32_t *sketches, uint32_t nq,
                                   uint16_t *counts, uint64_t stride, uint32_t threshold,
                                   uint32_t cap, int32_t *cand, int32_t *n_cand, int mem);
+
+/* ---- many host threads on one handle ------------------------------------------------------
+ * A handle is single-caller (see the top of this file).  The reference's drivers, however, call
+ * compute_sketch / insert_sketch / query_sketch from every thread of an `omp parallel` region on
+ * one Index (src/niqki_index.cpp:391-401, :415-428, :479-490, :525-538).  These four entry points
+ * keep that contract: any number of host threads may call them on one handle at the same time
+ * (and ONLY them, while such calls are in flight).  Concurrent callers are combined into batches --
+ * the first thread to arrive leads a batch, threads that arrive while it is on the GPU form the
+ * next one -- and each batch runs through niqki_sketch / niqki_insert / niqki_query
+ * (NIQKI_MEM_HOST): same results, about one launch per `threads` records instead of one per record.
+ *   niqki_sketch_shared           Index::compute_sketch of one record (len bytes) -> sketch[2^S]
+ *   niqki_insert_shared           Index::insert_sketch; *genome_id (may be NULL) = the id it got:
+ *                                 ids are handed out in arrival order, as the reference's critical
+ *                                 section does with several threads (:396-401, :486-490)
+ *   niqki_query_shared            Index::query_sketch: *n_hits = number of hits, the first
+ *                                 min(*n_hits, capacity) written in the reference's order
+ *   niqki_query_sequence_shared   Index::query_sequence (:691-695)
+ * niqki_shared_stats: batches run so far, requests served, the largest batch (any may be NULL). */
+int niqki_sketch_shared(niqki_index *ix, const uint8_t *seq, uint64_t len, int32_t *sketch);
+int niqki_insert_shared(niqki_index *ix, const int32_t *sketch, uint32_t *genome_id);
+int niqki_query_shared(niqki_index *ix, const int32_t *sketch, uint64_t *n_hits, uint32_t *hit_counts,
+                       uint32_t *hit_gids, uint64_t capacity);
+int niqki_query_sequence_shared(niqki_index *ix, const uint8_t *seq, uint64_t len, uint64_t *n_hits,
+                                uint32_t *hit_counts, uint32_t *hit_gids, uint64_t capacity);
+int niqki_shared_stats(const niqki_index *ix, uint64_t *batches, uint64_t *requests,
+                       uint64_t *largest_batch);
 
 /* Index::query_sketch (src/niqki_index.cpp:633-687), batched: both halves. */
 int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq,

@@ -84,6 +84,11 @@ ABI = [
     ("niqki_candidates_from_counts", _int, [_vp, _vp, _u32, _u64, _u32, _u32, _u32, _vp, _vp, _int]),
     ("niqki_query_counts_candidates", _int, [_vp, _vp, _u32, _vp, _u64, _u32, _u32, _vp, _vp, _int]),
     ("niqki_query", _int, [_vp, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_sketch_shared", _int, [_vp, _vp, _u64, _vp]),
+    ("niqki_insert_shared", _int, [_vp, _vp, C.POINTER(_u32)]),
+    ("niqki_query_shared", _int, [_vp, _vp, C.POINTER(_u64), _vp, _vp, _u64]),
+    ("niqki_query_sequence_shared", _int, [_vp, _vp, _u64, C.POINTER(_u64), _vp, _vp, _u64]),
+    ("niqki_shared_stats", _int, [_vp, C.POINTER(_u64), C.POINTER(_u64), C.POINTER(_u64)]),
     ("niqki_query_survivors", _int, [_vp, _vp, _u32, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _int]),
     ("niqki_survivor_counts", _int, [_vp, _vp, _u32, _vp, _u32, _vp, _vp, _u32, _vp, _int]),
     ("niqki_hits_from_candidates", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u64, _int]),
@@ -225,6 +230,42 @@ class Engine:
     # -- plumbing
     def set_stream(self, stream_ptr):
         self._ck(self.L.niqki_set_stream(self.h, stream_ptr))
+
+    # -- many host threads on one handle (niqki_*_shared: callers are combined into batches)
+    def sketch_shared(self, seq):
+        s = np.ascontiguousarray(seq, dtype=np.uint8)
+        out = np.empty(self.F, dtype=np.int32)
+        self._ck(self.L.niqki_sketch_shared(self.h, _p(s), s.size, _p(out)))
+        return out
+
+    def insert_shared(self, sketch):
+        sk = np.ascontiguousarray(sketch, dtype=np.int32)
+        gid = _u32(0)
+        self._ck(self.L.niqki_insert_shared(self.h, _p(sk), C.byref(gid)))
+        return gid.value
+
+    def query_shared(self, sketch, capacity=1024):
+        sk = np.ascontiguousarray(sketch, dtype=np.int32)
+        n = _u64(0)
+        hc, hg = np.empty(capacity, np.uint32), np.empty(capacity, np.uint32)
+        self._ck(self.L.niqki_query_shared(self.h, _p(sk), C.byref(n), _p(hc), _p(hg), capacity))
+        if n.value > capacity:
+            return self.query_shared(sketch, int(n.value))
+        return hc[:n.value].copy(), hg[:n.value].copy()
+
+    def query_sequence_shared(self, seq, capacity=1024):
+        s = np.ascontiguousarray(seq, dtype=np.uint8)
+        n = _u64(0)
+        hc, hg = np.empty(capacity, np.uint32), np.empty(capacity, np.uint32)
+        self._ck(self.L.niqki_query_sequence_shared(self.h, _p(s), s.size, C.byref(n), _p(hc), _p(hg), capacity))
+        if n.value > capacity:
+            return self.query_sequence_shared(seq, int(n.value))
+        return hc[:n.value].copy(), hg[:n.value].copy()
+
+    def shared_stats(self):
+        b, r, m = _u64(0), _u64(0), _u64(0)
+        self._ck(self.L.niqki_shared_stats(self.h, C.byref(b), C.byref(r), C.byref(m)))
+        return {"batches": b.value, "requests": r.value, "largest_batch": m.value}
 
     def get_stream(self):
         """The hipStream_t the handle enqueues on (an int, for torch.cuda.ExternalStream)."""

@@ -731,6 +731,7 @@ void niqki_destroy(niqki_index *ix) {
   if (ix->ev_fork) (void)hipEventDestroy(ix->ev_fork);
   if (ix->ev_join) (void)hipEventDestroy(ix->ev_join);
   if (ix->own_stream) (void)hipStreamDestroy(ix->stream);
+  nqi::shared_free(ix);
   delete ix;
 }
 

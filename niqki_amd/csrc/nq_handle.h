@@ -20,6 +20,8 @@ struct ProfSpan {
   hipEvent_t a, b;
 };
 
+void shared_free(struct ::niqki_index *ix);   // nq_shared.hip
+
 }  // namespace nqi
 
 struct niqki_index {
@@ -89,6 +91,8 @@ struct niqki_index {
   uint32_t g_base = 0;     // its first genome
   uint32_t delta_n = 0;    // genomes the delta segment covers (0 = there is none)
   int incremental = 1;     // option "incremental_build"
+
+  void *shared_state = nullptr;   // nq_shared.hip: the combiner of the *_shared (many host threads) entry points
 
   int gather_variant = 0;
   uint32_t last_form = 0;        // stat "last_gather_form": 1 = look-up pre-pass, 2 = its streamed-rows form, 4 = locality order

@@ -25,7 +25,7 @@ for pm in "" "--priority-streams"; do
   python3 $R/tools/prof_summary.py /tmp/ktp > $R/gpurun_out/${TAG}_pipelined${pm}_kernel_trace_summary.txt
 done
 cd $R
-bash tools/pmc_bench.sh ${TAG}_default --no-extra || exit 1
+bash tools/pmc_bench.sh ${TAG}_default || exit 1
 # two processes on this one GPU (bench.py --gpus 2 starts its own ranks when no launcher did): gloo for bench.py's own barrier, the library's ipc transport
 # for the exchange; with and without the next batch's sketch kernel beside the exchange
 for ov in "" "--no-overlap"; do
