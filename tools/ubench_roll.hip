@@ -21,6 +21,7 @@
 using namespace nq;
 
 __device__ unsigned long long ub_clk[2];
+constexpr uint32_t kRegion = 32;   // groups of 16 bases a lane's input region holds (re-read: cache resident)
 
 template <int VAR>
 __global__ __launch_bounds__(1024) void roll_kernel(const uint8_t *bytes, const uint32_t *packed, uint32_t groups, uint32_t thr,
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(1024) void roll_kernel(const uint8_t *bytes, const 
   uint32_t acc = 0;
   if (VAR == 2) {
     // packed stream of this lane: `groups` words (16 bases each, first base in the top bits)
-    const uint32_t *pw = packed + lane_id * (uint64_t)(groups + 4);
+    // (all workgroups read the same 1024 lane regions of 32 groups: the inputs stay in L2, the loop is what is timed)
+    const uint32_t *pw = packed + (uint64_t)tid * (kRegion + 4);
     uint32_t w2 = pw[0], w1 = pw[1];                 // the two words before the current one
     auto comp_rev = [](uint32_t w) {                 // complemented bases, digit order reversed
       uint32_t x = __builtin_bitreverse32(w);
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(1024) void roll_kernel(const uint8_t *bytes, const 
     };
     uint32_t v2 = comp_rev(w2), v1 = comp_rev(w1);
     for (uint32_t g = 0; g < groups; ++g) {
-      const uint32_t wc = pw[g + 2];
+      const uint32_t wc = pw[(g & (kRegion - 1)) + 2];
       const uint32_t vc = comp_rev(wc);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -80,10 +82,10 @@ __global__ __launch_bounds__(1024) void roll_kernel(const uint8_t *bytes, const 
       w2 = w1; w1 = wc; v2 = v1; v1 = vc;
     }
   } else {
-    const uint8_t *base = bytes + lane_id * (uint64_t)(groups * 16 + 64);
+    const uint8_t *base = bytes + (uint64_t)tid * (kRegion * 16 + 64) + 1;   // (an odd start: the byte re-alignment is part of the loop)
     const uintptr_t a0 = (uintptr_t)base;
     const uint32_t sh = (uint32_t)(a0 & 3u);
-    const uint32_t *qa = (const uint32_t *)(a0 & ~(uintptr_t)3);
+    const uint32_t *qa0 = (const uint32_t *)(a0 & ~(uintptr_t)3), *qa = qa0;
     uint64_t e[16];
     {
       const uint4 A = *(const uint4 *)qa;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(1024) void roll_kernel(const uint8_t *bytes, const 
       }
     };
     for (uint32_t g = 0; g < groups; ++g) {
-      qa += 4;
+      qa = qa0 + 4 * ((g + 1) & (kRegion - 1));
       const uint4 A = *(const uint4 *)qa;
       const uint32_t B = qa[4];
 #pragma unroll
@@ -203,8 +205,8 @@ static int run(const uint8_t *bytes, const uint32_t *packed, uint32_t groups, in
 int main(int argc, char **argv) {
   const uint32_t groups = argc > 1 ? (uint32_t)atoi(argv[1]) : 512;
   const int reps = argc > 2 ? atoi(argv[2]) : 5;
-  const uint64_t lanes = 256ull * 1024;
-  const uint64_t n_bytes = lanes * (groups * 16 + 64) + 4096, n_words = lanes * (groups + 4) + 64;
+  const uint64_t lanes = 1024;
+  const uint64_t n_bytes = lanes * (kRegion * 16 + 64) + 4096, n_words = lanes * (kRegion + 4) + 64;
   uint8_t *bytes; uint32_t *packed, *sink;
   CK(hipMalloc(&bytes, n_bytes));
   CK(hipMalloc(&packed, n_words * 4));
