@@ -192,22 +192,14 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
 
   struct Look { Entry e[NE]; };
   // HM: a single-tile index with its per-slot class mask (IndexView::hmask): a fingerprint whose class holds no
-  // bucket in its slot is turned into "no fingerprint" (-1) as it is loaded -- it is never looked up, the table
-  // line is never requested.  (The mask word rides with the fingerprint: same slot, same pipeline stage.)
+  // bucket in its slot is never looked up, its table line never requested (the masked loop below).
   constexpr bool HM_FORM = NE == 1 && NT == 1 && !STASH_IN && !PRE;
   const uint16_t *hm = HM_FORM ? v.hmask : nullptr;
   auto slot_ok = [&](uint32_t it) -> bool { return it < n_it && it * 64 + lane < v.f_local; };
   auto load_fp = [&](uint32_t it) -> int32_t {
     if (STASH_IN || PRE) return 0;
-    uint32_t s = it * 64 + lane;
-    s = s < v.f_local ? s : v.f_local - 1;
-    int32_t fp = sk[s];
-    if (HM_FORM && hm) {   // (uniform)
-      const uint32_t m = hm[s];
-      const bool in = fp >= 0 && (uint32_t)fp < R && ((m >> ((uint32_t)fp >> v.hmask_shift)) & 1u);
-      fp = in ? fp : -1;
-    }
-    return fp;
+    const uint32_t s = it * 64 + lane;
+    return sk[s < v.f_local ? s : v.f_local - 1];
   };
   auto valid_of = [&](uint32_t it, int32_t fp) -> bool {
     if (STASH_IN || PRE) return slot_ok(it);
@@ -226,14 +218,8 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
     } else {
       const bool ok = fp >= 0 && (uint32_t)fp < R;
       const Entry *p = v.entries + ((uint64_t)s * R + (ok ? (uint32_t)fp : 0u)) * v.n_tiles + (STASH_OUT ? 0u : t);
-      if (HM_FORM && hm) {
-        // masked form: only the lanes that still hold a fingerprint request their table line (few of a read's)
-        L.e[0] = Entry{0u, 0u};
-        if (ok) L.e[0] = p[0];
-      } else {
 #pragma unroll
-        for (int k = 0; k < NE; ++k) L.e[k] = p[k];
-      }
+      for (int k = 0; k < NE; ++k) L.e[k] = p[k];
     }
     return L;
   };
@@ -258,6 +244,85 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
       walk64<UNROLL, MODE>(gl, a, x.pos, x.len, lane, cnt, sink);
     }
   };
+
+  // cut the wave's 64 buckets (start `pos`, `rem` ids left; rem = 0: none) into chunks of <= 64 ids, at most 3 per
+  // lane and round (q_count < 64 on entry, so at most 63 + 192 items are ever queued), and walk full batches
+  auto cut_and_walk = [&](uint32_t pos, uint32_t rem) {
+    const uint32_t step = 64u >> a;  // units per 64 ids (align_log2 <= 6)
+    do {
+      uint32_t nch = (rem + 63) >> 6;
+      if (nch > 3) nch = 3;
+      uint32_t incl = nch;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        uint32_t y = __shfl_up(incl, o, 64);
+        if (lane >= (uint32_t)o) incl += y;
+      }
+      const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+      uint32_t slot = q_head + q_count + incl - nch;
+#pragma unroll
+      for (uint32_t k = 0; k < 3; ++k)
+        if (k < nch) {
+          const uint32_t left = rem - 64 * k;
+          wq[(slot + k) & (kQueue - 1)] = Item{pos + step * k, left < 64 ? left : 64u};
+        }
+      q_count += total;
+      pos += step * nch;
+      rem -= rem < 192 ? rem : 192u;
+      drain();
+    } while (__any(rem != 0));
+  };
+
+  if (HM_FORM && hm) {
+    // Masked form (single-tile index with its per-slot class mask): most of a query's fingerprints fall into
+    // classes that hold no bucket in their slot -- for a short read against a genome index, ~99 % -- so the loop
+    // is bound by the latency of its own input.  All loads of kDeep iterations are issued before any is used:
+    // fingerprints and mask words first, then (only for lanes that still hold a fingerprint, only in iterations
+    // where some lane does) the table entries.
+    constexpr int kDeep = 8;
+    for (uint32_t it0 = it_lo + wave; it0 < n_it; it0 += kDeep * NW) {
+      int32_t fpv[kDeep];
+      uint32_t mw[kDeep];
+#pragma unroll
+      for (int k = 0; k < kDeep; ++k) {
+        uint32_t s = (it0 + k * NW) * 64 + lane;
+        s = s < v.f_local ? s : v.f_local - 1;
+        fpv[k] = sk[s];
+        mw[k] = hm[s];
+      }
+      Entry en[kDeep];
+      bool live[kDeep];
+#pragma unroll
+      for (int k = 0; k < kDeep; ++k) {
+        const uint32_t itk = it0 + k * NW;
+        const int32_t fp = fpv[k];
+        const bool ok = slot_ok(itk) && fp >= 0 && (uint32_t)fp < R && ((mw[k] >> ((uint32_t)fp >> v.hmask_shift)) & 1u);   // :654
+        live[k] = __any(ok);
+        en[k] = Entry{0u, 0u};
+        if (ok) {
+          uint32_t s = itk * 64 + lane;
+          en[k] = v.entries[((uint64_t)s * R + (uint32_t)fp) * v.n_tiles + t];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kDeep; ++k)
+        if (live[k]) {   // (wave-uniform)
+          if (MODE == 6) { sink += en[k].start ^ en[k].len; continue; }
+          cut_and_walk(en[k].start, en[k].len);
+        }
+    }
+    if (q_count) {  // the last partial batch; "no chunk" = the tile's spare line of padding ids
+      if constexpr (PAIR) {
+        if (lane >= q_count) wq[q_head + lane] = Item{my_units[v.f_local], 0u};
+        pw.batch(wq + q_head);
+      } else {
+        Item x = wq[(q_head + lane) & (kQueue - 1)];
+        if (lane >= q_count) x = Item{PAD ? my_units[v.f_local] : 0u, 0u};
+        walk64<UNROLL, MODE>(gl, a, x.pos, x.len, lane, cnt, sink);
+      }
+    }
+    return;
+  }
 
   // software pipeline: table look-ups run two iterations ahead of the walk, fingerprints
   // three (a pass over short buckets has little walk work to hide a look-up behind)
@@ -294,7 +359,6 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
     const bool nxt2_ok = valid_of(it + 2 * NW, fp2);
     fp2 = load_fp(it + 3 * NW);
     uint32_t pos = cur.e[0].start, rem = cur_ok ? cur.e[0].len : 0u;
-    const uint32_t step = 64u >> a;  // units per 64 ids (align_log2 <= 6)
     if (STASH_OUT) {
       const uint32_t s = it * 64 + lane;
       if (s < v.f_local) {
@@ -304,31 +368,7 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
       }
     }
     if (MODE == 6) { sink += pos ^ rem; cur = nxt; cur_ok = nxt_ok; nxt = nxt2; nxt_ok = nxt2_ok; continue; }
-    if (HM_FORM && !__any(rem != 0)) { cur = nxt; cur_ok = nxt_ok; nxt = nxt2; nxt_ok = nxt2_ok; continue; }   // 64 slots without a bucket
-    // cut the 64 buckets into chunks of <= 64 ids, at most 3 per lane and round
-    // (q_count < 64 here, so at most 63 + 192 items are ever queued)
-    do {
-      uint32_t nch = (rem + 63) >> 6;
-      if (nch > 3) nch = 3;
-      uint32_t incl = nch;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        uint32_t y = __shfl_up(incl, o, 64);
-        if (lane >= (uint32_t)o) incl += y;
-      }
-      const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-      uint32_t slot = q_head + q_count + incl - nch;
-#pragma unroll
-      for (uint32_t k = 0; k < 3; ++k)
-        if (k < nch) {
-          const uint32_t left = rem - 64 * k;
-          wq[(slot + k) & (kQueue - 1)] = Item{pos + step * k, left < 64 ? left : 64u};
-        }
-      q_count += total;
-      pos += step * nch;
-      rem -= rem < 192 ? rem : 192u;
-      drain();
-    } while (__any(rem != 0));
+    cut_and_walk(pos, rem);
     cur = nxt;
     cur_ok = nxt_ok;
     nxt = nxt2;
