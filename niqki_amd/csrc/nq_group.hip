@@ -821,6 +821,7 @@ int all_to_all(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::
   if (g->transport == niqki_group::kRccl) {
     NQ_GN(g, rccl().GroupStart());
     for (uint32_t l = 0; l < g->n_local; ++l) {
+      NQ_GH(g, hipSetDevice(g->sh[l]->device));   // (several communicators in one thread: each call on its own device)
       const char *s = (const char *)(g->ws[l].*send).p;
       char *r = (char *)(g->ws[l].*recv).p;
       for (uint32_t p = 0; p < g->world; ++p) {
@@ -856,8 +857,10 @@ int all_to_all(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::
 int all_gather(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::*recv, size_t bytes) {
   if (g->transport == niqki_group::kRccl) {
     NQ_GN(g, rccl().GroupStart());
-    for (uint32_t l = 0; l < g->n_local; ++l)
+    for (uint32_t l = 0; l < g->n_local; ++l) {
+      NQ_GH(g, hipSetDevice(g->sh[l]->device));
       NQ_GN(g, rccl().AllGather((g->ws[l].*send).p, (g->ws[l].*recv).p, bytes, ncclUint8, g->comm[l], g->sh[l]->stream));
+    }
     NQ_GN(g, rccl().GroupEnd());
     return NIQKI_OK;
   }
@@ -886,8 +889,10 @@ int all_gather(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::
 int reduce_scatter_u32(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::*recv, size_t count) {
   if (g->transport == niqki_group::kRccl) {
     NQ_GN(g, rccl().GroupStart());
-    for (uint32_t l = 0; l < g->n_local; ++l)
+    for (uint32_t l = 0; l < g->n_local; ++l) {
+      NQ_GH(g, hipSetDevice(g->sh[l]->device));
       NQ_GN(g, rccl().ReduceScatter((g->ws[l].*send).p, (g->ws[l].*recv).p, count, ncclUint32, ncclSum, g->comm[l], g->sh[l]->stream));
+    }
     NQ_GN(g, rccl().GroupEnd());
     return NIQKI_OK;
   }

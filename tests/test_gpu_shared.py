@@ -63,3 +63,32 @@ def test_concurrent_sketch_insert_query_on_one_handle(native, po):
         ehc, ehg = ix.query(exp_sk[i])
         assert np.array_equal(hc[off[i]:off[i + 1]], ehc) and np.array_equal(hg[off[i]:off[i + 1]], ehg)
     e.close()
+
+
+def test_stream_priority_option_changes_no_result(native, po):
+    """option "stream_priority": the handle moves to a stream of its own at the top / bottom of the device's priority
+    range (also after niqki_set_stream); answers and the stream contract stay what they were."""
+    import torch
+    K, S, W, H, J = 31, 9, 10, 4, 0.05
+    p = po.make_params(K, S, W, H, J)
+    genomes = [native.synth_genome_host(23, g // 4, g % 4, 200 * (g % 4), 20_000) for g in range(16)]
+    exp = np.stack([po.compute_sketch(p, g) for g in genomes])
+    ix = po.Index(p, exp)
+    e = native.Engine(K=K, S=S, W=W, H=H, J=J)
+    e.set_stream(torch.cuda.current_stream().cuda_stream)      # a caller's stream first ...
+    for prio in (1, -1, 0):
+        e.set_option("stream_priority", prio)                   # ... then a stream of the handle's own
+        assert e.get_stream() not in (0, torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(native.NiqkiError):
+        e.set_option("stream_priority", 2)
+    sk = e.sketch(genomes)
+    assert np.array_equal(sk, exp)
+    e.insert(sk)
+    off, hc, hg = e.query(exp)
+    for i in range(len(genomes)):
+        ehc, ehg = ix.query(exp[i])
+        assert np.array_equal(hc[off[i]:off[i + 1]], ehc) and np.array_equal(hg[off[i]:off[i + 1]], ehg)
+    e.set_stream(torch.cuda.current_stream().cuda_stream)      # and back onto the caller's
+    off2, hc2, hg2 = e.query(exp)
+    assert np.array_equal(off2, off) and np.array_equal(hc2, hc) and np.array_equal(hg2, hg)
+    e.close()
