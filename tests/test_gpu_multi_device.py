@@ -102,6 +102,15 @@ def test_host_program_on_distinct_devices(tmp_path_factory, native, gold, gpus):
     assert_same_text(gunzip(wd / "md_matrix.gz").decode(), meta["cli"]["matrix"])
 
 
+def test_worker_over_rccl_at_world_1(tmp_path, native, po):
+    """the rccl form of the multi-process harness above (id made without NIQKI_GROUP_TRANSPORT, worker's transport
+    switch, RCCL communicator, collectives, begin / end halves) with the one rank a one-GPU box can give it"""
+    S, W, N, NQ, MS = 9, 8, 700, 9, 40
+    sk, q = make_data(S, W, N, NQ, 5)
+    res = run_world(tmp_path, native, 1, sk, q, S, W, MS, "sparse", 256, transport="rccl", devices=1)
+    check_world(res, native, po, sk, q, S, W, MS, 1, "sparse", 256)
+
+
 def test_gated_tests_are_collected_here():
     """the box this runs on says how many of the above really ran"""
     n = n_devices()
