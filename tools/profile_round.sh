@@ -29,7 +29,7 @@ bash tools/pmc_bench.sh ${TAG}_default || exit 1
 # two processes on this one GPU (bench.py --gpus 2 starts its own ranks when no launcher did): gloo for bench.py's own barrier, the library's ipc transport
 # for the exchange; with and without the next batch's sketch kernel beside the exchange
 for ov in "" "--no-overlap"; do
-  timeout -k 10 600 python3 bench.py --gpus 2 --steps 9 --warmup 2 --no-cpu --no-extra $ov > gpurun_out/${TAG}_bench_n2_ipc_one_gpu${ov}.json 2> gpurun_out/${TAG}_bench_n2.err || { tail -5 gpurun_out/${TAG}_bench_n2.err; exit 1; }
+  timeout -k 10 600 python3 bench.py --gpus 2 --steps 9 --warmup 2 --no-cpu --no-extra --verify $ov > gpurun_out/${TAG}_bench_n2_ipc_one_gpu${ov}.json 2> gpurun_out/${TAG}_bench_n2.err || { tail -5 gpurun_out/${TAG}_bench_n2.err; exit 1; }
 done
 timeout -k 10 600 python3 bench.py --shard-of 8 --no-cpu > gpurun_out/${TAG}_shard_of_8.json 2> gpurun_out/${TAG}_shard_of_8.err || exit 1
 # the weak-scaling shape of --gpus 8 on rank 0 (every rank brings 4096 queries), and all 8 ranks of the group on this one GPU
