@@ -92,3 +92,33 @@ def test_select_best_h_random(native, po, seed):
         assert np.array_equal(hc[off[q]:off[q + 1]], ec) and np.array_equal(hg[off[q]:off[q + 1]], eg)
     assert e.export_dump() == ix.dump_bytes()
     e.close()
+
+
+@pytest.mark.parametrize("seed", range(8 * SCALE))
+def test_long_records_random_parameters(native, po, seed):
+    """The filtered long-record sketch path (candidate filter + exact re-run) over random K (17..31 take the fast loop,
+    below the generic one), S, W, H: a 300 kbp record with dirty stretches, and the same bases as three records of one
+    sketch (whole-file mode) -- against the oracle."""
+    rng = np.random.default_rng(7000 + seed)
+    K = int(rng.integers(17, 32)) if seed % 4 else int(rng.integers(5, 17))
+    S = int(rng.integers(8, 13))
+    W = int(rng.integers(6, 13))
+    H = int(rng.integers(2, min(W, 5) + 1))
+    p = po.make_params(K, S, W, H, 0.0)
+    e = native.Engine(K=K, S=S, W=W, H=H)
+    L = int(rng.integers(250_000, 350_000))
+    g = random_record(rng, L, dirty=False)
+    for _ in range(3):                                   # a few dirty stretches and single dirty bytes
+        a = int(rng.integers(0, L - 200))
+        g[a:a + int(rng.integers(1, 120))] = ord("N")
+    g[rng.integers(0, L, 20)] = np.frombuffer(b"acgtnRY-", np.uint8)[rng.integers(0, 8, 20)]
+    sk = e.sketch([g])
+    assert np.array_equal(sk[0], po.compute_sketch(p, g)), (K, S, W, H)
+    cuts = sorted(int(x) for x in rng.integers(K + 1, L - K - 1, 2))
+    parts = [g[:cuts[0]], g[cuts[0]:cuts[1]], g[cuts[1]:]]
+    sk2 = e.sketch(parts, entry_rec=np.array([0, 3], np.uint32))
+    acc = np.full(1 << S, -1, np.int32)
+    for part in parts:
+        po.sketch_accumulate(p, part, acc)
+    assert np.array_equal(sk2[0], po.densify(p, acc)[0]), (K, S, W, H)
+    e.close()
