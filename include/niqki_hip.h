@@ -463,6 +463,25 @@ const char *niqki_group_last_error(const niqki_group *g);
  * partial count of at least half the candidate threshold) a shard keeps per query, default 1024,
  * at most 4096. */
 int niqki_group_set_option(niqki_group *g, const char *key, int64_t value);
+/* The arithmetic of one query batch of a group, as niqki_group_query decides it -- a pure function (no device, no
+ * handle: callable on a host without a GPU; the CPU test of the exchange protocol over gloo takes its slot
+ * ranges, thresholds and buffer shapes from here and from niqki_group_slot_range, tests/test_dist_cpu.py).
+ *   world, S, min_score     the group's shape (Index::query_sketch's threshold, src/niqki_index.cpp:646-650)
+ *   exchange_option         option "exchange": 0 = choose, 1 = sparse, 2 = dense
+ *   per, n_genomes          queries per rank in the batch, genomes indexed
+ *   cand_cap                option "cand_cap" */
+typedef struct niqki_group_plan {
+  uint32_t sparse;          /* 1 = sparse candidate exchange, 0 = dense reduce-scatter of the counter rows */
+  uint32_t cand_threshold;  /* ceil(min_score / world): a partial count from which a genome is a candidate */
+  uint32_t surv_threshold;  /* max(1, cand_threshold / 2): ... from which a shard keeps it as a survivor */
+  uint32_t slice_slots;     /* ceil(2^S / world): cells per query and peer in the slice exchange (int16 each) */
+  uint64_t slice_bytes;     /* bytes of one peer's part of the slice exchange (per queries, 16-byte rounded) */
+  uint64_t cand_blob_bytes; /* bytes of a rank's all-gathered candidate blob: world*per lists of cand_cap ids + 2 sizes each */
+  uint64_t sum_words;       /* u32 words a rank receives from the reduce-scatter: candidates' packed u16 counts, or dense rows */
+  uint64_t row_stride;      /* u16 cells per counter row (NIQKI_ROW_STRIDE(n_genomes)) */
+} niqki_group_plan;
+int niqki_group_plan_batch(uint32_t world, uint32_t S, uint32_t min_score, int exchange_option, uint32_t per,
+                           uint32_t n_genomes, uint32_t cand_cap, niqki_group_plan *out);
 /* "overflows" (sparse steps redone densely so far), "rccl" (1 = RCCL transport),
  * "transport" (0 = device copies inside one process, 1 = RCCL, 2 = ipc),
  * "sparse" (1 = the sparse exchange is selected), "ipc_words_kind" (ipc transport: where this rank's

@@ -38,6 +38,12 @@ class RawBatch(C.Structure):
                 ("max_entries", C.c_uint32)]
 
 
+class GroupPlan(C.Structure):
+    _fields_ = [("sparse", C.c_uint32), ("cand_threshold", C.c_uint32), ("surv_threshold", C.c_uint32),
+                ("slice_slots", C.c_uint32), ("slice_bytes", C.c_uint64), ("cand_blob_bytes", C.c_uint64),
+                ("sum_words", C.c_uint64), ("row_stride", C.c_uint64)]
+
+
 class StageInfo(C.Structure):
     _fields_ = [("n_entry", C.c_uint32), ("n_rec", C.c_uint32), ("consumed", C.c_uint64),
                 ("seq_bytes", C.c_uint64)]
@@ -113,6 +119,7 @@ ABI = [
     ("niqki_query_gathered", _int, [_vp, _vp, _u32, _vp, _int]),
     ("niqki_group_slot_range", None, [_u32, _u32, _u32, C.POINTER(_u32), C.POINTER(_u32)]),
     ("niqki_group_new_id", _int, [_vp]),
+    ("niqki_group_plan_batch", _int, [_u32, _u32, _u32, _int, _u32, _u32, _u32, C.POINTER(GroupPlan)]),
     ("niqki_group_create", _int, [_vp, _u32, _u32, _u32, _vp, C.POINTER(_vp)]),
     ("niqki_group_destroy", None, [_vp]),
     ("niqki_group_last_error", C.c_char_p, [_vp]),
@@ -589,6 +596,15 @@ def group_slot_range(rank, world, S):
     b, e = _u32(0), _u32(0)
     lib().niqki_group_slot_range(rank, world, S, C.byref(b), C.byref(e))
     return b.value, e.value
+
+
+def group_plan(world, S, min_score, exchange_option, per, n_genomes, cand_cap):
+    """niqki_group_plan_batch: the decisions and sizes of one query batch of a group (pure arithmetic: no GPU)."""
+    p = GroupPlan()
+    rc = lib().niqki_group_plan_batch(world, S, min_score, exchange_option, per, n_genomes, cand_cap, C.byref(p))
+    if rc:
+        raise NiqkiError(rc, "niqki_group_plan_batch: invalid arguments")
+    return p
 
 
 def group_new_id():

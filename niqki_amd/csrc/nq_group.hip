@@ -923,6 +923,23 @@ int reduce_scatter_u32(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_gro
 
 // bytes of one destination's slices of `per` queries (16-byte granular for the pull kernel)
 size_t slice_bytes(uint32_t per, uint32_t w_max) { return (((size_t)per * w_max * 2) + 15) & ~(size_t)15; }
+// the decisions and sizes of one query batch (niqki_group_plan_batch: also what the CPU test of the protocol uses)
+void plan_batch(uint32_t G, uint32_t S, uint32_t min_score, int exchange, uint32_t per, uint32_t N, uint32_t C, niqki_group_plan *o) {
+  const uint32_t F = 1u << S, nq_ = G * per;
+  bool sparse = exchange == 1 || (exchange == 0 && min_score >= 4 * G);
+  if (min_score < G || N == 0) sparse = false;                    // ceil(min_score / G) must be >= 1
+  if ((uint64_t)G * C > nq::kCandMax) sparse = false;             // (cand_hits_kernel orders a query's candidates in LDS)
+  o->sparse = sparse ? 1u : 0u;
+  o->cand_threshold = (min_score + G - 1) / G;
+  o->surv_threshold = std::max(1u, o->cand_threshold / 2);
+  o->slice_slots = (F + G - 1) / G;
+  o->slice_bytes = slice_bytes(per, o->slice_slots);
+  o->cand_blob_bytes = (((size_t)nq::cand_blob_ints(nq_, C) * 4) + 15) & ~(size_t)15;
+  o->row_stride = NIQKI_ROW_STRIDE(N);
+  const bool wide = S > 15;                                       // cross-shard sums reach 2^16: they travel as u32
+  o->sum_words = sparse ? (wide ? (uint64_t)per * G * C : (uint64_t)per * G * C / 2)
+                        : (wide ? (uint64_t)per * o->row_stride : (uint64_t)per * (o->row_stride / 2));
+}
 size_t blob_bytes(uint32_t nq_, uint32_t C) { return (((size_t)nq::cand_blob_ints(nq_, C) * 4) + 15) & ~(size_t)15; }
 
 // steps 1-3 shared by insert and query: local sketches -> compact rows of all world*per sketches
@@ -1106,6 +1123,13 @@ void niqki_group_destroy(niqki_group *g) {
 
 const char *niqki_group_last_error(const niqki_group *g) { return g ? g->err.c_str() : ""; }
 
+int niqki_group_plan_batch(uint32_t world, uint32_t S, uint32_t min_score, int exchange_option, uint32_t per, uint32_t n_genomes,
+                           uint32_t cand_cap, niqki_group_plan *out) {
+  if (!out || world == 0 || world > kMaxWorld || S == 0 || S > 16 || exchange_option < 0 || exchange_option > 2) return NIQKI_E_INVALID;
+  plan_batch(world, S, min_score, exchange_option, per, n_genomes, cand_cap, out);
+  return NIQKI_OK;
+}
+
 int niqki_group_set_option(niqki_group *g, const char *key, int64_t value) {
   if (!g || !key) return NIQKI_E_INVALID;
   if (!std::strcmp(key, "exchange")) {
@@ -1135,7 +1159,9 @@ int niqki_group_get_stat(const niqki_group *g, const char *key, uint64_t *value)
   if (!std::strcmp(key, "ipc_arena_fine")) { *value = g->ipc.arena_fine ? 1 : 0; return NIQKI_OK; }
   if (!std::strcmp(key, "sparse")) {
     const uint32_t ms = g->sh[0]->d.min_score;
-    *value = (g->exchange == 1 || (g->exchange == 0 && ms >= 4 * g->world)) ? 1 : 0;
+    niqki_group_plan plan;
+    plan_batch(g->world, g->sh[0]->d.S, ms, g->exchange, 1, std::max(1u, g->sh[0]->n_genomes), g->cand_cap, &plan);
+    *value = plan.sparse;
     return NIQKI_OK;
   }
   return NIQKI_E_INVALID;
@@ -1312,14 +1338,14 @@ int niqki_group_query_begin(niqki_group *g, const int32_t *const *local_sketches
   pd.active = true;
   if (per == 0) return NIQKI_OK;
   const uint32_t min_score = g->sh[0]->d.min_score;
-  bool sparse = g->exchange == 1 || (g->exchange == 0 && min_score >= 4 * G);
-  if (min_score < G || N == 0) sparse = false;   // ceil(min_score / G) must be >= 1
-  if ((uint64_t)G * g->cand_cap > nq::kCandMax) sparse = false;   // (cand_hits_kernel orders a query's candidates in LDS)
+  niqki_group_plan plan;
+  plan_batch(G, g->sh[0]->d.S, min_score, g->exchange, per, N, g->cand_cap, &plan);
+  const bool sparse = plan.sparse != 0;
   pd.sparse = sparse;
   int rc = prepare_batch(g, per, N, true, sparse);
   if (!rc) rc = exchange_slices(g, local_sketches, per);
   if (rc) { pd.active = false; return rc; }
-  const uint32_t C = g->cand_cap, SC = g->surv_cap, thr = (min_score + G - 1) / G;
+  const uint32_t C = g->cand_cap, SC = g->surv_cap, thr = plan.cand_threshold;
   if (sparse) {
     // 3. gather over the local slots WITHOUT counter rows: what leaves the kernel is, per query, the candidates
     //    (partial count >= ceil(min_score / G): their ids travel) and the survivors (partial count >= half of
@@ -1343,7 +1369,7 @@ int niqki_group_query_begin(niqki_group *g, const int32_t *const *local_sketches
       co.cap = C;
       co.surv = (int2 *)w.surv.p;
       co.surv_n = co.n + nq;
-      co.surv_thr = std::max(1u, thr / 2);
+      co.surv_thr = plan.surv_threshold;
       co.surv_cap = SC;
       NQ_G(g, l, nqi::counts_dev(ix, (const int32_t *)w.allsk.p, ix->d.slot_end - ix->d.slot_begin, 0, nq, nullptr, stride, nullptr, &co));
     }

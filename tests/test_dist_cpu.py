@@ -133,6 +133,23 @@ def test_slot_sharded_query_world2(exchange):
     assert dict(ret) == {0: True, 1: True}
 
 
+def test_group_plan_is_the_products():
+    """niqki_group_plan_batch (pure arithmetic inside libniqki_hip.so, the function nq_group.hip calls for every
+    batch): thresholds, the sparse / dense decision and the sizes of what travels, for the north-star group."""
+    import niqki_amd
+    p = niqki_amd.group_plan(8, 15, 3276, 0, 512, 100_000, 256)
+    assert (p.sparse, p.cand_threshold, p.surv_threshold, p.slice_slots) == (1, 410, 205, 4096)
+    assert p.slice_bytes == 512 * 4096 * 2 and p.row_stride == niqki_amd.row_stride(100_000)
+    assert p.cand_blob_bytes == (4096 * 256 + 2 * 4096) * 4 and p.sum_words == 512 * 8 * 256 // 2
+    assert niqki_amd.group_plan(8, 15, 3276, 2, 512, 100_000, 256).sparse == 0            # option: dense
+    assert niqki_amd.group_plan(8, 15, 3276, 2, 512, 100_000, 256).sum_words == 512 * (p.row_stride // 2)
+    assert niqki_amd.group_plan(8, 15, 20, 0, 512, 100_000, 256).sparse == 0              # min_score < 4 * world: dense
+    assert niqki_amd.group_plan(8, 15, 5, 1, 512, 100_000, 256).sparse == 0               # min_score < world: never sparse
+    assert niqki_amd.group_plan(2, 16, 6553, 0, 64, 1000, 256).sum_words == 64 * 2 * 256  # S = 16: sums travel as u32
+    with pytest.raises(niqki_amd.NiqkiError):
+        niqki_amd.group_plan(0, 15, 1, 0, 1, 1, 2)
+
+
 def test_slot_ranges_partition_the_sketch():
     for F in (32768, 4096, 64):
         for world in (1, 2, 3, 4, 8):

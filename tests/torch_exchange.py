@@ -1,16 +1,22 @@
 """The slot-shard exchange protocol of niqki_amd/csrc/nq_group.hip written with torch collectives
 (gloo on CPU): what tests/test_dist_cpu.py runs with an oracle-backed stand-in engine, so that the
 N > 1 logic -- slot slices, packed u16 reduce-scatter, sparse candidate exchange with its overflow
-fallback, per-rank threshold -- is checked without GPUs.  Test infrastructure, not product code."""
+fallback, per-rank threshold -- is checked without GPUs.  Test infrastructure, not product code.
+
+What the PRODUCT decides about a batch is not restated here: slot ranges come from niqki_group_slot_range and
+the sparse / dense decision, the candidate threshold and the counter row stride from niqki_group_plan_batch --
+the two pure functions of libniqki_hip.so that nq_group.hip itself calls (the library loads without a GPU)."""
 import torch
 import torch.distributed as dist
 
-from niqki_amd.capi import row_stride
+from niqki_amd.capi import group_plan, group_slot_range, row_stride
 
 
 def slot_range(rank, world, F):
-    """Slots [begin, end) owned by `rank`; F = 2^S and world need not divide it."""
-    return (F * rank) // world, (F * (rank + 1)) // world
+    """Slots [begin, end) owned by `rank` (niqki_group_slot_range); F = 2^S and world need not divide it."""
+    S = F.bit_length() - 1
+    assert 1 << S == F
+    return group_slot_range(rank, world, S)
 
 
 def padded_batch(nq, world):
@@ -36,10 +42,15 @@ class TorchExchange:
         # sketch cells are -1 or a fingerprint below 2^W <= 2^15: they travel as int16 when the
         # caller says so (not after niqki_select_best_H, whose cells may exceed 2^W)
         self.compact = compact_sketches
-        if exchange == "auto":
-            exchange = "sparse" if self.min_score >= 4 * self.world else "reduce_scatter"
-        if exchange == "sparse" and self.min_score < self.world:
+        # the product's own decision for this group shape (option "exchange": 0 = choose, 1 = sparse, 2 = dense)
+        S = F.bit_length() - 1
+        opt = {"auto": 0, "sparse": 1}.get(exchange, 2)
+        self.plan = group_plan(self.world, S, self.min_score, opt, 1, max(n_genomes, 1), cand_cap)
+        assert self.plan.row_stride == self.stride
+        if exchange == "sparse" and not self.plan.sparse:
             raise ValueError("the sparse exchange needs min_score >= number of shards")
+        if exchange == "auto":
+            exchange = "sparse" if self.plan.sparse else "reduce_scatter"
         self.exchange = exchange
         self.overflow = torch.zeros(1, dtype=torch.int32, device=device)  # sticky: a sparse step overflowed
         self._bufs = {}
@@ -96,7 +107,7 @@ class TorchExchange:
         G, C = self.world, self.cand_cap
         nq = counts.shape[0]
         per = nq // G
-        thr = -(-self.min_score // G)  # ceil
+        thr = self.plan.cand_threshold   # ceil(min_score / G), as the product computes it
         cand = self._buf("cand", (nq, C), torch.int32)
         ncand = self._buf("ncand", (nq,), torch.int32)
         self.e.candidates_dev(counts, nq, self.stride, self.N, thr, C, cand, ncand)
