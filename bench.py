@@ -787,6 +787,9 @@ def main():
             pipelined = {"value": n_pl * per / tp, "unit": "genomes/s", "ms_per_step": tp / n_pl * 1e3, "steps": n_pl,
                          "ms_per_step_default_priority": tp0 / n_pl * 1e3, "ms_per_step_priority_streams": tp1 / n_pl * 1e3,
                          "floor_ms_if_kernels_could_share_cus": max(prof["sketch"][0], prof["gather"][0] + prof["hits"][0]) / max(1, args.steps),
+                         "floor_note": "max(sketch, gather + hits) per step: a bound for kernels that need different resources; these "
+                                       "two share the vector issue (0.89 of it for the sketch kernel, 0.64 for the gather launch), which "
+                                       "alone is 21 ms per step (DESIGN.md 4.4)",
                          "note": "batch i+1 sketched on a second handle's stream beside batch i's gather and hits kernels "
                                  "(bench.py --pipeline makes this the timed line); value = the faster of the two stream set-ups. "
                                  "The two kernels cannot share a CU (128 KB of LDS each) and each keeps its CUs busy (the gather "
