@@ -306,3 +306,45 @@ def test_sketch_size_16_sharded(workdir, monkeypatch):
     assert_same_text(gunzip(workdir / "s16g_hits.gz").decode(), exp["hits"])
     run(workdir, ["--gpus", "2", "-M", "fof.txt", "-S", "16", "-W", "8", "-J", "0.1", "-O", "s16g_matrix.gz"])
     assert_same_text(gunzip(workdir / "s16g_matrix.gz").decode(), exp["matrix"])
+
+
+REF_GPU = os.path.join(ROOT, "oracle", "_ref", "niqki_ref_gpu")
+
+
+def _normalised(text):
+    """the lines as sorted bags of tokens, themselves sorted: what does not depend on the order in which threads
+    were handed their genome ids (ties between equal counts are listed by descending id) or wrote their lines"""
+    return sorted(tuple(sorted(t for t in line.split(" ") if t)) for line in text.split("\n") if line.strip())
+
+
+@pytest.mark.skipif(not os.path.exists(REF_GPU), reason="oracle/_ref/niqki_ref_gpu is built where /root/reference exists (oracle/Makefile)")
+def test_the_reference_program_itself_on_the_c_abi(workdir, gold):
+    """The drop-in, end to end: the REFERENCE's own main, option parser, file readers, `omp parallel` record loops and
+    writers (oracle/_ref/libniqki_ref.so + src/niqki.cpp, compiled where they lie) with compute_sketch / insert_sketch /
+    query_sketch bound to libniqki_hip.so (oracle/ref_gpu_ops.cpp: symbol precedence, no reference file modified --
+    INTEGRATION.md's minimal patch).  One thread: the reference CLI's golden texts byte for byte.  Eight threads (the
+    reference then hands out genome ids in thread arrival order; the *_shared entry points combine
+    the callers into batches): the same hits per query."""
+    _, meta = gold
+
+    import re
+
+    def run_ref(args, threads):
+        r = subprocess.run([REF_GPU] + args, cwd=workdir, capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, OMP_NUM_THREADS=str(threads), NIQKI_REF_GPU_REPORT="1"))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        # the binding took: the operators' calls were answered by the library (else the reference's CPU code
+        # would have produced the same text)
+        m = re.search(r"niqki_ref_gpu: (\d+) calls .* in (\d+) batches \(largest (\d+)\), (\d+) genomes indexed on the GPU", r.stderr)
+        assert m, r.stderr[-2000:]
+        calls, batches, largest, indexed = (int(x) for x in m.groups())
+        assert calls >= 3 * indexed > 0 and batches >= 1        # a sketch + an insert per indexed record, a sketch (+ query) per query
+        return calls, batches, largest
+    run_ref(["-I", "fof.txt", "-Q", "fof.txt", "-S", "10", "-J", "0.1", "-O", "refgpu_hits.gz"], 1)
+    assert_same_text(gunzip(workdir / "refgpu_hits.gz").decode(), meta["cli"]["hits"])
+    run_ref(["-i", "reads.fa", "-l", "reads.fa", "-S", "10", "-W", "10", "-J", "0.2", "-O", "refgpu_lines.gz"], 1)
+    assert_same_text(gunzip(workdir / "refgpu_lines.gz").decode(), meta["cli"]["lines"])
+    calls, batches, largest = run_ref(["-I", "fof.txt", "-Q", "fof.txt", "-S", "10", "-J", "0.1", "-O", "refgpu_hits8.gz"], 8)
+    assert _normalised(gunzip(workdir / "refgpu_hits8.gz").decode()) == _normalised(meta["cli"]["hits"])
+    calls, batches, largest = run_ref(["-i", "reads.fa", "-l", "reads.fa", "-S", "10", "-W", "10", "-J", "0.2", "-O", "refgpu_lines8.gz"], 8)
+    assert _normalised(gunzip(workdir / "refgpu_lines8.gz").decode()) == _normalised(meta["cli"]["lines"])
