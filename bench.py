@@ -1399,6 +1399,8 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
                "--dir", os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "niqki_bench_cli_%d" % os.getpid())]
         if gz:
             cmd.append("--gz")
+        else:
+            cmd += ["--reference", "128"]
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
             j = json.loads(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else None
@@ -1408,6 +1410,10 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
             cli[tag] = {"files": n_files, "index_genomes_per_s": j["index_genomes_per_s"], "query_genomes_per_s": j["query_genomes_per_s"],
                         "index_file_GBps": j["index_fasta_GBps"], "process_startup_s": j["startup_s"],
                         "query_phase_split_s": j.get("query_phase_split_s")}
+            if j.get("reference_program"):
+                # the reference's OWN program on the first files: its CPU path, and the same binary with its three
+                # operators bound to the C ABI (oracle/ref_gpu_ops.cpp) -- what INTEGRATION.md's minimal patch gives
+                cli[tag]["reference_program"] = j["reference_program"]
     out["cli_files"] = {"workload": "niqki -I fof -Q fof -J 0.1 on 5 Mbp FASTA files (70 columns) in the page cache, whole-file mode",
                         **cli} if cli else None
     return out

@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--gz", action="store_true")
     ap.add_argument("--dir", default="/dev/shm/niqki_cli_bench")
     ap.add_argument("--extra", default="", help="extra CLI options, space separated")
+    ap.add_argument("--reference", type=int, default=0,
+                    help="also run the reference's own program (oracle/_ref/niqki_ref: CPU; niqki_ref_gpu: its operators bound to "
+                         "the C ABI) on the first N files")
     args = ap.parse_args()
     import niqki_amd
     shutil.rmtree(args.dir, ignore_errors=True)
@@ -95,6 +98,50 @@ def main():
             cp, dv, ou = (float(x) for x in m.groups())
             # (copy_and_frame: what the main thread still waits for -- the copy of batch i+1 runs under batch i)
             res["query_phase_split_s"] = {"copy_and_frame": cp, "sketch_and_query": dv, "output": ou}
+        # the REFERENCE's own program on the same files (oracle/_ref, where it travelled with the repo): its CPU path,
+        # and the same program with compute_sketch / insert_sketch / query_sketch bound to the C ABI
+        # (oracle/ref_gpu_ops.cpp) -- wall time of `-I fof -Q fof` on the first files, threads = the CPUs this job has
+        ref_cpu = os.path.join(ROOT, "oracle", "_ref", "niqki_ref")
+        ref_gpu = os.path.join(ROOT, "oracle", "_ref", "niqki_ref_gpu")
+        if not args.gz and args.reference and os.path.exists(ref_cpu) and os.path.exists(ref_gpu):
+            n_ref = min(args.genomes, args.reference)
+            open(os.path.join(args.dir, "ref.txt"), "w").write("\n".join(names[:n_ref]) + "\n")
+            try:
+                threads = len(os.sched_getaffinity(0))
+                q = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q[0] != "max":
+                    threads = max(1, min(threads, int(round(float(q[0]) / float(q[1])))))
+            except (OSError, ValueError, IndexError, AttributeError):
+                threads = os.cpu_count() or 1
+            renv = dict(os.environ, OMP_NUM_THREADS=str(threads), NIQKI_REF_GPU_REPORT="1")
+            ref = {"files": n_ref, "threads": threads}
+            for tag, binary in (("reference_cpu", ref_cpu), ("reference_on_c_abi", ref_gpu)):
+                t0 = time.time()
+                r = subprocess.run([binary, "-I", "ref.txt", "-Q", "ref.txt", "-J", "0.1", "-O", tag + ".gz"] + extra, cwd=args.dir,
+                                   capture_output=True, text=True, timeout=1800, env=renv)
+                dt = time.time() - t0
+                if r.returncode != 0:
+                    ref[tag] = {"error": (r.stderr or r.stdout)[-300:]}
+                    continue
+                ref[tag] = {"wall_s": round(dt, 3), "genomes_per_s_index_plus_query": round(2 * n_ref / dt, 1)}
+                rep = [l for l in r.stderr.splitlines() if l.startswith("niqki_ref_gpu:")]
+                if rep:
+                    ref[tag]["report"] = rep[-1]
+            t0 = time.time()
+            r = subprocess.run([BIN, "-I", "ref.txt", "-Q", "ref.txt", "-J", "0.1", "-O", "ours_ref.gz"] + extra, cwd=args.dir,
+                               capture_output=True, text=True, timeout=1800, env=env)
+            ref["niqki_host_program"] = {"wall_s": round(time.time() - t0, 3), "genomes_per_s_index_plus_query": round(2 * n_ref / (time.time() - t0), 1)}
+            same = None
+            try:
+                a = gzip.open(os.path.join(args.dir, "reference_cpu.gz")).read().decode().split("\n")
+                b = gzip.open(os.path.join(args.dir, "reference_on_c_abi.gz")).read().decode().split("\n")
+                c = gzip.open(os.path.join(args.dir, "ours_ref.gz")).read().decode().split("\n")
+                norm = lambda ls: sorted(tuple(sorted(t for t in l.split(" ") if t)) for l in ls if l.strip())  # noqa: E731
+                same = norm(a) == norm(b) == norm(c)
+            except (OSError, ValueError):
+                pass
+            ref["outputs_equal"] = same
+            res["reference_program"] = ref
         if args.reads:
             rng = np.random.default_rng(3)
             src = niqki_amd.synth_genome_host(11, 0, 0, 0, args.len)
