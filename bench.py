@@ -13,7 +13,8 @@ ring).  N > 1 (torch.distributed.run, one rank per GPU): the index is sharded by
 sketch-slot range, the exchange (RCCL all-to-all of sketch slices, sparse
 candidate exchange or reduce-scatter of the packed hit vectors) runs inside
 libniqki_hip.so (niqki_group_*); torch.distributed only carries the group id
-and the timing barrier.  Total work is fixed, so scaling is "strong".
+and the timing barrier.  Every rank brings its own --batch query genomes per step ("scaling": "weak"; --scaling
+strong cuts one batch over the ranks).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the gather-histogram kernel
 (the HBM-bound kernel SURVEY.md 8d grades), timed live with HIP events on the
@@ -209,7 +210,11 @@ def main():
     ap.add_argument("--steps", type=int, default=9)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genomes", type=int, default=100_000)
-    ap.add_argument("--batch", type=int, default=4096, help="query genomes per step (whole job)")
+    ap.add_argument("--batch", type=int, default=4096, help="query genomes per step: per GPU (N = 1, and N > 1 with --scaling weak), "
+                                                            "or of the whole job (--scaling strong, --shard-of)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = every rank brings --batch query genomes per step (default), strong = one batch of "
+                         "--batch queries is cut over the ranks")
     ap.add_argument("--ring", type=int, default=3,
                     help="distinct query batches kept resident in HBM; step i uses batch i mod ring")
     ap.add_argument("--len", type=int, default=5_000_000)
@@ -418,7 +423,11 @@ def main():
     del seqbuf
 
     # ---- query inputs resident in HBM: a ring of distinct batches, this rank's share ----
-    per = (args.batch + G - 1) // G            # queries this GPU sketches per step
+    # N > 1: by default every rank brings --batch queries of its own (weak scaling: the step's fixed costs -- the
+    # exchange's launches and collective calls -- stay what they are while every shard's gather sees world x batch
+    # query slices); --scaling strong cuts ONE batch of --batch queries over the ranks instead
+    weak = use_dist and world > 1 and args.scaling == "weak"
+    per = args.batch if weak else (args.batch + G - 1) // G            # queries this GPU sketches per step
     nq_all = per * G                           # queries its gather kernel sees per step
     nq_gather = nq_all if (use_dist or emu) else per
     n_steps_all = args.warmup + args.steps
@@ -824,7 +833,7 @@ def main():
             "value_at_median_step": nq_all / (ms_median * 1e-3),
             "step_ms_min_max": [step_ms[0], step_ms[-1]],
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if (weak or world == 1) else "strong",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
