@@ -35,12 +35,12 @@ count of a genome is a sum over slots, so a query step has exactly one exchange 
 import torch
 import torch.distributed as dist
 
-from .capi import row_stride
+from .capi import group_slot_range
 
 
 def slot_range(rank, world, F):
-    """Slots [begin, end) owned by `rank`; F = 2^S and world need not divide it."""
-    return (F * rank) // world, (F * (rank + 1)) // world
+    """Slots [begin, end) owned by `rank` (niqki_group_slot_range: the library's own cut; F = 2^S)."""
+    return group_slot_range(rank, world, F.bit_length() - 1)
 
 
 def padded_batch(nq, world):
