@@ -15,8 +15,10 @@
 // patch" carried out without touching a reference file: oracle/_ref/niqki_ref_gpu is the reference's command
 // line, option parser, file readers and writers on top of the C ABI's *_shared entry points.
 //
-// What still belongs to the reference in that binary and is NOT bound: dump / load and --matrix walk its own
-// bucket vectors (which stay empty here); tests/test_cli_gpu.py uses the index + query and lines modes only.
+// Also bound, because they walk the reference's own bucket vectors (which stay empty here): the counting loop of
+// --matrix, Index::query_range (:570-610; the reference's output_matrix still formats the rows), and the payload of
+// --dump, Index::dump_index_disk (:42-59).  NOT bound: the loading constructor (--load), whose members only the
+// reference's own constructor can set.
 #include "niqki_index.h"          // the reference's header: -I/root/reference/src
 #include "../include/niqki_hip.h"
 
@@ -24,6 +26,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <zlib.h>
 
 namespace {
 
@@ -111,4 +114,49 @@ query_output Index::query_sketch(const vector<int32_t> &sketch) const {
   r.reserve(n);
   for (uint64_t i = 0; i < n; ++i) r.push_back({c[i], gg[i]});   // already (count desc, gid desc), :685
   return r;
+}
+
+// everything the reference has inserted so far is in the GPU index (single caller: main's thread)
+static Bound *settled(const Index *ix) {
+  Bound *b = bound_of(ix);
+  std::lock_guard<std::mutex> g(b->m);
+  flush_ready(b);
+  if (!b->pending.empty()) die("a genome id was never inserted", b->h);
+  return b;
+}
+
+// --matrix: the columns [begin, end) of the all-pairs hit counts, then the reference's own row formatting
+void Index::query_range(uint32_t begin, uint32_t end) const {
+  Bound *b = settled(this);
+  const uint32_t batch = end - begin, N = genome_numbers;
+  const uint64_t stride = NIQKI_ROW_STRIDE(N);
+  std::vector<uint16_t> counts((size_t)batch * stride);
+  if (niqki_matrix_range(b->h, begin, end, counts.data(), stride, NIQKI_MEM_HOST) != NIQKI_OK) die("niqki_matrix_range", b->h);
+  query_output row;
+  for (uint32_t t = 0; t < batch; ++t) {
+    row.clear();
+    for (uint32_t a = 0; a < N; ++a) {
+      const uint32_t c = counts[(size_t)t * stride + a];
+      if (c >= min_score) row.push_back({c, a});
+    }
+    output_matrix(row, filenames[begin + t]);   // the reference's (through the PLT)
+  }
+}
+
+// --dump: the index payload from the GPU, the names behind it, gzip (the reference's reader takes any gzip stream)
+void Index::dump_index_disk(const string &filestr) const {
+  Bound *b = settled(this);
+  uint64_t need = 0;
+  if (niqki_export_dump(b->h, nullptr, 0, &need) != NIQKI_OK) die("niqki_export_dump (size)", b->h);
+  std::vector<uint8_t> buf(need);
+  if (niqki_export_dump(b->h, buf.data(), need, &need) != NIQKI_OK) die("niqki_export_dump", b->h);
+  gzFile f = gzopen(filestr.c_str(), "wb1");
+  if (!f) { std::fprintf(stderr, "niqki_ref_gpu: cannot write %s\n", filestr.c_str()); std::exit(3); }
+  for (uint64_t off = 0; off < need; off += (1u << 30))
+    gzwrite(f, buf.data() + off, (unsigned)std::min<uint64_t>(need - off, 1u << 30));
+  for (const string &name : filenames) {
+    gzwrite(f, name.data(), (unsigned)name.size());
+    gzwrite(f, "\n", 1);
+  }
+  gzclose(f);
 }
