@@ -17,8 +17,8 @@
 //
 // Also bound, because they walk the reference's own bucket vectors (which stay empty here): the counting loop of
 // --matrix, Index::query_range (:570-610; the reference's output_matrix still formats the rows), and the payload of
-// --dump, Index::dump_index_disk (:42-59).  NOT bound: the loading constructor (--load), whose members only the
-// reference's own constructor can set.
+// --dump, Index::dump_index_disk (:42-59).  --load needs no binding of its own: the reference's constructor fills its
+// bucket vectors from the file, and the first bound call rebuilds the GPU index from them (bound_of).
 #include "niqki_index.h"          // the reference's header: -I/root/reference/src
 #include "../include/niqki_hip.h"
 
@@ -65,6 +65,22 @@ Bound *bound_of(const Index *ix) {
   niqki_params p{};
   p.K = ix->K; p.S = ix->lF; p.W = ix->W; p.H = ix->H; p.min_score = ix->min_score; p.device = -1;
   if (niqki_create(&p, &b->h) != NIQKI_OK) die("niqki_create", nullptr);
+  // An Index that came out of the reference's LOADING constructor (--load, :63-102) holds the dump in its bucket
+  // vectors (in this binary nothing else ever fills them: insert_sketch is bound).  A densified sketch has a value
+  // in every slot, so a look at the buckets of the first slots tells.
+  bool loaded = false;
+  for (uint64_t bkt = 0, n = std::min<uint64_t>(ix->F, 8) * (uint64_t)ix->fingerprint_range; bkt < n && !loaded; ++bkt)
+    loaded = !ix->Buckets[bkt].empty();
+  if (loaded) {
+    // Bucket fp + slot * 2^W lists the genomes whose sketch has fp in that slot (:362-370): the sketches are read
+    // back from the buckets and inserted in id order -- the GPU index is the loaded one.
+    const uint64_t F_ = ix->F, R = (uint64_t)ix->fingerprint_range, N = ix->genome_numbers;
+    std::vector<int32_t> sk(N * F_, -1);
+    for (uint64_t bkt = 0; bkt < F_ * R; ++bkt)
+      for (gid g : ix->Buckets[bkt]) sk[(uint64_t)g * F_ + bkt / R] = (int32_t)(bkt % R);
+    if (niqki_insert(b->h, sk.data(), (uint32_t)N, NIQKI_MEM_HOST) != NIQKI_OK) die("niqki_insert (loaded index)", b->h);
+    b->flushed = (uint32_t)N;
+  }
   g_bound[ix] = b;
   return b;
 }

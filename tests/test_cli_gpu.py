@@ -351,6 +351,9 @@ def test_the_reference_program_itself_on_the_c_abi(workdir, gold):
     run_ref(["-I", "fof.txt", "-S", "10", "-J", "0.1", "-O", "refgpu_tmp.gz", "-D", "refgpu.dump"], 1)
     raw = gunzip(workdir / "refgpu.dump")
     assert len(raw) == meta["cli"]["dump_len"] and hashlib.md5(raw).hexdigest() == meta["cli"]["dump_md5"]
+    # --load: the reference's own constructor reads the dump, the GPU index is rebuilt from its bucket vectors
+    run_ref(["-L", "refgpu.dump", "-Q", "fof.txt", "-O", "refgpu_loaded.gz"], 1)
+    assert_same_text(gunzip(workdir / "refgpu_loaded.gz").decode(), meta["cli"]["hits_loaded"])
     calls, batches, largest = run_ref(["-I", "fof.txt", "-Q", "fof.txt", "-S", "10", "-J", "0.1", "-O", "refgpu_hits8.gz"], 8)
     assert _normalised(gunzip(workdir / "refgpu_hits8.gz").decode()) == _normalised(meta["cli"]["hits"])
     calls, batches, largest = run_ref(["-i", "reads.fa", "-l", "reads.fa", "-S", "10", "-W", "10", "-J", "0.2", "-O", "refgpu_lines8.gz"], 8)
