@@ -1132,16 +1132,20 @@ __global__ __launch_bounds__(1024) void hits_count_kernel(HitsArgs a) {
 }
 
 // hit_off[0..nq): per-query totals -> exclusive prefix, hit_off[nq] = grand total.  One workgroup walks
-// the totals 1024 at a time (coalesced): wave scan, the 16 wave totals through LDS, a running base.
+// the totals 4096 at a time (four consecutive queries per thread, coalesced 32-byte pieces): thread sums, wave
+// scan, the 16 wave totals through LDS, a running base.
 __global__ __launch_bounds__(1024) void hits_scan_kernel(HitsArgs a) {
   __shared__ unsigned long long wave_tot[2][16];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   unsigned long long base = 0;
   uint32_t flip = 0;
-  for (uint32_t q0 = 0; q0 < a.nq; q0 += 1024, flip ^= 1u) {
-    const uint32_t q = q0 + tid;
-    const unsigned long long x = q < a.nq ? a.hit_off[q] : 0ull;
-    unsigned long long incl = x;
+  for (uint32_t q0 = 0; q0 < a.nq; q0 += 4096, flip ^= 1u) {
+    const uint32_t q = q0 + 4 * tid;
+    unsigned long long x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = q + j < a.nq ? a.hit_off[q + j] : 0ull;
+    const unsigned long long mine = x[0] + x[1] + x[2] + x[3];
+    unsigned long long incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const unsigned long long y = __shfl_up(incl, o, 64);
@@ -1156,7 +1160,12 @@ __global__ __launch_bounds__(1024) void hits_scan_kernel(HitsArgs a) {
       if (w < wave) before += t;
       total += t;
     }
-    if (q < a.nq) a.hit_off[q] = base + before + incl - x;
+    unsigned long long run = base + before + incl - mine;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (q + j < a.nq) a.hit_off[q + j] = run;
+      run += x[j];
+    }
     base += total;
   }
   if (tid == 0) a.hit_off[a.nq] = base;
