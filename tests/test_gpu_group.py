@@ -78,6 +78,10 @@ def test_emulated_slot_shards_equal_the_whole_index(native, po, world, exchange)
     if exchange == "overflow":
         grp.set_option("cand_cap", 2)                        # lists overflow -> the step is redone densely
     per = -(-NQ // world)
+    # what the group will do is what the pure plan function says (the function nq_group.hip calls per batch, and the
+    # one the CPU protocol test over gloo takes its decisions from)
+    plan = native.group_plan(world, S, MS, 2 if exchange == "dense" else 1, per, N, 2 if exchange == "overflow" else 256)
+    assert grp.stat("sparse") == plan.sparse and plan.cand_threshold == -(-MS // world) and plan.slice_slots == -(-(1 << S) // world)
     got = run_group(native, torch, engines, grp, sk, q, per)
     p = po.make_params(31, S, W, 3, 0.0)
     p.min_score = MS
