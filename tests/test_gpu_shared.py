@@ -92,3 +92,30 @@ def test_stream_priority_option_changes_no_result(native, po):
     off2, hc2, hg2 = e.query(exp)
     assert np.array_equal(off2, off) and np.array_equal(hc2, hc) and np.array_equal(hg2, hg)
     e.close()
+
+
+@pytest.mark.parametrize("mode", [["--no-legs"], ["--pipeline", "--no-legs"], ["--pipeline", "--priority-streams", "--no-legs"],
+                                  ["--no-cpu", "--no-extra", "--no-pmc"]])
+def test_bench_modes_on_a_small_index(tmp_path, mode):
+    """bench.py's other modes at a small size (the timed-steps-only run that tools/profile_round.sh traces, the
+    pipelined step with and without priority streams, a run with the legs): one JSON line with the record's fields;
+    the roofline fraction is a fraction."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--genomes", "3000", "--batch", "256", "--steps", "3", "--warmup", "1"] + mode
+    r = subprocess.run(cmd, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    rf = j["roofline"]
+    assert j["n_gpus"] == 1 and j["value"] > 0 and j["unit"] == "genomes/s" and j["scaling"] == "weak"
+    assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1.0 and rf["frac_basis"] and rf["frac_algorithmic"] > 0 and rf["frac_layout_min"] > 0
+    assert rf["launches"] == 3 and j["kernels"]["sketch"]["launches"] == 3
+    if "--no-legs" in mode:
+        assert j["cpu_baseline"] is None and j["pipelined_step"] is None and j["end_to_end_d2h"] is None and "extra_workloads" not in j
+    else:
+        assert j["pipelined_step"]["ms_per_step_priority_streams"] > 0 and j["end_to_end_d2h"]["value"] > 0
