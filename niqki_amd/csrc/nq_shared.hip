@@ -133,11 +133,16 @@ int submit(niqki_index *ix, Request &r) {
     lk.unlock();
     // inserts first (arrival order), then sketches, then queries: requests of one thread never overlap, and the
     // order between different threads' requests is as undefined as in the reference's parallel loops
-    for (Kind k : {kInsert, kSketch, kQuery, kQuerySeq}) {
-      std::vector<Request *> rs;
+    try {
+      for (Kind k : {kInsert, kSketch, kQuery, kQuerySeq}) {
+        std::vector<Request *> rs;
+        for (Request *q : batch)
+          if (q->kind == k) rs.push_back(q);
+        if (!rs.empty()) run_kind(ix, *c, rs);
+      }
+    } catch (...) {   // (an allocation of the leader's scratch failed: the waiting threads must still be released)
       for (Request *q : batch)
-        if (q->kind == k) rs.push_back(q);
-      if (!rs.empty()) run_kind(ix, *c, rs);
+        if (q->rc == NIQKI_OK) q->rc = NIQKI_E_NOMEM;
     }
     lk.lock();
     c->batches += 1;
