@@ -89,7 +89,7 @@ def check_world(res, native, po, sk, q, S, W, MS, world, exchange, cand_cap):
 # (words: where the sequence words a peer's running kernel polls live -- fine-grained device memory by default,
 # the processes' shared block page-locked into every device where that cannot be made)
 @pytest.mark.parametrize("world,exchange,cand_cap,words", [(2, "sparse", 256, None), (2, "dense", 256, "host"), (3, "sparse", 2, None),
-                                                           (2, "sparse", 256, "coarse")])
+                                                           (2, "sparse", 256, "coarse"), (5, "sparse", 256, None), (4, "dense", 256, None)])
 def test_one_process_per_rank_on_one_gpu(tmp_path, native, po, world, exchange, cand_cap, words):
     S, W, N, NQ, MS = 9, 8, 1500, 23, 40
     sk, q = make_data(S, W, N, NQ, 31 + world)
