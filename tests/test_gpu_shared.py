@@ -119,3 +119,39 @@ def test_bench_modes_on_a_small_index(tmp_path, mode):
         assert j["cpu_baseline"] is None and j["pipelined_step"] is None and j["end_to_end_d2h"] is None and "extra_workloads" not in j
     else:
         assert j["pipelined_step"]["ms_per_step_priority_streams"] > 0 and j["end_to_end_d2h"]["value"] > 0
+
+
+def test_shared_entry_points_under_mixed_load(native, po):
+    """64 threads, each a random sequence of sketch / query / query-by-sequence calls on ONE handle while the others do
+    the same (an index that does not change during the phase: every answer can be checked); then a phase of
+    concurrent inserts; then queries again against the grown index."""
+    import random
+    K, S, W, H, J = 31, 8, 10, 4, 0.05
+    p = po.make_params(K, S, W, H, J)
+    e = native.Engine(K=K, S=S, W=W, H=H, J=J)
+    genomes = [native.synth_genome_host(29, g // 5, g % 5, 150 * (g % 5), 6_000 + 11 * g) for g in range(40)]
+    exp_sk = [po.compute_sketch(p, g) for g in genomes]
+    e.insert(np.stack(exp_sk[:20]))
+    ix = po.Index(p, np.stack(exp_sk[:20]))
+
+    def worker(t, index, n_ops):
+        rnd = random.Random(1000 + t)
+        for _ in range(n_ops):
+            g = rnd.randrange(len(genomes))
+            op = rnd.randrange(3)
+            if op == 0:
+                assert np.array_equal(e.sketch_shared(genomes[g]), exp_sk[g])
+            else:
+                hc, hg = e.query_shared(exp_sk[g], capacity=rnd.choice([1, 8, 64])) if op == 1 else e.query_sequence_shared(genomes[g], capacity=8)
+                ehc, ehg = index.query(exp_sk[g])
+                assert np.array_equal(hc, ehc) and np.array_equal(hg, ehg), (t, g, op)
+        return True
+    assert all(run_threads(64, lambda t: worker(t, ix, 12)))
+    gids = run_threads(20, lambda i: e.insert_shared(exp_sk[20 + i]))
+    assert sorted(gids) == list(range(20, 40))
+    order = [20 + int(i) for i in np.argsort(gids)]
+    ix2 = po.Index(p, np.stack(exp_sk[:20] + [exp_sk[i] for i in order]))
+    assert all(run_threads(64, lambda t: worker(t, ix2, 6)))
+    st = e.shared_stats()
+    assert st["largest_batch"] >= 4 and st["batches"] < st["requests"]
+    e.close()
