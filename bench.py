@@ -900,7 +900,8 @@ def main():
 def roofline_record(achieved_alg, traffic, traffic_source, live, gather_ms, launches, alg_bytes, layout_min, copy_gbs, measured_in,
                     T, n_q_local, pipeline):
     """The `roofline` object of the line.  `frac` is what the memory system moved (PMC counters, per launch) over the
-    launch time over the spec peak -- at most 1 by construction; without a counter measurement for this shape, the bytes
+    launch time over the spec peak -- bytes that really crossed the L2's memory side (only a working set that the 256 MB
+    Infinity Cache serves could push it past 1: not this 17 GB index); without a counter measurement for this shape, the bytes
     the layout cannot avoid stand in (a lower bound of the traffic).  SURVEY.md 8(d)'s algorithmic figure (4-byte ids,
     every query's lines counted for itself) is `achieved` / `frac_algorithmic`: the layout stores 2-byte ids and an
     XCD's L2 serves lines that neighbouring queries share, so that one can pass 1."""
