@@ -1826,7 +1826,7 @@ int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value) {
   if (!ix || !key || !value) return NIQKI_E_INVALID;
   const uint32_t f_all = ix->resident_bytes ? ix->full_end - ix->full_begin : ix->d.slot_end - ix->d.slot_begin;
   if (!std::strcmp(key, "store_bytes")) { *value = (uint64_t)f_all * (ix->resident_bytes ? ix->host_cap : ix->cap) * 2; return NIQKI_OK; }
-  if (!std::strcmp(key, "index_bytes")) { *value = ix->built ? (uint64_t)ix->entries_bytes + ix->gids_bytes + ix->ptab_bytes + ix->alt.entries_bytes + ix->alt.gids_bytes + ix->alt.ptab_bytes : 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "index_bytes")) { *value = ix->built ? (uint64_t)ix->entries_bytes + ix->gids_bytes + ix->ptab_bytes + ix->hmask_bytes + ix->alt.entries_bytes + ix->alt.gids_bytes + ix->alt.ptab_bytes + ix->alt.hmask_bytes : 0; return NIQKI_OK; }
   if (!std::strcmp(key, "delta_genomes")) { *value = ix->delta_n; return NIQKI_OK; }
   if (!std::strcmp(key, "tiles")) { *value = ix->n_tiles; return NIQKI_OK; }
   if (!std::strcmp(key, "class_mask")) { *value = (ix->built && ix->hmask_ok) ? 1 : 0; return NIQKI_OK; }

@@ -60,6 +60,7 @@ struct Rccl {
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclSend) Send = nullptr;
@@ -81,6 +82,7 @@ struct Rccl {
     NQ_SYM(GetUniqueId, "ncclGetUniqueId")
     NQ_SYM(CommInitRank, "ncclCommInitRank")
     NQ_SYM(CommDestroy, "ncclCommDestroy")
+    NQ_SYM(CommCount, "ncclCommCount")
     NQ_SYM(GroupStart, "ncclGroupStart")
     NQ_SYM(GroupEnd, "ncclGroupEnd")
     NQ_SYM(Send, "ncclSend")
@@ -470,6 +472,24 @@ int gfail(niqki_group *g, int code, const std::string &msg) {
     if (r_ != ncclSuccess) return gfail(g, NIQKI_E_HIP, std::string(#call) + ": " + rccl().GetErrorString(r_)); \
   } while (0)
 
+// An RCCL group call that is closed on EVERY way out: a ncclSend / ncclRecv / collective that fails between
+// GroupStart and GroupEnd must not leave the communicators with an open group (the NQ_G* macros return from inside).
+struct RcclGroupScope {
+  bool open = false;
+  ncclResult_t begin() {
+    const ncclResult_t r = rccl().GroupStart();
+    open = r == ncclSuccess;
+    return r;
+  }
+  ncclResult_t end() {
+    open = false;
+    return rccl().GroupEnd();
+  }
+  ~RcclGroupScope() {
+    if (open) (void)rccl().GroupEnd();
+  }
+};
+
 // ---- ipc transport, host side ---------------------------------------------------------------------
 double now_s() {
   timespec ts;
@@ -819,7 +839,8 @@ int ipc_collective(niqki_group *g, Buf niqki_group::Ws::*send, Pull &&pull) {
 // recv[l] = [world][bytes] <- send[s] + l * bytes of every rank s (bytes: a multiple of 16)
 int all_to_all(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::*recv, size_t bytes) {
   if (g->transport == niqki_group::kRccl) {
-    NQ_GN(g, rccl().GroupStart());
+    RcclGroupScope grp;
+    NQ_GN(g, grp.begin());
     for (uint32_t l = 0; l < g->n_local; ++l) {
       NQ_GH(g, hipSetDevice(g->sh[l]->device));   // (several communicators in one thread: each call on its own device)
       const char *s = (const char *)(g->ws[l].*send).p;
@@ -829,7 +850,7 @@ int all_to_all(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::
         NQ_GN(g, rccl().Recv(r + (size_t)p * bytes, bytes, ncclUint8, (int)p, g->comm[l], g->sh[l]->stream));
       }
     }
-    NQ_GN(g, rccl().GroupEnd());
+    NQ_GN(g, grp.end());
     return NIQKI_OK;
   }
   if (g->transport == niqki_group::kIpc)
@@ -856,12 +877,13 @@ int all_to_all(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::
 // recv[l] = [world][bytes] <- send[s] of every rank s (bytes: a multiple of 16)
 int all_gather(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::*recv, size_t bytes) {
   if (g->transport == niqki_group::kRccl) {
-    NQ_GN(g, rccl().GroupStart());
+    RcclGroupScope grp;
+    NQ_GN(g, grp.begin());
     for (uint32_t l = 0; l < g->n_local; ++l) {
       NQ_GH(g, hipSetDevice(g->sh[l]->device));
       NQ_GN(g, rccl().AllGather((g->ws[l].*send).p, (g->ws[l].*recv).p, bytes, ncclUint8, g->comm[l], g->sh[l]->stream));
     }
-    NQ_GN(g, rccl().GroupEnd());
+    NQ_GN(g, grp.end());
     return NIQKI_OK;
   }
   if (g->transport == niqki_group::kIpc)
@@ -888,12 +910,13 @@ int all_gather(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::
 // recv[l][i] = sum over ranks s of send[s][rank(l) * count + i], u32 words
 int reduce_scatter_u32(niqki_group *g, Buf niqki_group::Ws::*send, Buf niqki_group::Ws::*recv, size_t count) {
   if (g->transport == niqki_group::kRccl) {
-    NQ_GN(g, rccl().GroupStart());
+    RcclGroupScope grp;
+    NQ_GN(g, grp.begin());
     for (uint32_t l = 0; l < g->n_local; ++l) {
       NQ_GH(g, hipSetDevice(g->sh[l]->device));
       NQ_GN(g, rccl().ReduceScatter((g->ws[l].*send).p, (g->ws[l].*recv).p, count, ncclUint32, ncclSum, g->comm[l], g->sh[l]->stream));
     }
-    NQ_GN(g, rccl().GroupEnd());
+    NQ_GN(g, grp.end());
     return NIQKI_OK;
   }
   const uint32_t blocks = (uint32_t)std::min<uint64_t>((count + 255) / 256, 8192);
@@ -1057,10 +1080,11 @@ int niqki_group_create(niqki_index *const *shards, uint32_t n_local, uint32_t fi
   }
   const char *tenv = std::getenv("NIQKI_GROUP_TRANSPORT");
   const bool want_ipc = tenv && !std::strcmp(tenv, "ipc"), want_local = tenv && !std::strcmp(tenv, "local");
+  const bool want_rccl = tenv && !std::strcmp(tenv, "rccl");   // asked for by name: RCCL decides whether it takes the devices
   if (want_ipc && n_local == 1 && world > 1) g->transport = niqki_group::kIpc;
-  else if (n_local == world && (shared_device || want_local || want_ipc)) g->transport = niqki_group::kLocal;
+  else if (n_local == world && !want_rccl && (shared_device || want_local || want_ipc)) g->transport = niqki_group::kLocal;
   else g->transport = niqki_group::kRccl;
-  if (g->transport != niqki_group::kIpc && shared_device && n_local != world)
+  if (g->transport != niqki_group::kIpc && shared_device && n_local != world && !want_rccl)
     return bail(NIQKI_E_INVALID, "shards that share a device need all ranks in one process (or NIQKI_GROUP_TRANSPORT=ipc)");
   if (g->transport == niqki_group::kIpc && n_local != 1)
     return bail(NIQKI_E_INVALID, "the ipc transport wants one rank per process (or all ranks in one: local)");
@@ -1157,6 +1181,22 @@ int niqki_group_get_stat(const niqki_group *g, const char *key, uint64_t *value)
   if (!std::strcmp(key, "transport")) { *value = (uint64_t)g->transport; return NIQKI_OK; }   // 0 local, 1 rccl, 2 ipc
   if (!std::strcmp(key, "ipc_words_kind")) { *value = g->ipc.words_kind; return NIQKI_OK; }   // 0 coarse, 1 fine-grained, 2 host block
   if (!std::strcmp(key, "ipc_arena_fine")) { *value = g->ipc.arena_fine ? 1 : 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "ranks_seen")) {
+    // how many ranks the transport itself knows of: the communicator's size as RCCL reports it, the peers whose
+    // sequence words this process has mapped (ipc), the shards of the process (local)
+    if (g->transport == niqki_group::kRccl) {
+      int n = 0;
+      if (g->comm.empty() || !g->comm[0] || rccl().CommCount(g->comm[0], &n) != ncclSuccess) return NIQKI_E_STATE;
+      *value = (uint64_t)n;
+    } else if (g->transport == niqki_group::kIpc) {
+      uint64_t n = 0;
+      for (uint32_t s = 0; s < g->world; ++s) n += g->ipc.peer_flags[s] ? 1 : 0;
+      *value = n;
+    } else {
+      *value = g->n_local;
+    }
+    return NIQKI_OK;
+  }
   if (!std::strcmp(key, "sparse")) {
     const uint32_t ms = g->sh[0]->d.min_score;
     niqki_group_plan plan;

@@ -35,12 +35,12 @@ count of a genome is a sum over slots, so a query step has exactly one exchange 
 import torch
 import torch.distributed as dist
 
-from .capi import group_slot_range
-
 
 def slot_range(rank, world, F):
-    """Slots [begin, end) owned by `rank` (niqki_group_slot_range: the library's own cut; F = 2^S)."""
-    return group_slot_range(rank, world, F.bit_length() - 1)
+    """Slots [begin, end) owned by `rank` (F = 2^S): niqki_group_slot_range's cut, floor(F * r / G).  Stated here in
+    Python so that the gloo / CPU protocol (tests/torch_exchange.py) also runs on a host without the built library
+    and the HIP runtime; tests/test_dist_cpu.py asserts that this is the library's cut wherever the library loads."""
+    return (F * rank) // world, (F * (rank + 1)) // world
 
 
 def padded_batch(nq, world):

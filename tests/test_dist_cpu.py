@@ -157,6 +157,13 @@ def test_slot_ranges_partition_the_sketch():
             assert cuts[0][0] == 0 and cuts[-1][1] == F
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
     assert padded_batch(10, 4) == 3
+    # the pure-Python cut of niqki_amd/dist.py (usable without the built library) is the library's own
+    import niqki_amd
+    from niqki_amd import dist as nd
+    for S in (6, 12, 15, 16):
+        for world in (1, 2, 3, 5, 8, 64):
+            for r in range(world):
+                assert nd.slot_range(r, world, 1 << S) == niqki_amd.group_slot_range(r, world, S)
 
 
 def test_bench_launcher_starts_ranks_and_relays_their_exit_code(tmp_path):

@@ -155,3 +155,40 @@ def test_shared_entry_points_under_mixed_load(native, po):
     st = e.shared_stats()
     assert st["largest_batch"] >= 4 and st["batches"] < st["requests"]
     e.close()
+
+
+def test_shared_queries_with_more_hits_than_the_first_internal_capacity(native, po):
+    """A combined batch whose queries have far more than 64 hits each: the batch's first capacity (64 per query) is too
+    small, niqki_query says NIQKI_E_CAPACITY with exact offsets, and the combiner must run the batch again with room
+    for all -- inside the library, whatever capacity each caller passed (the header's contract: *n_hits may exceed
+    capacity, the first `capacity` hits are written).  300 near-identical genomes, 24 threads."""
+    K, S, W, H, J = 31, 8, 10, 4, 0.3
+    p = po.make_params(K, S, W, H, J)
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, 1 << W, 1 << S).astype(np.int32)
+    sk = np.tile(base, (300, 1))
+    flip = rng.random(sk.shape) < 0.1                       # every genome differs from the base in ~10 % of its slots
+    sk[flip] = rng.integers(0, 1 << W, int(flip.sum()))
+    e = native.Engine(K=K, S=S, W=W, H=H, J=J)
+    e.insert(sk)
+    ix = po.Index(p, sk)
+    L = native.lib()
+    import ctypes as C
+
+    def one(i):
+        q = np.ascontiguousarray(sk[(7 * i) % 300])
+        cap = [0, 3, 50, 400][i % 4]
+        n = C.c_uint64(0)
+        hc, hg = np.zeros(max(cap, 1), np.uint32), np.zeros(max(cap, 1), np.uint32)
+        rc = L.niqki_query_shared(e.h, q.ctypes.data, C.byref(n), hc.ctypes.data if cap else None, hg.ctypes.data if cap else None, cap)
+        assert rc == 0, (i, rc)                             # never NIQKI_E_CAPACITY: that is the library's to handle
+        ehc, ehg = ix.query(q)
+        assert n.value == len(ehc) and len(ehc) > 200, (i, n.value, len(ehc))
+        w = min(cap, len(ehc))
+        assert np.array_equal(hc[:w], ehc[:w]) and np.array_equal(hg[:w], ehg[:w]), i
+        return int(n.value)
+    hits = run_threads(24, one)
+    assert min(hits) > 200
+    st = e.shared_stats()
+    assert st["requests"] == 24
+    e.close()
