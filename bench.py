@@ -857,6 +857,15 @@ def main():
                 "exchange_redone_densely": sq.overflows if use_dist else 0,
                 "exchange_bytes_per_rank_per_step": xbytes,
                 "exchange_avg_gbs_per_rank": (xbytes / (dt / args.steps) / 1e9) if xbytes else None,
+                # did the transport itself see N ranks?  (the communicator's size as RCCL reports it / the peers whose
+                # sequence words this rank has mapped over ipc: niqki_group_get_stat "ranks_seen")
+                "transport_ranks_seen": sq.ranks_seen if use_dist else None,
+                # bytes a rank sends to ONE peer per step over the device time of the step's exchange-class spans on rank 0
+                # (slice packing, the collectives, candidate look-ups: NIQKI_KC_EXCHANGE) -- xGMI is point to point, one
+                # link per peer (153 GB/s each); a lower bound of the link rate while data moves
+                "exchange_ms_per_step": (prof["exchange"][0] / max(1, args.steps)) if use_dist else None,
+                "exchange_gbs_per_link": (xbytes / max(1, world - 1) / (prof["exchange"][0] / max(1, args.steps) * 1e-3) / 1e9)
+                if (xbytes and use_dist and world > 1 and prof["exchange"][0] > 0) else None,
                 "tile_genomes": eng.tile_genomes(), "index_build_s": round(t_index, 2),
                 "hits_per_query": total_hits / max(1, args.steps * per), "hit_overflow": overflow,
             },

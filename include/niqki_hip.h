@@ -148,7 +148,12 @@ int niqki_synchronize(niqki_index *ix);
  * "stream_priority" (1 / 0 / -1: the handle gets a stream of its own, made at the top / default / bottom of
  * the device's stream priority range -- also after niqki_set_stream, whose stream stays the caller's --, so
  * that e.g. a query handle's short kernels are dispatched ahead of another handle's long sketch kernel;
- * niqki_get_stream returns it). */
+ * niqki_get_stream returns it),
+ * "hit_lists" (1 = default: on an index of ONE counter tile of at most 12 288 genomes -- the short-read shape of
+ * src/niqki_index.cpp:412-430 -- niqki_query* / niqki_staged_query take a query's thresholded hits out of the gather
+ * kernel while its counters are in LDS, already ordered, instead of writing a 2N-byte counter row per query and reading
+ * it again; 0 = always through counter rows), "hit_list_cap" (1..2048, default 256: hits per query such a list holds; a
+ * query with more -- min_score 0: every genome -- leaves through its counter row and is ordered from there). */
 int niqki_set_option(niqki_index *ix, const char *key, int64_t value);
 
 /* Pre-sizes the sketch store for n_genomes (optional; the store grows). */
@@ -487,7 +492,9 @@ int niqki_group_plan_batch(uint32_t world, uint32_t S, uint32_t min_score, int e
  * "sparse" (1 = the sparse exchange is selected), "ipc_words_kind" (ipc transport: where this rank's
  * sequence words live -- 1 = fine-grained device memory mapped by the peers, 2 = the processes' shared block
  * page-locked and mapped into every device, 0 = plain device memory), "ipc_arena_fine" (1 = its exchange
- * buffers are fine-grained device memory). */
+ * buffers are fine-grained device memory), "ranks_seen" (how many ranks the transport itself knows of: the
+ * communicator's size as RCCL reports it, the peers whose sequence words this process has mapped (ipc), the shards of
+ * the process (local) -- equal to `world` when the group really spans what the caller thinks it spans). */
 int niqki_group_get_stat(const niqki_group *g, const char *key, uint64_t *value);
 /* Index::insert_sketch for a batch of world * per sketches of which rank r holds rows
  * [r*per, (r+1)*per) (local_sketches[i]: per x 2^S int32, device memory); the first
@@ -546,7 +553,7 @@ enum niqki_kernel_class {
  * slots per page; 1 / all slots unless the index is paged), "delta_genomes" (genomes indexed by
  * the delta segment, see option "incremental_build"), "last_gather_form" (launch form the last
  * counter call used: bit 0 look-up pre-pass, bit 1 its streamed-rows kernel, bit 2 locality
- * order), "class_mask" (1 = the built index carries its per-slot class mask: single-tile
+ * order), "last_hits_form" (1 = the last niqki_query* call took the hit-list form, option "hit_lists"), "class_mask" (1 = the built index carries its per-slot class mask: single-tile
  * indexes; the gather kernel then looks up only fingerprints whose sixteenth of the
  * fingerprint range holds a bucket in their slot -- a short read against a genome index
  * skips nearly all of its 2^S table look-ups; results are unaffected; NIQKI_HMASK=0 in the

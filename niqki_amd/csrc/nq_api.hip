@@ -354,6 +354,10 @@ int counts_paged(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, ui
 // counts for nq device-resident sketches into a device buffer
 int counts_dev(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq,
                uint16_t *counts, uint64_t stride, uint16_t *counts2, const nq::CandOut *co) {
+  if (co && co->hl) {   // hit lists (query_hits_dev has checked the index shape)
+    if (ix->resident_bytes || two_planes(ix) || co->cand || !counts) return fail(ix, NIQKI_E_INVALID, "hit lists: resident single-plane handles, with counter rows to fall back on");
+    return counts_resident(ix, sketches, q_stride, q_off, nq, counts, stride, false, nullptr, co);
+  }
   if (co && (ix->resident_bytes || two_planes(ix) || !co->cand || !co->n || !co->cap))
     return fail(ix, NIQKI_E_INVALID, "candidate lists: not on a paged or whole-range S = 16 handle; cand, n_cand and cap > 0 needed");
   if (ix->resident_bytes) return counts_paged(ix, sketches, q_stride, q_off, nq, counts, stride, counts2);
@@ -469,9 +473,9 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
     nq::CandOut c;
     if (co) {
       c = *co;
-      c.cand += (size_t)q0 * co->cap;
-      c.n += q0;
+      if (co->cand) { c.cand += (size_t)q0 * co->cap; c.n += q0; }
       if (co->surv) { c.surv += (size_t)q0 * co->surv_cap; c.surv_n += q0; }
+      if (co->hl) { c.hl += (size_t)q0 * co->hl_cap; c.hl_n += q0; }
     }
     NQ_HIP(ix, nq::launch_gather(v, sketches + (size_t)q0 * q_stride, n, counts ? counts + (size_t)q0 * stride : nullptr,
                                  counts2 ? counts2 + (size_t)q0 * stride : nullptr, stride,
@@ -523,6 +527,63 @@ int hits_dev(niqki_index *ix, const uint16_t *counts, uint32_t nq, uint64_t stri
   return NIQKI_OK;
 }
 
+// Index::query_sketch (src/niqki_index.cpp:633-687) for nq device-resident whole sketches into device buffers: counters,
+// threshold, order.  c1 / c2: counter planes of nq rows (c2 only on a two-plane handle).  On a single-tile, single-
+// segment index with a small tile -- the short-read shape -- the hits leave the gather kernel as ordered lists and no
+// counter row is written or read again, except for a query with more than hit_list_cap hits.
+int query_hits_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *c1, uint16_t *c2, uint64_t stride,
+                   unsigned long long *hit_off, uint32_t *hc, uint32_t *hg, uint64_t capacity, bool check_capacity,
+                   uint64_t *total_out) {
+  int rc = build_if_needed(ix);
+  if (rc) return rc;
+  const uint32_t N = ix->built_n;
+  const bool lists = ix->hit_lists && nq && N && !ix->resident_bytes && !two_planes(ix) && ix->n_tiles == 1 && ix->delta_n == 0 &&
+                     ix->tile <= nq::kHitListMaxTile && ix->g_base == 0 && N <= 65536u;
+  ix->last_hits_form = lists ? 1u : 0u;
+  if (!lists) {
+    if ((rc = counts_dev(ix, sketches, ix->d.F, first_slot(ix), nq, c1, stride, c2))) return rc;
+    return hits_dev(ix, c1, nq, stride, 0, N, hit_off, hc, hg, capacity, check_capacity, total_out, c2);
+  }
+  const uint32_t cap = std::min<uint32_t>((std::max<uint32_t>(ix->hit_list_cap, 1) + 3u) & ~3u, nq::kHitListMaxCap);
+  if ((rc = ensure(ix, ix->ws_hl, (size_t)nq * cap * 4))) return rc;
+  if ((rc = ensure(ix, ix->ws_blk, ((size_t)nq * 2 + 1) * 4))) return rc;   // the lists' sizes, then the overflowing queries
+  nq::CandOut co;
+  co.hl = (uint32_t *)ix->ws_hl.p;
+  co.hl_n = (uint32_t *)ix->ws_blk.p;
+  co.hl_over = (uint32_t *)ix->ws_blk.p + nq;
+  if ((rc = ensure(ix, ix->ws_tc, (size_t)std::max<uint64_t>(capacity, 1) * 4))) return rc;   // (lists of > 2048 hits)
+  if ((rc = ensure(ix, ix->ws_tg, (size_t)std::max<uint64_t>(capacity, 1) * 4))) return rc;
+  co.hl_cap = cap;
+  co.hl_min = ix->d.min_score;
+  if ((rc = counts_dev(ix, sketches, ix->d.F, first_slot(ix), nq, c1, stride, nullptr, &co))) return rc;
+  nq::HitsArgs a{};
+  a.counts = c1;
+  a.counts2 = nullptr;
+  a.stride = stride;
+  a.nq = nq;
+  a.gid_begin = 0;
+  a.n_gids = N;
+  a.min_score = ix->d.min_score;
+  a.hit_off = hit_off;
+  a.hit_counts = hc;
+  a.hit_gids = hg;
+  a.tmp_counts = (uint32_t *)ix->ws_tc.p;
+  a.tmp_gids = (uint32_t *)ix->ws_tg.p;
+  a.capacity = capacity;
+  uint32_t *over = (uint32_t *)ix->ws_blk.p + nq;
+  Span sp(ix, NIQKI_KC_HITS);
+  NQ_HIP(ix, nq::launch_hitlist_scan((const uint32_t *)ix->ws_blk.p, a, cap, over, ix->stream));
+  if (check_capacity) {
+    unsigned long long total = 0;
+    NQ_HIP(ix, hipMemcpyAsync(&total, hit_off + nq, 8, hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    if (total_out) *total_out = total;
+    if (total > capacity) return NIQKI_E_CAPACITY;
+  }
+  NQ_HIP(ix, nq::launch_hitlist_emit(a, (const uint32_t *)ix->ws_hl.p, cap, over, ix->stream));
+  return NIQKI_OK;
+}
+
 // Hits of nq sketches (host memory, or device-resident when sk_dev) into HOST arrays:
 // batches of query_batch sketches, hits appended in query order.
 int query_to_host(niqki_index *ix, const int32_t *sketches, bool sk_dev, uint32_t nq, uint64_t *hit_off,
@@ -551,10 +612,9 @@ int query_to_host(niqki_index *ix, const int32_t *sketches, bool sk_dev, uint32_
       NQ_HIP(ix, hipMemcpyAsync(ix->ws_sk.p, d_sk, (size_t)n * ix->d.F * 4, hipMemcpyHostToDevice, ix->stream));
       d_sk = (const int32_t *)ix->ws_sk.p;
     }
-    if ((rc = counts_dev(ix, d_sk, ix->d.F, first_slot(ix), n, c1, stride, c2))) return rc;
     uint64_t total = 0;
-    rc = hits_dev(ix, c1, n, stride, 0, N, (unsigned long long *)ix->ws_hitoff.p,
-                  (uint32_t *)ix->ws_hc.p, (uint32_t *)ix->ws_hg.p, room, true, &total, c2);
+    rc = query_hits_dev(ix, d_sk, n, c1, c2, stride, (unsigned long long *)ix->ws_hitoff.p, (uint32_t *)ix->ws_hc.p,
+                        (uint32_t *)ix->ws_hg.p, room, true, &total);
     if (rc && rc != NIQKI_E_CAPACITY) return rc;
     NQ_HIP(ix, hipMemcpyAsync(off.data(), ix->ws_hitoff.p, (size_t)(n + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
     if (rc == NIQKI_OK && total) {
@@ -710,7 +770,7 @@ void niqki_destroy(niqki_index *ix) {
   for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
                  &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash,
                  &ix->ws_raw, &ix->ws_raw2, &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
-                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order, &ix->ws_pre})
+                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order, &ix->ws_pre, &ix->ws_hl})
     if (b->p) (void)hipFree(b->p);
   for (Buf *b : {&ix->pg_store, &ix->pg_stage})
     if (b->p) (void)hipFree(b->p);
@@ -778,6 +838,12 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
   if (!std::strcmp(key, "lookup_prepass")) {
     if (value < -1 || value > 1) return fail(ix, NIQKI_E_INVALID, "lookup_prepass: -1 = when it pays, 0 = never, 1 = whenever usable");
     ix->lookup_prepass = (int)value;
+    return NIQKI_OK;
+  }
+  if (!std::strcmp(key, "hit_lists")) { ix->hit_lists = value != 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "hit_list_cap")) {
+    if (value < 1 || value > (int64_t)nq::kHitListMaxCap) return fail(ix, NIQKI_E_INVALID, "hit_list_cap must be in 1..2048");
+    ix->hit_list_cap = (uint32_t)value;
     return NIQKI_OK;
   }
   if (!std::strcmp(key, "query_batch")) { if (value < 1) return NIQKI_E_INVALID; ix->query_batch = (uint32_t)value; return NIQKI_OK; }
@@ -1173,8 +1239,7 @@ int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint64_t 
     const size_t plane = std::max<size_t>((size_t)nq * stride * 2, 2);
     if ((rc = ensure(ix, ix->ws_counts, plane * (two_planes(ix) ? 2 : 1)))) return rc;
     uint16_t *c1 = (uint16_t *)ix->ws_counts.p, *c2 = two_planes(ix) ? (uint16_t *)((char *)ix->ws_counts.p + plane) : nullptr;
-    if ((rc = counts_dev(ix, sketches, ix->d.F, first_slot(ix), nq, c1, stride, c2))) return rc;
-    return hits_dev(ix, c1, nq, stride, 0, N, (unsigned long long *)hit_off, hit_counts, hit_gids, capacity, false, nullptr, c2);
+    return query_hits_dev(ix, sketches, nq, c1, c2, stride, (unsigned long long *)hit_off, hit_counts, hit_gids, capacity, false, nullptr);
   }
   return query_to_host(ix, sketches, false, nq, hit_off, hit_counts, hit_gids, capacity);
 }
@@ -1831,6 +1896,7 @@ int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value) {
   if (!std::strcmp(key, "tiles")) { *value = ix->n_tiles; return NIQKI_OK; }
   if (!std::strcmp(key, "class_mask")) { *value = (ix->built && ix->hmask_ok) ? 1 : 0; return NIQKI_OK; }
   if (!std::strcmp(key, "last_gather_form")) { *value = ix->last_form; return NIQKI_OK; }
+  if (!std::strcmp(key, "last_hits_form")) { *value = ix->last_hits_form; return NIQKI_OK; }
   if (!std::strcmp(key, "page_slots")) { *value = ix->resident_bytes ? page_slots(ix) : f_all; return NIQKI_OK; }
   if (!std::strcmp(key, "pages")) {
     const uint32_t ps = ix->resident_bytes ? page_slots(ix) : f_all;

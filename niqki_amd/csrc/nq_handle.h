@@ -100,9 +100,12 @@ struct niqki_index {
   uint32_t query_batch = 1024;
   int query_order = 1;           // option: order the queries of a launch for cache locality (1 = where it pays, 2 = wherever possible)
   int lookup_prepass = -1;       // option: slot-major table look-up pre-pass: -1 = when it pays, 0 = never, 1 = whenever usable
+  int hit_lists = 1;             // option: queries of a single small tile leave the gather kernel as ordered hit lists (no counter rows)
+  uint32_t hit_list_cap = 256;   // option: hits per query such a list holds; a query with more goes through its counter row
+  uint32_t last_hits_form = 0;   // stat "last_hits_form": 1 = the last query call took the hit-list form
 
   nqi::Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
-      ws_misc, ws_stash;
+      ws_misc, ws_stash, ws_hl;
   // staged batch (niqki_stage_raw): framing results live in ws_seq / ws_recoff / ws_entry
   nqi::Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk, ws_order, ws_pre;
   struct {

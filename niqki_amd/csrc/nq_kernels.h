@@ -149,7 +149,22 @@ struct CandOut {
   int2 *surv = nullptr;
   int32_t *surv_n = nullptr;
   uint32_t surv_thr = 0, surv_cap = 0;
+  // Hit lists (single-tile, single-segment indexes with small tiles: the short-read shape): the thresholded hits of
+  // a query -- Index::query_sketch's result, src/niqki_index.cpp:662-666,:685 -- leave the kernel while its
+  // counters are still in LDS, already ordered by descending (count, gid): hl[q*hl_cap + i] = count << 16 | gid
+  // (a count <= 2^15, a genome id < 2^16 on such an index: the packed words order like the pairs) and hl_n[q] = how
+  // many there are.  Only a query with more than hl_cap hits writes its 2N-byte counter row (to `counts`, which must
+  // be given) and leaves hl_n[q] > hl_cap: launch_hitlist_emit thresholds and orders that row.
+  // Not together with cand / surv.  hl_cap: a multiple of 4.
+  uint32_t *hl = nullptr;
+  uint32_t *hl_n = nullptr;
+  uint32_t *hl_over = nullptr;   // nq + 1 words: [0] is zeroed by the launch (launch_hitlist_scan lists the overflowing queries there)
+  uint32_t hl_cap = 0, hl_min = 0;
 };
+// the largest tile the hit-list form takes (the 256-thread launch shape: counters + queues + list within a CU's LDS
+// several times over)
+constexpr uint32_t kHitListMaxTile = 12288;
+constexpr uint32_t kHitListMaxCap = 2048;
 hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t nq,
                          uint16_t *counts, uint16_t *counts2, uint64_t stride, Entry *stash, const uint32_t *order,
                          int variant, bool pre, hipStream_t stream, const CandOut &co = CandOut());
@@ -193,6 +208,12 @@ constexpr uint32_t kHitsBlk = 4096;  // genomes per compaction block
 hipError_t launch_candidates(const uint16_t *counts, uint64_t stride, uint32_t nq, uint32_t n_gids, uint32_t thr,
                              uint32_t cap, int32_t *cand, int32_t *n, hipStream_t stream);
 hipError_t launch_hits_count(const HitsArgs &a, hipStream_t stream);
+// After a gather launch with hit lists (CandOut::hl): launch_hitlist_scan turns the queries' hit counts n[0..nq) into
+// the offsets a.hit_off (hit_off[nq] = total); launch_hitlist_emit copies every query's ordered list to its place in
+// hit_counts / hit_gids, and thresholds + orders the counter row (a.counts) of a query whose list overflowed.
+// over: nq + 1 words of scratch (the queries whose lists overflowed, made by the scan, taken by the emit launch)
+hipError_t launch_hitlist_scan(const uint32_t *n, const HitsArgs &a, uint32_t hl_cap, uint32_t *over, hipStream_t stream);
+hipError_t launch_hitlist_emit(const HitsArgs &a, const uint32_t *hl, uint32_t hl_cap, const uint32_t *over, hipStream_t stream);
 hipError_t launch_hits_emit(const HitsArgs &a, hipStream_t stream);
 
 // ---- FASTA / FASTQ framing (nq_ingest.hip) --------------------------------------

@@ -773,6 +773,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
   // parks the running totals there before the barrier that ends a walk and takes them back after the scan.
   uint32_t *lds_n = (uint32_t *)queue;
   uint32_t n_surv = 0, n_cand = 0;
+  if (co.hl_over && blockIdx.x == 0 && tid == 0) co.hl_over[0] = 0u;   // the scan that follows counts the overflowing lists here
   if (want_cand && tid == 0) {
     n_cand = (uint32_t)co.n[q];
     if (want_surv) n_surv = (uint32_t)co.surv_n[q];
@@ -846,6 +847,8 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
       uint4 *c4 = (uint4 *)cnt;   // (the dynamic LDS block is 16-byte aligned)
       for (uint32_t i = tid; i < n_words / 4; i += BLOCK) c4[i] = make_uint4(0, 0, 0, 0);
       for (uint32_t i = (n_words & ~3u) + tid; i < n_words; i += BLOCK) cnt[i] = 0;
+      if (co.hl)
+        for (uint32_t i = tid; i < co.hl_cap; i += BLOCK) ((uint32_t *)(queue + (BLOCK / 64) * kQueue))[i] = 0u;
       lds_barrier();
     }
     zeroed = false;
@@ -861,6 +864,7 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
     }
     if (MODE != 0) cnt[tid % n_words] ^= sink;
     if (want_cand && tid == 0) { lds_n[0] = n_surv; lds_n[1] = n_cand; }
+    if (co.hl && tid == 0) lds_n[0] = 0;
     NQ_GCLK_WAVE(16 + 16 * (t & 1));
     NQ_GCLK(2 + 4 * (t & 1));
     lds_barrier();
@@ -901,6 +905,55 @@ __global__ __launch_bounds__(BLOCK) void gather_kernel(IndexView v, const int32_
       if (tid == 0) { n_surv = lds_n[0]; n_cand = lds_n[1]; }
       NQ_GCLK(4 + 4 * (t & 1));
       continue;
+    }
+    if (co.hl) {
+      // Hit lists (launch_gather: one tile, one plane, nothing to add to): the query's hits are picked while its
+      // counters are in LDS -- count >= min_score, src/niqki_index.cpp:662-666 -- and ordered here, by rank: the keys
+      // count << 32 | gid are distinct, so an entry's place under greater<pair<count, gid>> (:685) is the number of
+      // entries with a larger key.  A short read against a genome index has a few dozen hits: no 2N-byte counter row
+      // is written for it, none read again.  A query with more than hl_cap hits (min_score 0: every genome) leaves
+      // through its counter row as before; launch_hitlist_emit orders it.
+      uint32_t *list = (uint32_t *)(queue + (BLOCK / 64) * kQueue);   // hl_cap packed entries: count << 16 | gid
+      const uint32_t cap = co.hl_cap, ms = co.hl_min;
+      for (uint32_t i = tid; i < n_words; i += BLOCK) {   // (hits are few: an LDS atomic each; ballot ranking was slower)
+        const uint32_t c = cnt[i], lo = c & 0xFFFFu, hi = c >> 16;
+        if (lo >= ms) {
+          const uint32_t at = atomicAdd(&lds_n[0], 1u);
+          if (at < cap) list[at] = (lo << 16) | (v.g_base + 2 * i);
+        }
+        if (2 * i + 1 < n_t && hi >= ms) {
+          const uint32_t at = atomicAdd(&lds_n[0], 1u);
+          if (at < cap) list[at] = (hi << 16) | (v.g_base + 2 * i + 1);
+        }
+      }
+      lds_barrier();
+      const uint32_t total = lds_n[0];
+      if (total <= cap) {
+        // (entries are read four at a time; the list was zeroed with the counters, and key 0 -- the places behind
+        // the last entry -- is larger than no key: a real key 0 is count 0 of genome 0, the smallest there is)
+        const uint32_t t4 = (total + 3u) & ~3u;
+        uint32_t *out = co.hl + (uint64_t)q * cap;
+        for (uint32_t i = tid; i < total; i += BLOCK) {
+          const uint32_t key = list[i];
+          uint32_t rank = 0;
+          for (uint32_t j = 0; j < t4; j += 4) {   // (all lanes read the same four entries: a broadcast)
+            const uint4 o = *(const uint4 *)(list + j);
+            rank += (o.x > key) + (o.y > key) + (o.z > key) + (o.w > key);
+          }
+          out[rank] = key;
+        }
+      } else {
+        uint16_t *row = plane + (uint64_t)q * stride + v.g_base;
+        if (((uintptr_t)row & 3u) == 0) {
+          uint32_t *out = (uint32_t *)row;
+          for (uint32_t i = tid; i < n_t / 2; i += BLOCK) out[i] = cnt[i];
+          if ((n_t & 1u) && tid == 0) row[n_t - 1] = (uint16_t)(cnt[n_t / 2] & 0xFFFFu);
+        } else {
+          for (uint32_t i = tid; i < n_t; i += BLOCK) row[i] = (uint16_t)(cnt[i >> 1] >> ((i & 1u) * 16u));
+        }
+      }
+      if (tid == 0) co.hl_n[q] = total;
+      continue;   // (one tile: nothing of this workgroup follows that touches LDS)
     }
     uint16_t *row = plane + (uint64_t)q * stride + v.g_base;
     if (v.stripe > 1 && v.n_tiles > 1 && ((uintptr_t)row & 3u) == 0) {
@@ -995,7 +1048,10 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
   if (co.cand && (v.accumulate || v.f_local > kPassSlots || !co.n)) return hipErrorInvalidValue;
   if (co.surv && (!co.cand || !co.surv_n || co.surv_thr > co.thr || !co.surv_cap)) return hipErrorInvalidValue;
   if (!counts && !co.surv) return hipErrorInvalidValue;
-#define NQ_GATHER_LDS(B) ((size_t)((v.tile + 1) / 2 + (v.padded ? kPadWords : 0u)) * 4 + (size_t)(B / 64) * kQueue * sizeof(Item))
+  if (co.hl && (co.cand || !co.hl_n || !counts || !co.hl_cap || (co.hl_cap & 3u) || co.hl_cap > kHitListMaxCap || v.g_base + v.n_genomes > 65536u || v.n_tiles != 1 || v.accumulate ||
+                v.f_local > kPassSlots || v.tile > kHitListMaxTile))
+    return hipErrorInvalidValue;
+#define NQ_GATHER_LDS(B) ((size_t)((v.tile + 1) / 2 + (v.padded ? kPadWords : 0u)) * 4 + (size_t)(B / 64) * kQueue * sizeof(Item) + (size_t)co.hl_cap * (co.hl ? 4 : 0))
   // with a locality order the grid is padded to whole groups on every XCD
   const uint32_t per_round = kXcds * kOrderGroup;
   dim3 grid(order ? (nq + per_round - 1) / per_round * per_round : nq);
@@ -1330,6 +1386,255 @@ hipError_t launch_plane_add16(uint16_t *a, const uint16_t *b, uint64_t n, hipStr
 hipError_t launch_plane_sum32(const uint16_t *a, const uint16_t *b, uint32_t *out, uint64_t n, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(plane_sum32_kernel, dim3((uint32_t)std::min<uint64_t>((n + 255) / 256, 16384)), dim3(256), 0, stream, a, b, out, n);
+  return hipGetLastError();
+}
+
+// After a gather launch with hit lists (CandOut::hl).
+// hitlist_scan_kernel: hit_off[0..nq] = exclusive prefix of n[0..nq), 4096 queries per workgroup -- a workgroup first
+// adds up what lies before its block (at most a few hundred KB of u32, from L2), then scans its own 4096 -- and the
+// queries whose lists overflowed (n > hl_cap) are collected in over[1 ..], over[0] = how many (preset to 0).
+__global__ __launch_bounds__(1024) void hitlist_scan_kernel(const uint32_t *n, uint32_t nq, uint32_t hl_cap, unsigned long long *hit_off,
+                                                            uint32_t *over) {
+  __shared__ unsigned long long wave_tot[16];
+  __shared__ unsigned long long s_base;
+  __shared__ uint32_t s_over, s_over_base;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t q0 = blockIdx.x * 4096u;
+  if (tid == 0) s_over = 0;
+  unsigned long long part = 0;
+  {   // (q0 is a multiple of 4096: whole 16-byte pieces, four independent loads in flight per thread)
+    const uint4 *n4 = (const uint4 *)n;
+    const uint32_t m = q0 / 4;
+    uint32_t i = tid;
+    for (; i + 3 * 1024 < m; i += 4 * 1024) {
+      const uint4 a0 = n4[i], a1 = n4[i + 1024], a2 = n4[i + 2048], a3 = n4[i + 3072];
+      part += (unsigned long long)a0.x + a0.y + a0.z + a0.w + a1.x + a1.y + a1.z + a1.w;
+      part += (unsigned long long)a2.x + a2.y + a2.z + a2.w + a3.x + a3.y + a3.z + a3.w;
+    }
+    for (; i < m; i += 1024) {
+      const uint4 a0 = n4[i];
+      part += (unsigned long long)a0.x + a0.y + a0.z + a0.w;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+  if (lane == 0) wave_tot[wave] = part;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned long long b = 0;
+    for (uint32_t w = 0; w < 16; ++w) b += wave_tot[w];
+    s_base = b;
+  }
+  __syncthreads();
+  const unsigned long long base = s_base;
+  const uint32_t q = q0 + 4 * tid;
+  unsigned long long x[4];
+  uint32_t n_over = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    x[j] = q + j < nq ? n[q + j] : 0ull;
+    n_over += x[j] > hl_cap ? 1u : 0u;
+  }
+  uint32_t my_over = n_over ? atomicAdd(&s_over, n_over) : 0u;
+  const unsigned long long mine = x[0] + x[1] + x[2] + x[3];
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long y = __shfl_up(incl, o, 64);
+    if (lane >= (uint32_t)o) incl += y;
+  }
+  __syncthreads();   // (wave_tot is reused; s_over is complete)
+  if (lane == 63) wave_tot[wave] = incl;
+  if (tid == 0 && s_over) s_over_base = atomicAdd(&over[0], s_over);
+  __syncthreads();
+  unsigned long long before = 0, total = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < 16; ++w) {
+    const unsigned long long t = wave_tot[w];
+    if (w < wave) before += t;
+    total += t;
+  }
+  unsigned long long run = base + before + incl - mine;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (q + j < nq) hit_off[q + j] = run;
+    run += x[j];
+    if (x[j] > hl_cap) over[1 + s_over_base + my_over++] = q + j;
+  }
+  if (tid == 0 && q0 + 4096u >= nq) hit_off[nq] = base + total;
+}
+
+// 256 * ITEMS keys (count << 16 | gid, zero = none) from LDS, ordered descending by a bitonic network over the 256
+// threads of a workgroup, the first n_out unpacked to hc / hg.  Element i = r * 256 + tid lives in register k[r]:
+// a stage whose partner i ^ j lies in the same thread (j >= 256) or the same wave (j < 64) needs no LDS and no
+// barrier; only the strides 64 and 128 go through LDS (9 of the 66 stages of 2048 keys).
+template <int ITEMS>
+__device__ __forceinline__ void bitonic_desc_256(uint32_t *keys, uint32_t tid, uint32_t n_out, uint32_t *hc, uint32_t *hg) {
+  uint32_t k[ITEMS];
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) k[r] = keys[r * 256 + tid];
+  constexpr uint32_t P = 256u * ITEMS;
+#pragma unroll
+  for (uint32_t kk = 2; kk <= P; kk <<= 1) {
+#pragma unroll
+    for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+      if (j >= 256) {   // partner in this thread
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+          const int r2 = r ^ (int)(j >> 8);
+          if (r2 > r) {
+            const bool desc = (((uint32_t)r * 256u) & kk) == 0;   // (kk > j >= 256: bit kk of i is a bit of r)
+            const uint32_t x = k[r], y = k[r2];
+            const uint32_t hi = x > y ? x : y, lo = x > y ? y : x;
+            k[r] = desc ? hi : lo;
+            k[r2] = desc ? lo : hi;
+          }
+        }
+      } else {
+        if (j >= 64) {   // partner in another wave: through LDS
+          __syncthreads();
+#pragma unroll
+          for (int r = 0; r < ITEMS; ++r) keys[r * 256 + tid] = k[r];
+          __syncthreads();
+        }
+        const bool lower = (tid & j) == 0;
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+          const uint32_t i = (uint32_t)r * 256u + tid;
+          const bool desc = (i & kk) == 0;
+          const uint32_t x = k[r];
+          const uint32_t y = j >= 64 ? keys[r * 256 + (tid ^ j)] : (uint32_t)__shfl_xor((int)x, (int)j, 64);
+          const uint32_t hi = x > y ? x : y, lo = x > y ? y : x;
+          k[r] = (desc == lower) ? hi : lo;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ITEMS; ++r) {
+    const uint32_t i = (uint32_t)r * 256u + tid;
+    if (i < n_out) { hc[i] = k[r] >> 16; hg[i] = k[r] & 0xFFFFu; }
+  }
+}
+
+// hitlist_emit_kernel, two parts.  First, one wave per query (4 per workgroup): a query whose list fits -- the usual
+// case -- is a copy of its ordered entries to [hit_off[q], hit_off[q+1]).  Then the queries whose lists overflowed, one
+// workgroup each (grid-stride over the list the scan made): the hits are thresholded from the query's counter row
+// (src/niqki_index.cpp:662-666) into LDS as count << 16 | gid -- distinct keys whose descending order is
+// greater<pair<count, gid>> (:685) -- and ordered there by a bitonic network.  keys: P words of LDS (P >= 256).
+__global__ __launch_bounds__(256) void hitlist_emit_kernel(HitsArgs a, const uint32_t *hl, uint32_t hl_cap, const uint32_t *over, uint32_t P) {
+  extern __shared__ __align__(16) uint32_t keys[];
+  __shared__ uint32_t s_n;
+  const uint32_t tid = threadIdx.x;
+  {
+    const uint32_t lane = tid & 63u, q = blockIdx.x * 4 + (tid >> 6);
+    if (q < a.nq) {
+      const unsigned long long seg0 = a.hit_off[q], n_all = a.hit_off[q + 1] - seg0;
+      if (n_all && n_all <= hl_cap) {
+        const uint32_t *src = hl + (uint64_t)q * hl_cap;
+        for (uint32_t i = lane; i < (uint32_t)n_all; i += 64) {
+          const unsigned long long pos = seg0 + i;
+          if (pos < a.capacity) {
+            const uint32_t e = src[i];
+            a.hit_counts[pos] = e >> 16;
+            a.hit_gids[pos] = e & 0xFFFFu;
+          }
+        }
+      }
+    }
+  }
+  const uint32_t n_over = over[0];
+  for (uint32_t k = blockIdx.x; k < n_over; k += gridDim.x) {
+    const uint32_t q = over[1 + k];
+    const unsigned long long seg0 = a.hit_off[q], n_all = a.hit_off[q + 1] - seg0;
+    const uint16_t *row = a.counts + (uint64_t)q * a.stride + a.gid_begin;
+    if (n_all > P) {
+      // more hits than the network holds (a threshold that lets a sixth of the index through): one wave thresholds the
+      // row in descending gid and orders it with the stable radix passes of hits_sort_kernel, through tmp_*
+      if (tid < 64) {
+        uint32_t *cur = keys;   // 256 words
+        const uint32_t lane = tid;
+        const uint64_t lt_mask = (1ULL << lane) - 1ULL;
+        unsigned long long run = 0;
+        for (uint32_t top = (a.n_gids + 63u) & ~63u; top > 0; top -= 64) {
+          const uint32_t i = top - 1 - lane;
+          const uint32_t c = i < a.n_gids ? (uint32_t)row[i] : 0u;
+          const bool hit = i < a.n_gids && c >= a.min_score;
+          const uint64_t bal = __ballot(hit);
+          if (hit) {
+            const unsigned long long pos = seg0 + run + __popcll(bal & lt_mask);
+            if (pos < a.capacity) { a.hit_counts[pos] = c; a.hit_gids[pos] = a.gid_begin + i; }
+          }
+          run += __popcll(bal);
+        }
+        unsigned long long seg1 = seg0 + n_all;
+        if (seg1 > a.capacity) seg1 = a.capacity;
+        if (seg0 < seg1) {
+          const unsigned long long n = seg1 - seg0;
+          uint32_t *tc = a.tmp_counts + seg0, *tg = a.tmp_gids + seg0;
+          uint32_t *hc = a.hit_counts + seg0, *hg = a.hit_gids + seg0;
+          __threadfence_block();
+          radix_pass_desc(hc, hg, tc, tg, n, 0, cur, lane);
+          __threadfence_block();
+          radix_pass_desc(tc, tg, hc, hg, n, 8, cur, lane);
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    if (tid == 0) s_n = 0;
+    // the network's size for this query
+    uint32_t Pq = 256;
+    while (Pq < n_all) Pq <<= 1;   // (n_all <= P here, and P >= 256 is a power of two)
+    for (uint32_t i = tid; i < Pq; i += 256) keys[i] = 0u;
+    __syncthreads();
+    // 8 counters per lane and load (rows start on 128-byte lines: NIQKI_ROW_STRIDE)
+    const bool vec = (((uintptr_t)row) & 15u) == 0;
+    for (uint32_t i0 = tid * 8; i0 < a.n_gids; i0 += 256 * 8) {
+      uint32_t c[8];
+      if (vec && i0 + 8 <= a.n_gids) {
+        const uint4 w = *(const uint4 *)(row + i0);
+        c[0] = w.x & 0xFFFFu; c[1] = w.x >> 16; c[2] = w.y & 0xFFFFu; c[3] = w.y >> 16;
+        c[4] = w.z & 0xFFFFu; c[5] = w.z >> 16; c[6] = w.w & 0xFFFFu; c[7] = w.w >> 16;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c[j] = i0 + j < a.n_gids ? (uint32_t)row[i0 + j] : 0u;
+      }
+      uint32_t m = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m |= (uint32_t)(i0 + j < a.n_gids && c[j] >= a.min_score) << j;
+      if (m) {
+        uint32_t at = atomicAdd(&s_n, (uint32_t)__builtin_popcount(m));
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (m >> j & 1u) keys[at++] = (c[j] << 16) | (a.gid_begin + i0 + j);
+      }
+    }
+    __syncthreads();
+    // bitonic sort, descending (the zero keys behind the n_all real ones end up last: a real key 0 -- count 0 of
+    // genome 0 at min_score 0 -- is the smallest key and belongs there too), in registers: see bitonic_desc_256
+    const unsigned long long room = seg0 < a.capacity ? a.capacity - seg0 : 0ull;
+    const uint32_t n_out = (uint32_t)(n_all < room ? n_all : room);
+    if (Pq <= 256) bitonic_desc_256<1>(keys, tid, n_out, a.hit_counts + seg0, a.hit_gids + seg0);
+    else if (Pq == 512) bitonic_desc_256<2>(keys, tid, n_out, a.hit_counts + seg0, a.hit_gids + seg0);
+    else if (Pq == 1024) bitonic_desc_256<4>(keys, tid, n_out, a.hit_counts + seg0, a.hit_gids + seg0);
+    else bitonic_desc_256<8>(keys, tid, n_out, a.hit_counts + seg0, a.hit_gids + seg0);
+    __syncthreads();
+  }
+}
+
+hipError_t launch_hitlist_scan(const uint32_t *n, const HitsArgs &a, uint32_t hl_cap, uint32_t *over, hipStream_t stream) {
+  if (a.nq == 0) return hipSuccess;   // (over[0] = 0: the gather launch that made n has done it, CandOut::hl_over)
+  hipLaunchKernelGGL(hitlist_scan_kernel, dim3((a.nq + 4095u) / 4096u), dim3(1024), 0, stream, n, a.nq, hl_cap, a.hit_off, over);
+  return hipGetLastError();
+}
+
+hipError_t launch_hitlist_emit(const HitsArgs &a, const uint32_t *hl, uint32_t hl_cap, const uint32_t *over, hipStream_t stream) {
+  if (a.nq == 0) return hipSuccess;
+  // (the network: 2048 keys = 8 KB of LDS, eight workgroups per CU; a query with more hits takes the wave path)
+  uint32_t P = 256;
+  while (P < a.n_gids && P < 2048u) P <<= 1;
+  hipLaunchKernelGGL(hitlist_emit_kernel, dim3((a.nq + 3) / 4), dim3(256), (size_t)P * 4, stream, a, hl, hl_cap, over, P);
   return hipGetLastError();
 }
 

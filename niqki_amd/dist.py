@@ -73,6 +73,11 @@ class ShardedQuery:
         self.transport = ("local", "rccl", "ipc")[self.g.stat("transport")]
 
     @property
+    def ranks_seen(self):
+        """Ranks the transport itself knows of (RCCL: ncclCommCount; ipc: peers mapped): world when all is well."""
+        return self.g.stat("ranks_seen")
+
+    @property
     def overflows(self):
         return self.g.stat("overflows")
 

@@ -39,6 +39,7 @@ def main():
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     grp = niqki_amd.Group([eng], first_rank=rank, world=world, group_id=gid)
     assert grp.stat("transport") == {"ipc": 2, "rccl": 1}[transport]
+    assert grp.stat("ranks_seen") == world
     words_kind = grp.stat("ipc_words_kind") if transport == "ipc" else -1
     want = os.environ.get("NIQKI_IPC_WORDS")
     if transport == "ipc" and want in ("host", "coarse"):

@@ -114,6 +114,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["value"] > 0
     assert j["config"]["transport"] == "ipc" and j["verify"]["hit_lists_equal_whole_range_handle"] is True
+    assert j["config"]["transport_ranks_seen"] == j["n_gpus"] and j["config"]["exchange_gbs_per_link"] > 0
 
 
 def test_bench_starts_its_own_ranks(tmp_path):
@@ -130,3 +131,4 @@ def test_bench_starts_its_own_ranks(tmp_path):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["ranks_share_devices"] is True
     assert j["config"]["transport"] == "ipc" and j["verify"]["hit_lists_equal_whole_range_handle"] is True
+    assert j["config"]["transport_ranks_seen"] == j["n_gpus"] and j["config"]["exchange_gbs_per_link"] > 0

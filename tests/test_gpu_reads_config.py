@@ -85,6 +85,35 @@ def test_config5_reads_vs_10k_index(native, po, monkeypatch):
         if hi > lo:
             assert int(src_g[i]) // 100 in set((hg[lo:hi] // 100).tolist()) or cols[src_g[i]] < min_score
     assert n_hit_reads >= len(CHECK) // 4
+    # The hits left the gather kernel as ordered lists (single small tile: no counter row per read) ...
+    assert e.stat("last_hits_form") == 1
+    nh = int(off[NR])
+    per_read = np.diff(off)
+    assert per_read.max() > 256, "the batch should hold reads whose lists overflow the default capacity"
+
+    def again():
+        o = torch.zeros(NR + 1, dtype=torch.int64, device=dev)
+        c, g = torch.zeros(cap, dtype=torch.int32, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
+        e.query_sequences_dev(reads, rro, NR, o, c, g, cap)
+        e.synchronize()
+        return o, c, g
+    # ... with a list capacity that nearly every read with hits overflows (forced fall-back to the counter row), with the
+    # largest capacity, and in the form that writes and re-reads every counter row: the same bytes
+    for key, val, form in (("hit_list_cap", 4, 1), ("hit_list_cap", 2048, 1), ("hit_lists", 0, 0)):
+        e.set_option(key, val)
+        o, c, g = again()
+        assert e.stat("last_hits_form") == form
+        assert torch.equal(o, d_off) and torch.equal(c[:nh], d_hc[:nh]) and torch.equal(g[:nh], d_hg[:nh]), (key, val)
+    e.set_option("hit_lists", 1)
+    e.set_option("hit_list_cap", 256)
+    # a capacity below the total: offsets exact, the hits that fit are the first ones
+    small = int(off[NR // 2]) + 5
+    o = torch.zeros(NR + 1, dtype=torch.int64, device=dev)
+    c, g = torch.zeros(small, dtype=torch.int32, device=dev), torch.zeros(small, dtype=torch.int32, device=dev)
+    e.query_sequences_dev(reads, rro, NR, o, c, g, small)
+    e.synchronize()
+    whole = int(off[NR // 2])          # (queries that end within the capacity are complete)
+    assert torch.equal(o, d_off) and torch.equal(c[:whole], d_hc[:whole]) and torch.equal(g[:whole], d_hg[:whole])
     # the per-slot class mask (single-tile index) was in use ...
     assert e.stat("class_mask") == 1
     # ... and an index built without it answers the same bytes (the mask only skips look-ups of empty buckets)
