@@ -412,7 +412,7 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
   // with the look-ups inside the gather kernel -- the default for batches of >= 1024 queries.
   // (not on a paged index: the packed copy would be made again for every page, outside its memory budget)
   if (ix->lookup_prepass < 0)
-    pre = pre && ((ix->n_tiles > 4 && nq >= 256) || (nq::lookup_wants_packed(v) && nq >= 1024 && !ix->resident_bytes));
+    pre = pre && ((ix->n_tiles > 4 && nq >= 256) || (nq::lookup_wants_packed(v) && nq >= 1024 && !ix->resident_bytes && ix->n_tiles <= 2));
   // locality order of each launch: worth its probe on large indexes and real batches.  It takes ~8 % off
   // the gather kernel and costs 0.1 ms per 4096 queries at 100 000 genomes whatever the slot count:
   // measured even on a slot shard of 4096 slots (1.56 against 1.57 ms per 4096 queries), +4 % at 8192.
@@ -425,7 +425,9 @@ int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride,
   uint32_t chunk = nq;
   if (per_query) chunk = (uint32_t)std::max<size_t>(4096, ((size_t)128 << 20) / per_query);
   if (ordered || pre) chunk = 4096;
-  if (pre && per_query * chunk > ((size_t)2 << 30)) chunk = std::max<uint32_t>(256, (uint32_t)((((size_t)2 << 30) / per_query) & ~(size_t)255));
+  // (the pre-pass words of a launch: at most 8 GiB -- a launch of 4096 queries on up to 16 tiles at S = 15; the streamed
+  // form reads the table once per launch, so fewer, larger launches halve its traffic on a 500 000-genome index)
+  if (pre && per_query * chunk > ((size_t)8 << 30)) chunk = std::max<uint32_t>(256, (uint32_t)((((size_t)8 << 30) / per_query) & ~(size_t)255));
   if (pre) {
     if (nq::lookup_wants_packed(v) && !ix->ptab_ok) {   // packed copy of the table, once per build
       const size_t want = (size_t)f_local * ix->d.R * ix->n_tiles * 4;

@@ -23,6 +23,7 @@
 #include "nq_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace nq {
 
@@ -252,14 +253,13 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
     do {
       uint32_t nch = (rem + 63) >> 6;
       if (nch > 3) nch = 3;
-      uint32_t incl = nch;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        uint32_t y = __shfl_up(incl, o, 64);
-        if (lane >= (uint32_t)o) incl += y;
-      }
-      const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-      uint32_t slot = q_head + q_count + incl - nch;
+      // exclusive prefix of nch (two bits) over the lanes from two ballots: bit counts below the lane (v_mbcnt) instead
+      // of a six-step shuffle scan through the LDS crossbar
+      const uint64_t b0 = __ballot((nch & 1u) != 0), b1 = __ballot((nch & 2u) != 0);
+      const uint32_t excl = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                            2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+      const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1);
+      uint32_t slot = q_head + q_count + excl;
 #pragma unroll
       for (uint32_t k = 0; k < 3; ++k)
         if (k < nch) {
@@ -468,6 +468,10 @@ __global__ __launch_bounds__(kPreBlock) void lookup_kernel(IndexView v, const in
 // eight neighbouring lanes store one 128-byte line of pre[q][t][s] together.  The workgroups of one
 // slot block (nq / 1024) are neighbours in one XCD's dispatch order: the row comes from HBM once.
 constexpr uint32_t kRowSlots = 32, kRowBlock = 1024;
+// The packed table (IndexView::ptab, one word per entry) keeps the tiles in GROUPS of two: the words of tiles
+// t0, t0 + 1 (t0 even) of all slots lie together as [f_local][R][2] from this word on ([f_local][R][1] for a last
+// odd tile) -- a launch over one group streams exactly its own rows.  With <= 2 tiles this is the whole table.
+__host__ __device__ inline uint64_t packed_table_offset(const IndexView &v, uint32_t t0) { return (uint64_t)v.f_local * v.d.R * t0; }
 __device__ __forceinline__ void wave_lds_fence() {   // this wave's LDS traffic so far has completed
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -476,9 +480,12 @@ __device__ __forceinline__ void wave_lds_fence() {   // this wave's LDS traffic 
 __device__ __forceinline__ void lds_barrier() {   // a workgroup barrier that waits for LDS traffic only:
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the row loads in flight stay in flight
 }
+// NT tiles from tile t0 on per launch (a tile GROUP: the packed table keeps the rows of a group together, see
+// packed_table_offset): an index of more than 2 tiles takes ceil(n_tiles / 2) launches, each streaming its group's
+// part of the table once.
 template <int NT, int PER>   // PER: 16-byte pieces of a packed row per thread (R * NT / 4096)
 __global__ __launch_bounds__(kRowBlock) void lookup_rows_kernel(IndexView v, const int32_t *sketches, uint32_t nq,
-                                                                uint32_t n_qchunk, uint32_t *pre) {
+                                                                uint32_t n_qchunk, uint32_t *pre, uint32_t t0) {
   extern __shared__ __align__(16) uint32_t rows[];   // 4 buffers of R * NT words; at the end 1024 x 17 words
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t n_sb = v.f_local / kRowSlots;
@@ -502,7 +509,7 @@ __global__ __launch_bounds__(kRowBlock) void lookup_rows_kernel(IndexView v, con
   // flight before any LDS read it can see, so the pipeline's waits and the look-up read are written by
   // hand: loads of one kind retire in issue order (vmcnt), and a wave passes the row's barrier only when
   // its own pieces of that row have landed.
-  const uint4 *row0 = (const uint4 *)(v.ptab + (uint64_t)sb * kRowSlots * RW) + tid;
+  const uint4 *row0 = (const uint4 *)(v.ptab + packed_table_offset(v, t0) + (uint64_t)sb * kRowSlots * RW) + tid;
   const uint32_t row_u4 = RW / 4;   // 16-byte pieces per row
   const uint32_t wbase = tid & ~63u;
   auto request = [&](int i) {
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(kRowBlock) void lookup_rows_kernel(IndexView v, con
       const uint32_t *sp = rows + src_t * (kRowSlots + 1u) + piece * 4u;                                             \
       const uint4 w = make_uint4(sp[0], sp[1], sp[2], sp[3]);                                                        \
       const uint32_t qq = q0 + src_t;                                                                                \
-      if (qq < nq) *(uint4 *)(pre + ((uint64_t)qq * NT + (T)) * v.f_local + (uint64_t)sb * kRowSlots + piece * 4u) = w; \
+      if (qq < nq) *(uint4 *)(pre + ((uint64_t)qq * v.n_tiles + t0 + (T)) * v.f_local + (uint64_t)sb * kRowSlots + piece * 4u) = w; \
     }                                                                                                                \
     wave_lds_fence(); /* before the next tile overwrites the wave's words */                                         \
   }
@@ -568,21 +575,30 @@ __global__ __launch_bounds__(kRowBlock) void lookup_rows_kernel(IndexView v, con
   if (NT == 2) NQ_STORE_TILE(NT - 1)
 #undef NQ_STORE_TILE
 }
-// packed rows that two LDS buffers hold, dealt to 1024 threads in whole 16-byte loads
+// Packed rows that the LDS buffers hold, dealt to 1024 threads in whole 16-byte loads: tiles are taken two at a
+// time (rows of 2 R words = 32 KB at W = 12), a last odd tile alone.
 bool lookup_wants_packed(const IndexView &v) {
-  const uint32_t rw = v.d.R * v.n_tiles;
-  if (!launch_lookup_usable(v) || v.n_tiles > 2 || v.f_local % kRowSlots || rw * 4u > 32768u || rw % (4u * kRowBlock)) return false;
-  const uint32_t per = rw / (4u * kRowBlock);
-  return per == 1 || per == 2;
+  if (!launch_lookup_usable(v) || v.f_local % kRowSlots) return false;
+  auto row_ok = [&](uint32_t nt) {   // a group's packed row: within 32 KB, whole 16-byte pieces per thread, 1 or 2 of them
+    const uint32_t rw = v.d.R * nt;
+    if (rw * 4u > 32768u || rw % (4u * kRowBlock)) return false;
+    const uint32_t per = rw / (4u * kRowBlock);
+    return per == 1 || per == 2;
+  };
+  if (v.n_tiles >= 2 && !row_ok(2)) return false;
+  if ((v.n_tiles & 1u) && !row_ok(1)) return false;
+  return true;
 }
 
 __global__ __launch_bounds__(256) void pack_entries_kernel(IndexView v, uint32_t *ptab) {
   const uint64_t n = (uint64_t)v.f_local * v.d.R * v.n_tiles, step = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
     const uint32_t t = (uint32_t)(i % v.n_tiles);
-    const uint32_t s = (uint32_t)(i / ((uint64_t)v.d.R * v.n_tiles));
+    const uint64_t sf = i / v.n_tiles;   // slot * R + fp
+    const uint32_t s = (uint32_t)(sf / v.d.R);
     const Entry e = v.entries[i];
-    ptab[i] = ((e.start - v.slot_units[(uint64_t)t * (v.f_local + 1) + s]) << 16) | e.len;
+    const uint32_t t0 = t & ~1u, nt = v.n_tiles - t0 >= 2 ? 2u : 1u;   // the tile's group
+    ptab[packed_table_offset(v, t0) + sf * nt + (t - t0)] = ((e.start - v.slot_units[(uint64_t)t * (v.f_local + 1) + s]) << 16) | e.len;
   }
 }
 hipError_t launch_pack_entries(const IndexView &v, uint32_t *ptab, hipStream_t stream) {
@@ -610,17 +626,20 @@ hipError_t launch_lookup(const IndexView &v, const int32_t *sketches, uint32_t n
     const uint32_t n_sb = v.f_local / kRowSlots, n_qchunk = (nq + kRowBlock - 1) / kRowBlock;
     const uint64_t grid = (uint64_t)((n_sb + kXcds - 1) / kXcds * kXcds) * n_qchunk;
     if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const size_t lds = std::max<size_t>((size_t)v.d.R * v.n_tiles * 4 * 4, (size_t)kRowBlock * (kRowSlots + 1) * 4);
-    const uint32_t per = v.d.R * v.n_tiles / (4u * kRowBlock);
     hipError_t e = hipSuccess;
 #define NQ_LAUNCH_ROWS(NT, PER)                                                                                        \
   do {                                                                                                                 \
     e = hipFuncSetAttribute((const void *)lookup_rows_kernel<NT, PER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) return e;                                                                                     \
-    hipLaunchKernelGGL((lookup_rows_kernel<NT, PER>), dim3((uint32_t)grid), dim3(kRowBlock), lds, stream, v, sketches, nq, n_qchunk, pre); \
+    hipLaunchKernelGGL((lookup_rows_kernel<NT, PER>), dim3((uint32_t)grid), dim3(kRowBlock), lds, stream, v, sketches, nq, n_qchunk, pre, t0); \
   } while (0)
-    if (v.n_tiles == 1) { if (per == 1) NQ_LAUNCH_ROWS(1, 1); else NQ_LAUNCH_ROWS(1, 2); }
-    else { if (per == 1) NQ_LAUNCH_ROWS(2, 1); else NQ_LAUNCH_ROWS(2, 2); }
+    for (uint32_t t0 = 0; t0 < v.n_tiles; t0 += 2) {   // tile groups (packed_table_offset)
+      const uint32_t nt = v.n_tiles - t0 >= 2 ? 2u : 1u;
+      const size_t lds = std::max<size_t>((size_t)v.d.R * nt * 4 * 4, (size_t)kRowBlock * (kRowSlots + 1) * 4);
+      const uint32_t per = v.d.R * nt / (4u * kRowBlock);
+      if (nt == 1) { if (per == 1) NQ_LAUNCH_ROWS(1, 1); else NQ_LAUNCH_ROWS(1, 2); }
+      else { if (per == 1) NQ_LAUNCH_ROWS(2, 1); else NQ_LAUNCH_ROWS(2, 2); }
+    }
 #undef NQ_LAUNCH_ROWS
     return hipGetLastError();
   }

@@ -708,7 +708,8 @@ def test_candidates_picked_by_the_gather_kernel(native, n, tile, n_late):
 @pytest.mark.parametrize("n,tile", [(1000, 64), (1500, 128), (700, 64)])
 def test_more_than_four_tiles(native, po, n, tile):
     """5 to 16 counter tiles (what > 261 632 genomes get at the default tile size): the look-up
-    pre-pass walks the tiles four at a time and is the default there for real batches; the same
+    pre-pass is the default there for real batches (W = 6 here: its random-access form, four tiles at a
+    time; the streamed-rows form of W >= 11 indexes: test_prepass_with_table_rows_staged_in_lds); the same
     counters and hits with it, without it, and as the oracle; the dump merges all tiles."""
     rng = np.random.default_rng(n + tile)
     S, W = 6, 6
@@ -744,13 +745,15 @@ def test_more_than_four_tiles(native, po, n, tile):
     e.close()
 
 
-@pytest.mark.parametrize("W,tile", [(12, 0), (12, 256), (11, 256)])
+@pytest.mark.parametrize("W,tile", [(12, 0), (12, 256), (11, 256), (12, 128), (12, 64), (11, 64)])
 def test_prepass_with_table_rows_staged_in_lds(native, po, W, tile):
-    """The pre-pass form for W = 12 indexes of one or two tiles and real batches (a slot's whole
-    entry row copied into LDS, 1024 queries per workgroup; a last workgroup with idle threads):
-    same counters and hits as with the look-ups inside the gather kernel and as the oracle."""
+    """The pre-pass form that streams whole table rows through LDS (a slot's packed row of TWO tiles copied into
+    LDS, 1024 queries per workgroup; a last workgroup with idle threads) for W <= 12 indexes and real batches:
+    one or two tiles, and -- round 5 -- any tile count, the tiles taken two at a time from a packed table that keeps
+    each pair's rows together (3 tiles: a last lone tile; 5 tiles; 8 tiles at W = 11).  Same counters and hits as
+    with the look-ups inside the gather kernel and as the oracle; the form is asserted through last_gather_form."""
     rng = np.random.default_rng(77 + tile + W)
-    S, n = 6, 300
+    S, n = 6, (300 if tile in (0, 256) else (330 if tile == 128 else (290 if W == 12 else 500)))
     F = 1 << S
     fam = rng.integers(0, 1 << W, (5, F)).astype(np.int32)
     sk = fam[(np.arange(n) // 60) % 5].copy()
@@ -767,11 +770,12 @@ def test_prepass_with_table_rows_staged_in_lds(native, po, W, tile):
     e = native.Engine(K=31, S=S, W=W, H=4, J=0.3, tile_genomes=tile)
     e.insert(sk)
     e.build()
-    assert e.stat("tiles") == (2 if tile else 1)
+    assert e.stat("tiles") == (-(-n // tile) if tile else 1) and e.stat("tiles") in (1, 2, 3, 5, 8)
     res = {}
     for mode in (0, 1):
         e.set_option("lookup_prepass", mode)
         res[mode] = (e.query_counts(q), e.query(q))
+        assert (e.stat("last_gather_form") & 3) == (3 if mode else 0)      # pre-pass, in its streamed-rows form
     assert np.array_equal(res[0][0], res[1][0])
     assert all(np.array_equal(x, y) for x, y in zip(res[0][1], res[1][1]))
     cnt, (off, hc, hg) = res[1]

@@ -78,7 +78,71 @@ static void run(const uint8_t *tab, uint32_t n_lines, const char *what, uint32_t
          lines / blocks / (ms * 1e3), instr / blocks / (ms * 1e3), lines * 128 / ms / 1e6);
 }
 
-int main() {
+// form 4: the padded walk's own form (PairWalk: global_load_dword, two consecutive lines per instruction, 64-bit
+// addresses) over tables of 2 to 64 GB: what random 128-byte lines cost once the table outgrows the Infinity Cache
+// and the translation caches (a 500 000-genome index keeps 67 GB of ids).
+template <int UNROLL>
+__global__ __launch_bounds__(1024) void lines_big_kernel(const uint8_t *tab, uint64_t n_pairs, uint32_t rounds, uint32_t *out) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave_id = (blockIdx.x * 1024u + threadIdx.x) >> 6;
+  uint32_t acc = 0;
+  uint64_t pos = (((uint64_t)mix32(wave_id * 64u + lane) << 17) ^ mix32(lane * 977u + wave_id)) % n_pairs;
+  uint32_t ga[UNROLL], gb[UNROLL];
+  auto fetch = [&](uint32_t (&g)[UNROLL], uint32_t j0) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)pos, (j0 + u) & 63), hi = __builtin_amdgcn_readlane((uint32_t)(pos >> 32), (j0 + u) & 63);
+      const uint64_t off = (((uint64_t)hi << 32) | lo) * 256ull + lane * 4u;
+      g[u] = *(const __attribute__((address_space(1))) uint32_t *)(tab + off);
+    }
+  };
+  auto use = [&](uint32_t (&g)[UNROLL]) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc ^= g[u];
+  };
+  fetch(ga, 0);
+  for (uint32_t r = 0; r < rounds; ++r) {
+    fetch(gb, UNROLL);
+    use(ga);
+    pos = (((uint64_t)mix32((uint32_t)pos + r) << 17) ^ mix32((uint32_t)(pos >> 7) + lane)) % n_pairs;
+    fetch(ga, 0);
+    use(gb);
+  }
+  use(ga);
+  if (acc == 0x12345u) out[0] = acc;
+}
+
+static void run_big(const uint8_t *tab, size_t bytes, uint32_t *out) {
+  constexpr int U = 16;   // 16 loads = 32 lines per round, two rounds in flight: the kernel's depth
+  const uint32_t rounds = 200;
+  const int blocks = 256, waves_per_cu = 16;
+  hipEvent_t a, b;
+  hipEventCreate(&a); hipEventCreate(&b);
+  lines_big_kernel<U><<<blocks, 1024>>>(tab, bytes / 256, 4, out);
+  hipEventRecord(a);
+  lines_big_kernel<U><<<blocks, 1024>>>(tab, bytes / 256, rounds, out);
+  hipEventRecord(b);
+  hipEventSynchronize(b);
+  float ms;
+  hipEventElapsedTime(&ms, a, b);
+  const double lines = (double)blocks * waves_per_cu * (2.0 * rounds + 1) * U * 2;
+  printf("  form 4 global dword, 2 lines / instr, table %5zu GB: %7.1f lines/us/CU  %7.0f GB/s\n", bytes >> 30, lines / blocks / (ms * 1e3),
+         lines * 128 / ms / 1e6);
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1 && argv[1][0] == 'b') {   // ubench_lines big
+    uint32_t *out;
+    hipMalloc(&out, 64);
+    for (size_t gb : {size_t(2), size_t(8), size_t(16), size_t(64)}) {
+      uint8_t *t = nullptr;
+      if (hipMalloc(&t, gb << 30) != hipSuccess) { printf("  table %zu GB: allocation failed\n", gb); continue; }
+      hipMemset(t, 1, gb << 30);
+      run_big(t, gb << 30, out);
+      hipFree(t);
+    }
+    return 0;
+  }
   uint8_t *tab;
   uint32_t *out;
   const size_t big = 2ull << 30;
