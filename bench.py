@@ -1419,7 +1419,7 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
     # program's own phase clocks, its start-up reported beside them)
     import subprocess
     cli = {}
-    for tag, n_files, gz in (("plain_fasta", 512, False), ("gzip_fasta", 64, True)):
+    for tag, n_files, gz in (("plain_fasta", 2048, False), ("gzip_fasta", 64, True)):
         cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_cli.py"), "--genomes", str(n_files), "--len", str(L),
                "--dir", os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "niqki_bench_cli_%d" % os.getpid())]
         if gz:
@@ -1427,13 +1427,18 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
         else:
             cmd += ["--reference", "128"]
         try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             j = json.loads(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else None
         except (OSError, ValueError, IndexError, subprocess.SubprocessError):
             j = None
         if j:
             cli[tag] = {"files": n_files, "index_genomes_per_s": j["index_genomes_per_s"], "query_genomes_per_s": j["query_genomes_per_s"],
                         "index_file_GBps": j["index_fasta_GBps"], "process_startup_s": j["startup_s"],
+                        # the -I phase of the FIRST process that reads the freshly written files (tmpfs: slower for any
+                        # reader, `cat` included) beside the rate above, which is the -I phase of the `-I .. -Q ..` run
+                        "index_first_pass_genomes_per_s": j.get("index_first_pass_genomes_per_s"),
+                        "packed_fasta": "plain FASTA files travel as 2 bits per base in full A/C/G/T lines (niqki_pack_fasta, "
+                                        "made by the reader threads while they read); the device restores the files' bytes" if not gz else None,
                         "query_phase_split_s": j.get("query_phase_split_s")}
             if j.get("reference_program"):
                 # the reference's OWN program on the first files: its CPU path, and the same binary with its three

@@ -301,7 +301,10 @@ typedef struct niqki_raw_batch {
                                 pointers, file f's bytes start at file_ptr[f]; raw is then ignored */
   const uint64_t *file_off;  /* HOST array, n_files+1 offsets into raw (their differences are the
                                 file sizes when file_ptr is used) */
-  const uint8_t *file_type;  /* HOST array, n_files: 'A' FASTA / 'Q' FASTQ (get_data_type, :944-952) */
+  const uint8_t *file_type;  /* HOST array, n_files: 'A' FASTA / 'Q' FASTQ (get_data_type, :944-952); 'a' = a FASTA
+                                file handed over as the container niqki_pack_fasta made of it (host memory space, the
+                                file_ptr form, whole mode): 2 bits per base across PCIe, the device writes the file's
+                                own bytes back before it frames them -- same results as 'A' on the file itself */
   uint32_t n_files;
   uint32_t lines;            /* 0: one sketch per file (whole mode); 1: one sketch per record longer
                                 than K (lines mode, n_files must be 1) */
@@ -341,6 +344,17 @@ int niqki_staged_query(niqki_index *ix, uint64_t *hit_off, uint32_t *hit_counts,
  * seqs seq_bytes, entry_rec n_entry+1, hdr_pos n_rec.  For tests and diagnosis. */
 int niqki_staged_records(niqki_index *ix, uint64_t *rec_off, uint8_t *seqs,
                          uint32_t *entry_rec, uint64_t *hdr_pos);
+/* Packed FASTA: what a host-to-device copy of whole genomes costs is 1 byte per base; a FASTA file is almost
+ * entirely full lines of one width holding A, C, G, T only.  niqki_pack_fasta turns the bytes of a file into a
+ * container in which every run of such lines travels as 2 bits per base and everything else -- header lines, lines
+ * with any other byte, a last line without its newline -- verbatim; staged with file_type 'a', the device restores
+ * the file's exact bytes (so Index::Biogetline's framing, src/niqki_index.cpp:890-941, sees what it would have seen).
+ * Host code, no device needed.  niqki_pack_fasta returns the container's size, or 0 when the file is not worth
+ * packing (reads, FASTQ, CRLF lines: hand it over raw); capacity >= niqki_pack_bound(n).  niqki_unpack_fasta is the
+ * host restatement of the device pass (raw == NULL: only *raw_len). */
+size_t niqki_pack_bound(size_t n);
+size_t niqki_pack_fasta(const uint8_t *raw, size_t n, uint8_t *out, size_t capacity);
+int niqki_unpack_fasta(const uint8_t *container, size_t len, uint8_t *raw, size_t capacity, size_t *raw_len);
 /* Page-locked host memory for raw batches (plain malloc'ed memory works too, slower). */
 void *niqki_host_alloc(size_t bytes);
 void niqki_host_free(void *p);

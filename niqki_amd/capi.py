@@ -105,6 +105,9 @@ ABI = [
     ("niqki_staged_insert", _int, [_vp]),
     ("niqki_staged_query", _int, [_vp, _vp, _vp, _vp, _u64, _int]),
     ("niqki_staged_records", _int, [_vp, _vp, _vp, _vp, _vp]),
+    ("niqki_pack_bound", C.c_size_t, [C.c_size_t]),
+    ("niqki_pack_fasta", C.c_size_t, [_vp, C.c_size_t, _vp, C.c_size_t]),
+    ("niqki_unpack_fasta", _int, [_vp, C.c_size_t, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     ("niqki_host_alloc", _vp, [C.c_size_t]),
     ("niqki_host_free", None, [_vp]),
     ("niqki_matrix_range", _int, [_vp, _u32, _u32, _vp, _u64, _int]),
@@ -175,6 +178,29 @@ def row_stride(n):
 
 def min_score(J, S):
     return lib().niqki_min_score(J, S)
+
+
+def pack_fasta(data):
+    """niqki_pack_fasta: the packed container of a FASTA file's bytes (np.uint8 array), or None when the file is not
+    worth packing (hand it over raw).  Host code: no GPU needed."""
+    raw = np.frombuffer(bytes(data), dtype=np.uint8)
+    out = np.empty(lib().niqki_pack_bound(raw.size), dtype=np.uint8)
+    n = lib().niqki_pack_fasta(raw.ctypes.data if raw.size else None, raw.size, out.ctypes.data, out.size)
+    return out[:n].copy() if n else None
+
+
+def unpack_fasta(container):
+    """niqki_unpack_fasta: the file's bytes back (the host restatement of the device pass)."""
+    c = np.ascontiguousarray(container, dtype=np.uint8)
+    n = C.c_size_t(0)
+    rc = lib().niqki_unpack_fasta(c.ctypes.data, c.size, None, 0, C.byref(n))
+    if rc:
+        raise NiqkiError(rc, "niqki_unpack_fasta: not a well-formed container")
+    out = np.empty(max(n.value, 1), dtype=np.uint8)
+    rc = lib().niqki_unpack_fasta(c.ctypes.data, c.size, out.ctypes.data, out.size, C.byref(n))
+    if rc:
+        raise NiqkiError(rc, "niqki_unpack_fasta failed")
+    return out[:n.value]
 
 
 def synth_genome_host(seed, family, member, rate14, length):

@@ -3,6 +3,7 @@
 // compute happens on the host here and there is no CPU fallback: without a
 // gfx950 device niqki_create fails.
 #include "nq_handle.h"
+#include "nq_pack.h"
 #include "nq_synth.h"
 
 #include <algorithm>
@@ -772,7 +773,7 @@ void niqki_destroy(niqki_index *ix) {
   for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
                  &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash,
                  &ix->ws_raw, &ix->ws_raw2, &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
-                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order, &ix->ws_pre, &ix->ws_hl})
+                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order, &ix->ws_pre, &ix->ws_hl, &ix->ws_useg})
     if (b->p) (void)hipFree(b->p);
   for (Buf *b : {&ix->pg_store, &ix->pg_stage})
     if (b->p) (void)hipFree(b->p);
@@ -1335,9 +1336,43 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   ix->staged.sketched = false;
   *info = niqki_stage_info{0, 0, 0, 0};
   const uint32_t nf = b->n_files;
-  const uint64_t T = nf ? b->file_off[nf] : 0;
+  const uint64_t T = nf ? b->file_off[nf] : 0;   // bytes handed over ("wire" bytes: packed files count as their containers)
   if (nf && !b->raw && !b->file_ptr && T) return NIQKI_E_INVALID;
   if (b->file_ptr && mem != NIQKI_MEM_HOST) return fail(ix, NIQKI_E_INVALID, "file_ptr needs the host memory space");
+  // Packed FASTA files (file_type 'a': a container of niqki_pack_fasta): the device writes the file's own bytes back
+  // first (nq::unpack_kernel), so everything from here on sees raw files at their raw offsets.
+  bool any_packed = false;
+  for (uint32_t f = 0; f < nf; ++f) any_packed |= b->file_type[f] == 'a';
+  if (any_packed && (mem != NIQKI_MEM_HOST || !b->file_ptr || b->lines))
+    return fail(ix, NIQKI_E_INVALID, "packed files (type 'a'): host memory, the file_ptr form, whole-file mode");
+  std::vector<uint64_t> roff((size_t)nf + 1, 0);   // raw offsets of the files
+  std::vector<nq::UnpackSeg> segs;
+  uint64_t unpack_blocks = 0;
+  for (uint32_t f = 0; f < nf; ++f) {
+    if (b->file_off[f + 1] < b->file_off[f]) return fail(ix, NIQKI_E_INVALID, "file_off must be non-decreasing");
+    const uint64_t wire_len = b->file_off[f + 1] - b->file_off[f];
+    uint64_t raw_len = wire_len;
+    if (b->file_type[f] == 'a') {
+      const uint8_t *c = b->file_ptr[f];
+      if (!c || !nqp::valid(c, wire_len)) return fail(ix, NIQKI_E_INVALID, "file " + std::to_string(f) + " is not a well-formed packed container");
+      nqp::PackHeader h;
+      std::memcpy(&h, c, sizeof h);
+      raw_len = h.raw_len;
+      for (uint32_t k = 0; k < h.n_seg; ++k) {
+        nqp::PackSeg ps;
+        std::memcpy(&ps, c + sizeof(nqp::PackHeader) + (size_t)k * sizeof(nqp::PackSeg), sizeof ps);
+        segs.push_back(nq::UnpackSeg{roff[f] + ps.raw_off, b->file_off[f] + h.payload_off + ps.pk_off, ps.count, ps.width, (uint32_t)unpack_blocks, 0u});
+        unpack_blocks += (nqp::seg_raw_len(ps) + nq::kUnpackChunk - 1) / nq::kUnpackChunk;
+      }
+    } else if (any_packed && wire_len) {   // a raw file in a batch with packed ones: one raw segment
+      if (wire_len > 0xFFFFFFFFull) return fail(ix, NIQKI_E_INVALID, "a raw file of 4 GiB or more cannot share a batch with packed files");
+      segs.push_back(nq::UnpackSeg{roff[f], b->file_off[f], (uint32_t)wire_len, 0u, (uint32_t)unpack_blocks, 0u});
+      unpack_blocks += (wire_len + nq::kUnpackChunk - 1) / nq::kUnpackChunk;
+    }
+    roff[f + 1] = roff[f] + raw_len;
+  }
+  if (unpack_blocks > 0x7FFFFFFFull) return fail(ix, NIQKI_E_INVALID, "raw batch too large");
+  const uint64_t T_raw = roff[nf];
   // chunk table: chunks never span two files
   std::vector<uint8_t> meta((size_t)(nf + 1) * 12 + nf + 16);
   uint64_t *h_off = (uint64_t *)meta.data();
@@ -1345,15 +1380,15 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   uint8_t *h_type = meta.data() + (size_t)(nf + 1) * 12;
   uint64_t chunks = 0;
   for (uint32_t f = 0; f < nf; ++f) {
-    if (b->file_off[f + 1] < b->file_off[f]) return fail(ix, NIQKI_E_INVALID, "file_off must be non-decreasing");
-    if (b->file_type[f] != 'A' && b->file_type[f] != 'Q') return fail(ix, NIQKI_E_INVALID, "file_type must be 'A' or 'Q'");
-    h_off[f] = b->file_off[f];
+    const uint8_t ty = b->file_type[f] == 'a' ? (uint8_t)'A' : b->file_type[f];
+    if (ty != 'A' && ty != 'Q') return fail(ix, NIQKI_E_INVALID, "file_type must be 'A', 'Q' or 'a' (packed FASTA)");
+    h_off[f] = roff[f];
     h_first[f] = (uint32_t)chunks;
-    h_type[f] = b->file_type[f];
-    chunks += (b->file_off[f + 1] - b->file_off[f] + nq::kIngestChunk - 1) / nq::kIngestChunk;
+    h_type[f] = ty;
+    chunks += (roff[f + 1] - roff[f] + nq::kIngestChunk - 1) / nq::kIngestChunk;
   }
   if (chunks > 0x7FFFFFFFull) return fail(ix, NIQKI_E_INVALID, "raw batch too large");
-  h_off[nf] = T;
+  h_off[nf] = T_raw;
   h_first[nf] = (uint32_t)chunks;
   int rc;
   const uint8_t *d_raw = b->raw;
@@ -1364,14 +1399,31 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
                  std::equal(ix->pre.off.begin(), ix->pre.off.end(), b->file_off);
     ix->pre.valid = false;
     if (prefetched) {
-      std::swap(ix->ws_raw, ix->ws_raw2);
+      if (!any_packed) std::swap(ix->ws_raw, ix->ws_raw2);   // (packed: ws_raw2 stays the wire buffer, unpacked below)
       NQ_HIP(ix, hipStreamWaitEvent(ix->stream, ix->ev_copy, 0));
       d_raw = (const uint8_t *)ix->ws_raw.p;
     } else {
       NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream));
     }
   }
-  if (prefetched) {
+  if (any_packed) {
+    if (!prefetched) {   // the containers (and raw files) as they are, into the wire buffer
+      if ((rc = ensure(ix, ix->ws_raw2, (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
+      for (uint32_t f = 0; f < nf; ++f) {
+        const uint64_t n = b->file_off[f + 1] - b->file_off[f];
+        if (n) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_raw2.p + b->file_off[f], b->file_ptr[f], n, hipMemcpyHostToDevice, ix->stream));
+      }
+    }
+    if ((rc = ensure(ix, ix->ws_raw, (size_t)T_raw + 2 * NIQKI_SEQ_PAD))) return rc;
+    if ((rc = ensure(ix, ix->ws_useg, std::max<size_t>(segs.size() * sizeof(nq::UnpackSeg), 32)))) return rc;
+    if (!segs.empty()) {
+      NQ_HIP(ix, hipMemcpyAsync(ix->ws_useg.p, segs.data(), segs.size() * sizeof(nq::UnpackSeg), hipMemcpyHostToDevice, ix->stream));
+      Span sp(ix, NIQKI_KC_INGEST);
+      NQ_HIP(ix, nq::launch_unpack((const nq::UnpackSeg *)ix->ws_useg.p, (uint32_t)segs.size(), (uint32_t)unpack_blocks,
+                                   (const uint8_t *)ix->ws_raw2.p, (uint8_t *)ix->ws_raw.p, ix->stream));
+    }
+    d_raw = (const uint8_t *)ix->ws_raw.p;
+  } else if (prefetched) {
   } else if (mem == NIQKI_MEM_HOST) {
     if ((rc = ensure(ix, ix->ws_raw, (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
     if (b->file_ptr) {
@@ -1431,7 +1483,7 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   NQ_HIP(ix, hipMemcpyAsync(a.rec_off + n_rec, a.totals + 1, 8, hipMemcpyDeviceToDevice, ix->stream));
   NQ_HIP(ix, hipMemsetAsync(a.seqs + kept, 0, NIQKI_SEQ_PAD, ix->stream));
   uint32_t n_entry = nf;
-  uint64_t consumed = T;
+  uint64_t consumed = T_raw;
   const uint32_t *d_entry = a.file_nrec;  // whole mode: entry f = the records of file f
   if (b->lines) {
     const uint32_t n_use = b->final ? n_rec : (n_rec ? n_rec - 1 : 0);
@@ -1530,6 +1582,22 @@ int niqki_staged_records(niqki_index *ix, uint64_t *rec_off, uint8_t *seqs, uint
   if (hdr_pos && st.n_rec) NQ_HIP(ix, hipMemcpyAsync(hdr_pos, ix->ws_hdrpos.p, (size_t)st.n_rec * 8, hipMemcpyDeviceToHost, ix->stream));
   NQ_HIP(ix, hipStreamSynchronize(ix->stream));
   return NIQKI_OK;
+}
+
+// ---- packed FASTA (nq_pack.h): host code, no device needed ----
+size_t niqki_pack_bound(size_t n) { return nqp::pack_bound(n); }
+size_t niqki_pack_fasta(const uint8_t *raw, size_t n, uint8_t *out, size_t capacity) {
+  if (!raw || !out) return 0;
+  return nqp::pack(raw, n, out, capacity);
+}
+int niqki_unpack_fasta(const uint8_t *container, size_t len, uint8_t *raw, size_t capacity, size_t *raw_len) {
+  if (!container || !nqp::valid(container, len)) return NIQKI_E_INVALID;
+  nqp::PackHeader h;
+  std::memcpy(&h, container, sizeof h);
+  if (raw_len) *raw_len = (size_t)h.raw_len;
+  if (!raw) return NIQKI_OK;
+  if (h.raw_len > capacity) return NIQKI_E_CAPACITY;
+  return nqp::unpack(container, len, raw, capacity) ? NIQKI_OK : NIQKI_E_INVALID;
 }
 
 void *niqki_host_alloc(size_t bytes) {

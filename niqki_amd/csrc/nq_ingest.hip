@@ -541,6 +541,64 @@ __global__ __launch_bounds__(1024) void ingest_entries_kernel(const uint64_t *re
 
 }  // namespace
 
+// ---- packed FASTA back to the file's bytes (nq_pack.h) ----------------------------------------
+// One workgroup per kUnpackChunk raw bytes of a segment.  A periodic segment's byte r is '\n' at the end of
+// every line of `width` bases and otherwise the letter of a 2-bit code; a raw segment is a copy.  Whole dwords
+// are stored where the destination allows, the (at most 3 + 3) bytes around them singly: neighbouring chunks
+// and segments never share a store.
+__global__ __launch_bounds__(256) void unpack_kernel(const UnpackSeg *segs, uint32_t n_seg, const uint8_t *wire, uint8_t *raw) {
+  uint32_t lo = 0, hi = n_seg;   // last segment whose first block is <= blockIdx.x (uniform)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (segs[mid].first_block <= blockIdx.x) lo = mid; else hi = mid;
+  }
+  const UnpackSeg s = segs[lo];
+  const uint32_t tid = threadIdx.x;
+  const uint64_t seg_len = s.width ? (uint64_t)s.count * (s.width + 1ull) : (uint64_t)s.count;
+  const uint64_t r0 = (uint64_t)(blockIdx.x - s.first_block) * kUnpackChunk;
+  if (r0 >= seg_len) return;
+  const uint32_t nbytes = (uint32_t)(seg_len - r0 < kUnpackChunk ? seg_len - r0 : kUnpackChunk);
+  uint8_t *dst = raw + s.dst + r0;
+  const uint32_t head = (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u) < nbytes ? (uint32_t)((4u - ((uintptr_t)dst & 3u)) & 3u) : nbytes;
+  const uint32_t n_words = (nbytes - head) / 4, tail0 = head + 4 * n_words;
+  if (!s.width) {
+    const uint8_t *src = wire + s.src + r0;
+    if (tid < head) dst[tid] = src[tid];
+    for (uint32_t i = tid; i < n_words; i += 256) {
+      const uint8_t *p = src + head + 4 * i;
+      *(uint32_t *)(dst + head + 4 * i) = (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24;
+    }
+    if (tid < nbytes - tail0) dst[tail0 + tid] = src[tail0 + tid];
+    return;
+  }
+  const uint32_t W1 = s.width + 1u, wb = (s.width + 3u) / 4u;
+  const uint64_t line0 = r0 / W1;
+  const uint32_t col0 = (uint32_t)(r0 - line0 * W1);
+  const uint8_t *src = wire + s.src + line0 * wb;
+  constexpr uint32_t kLetters = 0x47544341u;   // 'A' 'C' 'T' 'G' by code
+  auto byte_at = [&](uint32_t l, uint32_t c) -> uint32_t {
+    return c == s.width ? (uint32_t)'\n' : (kLetters >> (8u * ((src[(uint64_t)l * wb + (c >> 2)] >> (2u * (c & 3u))) & 3u))) & 0xFFu;
+  };
+  if (tid < head) { const uint32_t rr = col0 + tid, l = rr / W1; dst[tid] = (uint8_t)byte_at(l, rr - l * W1); }
+  for (uint32_t i = tid; i < n_words; i += 256) {
+    const uint32_t rr = col0 + head + 4 * i;
+    uint32_t l = rr / W1, c = rr - l * W1, w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      w |= byte_at(l, c) << (8 * k);
+      if (++c == W1) { c = 0; ++l; }
+    }
+    *(uint32_t *)(dst + head + 4 * i) = w;
+  }
+  if (tid < nbytes - tail0) { const uint32_t rr = col0 + tail0 + tid, l = rr / W1; dst[tail0 + tid] = (uint8_t)byte_at(l, rr - l * W1); }
+}
+
+hipError_t launch_unpack(const UnpackSeg *segs, uint32_t n_seg, uint32_t n_blocks, const uint8_t *wire, uint8_t *raw, hipStream_t stream) {
+  if (n_seg == 0 || n_blocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(unpack_kernel, dim3(n_blocks), dim3(256), 0, stream, segs, n_seg, wire, raw);
+  return hipGetLastError();
+}
+
 hipError_t launch_ingest_scan(const IngestArgs &a, hipStream_t stream) {
   if (a.n_chunks) hipLaunchKernelGGL(ingest_scan_kernel, dim3(a.n_chunks), dim3(kIB), 0, stream, a);
   if (a.n_files) {

@@ -244,6 +244,17 @@ hipError_t launch_ingest_entries(const uint64_t *rec_off, const uint64_t *hdr_po
                                  uint32_t max_entries, uint32_t *entry_rec, uint64_t *entry_hdr,
                                  uint32_t *result, hipStream_t stream);
 
+// Packed FASTA (nq_pack.h) back to the files' bytes: segment k writes raw[dst ..) from wire[src ..); count / width as
+// nqp::PackSeg (width 0: `count` bytes copied; else `count` lines of `width` bases + '\n' from 2-bit codes);
+// first_block: exclusive prefix of ceil(raw length / kUnpackChunk) over the segments (n_blocks = its total).
+constexpr uint32_t kUnpackChunk = 16384;
+struct UnpackSeg {
+  uint64_t dst, src;
+  uint32_t count, width;
+  uint32_t first_block, pad_;
+};
+hipError_t launch_unpack(const UnpackSeg *segs, uint32_t n_seg, uint32_t n_blocks, const uint8_t *wire, uint8_t *raw, hipStream_t stream);
+
 // ---- synthetic genomes (nq_synth.hip) ----------------------------------------
 hipError_t launch_synth(uint64_t seed, const uint32_t *family, const uint32_t *member,
                         const uint32_t *rate14, uint32_t n, uint64_t len, uint64_t stride,

@@ -25,6 +25,7 @@
 #include <thread>
 #include <vector>
 
+#include "../csrc/nq_pack.h"
 #include "seqio.h"
 
 namespace nqhost {
@@ -139,14 +140,51 @@ bool gunzip_whole(int fd, size_t file_bytes, PinnedBuf &out) {
 
 // Whole content of a file, gunzipped when it starts with the gzip magic (the
 // reference's zstr::ifstream auto-detects the same way, src/zstr.hpp:190-203).
-void read_file_bytes(const std::string &path, PinnedBuf &out) {
+// want_pack: a plain (not gzipped) regular FASTA file may be handed over as its packed container
+// (nq_pack.h, what niqki_pack_fasta makes: 2 bits per base in full A/C/G/T lines, everything else verbatim; the device
+// restores the file's exact bytes) -- *packed says whether it was.
+void read_file_bytes(const std::string &path, PinnedBuf &out, bool want_pack = false, bool *packed = nullptr) {
   out.size = 0;
+  if (packed) *packed = false;
   const int fd = ::open(path.c_str(), O_RDONLY);
   if (fd < 0) throw std::runtime_error("cannot open '" + path + "'");
   struct stat st;
   if (fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("cannot stat '" + path + "'"); }
   unsigned char magic[2] = {0, 0};
   const ssize_t m = pread(fd, magic, 2, 0);
+  if (want_pack && packed && S_ISREG(st.st_mode) && st.st_size >= 4096 && !(m == 2 && magic[0] == 0x1F && magic[1] == 0x8B)) {
+    // packed while it is read: pieces of 256 KB go through the thread's cache (read() copies them there, the packer
+    // reads them from there), a quarter of the bytes is written out -- and later page-locked and sent
+    const size_t n = (size_t)st.st_size;
+    thread_local std::vector<uint8_t> piece, box;
+    const size_t bound = nqp::pack_bound(n);
+    if (box.size() < bound) box.resize(bound);
+    if (piece.size() < (size_t(256) << 10)) piece.resize(size_t(256) << 10);
+    nqp::Packer pk;
+    pk.begin(box.data(), box.size(), n);
+    size_t have = 0, done = 0;   // bytes in `piece` not yet taken / bytes of the file read so far
+    bool io_ok = true;
+    while (pk.ok && done < n) {
+      if (have == piece.size()) piece.resize(piece.size() * 2);   // one line longer than the piece (an unwrapped genome)
+      const ssize_t r = pread(fd, piece.data() + have, std::min(piece.size() - have, n - done), (off_t)done);
+      if (r <= 0) { io_ok = false; break; }
+      done += (size_t)r;
+      have += (size_t)r;
+      const size_t used = pk.feed(piece.data(), have, done == n);
+      have -= used;
+      if (have) std::memmove(piece.data(), piece.data() + used, have);
+    }
+    const size_t got = io_ok ? pk.finish() : 0;
+    if (got) {
+      out.reserve(got + 64);
+      std::memcpy(out.p, box.data(), got);
+      out.size = got;
+      *packed = true;
+      ::close(fd);
+      return;
+    }
+    // not worth packing (or the file changed under us): its bytes as they are, below
+  }
   if (m == 2 && magic[0] == 0x1F && magic[1] == 0x8B) {
     if (S_ISREG(st.st_mode) && gunzip_whole(fd, (size_t)st.st_size, out)) { ::close(fd); return; }
     out.size = 0;
@@ -185,8 +223,20 @@ unsigned host_threads() {
       if (n > 0) return (unsigned)std::min(n, 256);
     }
   }
-  const unsigned hw = std::thread::hardware_concurrency();
-  return hw ? std::min(hw, 64u) : 4u;
+  unsigned hw = std::thread::hardware_concurrency();
+  hw = hw ? std::min(hw, 64u) : 4u;
+  // A container's CPU quota (cgroup v2 cpu.max: "<quota> <period>" in microseconds, or "max"): threads beyond it only
+  // get the whole group throttled -- the main thread, which feeds the GPU, with them.  One CPU is left to that thread.
+  if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32] = {0};
+    unsigned long period = 0;
+    if (std::fscanf(f, "%31s %lu", q, &period) == 2 && period && std::strcmp(q, "max") != 0) {
+      const unsigned long cpus = std::strtoul(q, nullptr, 10) / period;
+      if (cpus >= 1) hw = (unsigned)std::min<unsigned long>(hw, std::max<unsigned long>(cpus > 2 ? cpus - 1 : cpus, 2));
+    }
+    std::fclose(f);
+  }
+  return hw;
 }
 
 // Reads the files of a list on several threads -- the reference does this part in
@@ -199,6 +249,7 @@ class OrderedFileReader {
   struct File {
     PinnedBuf buf;
     std::string err;
+    bool packed = false;   // buf holds the file's packed container (niqki_pack_fasta), not its bytes
   };
   // The page-locked buffers are shared by all readers of the process (index phase, then
   // query phase) and never freed: locking and unlocking 1.5 GB of pages costs more than
@@ -209,7 +260,7 @@ class OrderedFileReader {
     return *p;
   }
   OrderedFileReader(const std::vector<std::string> &paths, unsigned threads, size_t n_bufs)
-      : paths_(paths), bufs_(pool(n_bufs)), ready_(paths.size(), nullptr) {
+      : paths_(paths), bufs_(pool(n_bufs)), ready_(paths.size(), nullptr), pack_(std::getenv("NIQKI_HOST_NO_PACK") == nullptr) {
     for (size_t i = 0; i < n_bufs; ++i) free_.push_back(&bufs_[n_bufs - 1 - i]);  // LIFO: low indices first
     threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(paths.size(), 1));
     for (unsigned t = 0; t < threads; ++t) pool_.emplace_back([this] { work(); });
@@ -253,7 +304,10 @@ class OrderedFileReader {
         idx = issued_++;
       }
       f->err.clear();
-      try { read_file_bytes(paths_[idx], f->buf); } catch (const std::exception &e) { f->err = e.what(); f->buf.size = 0; }
+      f->packed = false;
+      try {
+        read_file_bytes(paths_[idx], f->buf, pack_ && data_type(paths_[idx]) == 'A', &f->packed);
+      } catch (const std::exception &e) { f->err = e.what(); f->buf.size = 0; f->packed = false; }
       {
         std::lock_guard<std::mutex> g(mu_);
         ready_[idx] = f;
@@ -269,9 +323,10 @@ class OrderedFileReader {
   std::condition_variable cv_free_, cv_ready_;
   size_t issued_ = 0, taken_ = 0;
   bool stop_ = false;
+  const bool pack_;   // plain FASTA files travel as packed containers (NIQKI_HOST_NO_PACK: as their bytes)
 };
 
-constexpr size_t kWholeBatchFiles = 128;               // files per GPU call (whole-file mode)
+constexpr size_t kWholeBatchFiles = 64;                // files per GPU call (whole-file mode)
 constexpr size_t kWholeBatchBytes = size_t(3) << 29;   // ... or 1.5 GB
 constexpr size_t kReaderBufs = 2 * kWholeBatchFiles + 32;
 }  // namespace
@@ -441,7 +496,7 @@ void Index::stage_batch(Batch &b, bool prefetch) {
     for (size_t i = lo; i < hi; ++i) {
       ptr[i - lo] = b.files[i]->buf.p;
       off[i - lo + 1] = off[i - lo] + b.files[i]->buf.size;
-      type[i - lo] = (uint8_t)data_type(b.names[i]);
+      type[i - lo] = b.files[i]->packed ? (uint8_t)'a' : (uint8_t)data_type(b.names[i]);
     }
     niqki_raw_batch rb{};
     rb.file_ptr = ptr.data();
@@ -592,10 +647,13 @@ void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*
   t_stage_ = t_dev_ = t_out_ = 0;
   const auto t_begin = clk::now();
   OrderedFileReader rd(paths, host_threads(), kReaderBufs);
-  size_t i = 0;
+  size_t i = 0, n_batches = 0;
   auto assemble = [&](Batch &b) {
     const auto t0 = clk::now();
-    while (b.files.size() < kWholeBatchFiles && b.bytes < kWholeBatchBytes) {
+    // the first batches are small (16, 32, 64 files): the GPU and the copy engine start while the reader threads are
+    // still page-locking their buffers and filling the pipeline
+    const size_t limit = std::min<size_t>(kWholeBatchFiles, size_t(16) << std::min<size_t>(n_batches++, 8));
+    while (b.files.size() < limit && b.bytes < kWholeBatchBytes) {
       auto *f = rd.next();
       if (!f) break;
       b.files.push_back(f);

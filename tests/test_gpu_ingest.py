@@ -299,3 +299,68 @@ def test_prefetched_batches_equal_plain_staging(native, po):
     e.stage_raw([], None, scattered=True, prefetch="this")
     e.close()
     ref.close()
+
+
+def test_packed_fasta_files_stage_like_their_raw_bytes(native, po):
+    """file_type 'a': a FASTA file handed over as its packed container (niqki_pack_fasta: 2 bits per base in full
+    A/C/G/T lines, the rest verbatim).  The device restores the file's bytes before it frames them, so the staged
+    records, header positions and sketches must be those of the raw file -- for clean genomes of several line widths,
+    files with dirty lines in between, several records, no final newline, and in batches that mix packed and raw
+    files; with the bytes copied by the call, and with niqki_stage_raw_prefetch having put them on their way."""
+    rng = np.random.default_rng(17)
+
+    def genome(n, width, **kw):
+        seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+        for at in kw.get("dirty", ()):
+            seq[at] = ord("N")
+        out = bytearray(kw.get("header", b">g text\n"))
+        for a in range(0, n, width):
+            out += bytes(seq[a:a + width]) + b"\n"
+        if kw.get("no_final_nl"):
+            del out[-1:]
+        return bytes(out)
+    files = [genome(200_000, 70), genome(123_457, 60, no_final_nl=True), genome(90_000, 80, dirty=(5, 40_000, 89_999)),
+             genome(50_000, 70) + genome(70_001, 70, header=b">second record\n") + b"\n\n" + genome(20_000, 33, header=b">third\n"),
+             genome(40_000, 16), genome(66_000, 1000), genome(300_000, 65536), genome(17_000, 127, header=b"no gt in the first line\n"),
+             make_fasta(rng, 30), genome(8000, 70)]
+    packed = [native.pack_fasta(f) for f in files]
+    assert sum(c is not None for c in packed) >= 8 and packed[8] is None       # (the record soup is not worth packing)
+    wire = [bytes(c) if c is not None else f for c, f in zip(packed, files)]
+    types = ["a" if c is not None else "A" for c in packed]
+    K, S = 31, 8
+    ref = native.Engine(K=K, S=S, W=10, H=3, J=0.0)
+    info_r, _ = ref.stage_raw(files, ["A"] * len(files))
+    recs_r, er_r, hp_r = ref.staged_records()
+    sk_r = ref.staged_sketch()
+    for mode in ("copy", "prefetch"):
+        e = native.Engine(K=K, S=S, W=10, H=3, J=0.0)
+        info, _ = e.stage_raw(wire, types, scattered=True, prefetch="this" if mode == "prefetch" else None)
+        assert (info.n_entry, info.n_rec, info.seq_bytes) == (info_r.n_entry, info_r.n_rec, info_r.seq_bytes), mode
+        assert info.consumed == sum(len(f) for f in files)                      # raw bytes, whatever travelled
+        recs, er, hp = e.staged_records()
+        assert recs == recs_r and np.array_equal(er, er_r) and np.array_equal(hp, hp_r), mode
+        assert np.array_equal(e.staged_sketch(), sk_r), mode
+        # a batch of packed files only, then a raw batch on the same handle (buffers change roles)
+        sel = [i for i, c in enumerate(packed) if c is not None][:3]
+        info2, _ = e.stage_raw([wire[i] for i in sel], ["a"] * 3, scattered=True)
+        r2, _, _ = e.staged_records()
+        info3, _ = ref.stage_raw([files[i] for i in sel], ["A"] * 3)
+        r3, _, _ = ref.staged_records()
+        assert r2 == r3 and info2.n_rec == info3.n_rec
+        info4, _ = e.stage_raw(files[:2], ["A", "A"], scattered=True, prefetch="this")
+        r4, _, _ = e.staged_records()
+        info5, _ = ref.stage_raw(files[:2], ["A", "A"])
+        r5, _, _ = ref.staged_records()
+        assert r4 == r5
+        e.close()
+    # what is not allowed: a damaged container, lines mode, the one-buffer form
+    e = native.Engine(K=K, S=S, W=10, H=3, J=0.0)
+    bad = bytearray(wire[0])
+    bad[8] ^= 1
+    for kw, fl, ty in ((dict(scattered=True), [bytes(bad)], ["a"]), (dict(scattered=True, lines=True), [wire[0]], ["a"]),
+                       (dict(), [wire[0]], ["a"])):
+        with pytest.raises(native.NiqkiError) as ei:
+            e.stage_raw(fl, ty, **kw)
+        assert ei.value.code == 1
+    e.close()
+    ref.close()

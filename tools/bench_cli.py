@@ -83,6 +83,7 @@ def main():
         run("warmup", ["-I", "one.txt", "-J", "0.1", "-O", "o0.gz"])
         res["startup_s"] = round(run("startup", ["-I", "one.txt", "-J", "0.1", "-O", "o0.gz"]), 3)
         dt = run("index_only", ["-I", "fof.txt", "-J", "0.1", "-O", "o1.gz"])
+        res["index_first_pass_genomes_per_s"] = round(args.genomes / phases["index_only"][0], 1)   # the first process to read the files
         run("index_query", ["-I", "fof.txt", "-Q", "fof.txt", "-J", "0.1", "-O", "o2.gz"])
         # rates from the program's phase clocks (process start-up is reported as startup_s)
         t_index, t_query = phases["index_query"][0], phases["index_query"][1]
