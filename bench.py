@@ -716,8 +716,9 @@ def main():
             h_hg = torch.empty(cap, dtype=torch.int32).pin_memory()
             cstream = torch.cuda.Stream(device=dev)
             done = [torch.cuda.Event() for _ in range(2)]
-            n_d2h = min(8, args.steps)
+            n_d2h = args.steps                            # the same number of steps as the timed line
             nh_tot = 0
+            ev_d = [torch.cuda.Event(enable_timing=True) for _ in range(n_d2h + 1)]
 
             def fetch(k, si):     # hits of step si (buffer set k) to the host, on the copy stream
                 nonlocal nh_tot
@@ -732,6 +733,7 @@ def main():
                 nh_tot += nh
             torch.cuda.synchronize()
             td = time.perf_counter()
+            ev_d[0].record()
             for j, si in enumerate(range(args.warmup, args.warmup + n_d2h)):
                 k = j % 2
                 bi = si % n_batches
@@ -739,15 +741,23 @@ def main():
                 eng.query_counts_dev(qsk[bi], per, counts, stride)
                 eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[si], hcs[k], hgs[k], cap)
                 done[k].record(torch.cuda.current_stream())
+                ev_d[j + 1].record()
                 if j:
                     fetch(1 - k, si - 1)                  # while step si runs
             fetch((n_d2h - 1) % 2, args.warmup + n_d2h - 1)
             torch.cuda.synchronize()
             td = time.perf_counter() - td
+            d_ms = sorted(ev_d[j].elapsed_time(ev_d[j + 1]) for j in range(n_d2h))
+            d_med = d_ms[len(d_ms) // 2] if len(d_ms) % 2 else 0.5 * (d_ms[len(d_ms) // 2 - 1] + d_ms[len(d_ms) // 2])
             d2h = {"value": n_d2h * per / td, "unit": "genomes/s", "ms_per_step": td / n_d2h * 1e3, "steps": n_d2h,
+                   "ms_per_step_median": d_med, "step_ms_min_max": [d_ms[0], d_ms[-1]],
+                   "value_at_median_step": per / (d_med * 1e-3),
+                   # against the timed line's own median step (the same steps without the copies): what the D2H of the hits costs
+                   "median_step_over_the_lines": d_med / ms_median if ms_median else None,
                    "hit_bytes_per_step": 8 * (per + 1) + 8 * nh_tot // n_d2h,
                    "note": "the timed step with hit_off, hit_counts and hit_gids copied into page-locked host memory by a copy "
-                           "stream while the next step runs (two sets of hit buffers)"}
+                           "stream while the next step runs (two sets of hit buffers); ms_per_step includes the last step's "
+                           "copy, which nothing overlaps, and the host's waits for the sizes"}
             del hcs, hgs
 
         # ---- the same steps with batch i+1 sketched beside batch i's gather (what --pipeline times as the line) ----
@@ -919,7 +929,8 @@ def roofline_record(achieved_alg, traffic, traffic_source, live, gather_ms, laun
     Infinity Cache serves could push it past 1: not this 17 GB index); without a counter measurement for this shape, the bytes
     the layout cannot avoid stand in (a lower bound of the traffic).  SURVEY.md 8(d)'s algorithmic figure (4-byte ids,
     every query's lines counted for itself) is `achieved` / `frac_algorithmic`: the layout stores 2-byte ids and an
-    XCD's L2 serves lines that neighbouring queries share, so that one can pass 1."""
+    XCD's L2 serves lines that neighbouring queries share, so that one can pass 1.  `achieved` is the same basis as
+    `frac` in GB/s (so frac = achieved / peak); the algorithmic rate is `achieved_algorithmic`."""
     n = max(1, launches)
     t_launch = gather_ms / n * 1e-3
     alg_l, lay_l = alg_bytes / n, layout_min / n
@@ -928,8 +939,11 @@ def roofline_record(achieved_alg, traffic, traffic_source, live, gather_ms, laun
     basis_gbs = real_gbs if real_gbs is not None else lay_gbs
     rec = {
         "kernel": "nq::gather_kernel (gather-histogram, rank 0's slot shard) incl. its look-up pre-pass and probe / order passes",
-        "bound": "hbm", "achieved": achieved_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # achieved = what the memory system moved per second (frac = achieved / peak); SURVEY.md 8(d)'s formula, which
+        # counts 4 bytes per id and can pass the peak, is achieved_algorithmic / frac_algorithmic
+        "bound": "hbm", "achieved": basis_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": (basis_gbs / HBM_PEAK_GBS) if basis_gbs else None,
+        "achieved_algorithmic": achieved_alg,
         "frac_basis": ("traffic: (2 x FETCH_SIZE + WRITE_SIZE) per launch / avg_launch_ms / peak" if real_gbs is not None
                        else "layout_min_bytes_per_launch / avg_launch_ms / peak (no counter measurement for this shape in this run: "
                             "a lower bound of the bytes moved)"),
@@ -941,9 +955,9 @@ def roofline_record(achieved_alg, traffic, traffic_source, live, gather_ms, laun
         "traffic_fetch_kb": live["fetch_kb"] if live else None, "traffic_write_kb": live["write_kb"] if live else None,
         "copy_gbs": copy_gbs,
         "copy_ceiling_frac": (real_gbs / copy_gbs) if (real_gbs and copy_gbs) else None,
-        "note": ("achieved / frac_algorithmic count the ALGORITHMIC bytes of SURVEY.md 8d (4 bytes per id as the reference stores "
+        "note": ("achieved_algorithmic / frac_algorithmic count the ALGORITHMIC bytes of SURVEY.md 8d (4 bytes per id as the reference stores "
                  "them, bucket lines that neighbouring queries share counted for each): the layout moves 2-byte ids and an XCD's "
-                 "L2 serves shared lines, so that figure can pass 1.  frac is the counter traffic; FETCH_SIZE counts requests that "
+                 "L2 serves shared lines, so that figure can pass 1.  achieved / frac are the counter traffic; FETCH_SIZE counts requests that "
                  "leave the L2, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM section), so frac is an UPPER bound of the "
                  "HBM-proper fraction.  traffic_over_layout_min: bytes moved over the bytes this layout cannot avoid (half-empty "
                  "128-byte bucket lines are the difference)"
@@ -1021,15 +1035,23 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
     rec = np.stack([seqs[i * stride_b:i * stride_b + L] for i in range(n_s)])
     rec_off = (np.arange(n_s + 1) * L).astype(np.uint64)
     # sketch leg at every thread count (each pass sketches all n_s genomes: a few seconds together)
-    t_sk, sk_cpu, best_threads, sk_table = None, None, cand[0], {}
+    # the headline runs on the CPUs this job HAS: the cgroup quota where there is one (more threads than that only
+    # time-slice), else the physical cores; the other counts make the scaling tables
+    quota_threads = max(1, min(omp_max, int(round(host["cgroup_cpu_quota"])))) if host["cgroup_cpu_quota"] else min(omp_max, phys)
+    t_sk, sk_cpu, sk_table = None, None, {}
     for th in cand:
         t0 = time.perf_counter()
         out = po.sketch_batch(p, rec.reshape(-1), rec_off, threads=th)
         t = time.perf_counter() - t0
         sk_table[th] = n_s / t
-        if t_sk is None or t < t_sk:
-            t_sk, sk_cpu, best_threads = t, out, th
-    cores = best_threads
+        if th == quota_threads:
+            t_sk, sk_cpu = t, out
+    if sk_cpu is None:
+        t0 = time.perf_counter()
+        sk_cpu = po.sketch_batch(p, rec.reshape(-1), rec_off, threads=quota_threads)
+        t_sk = time.perf_counter() - t0
+        sk_table[quota_threads] = n_s / t_sk
+    cores = quota_threads
     sk_gpu = qsk[bi, :n_s].cpu().numpy()
     parity_sketch = bool(np.array_equal(sk_cpu, sk_gpu))
     # gather leg: the oracle's query loop timed on EVERY sub-index of <= 16384 genomes the index is cut into
@@ -1053,7 +1075,7 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
                 t0 = time.perf_counter()
                 ix.query_batch(sk_cpu, threads=th)
                 q_table[th] = n_s / (time.perf_counter() - t0)
-            q_threads = max(q_table, key=q_table.get)
+            q_threads = quota_threads if quota_threads in q_table else max(q_table, key=q_table.get)
         ix.spread(q_threads)
         best = None
         for _ in range(2):        # first pass warms the pages, keep the faster
@@ -1128,16 +1150,60 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
                              "of %d queries against them -- one thread, the port timed on the same work beside it" % (n_r, n_ri, n_rq)}
         except Exception as e:      # noqa: BLE001 -- a baseline beside the baseline: never the run's failure
             ref = {"error": str(e)[:200]}
+    # ---- the REAL reference on the job's CPUs over the same sample: its own Index with ALL N genomes inserted (from the
+    # sketches the GPU stored -- sketch parity is checked above and in the tests), its compute_sketch and query_sketch
+    # driven from `cores` OpenMP threads, one record per thread at a time like its drivers (src/niqki_index.cpp:523-540;
+    # oracle/ref_harness.cpp ref_*_batch).  Same queries, same thread count as the port's headline.
+    reference = None
+    if po.have_ref() and hasattr(po.Ref, "query_batch") and not os.environ.get("NIQKI_BENCH_NO_REFERENCE_INDEX"):
+        try:
+            t0 = time.perf_counter()
+            r = po.Ref(K=K, S=S, W=W, H=H, J=J, out_path="/tmp/niqki_bench_ref_all_%d.gz" % os.getpid())
+            t_ctor = time.perf_counter() - t0
+            t_ins = 0.0
+            for b0 in range(0, N, 4096):
+                sub = eng.get_sketches(b0, min(4096, N - b0))
+                t0 = time.perf_counter()
+                r.insert_batch(sub, threads=cores)
+                t_ins += time.perf_counter() - t0
+                del sub
+            t0 = time.perf_counter()
+            r_sk = r.sketch_batch(rec.reshape(-1), rec_off, threads=cores)
+            t_rsk = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            r_off, r_hc, r_hg = r.query_batch(r_sk, threads=cores)
+            t_rq = time.perf_counter() - t0
+            same = bool(np.array_equal(r_sk, sk_gpu))
+            for i in range(n_par):   # the reference's own hit lists against the GPU's of the timed step
+                lo, hi = int(off[i]), int(off[i + 1])
+                rl, rh = int(r_off[i]), int(r_off[i + 1])
+                same &= bool(np.array_equal(g_hc[lo:hi].astype(np.uint32), r_hc[rl:rh]) and np.array_equal(g_hg[lo:hi].astype(np.uint32), r_hg[rl:rh]))
+            r.close()
+            try:
+                os.remove("/tmp/niqki_bench_ref_all_%d.gz" % os.getpid())
+            except OSError:
+                pass
+            reference = {"value": n_s / (t_rsk + t_rq), "unit": "genomes/s", "cores": cores, "kind": "reference",
+                         "sketch_genomes_per_s": n_s / t_rsk, "query_genomes_per_s": n_s / t_rq,
+                         "index_build_s": {"constructor": round(t_ctor, 2), "insert_%d_genomes" % N: round(t_ins, 2)},
+                         "gpu_hit_lists_equal_the_references": same,
+                         "sample": "%d query genomes of step %d through the reference's own Index (oracle/_ref/libniqki_ref.so, built from "
+                                   "/root/reference/src by oracle/Makefile) holding all %d genomes: compute_sketch + query_sketch from %d "
+                                   "OpenMP threads, one record per thread at a time like src/niqki_index.cpp:523-540 (%.2f + %.2f s)"
+                                   % (n_s, si, N, cores, t_rsk, t_rq)}
+        except Exception as e:      # noqa: BLE001 -- a baseline beside the baseline: never the run's failure
+            reference = {"error": str(e)[:200]}
     return {
         "value": val, "unit": "genomes/s", "cores": cores, "kind": "port",
+        "reference": reference,
         "host_logical_cpus": host["logical_cpus"], "host_physical_cores": host["physical_cores"],
         "host_affinity_cpus": host["affinity_cpus"], "host_cgroup_cpu_quota": host["cgroup_cpu_quota"],
         "threads_tried": cand,
         "sketch_genomes_per_s_by_threads": {str(k): v for k, v in sorted(sk_table.items())},
         "gather_queries_per_s_by_threads_first_sub_index": {str(k): v for k, v in sorted(q_table.items())},
         "gather_threads": q_threads,
-        "sample": "%d query genomes of step %d: sketch leg timed in full on %d threads (the fastest of the thread counts tried, "
-                  "%.2f s); gather leg = the oracle's query loop on %d threads (its own fastest) timed on each of the %d sub-indexes of "
+        "sample": "%d query genomes of step %d: sketch leg timed in full on %d threads (the CPUs this job has: its cgroup quota, else the "
+                  "physical cores; %.2f s); gather leg = the oracle's query loop on %d threads timed on each of the %d sub-indexes of "
                   "<= 16384 genomes that together hold all %d genomes, summed (%.2f s); the index arrays first touched by the "
                   "gathering threads" % (n_s, si, cores, t_sk, q_threads, n_sub_ix, N, t_q),
         "reference_sample": ref,

@@ -357,6 +357,11 @@ class Ref:
         L.ref_dump.argtypes = [C.c_void_p, C.c_char_p]
         L.ref_select_best_H.restype = C.c_uint32
         L.ref_select_best_H.argtypes = [C.c_void_p, C.c_double]
+        if hasattr(L, "ref_query_batch"):
+            L.ref_sketch_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+            L.ref_insert_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int]
+            L.ref_query_batch.restype = C.c_uint64
+            L.ref_query_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
         self._L = L
         self.S, self.K, self.W, self.H = S, K, W, H
         self.F = 1 << S
@@ -413,3 +418,25 @@ class Ref:
 
     def dump(self, path):
         self._L.ref_dump(self._h, path.encode())
+
+    # the reference's threaded driver loops on records in memory (oracle/ref_harness.cpp)
+    def sketch_batch(self, seqs, rec_off, threads=0):
+        s = _seq(seqs)
+        ro = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        out = np.empty((ro.size - 1, self.F), dtype=np.int32)
+        self._L.ref_sketch_batch(self._h, _ptr(s), _ptr(ro), ro.size - 1, _ptr(out), threads)
+        return out
+
+    def insert_batch(self, sketches, threads=0):
+        sk = np.ascontiguousarray(sketches, dtype=np.int32)
+        self._L.ref_insert_batch(self._h, _ptr(sk), sk.shape[0], threads)
+        self.n += sk.shape[0]
+
+    def query_batch(self, sketches, threads=0, cap=None):
+        sk = np.ascontiguousarray(sketches, dtype=np.int32)
+        n = sk.shape[0]
+        cap = cap if cap is not None else max(1, n * 4096)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        hc, hg = np.empty(cap, dtype=np.uint32), np.empty(cap, dtype=np.uint32)
+        tot = self._L.ref_query_batch(self._h, _ptr(sk), n, _ptr(off), _ptr(hc), _ptr(hg), cap, threads)
+        return off, hc[:min(tot, cap)], hg[:min(tot, cap)]

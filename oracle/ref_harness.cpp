@@ -14,6 +14,8 @@
 // directly.
 #include "niqki_index.h"
 
+#include <omp.h>
+
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -85,6 +87,60 @@ uint32_t ref_query_sketch(void *h, const int32_t *sk, uint32_t *counts,
     gids[i] = r[i].second;
   }
   return (uint32_t)r.size();
+}
+
+// ---- the reference's threaded driver loops without their file reading ------------------------------------
+// Its drivers call compute_sketch / insert_sketch / query_sketch from every thread of an `omp parallel` region
+// on one Index (src/niqki_index.cpp:391-401, :479-490, :525-538).  These three do the same on records that are
+// already in memory, so that bench.py can time the REAL reference on the host's threads beside the port
+// (cpu_baseline.reference): one record per thread at a time, the reference's own methods, its own locks.
+
+// compute_sketch of n records (record i = seqs[rec_off[i] .. rec_off[i+1])) -> out[n][F]
+void ref_sketch_batch(void *h, const char *seqs, const uint64_t *rec_off, uint32_t n, int32_t *out, int threads) {
+  Index *ix = static_cast<Index *>(h);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : omp_get_max_threads())
+  for (uint32_t i = 0; i < n; ++i) {
+    std::string s(seqs + rec_off[i], rec_off[i + 1] - rec_off[i]);
+    std::vector<int32_t> sk;
+    ix->compute_sketch(s, sk);
+    std::memcpy(out + (size_t)i * ix->F, sk.data(), sk.size() * sizeof(int32_t));
+  }
+}
+
+// insert_sketch of n sketches: ids in order (the bookkeeping of :396-401 done up front), the inserts themselves
+// from all threads under the reference's striped locks (:365-367), like insert_file_of_file_whole (:479-490)
+void ref_insert_batch(void *h, const int32_t *sk, uint32_t n, int threads) {
+  Index *ix = static_cast<Index *>(h);
+  const uint32_t first = ix->genome_numbers;
+  for (uint32_t i = 0; i < n; ++i) ix->filenames.push_back("g" + std::to_string(first + i));
+  ix->genome_numbers += n;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(threads > 0 ? threads : omp_get_max_threads())
+  for (uint32_t i = 0; i < n; ++i) {
+    std::vector<int32_t> v(sk + (size_t)i * ix->F, sk + (size_t)(i + 1) * ix->F);
+    ix->insert_sketch(v, first + i);
+  }
+}
+
+// query_sketch of n sketches (:525-538 without the output): hit_off[n+1] exact; the first `cap` hits written, in
+// query order, each list in the reference's order.  Returns the total.
+uint64_t ref_query_batch(void *h, const int32_t *sk, uint32_t n, uint64_t *hit_off, uint32_t *counts, uint32_t *gids,
+                         uint64_t cap, int threads) {
+  Index *ix = static_cast<Index *>(h);
+  std::vector<query_output> res(n);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : omp_get_max_threads())
+  for (uint32_t i = 0; i < n; ++i) {
+    std::vector<int32_t> v(sk + (size_t)i * ix->F, sk + (size_t)(i + 1) * ix->F);
+    res[i] = ix->query_sketch(v);
+  }
+  uint64_t at = 0;
+  hit_off[0] = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    for (size_t j = 0; j < res[i].size(); ++j)
+      if (at + j < cap) { counts[at + j] = res[i][j].first; gids[at + j] = res[i][j].second; }
+    at += res[i].size();
+    hit_off[i + 1] = at;
+  }
+  return at;
 }
 
 uint64_t ref_bucket_size(void *h, uint64_t bucket) {
