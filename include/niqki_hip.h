@@ -26,7 +26,27 @@
  * returns without synchronising unless stated otherwise).
  *
  * Sketch layout: F = 2^S int32 per sketch, row major, -1 = empty cell, exactly
- * the reference's vector<int32_t>.
+ * the reference's vector<int32_t>. *
+ * Not here: measurement, diagnosis and test support (synthetic inputs, per-kernel timers, the steps of the sparse
+ * multi-GPU exchange one by one ...) -- include/niqki_hip_bench.h.
+ *
+ * Environment variables the LIBRARY reads (none changes a result; options of niqki_set_option are the way to set
+ * anything per handle):
+ *   NIQKI_GROUP_TRANSPORT   rccl | ipc | local: transport of niqki_group_create / niqki_group_new_id (see "one index
+ *                           over several GPUs" below); default: RCCL, device copies for shards that share a device
+ *   NIQKI_IPC_WORDS         host | coarse: where an ipc rank keeps its sequence words (default: fine-grained device
+ *                           memory, the shared host block where that cannot be exported); NIQKI_IPC_ARENA=coarse:
+ *                           plain device memory for its exchange buffers.  Test switches.
+ *   NIQKI_LOOKUP_PREPASS    -1 | 0 | 1: initial value of option "lookup_prepass" of every handle (the test suite runs
+ *                           under both look-up paths this way)
+ *   NIQKI_TILE_STRIPE       overrides option "tile_stripe" at every index build (tests of the tile dealing)
+ *   NIQKI_HMASK=0           builds single-tile indexes without their per-slot class mask (stat "class_mask")
+ *   NIQKI_SKETCH_WAVE=0     short records take the workgroup sketch kernel instead of the one-wavefront one;
+ *   NIQKI_SKETCH_FILTER     0 = long records are sketched without the candidate filter, n >= 2 = with a fixed filter
+ *                           strength (default: chosen per sketch).  Test switches of nq_sketch.hip's launch shapes.
+ * The `niqki` host program reads NIQKI_HOST_THREADS (reader threads; default: the CPUs the process may use),
+ * NIQKI_HOST_TIMING (phase times on stderr), NIQKI_HOST_NO_PACK (plain FASTA files travel as their bytes),
+ * NIQKI_HOST_ZLIB_ONLY (no libdeflate), NIQKI_SHARDS_ON_ONE_DEVICE (--gpus N on one device: tests).
  */
 #ifndef NIQKI_HIP_H
 #define NIQKI_HIP_H
@@ -223,25 +243,6 @@ int niqki_hits_from_counts(niqki_index *ix, const uint16_t *counts, uint32_t nq,
                            uint64_t *hit_off, uint32_t *hit_counts,
                            uint32_t *hit_gids, uint64_t capacity, int mem);
 
-/* Multi-GPU helper (no reference counterpart; NIQKI_MEM_DEVICE only): for every
- * query the genomes whose counter in this shard's hit vector is >= threshold, at
- * most cap per query, unordered: cand[q*cap + i] (padded with -1), n_cand[q] =
- * how many qualified (may exceed cap).  A genome whose cross-shard sum reaches
- * min_score has a partial count >= ceil(min_score / shards) in some shard, so the
- * shards only need to exchange and sum these candidates. */
-int niqki_candidates_from_counts(niqki_index *ix, const uint16_t *counts, uint32_t nq,
-                                 uint64_t stride, uint32_t n_gids, uint32_t threshold,
-                                 uint32_t cap, int32_t *cand, int32_t *n_cand, int mem);
-
-/* niqki_query_counts and niqki_candidates_from_counts in one pass (NIQKI_MEM_DEVICE
- * only): the candidates are picked while a query's counters leave the gather kernel's
- * LDS, so the hit vectors are not read again (6.5 GB per 32 768 queries at 100 000
- * genomes).  Same outputs, the candidates of a query in another order.  Not on paged
- * or whole-range S = 16 handles.  What a slot shard of a niqki_group runs. */
-int niqki_query_counts_candidates(niqki_index *ix, const int32_t *sketches, uint32_t nq,
-                                  uint16_t *counts, uint64_t stride, uint32_t threshold,
-                                  uint32_t cap, int32_t *cand, int32_t *n_cand, int mem);
-
 /* ---- many host threads on one handle ------------------------------------------------------
  * A handle is single-caller (see the top of this file).  The reference's drivers, however, call
  * compute_sketch / insert_sketch / query_sketch from every thread of an `omp parallel` region on
@@ -258,15 +259,13 @@ int niqki_query_counts_candidates(niqki_index *ix, const int32_t *sketches, uint
  *   niqki_query_shared            Index::query_sketch: *n_hits = number of hits, the first
  *                                 min(*n_hits, capacity) written in the reference's order
  *   niqki_query_sequence_shared   Index::query_sequence (:691-695)
- * niqki_shared_stats: batches run so far, requests served, the largest batch (any may be NULL). */
+ * (niqki_shared_stats, niqki_hip_bench.h: batches run so far, requests served, the largest batch.) */
 int niqki_sketch_shared(niqki_index *ix, const uint8_t *seq, uint64_t len, int32_t *sketch);
 int niqki_insert_shared(niqki_index *ix, const int32_t *sketch, uint32_t *genome_id);
 int niqki_query_shared(niqki_index *ix, const int32_t *sketch, uint64_t *n_hits, uint32_t *hit_counts,
                        uint32_t *hit_gids, uint64_t capacity);
 int niqki_query_sequence_shared(niqki_index *ix, const uint8_t *seq, uint64_t len, uint64_t *n_hits,
                                 uint32_t *hit_counts, uint32_t *hit_gids, uint64_t capacity);
-int niqki_shared_stats(const niqki_index *ix, uint64_t *batches, uint64_t *requests,
-                       uint64_t *largest_batch);
 
 /* Index::query_sketch (src/niqki_index.cpp:633-687), batched: both halves. */
 int niqki_query(niqki_index *ix, const int32_t *sketches, uint32_t nq,
@@ -340,10 +339,6 @@ int niqki_staged_insert(niqki_index *ix);
 /* ... + query_sketch per entry; outputs as niqki_query. */
 int niqki_staged_query(niqki_index *ix, uint64_t *hit_off, uint32_t *hit_counts,
                        uint32_t *hit_gids, uint64_t capacity, int mem_space);
-/* Read the staged framing back (HOST arrays, any may be NULL): rec_off n_rec+1,
- * seqs seq_bytes, entry_rec n_entry+1, hdr_pos n_rec.  For tests and diagnosis. */
-int niqki_staged_records(niqki_index *ix, uint64_t *rec_off, uint8_t *seqs,
-                         uint32_t *entry_rec, uint64_t *hdr_pos);
 /* Packed FASTA: what a host-to-device copy of whole genomes costs is 1 byte per base; a FASTA file is almost
  * entirely full lines of one width holding A, C, G, T only.  niqki_pack_fasta turns the bytes of a file into a
  * container in which every run of such lines travels as 2 bits per base and everything else -- header lines, lines
@@ -408,35 +403,6 @@ int niqki_import_slots(niqki_index *ix, uint32_t slot_begin, uint32_t slot_end,
 int niqki_get_sketches(niqki_index *ix, uint32_t begin, uint32_t n,
                        int32_t *sketches, int mem);
 
-/* Sum over the shard's slots of the bucket length each query touches (the T
- * of the roofline formula).  Host out. Synchronises. */
-int niqki_query_gathered(niqki_index *ix, const int32_t *sketches, uint32_t nq,
-                         uint64_t *gathered_per_query, int mem);
-
-/* The sparse exchange WITHOUT counter rows, step by step (NIQKI_MEM_DEVICE only; what a slot shard of
- * a niqki_group runs -- exposed for tests and for timing one shard's compute):
- *   niqki_query_survivors       gather over the handle's slots; per query the candidates (count >=
- *                               cand_threshold: ids, as niqki_candidates_from_counts) and the survivors
- *                               (count >= surv_threshold <= cand_threshold: surv[q*surv_cap + i] =
- *                               {genome id, count} as two int32, n_surv[q] how many qualified).  No
- *                               2N-byte counter row per query is written.
- *   niqki_survivor_counts       counts[q*m + i] = the handle's count of genome ids[q*m + i] (-1: 0) for
- *                               query q: from the survivor list, or -- an id that is not among them --
- *                               counted exactly as the slots where the genome's stored sketch equals the
- *                               query's (sketches: the same rows as given to niqki_query_survivors).
- *   niqki_hits_from_candidates  the hits of nq queries from m candidate ids each and their (cross-shard)
- *                               sums: distinct ids with a sum >= min_score, ordered as niqki_query's.
- * m <= 4096, surv_cap <= 4096. */
-int niqki_query_survivors(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint32_t cand_threshold,
-                          uint32_t surv_threshold, uint32_t cand_cap, uint32_t surv_cap, int32_t *cand,
-                          int32_t *n_cand, int32_t *surv, int32_t *n_surv, int mem);
-int niqki_survivor_counts(niqki_index *ix, const int32_t *sketches, uint32_t nq, const int32_t *ids, uint32_t m,
-                          const int32_t *surv, const int32_t *n_surv, uint32_t surv_cap, uint16_t *counts,
-                          int mem);
-int niqki_hits_from_candidates(niqki_index *ix, const int32_t *ids, const uint16_t *totals, uint32_t nq,
-                               uint32_t m, uint64_t *hit_off, uint32_t *hit_counts, uint32_t *hit_gids,
-                               uint64_t capacity, int mem);
-
 /* ---- one index over several GPUs: slot-range shards -----------------------------
  * No reference counterpart (the reference is one process on one host); this is how
  * Index::insert_sketch / Index::query_sketch (src/niqki_index.cpp:362-370, :633-687)
@@ -482,25 +448,6 @@ const char *niqki_group_last_error(const niqki_group *g);
  * partial count of at least half the candidate threshold) a shard keeps per query, default 1024,
  * at most 4096. */
 int niqki_group_set_option(niqki_group *g, const char *key, int64_t value);
-/* The arithmetic of one query batch of a group, as niqki_group_query decides it -- a pure function (no device, no
- * handle: callable on a host without a GPU; the CPU test of the exchange protocol over gloo takes its slot
- * ranges, thresholds and buffer shapes from here and from niqki_group_slot_range, tests/test_dist_cpu.py).
- *   world, S, min_score     the group's shape (Index::query_sketch's threshold, src/niqki_index.cpp:646-650)
- *   exchange_option         option "exchange": 0 = choose, 1 = sparse, 2 = dense
- *   per, n_genomes          queries per rank in the batch, genomes indexed
- *   cand_cap                option "cand_cap" */
-typedef struct niqki_group_plan {
-  uint32_t sparse;          /* 1 = sparse candidate exchange, 0 = dense reduce-scatter of the counter rows */
-  uint32_t cand_threshold;  /* ceil(min_score / world): a partial count from which a genome is a candidate */
-  uint32_t surv_threshold;  /* max(1, cand_threshold / 2): ... from which a shard keeps it as a survivor */
-  uint32_t slice_slots;     /* ceil(2^S / world): cells per query and peer in the slice exchange (int16 each) */
-  uint64_t slice_bytes;     /* bytes of one peer's part of the slice exchange (per queries, 16-byte rounded) */
-  uint64_t cand_blob_bytes; /* bytes of a rank's all-gathered candidate blob: world*per lists of cand_cap ids + 2 sizes each */
-  uint64_t sum_words;       /* u32 words a rank receives from the reduce-scatter: candidates' packed u16 counts, or dense rows */
-  uint64_t row_stride;      /* u16 cells per counter row (NIQKI_ROW_STRIDE(n_genomes)) */
-} niqki_group_plan;
-int niqki_group_plan_batch(uint32_t world, uint32_t S, uint32_t min_score, int exchange_option, uint32_t per,
-                           uint32_t n_genomes, uint32_t cand_cap, niqki_group_plan *out);
 /* "overflows" (sparse steps redone densely so far), "rccl" (1 = RCCL transport),
  * "transport" (0 = device copies inside one process, 1 = RCCL, 2 = ipc),
  * "sparse" (1 = the sparse exchange is selected), "ipc_words_kind" (ipc transport: where this rank's
@@ -546,22 +493,6 @@ int niqki_group_staged_query(niqki_group *g, uint32_t per, const uint32_t *n_ent
                              uint32_t *const *hit_counts, uint32_t *const *hit_gids, uint64_t capacity,
                              int mem);
 
-/* ---- measurement support -------------------------------------------------- */
-
-enum niqki_kernel_class {
-  NIQKI_KC_SKETCH = 0,   /* rolling hash + per-slot min */
-  NIQKI_KC_DENSIFY = 1,
-  NIQKI_KC_GATHER = 2,   /* gather-histogram over the inverted index */
-  NIQKI_KC_HITS = 3,     /* threshold + compaction + sort */
-  NIQKI_KC_BUILD = 4,    /* insert transpose + CSR build */
-  NIQKI_KC_INGEST = 5,   /* FASTA / FASTQ framing */
-  NIQKI_KC_EXCHANGE = 6, /* slot-shard exchange: slice packing, candidate kernels, collectives */
-  NIQKI_KC_COUNT = 7
-};
-
-/* When enabled, every launch of the classes above is bracketed by HIP events
- * on the handle's stream; niqki_profile_read synchronises and returns the
- * accumulated device time and launch count since the last reset. */
 /* Sizes of the handle's state: "store_bytes" (sketch store), "index_bytes" (table + id lists of
  * the built index or resident page), "tiles", "pages" / "page_slots" (pages a query walks and
  * slots per page; 1 / all slots unless the index is paged), "delta_genomes" (genomes indexed by
@@ -573,41 +504,6 @@ enum niqki_kernel_class {
  * skips nearly all of its 2^S table look-ups; results are unaffected; NIQKI_HMASK=0 in the
  * environment builds indexes without it). */
 int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value);
-int niqki_profile_enable(niqki_index *ix, int on);
-int niqki_profile_reset(niqki_index *ix);
-int niqki_profile_read(niqki_index *ix, int kernel_class, double *ms,
-                       uint64_t *launches);
-
-/* Deterministic synthetic genomes (bench / parity inputs):
- * genome i is the ancestor of family[i] with per-base substitutions drawn for
- * (family[i], member[i]) at rate rate14[i]/16384.  Output: n records of len
- * bytes each, record i at out + i*stride.  Upper-case ACGT. The host and
- * device generators produce identical bytes. */
-int niqki_synth_genomes(niqki_index *ix, uint64_t seed, const uint32_t *family,
-                        const uint32_t *member, const uint32_t *rate14,
-                        uint32_t n, uint64_t len, uint64_t stride, uint8_t *out,
-                        int mem);
-void niqki_synth_genome_host(uint64_t seed, uint32_t family, uint32_t member,
-                             uint32_t rate14, uint64_t len, uint8_t *out);
-/* Deterministic synthetic reads (BASELINE.json's short-sequence config): read i is bases
- * [offset[i], offset[i]+len) of the genome (family[i], member[i], rate14[i]) above, with the
- * read's own substitutions at rate read_rate14/16384 keyed by read_id[i] on top.  Record i at
- * out + i*stride.  Host and device produce identical bytes. */
-int niqki_synth_reads(niqki_index *ix, uint64_t seed, const uint32_t *family, const uint32_t *member,
-                      const uint32_t *rate14, const uint64_t *offset, const uint32_t *read_id,
-                      uint32_t read_rate14, uint32_t n, uint32_t len, uint64_t stride, uint8_t *out,
-                      int mem);
-/* Integer-ALU ceilings of the device, measured live (SURVEY.md 8d asks for the sketch kernel as a
- * fraction of one): what = 0 independent 32-bit adds, 1 = 32-bit multiplies, 2 = the sketch
- * kernel's per-k-mer arithmetic alone (K = 31 roll + canonical choice + filter hash; no LDS,
- * memory or compaction), 3 = three-operand integer instructions (v_lshl_add_u32: the issue class of
- * every gfx950 vector opcode except add / sub / and / or / xor / mov / shift-right), 4 = a streaming
- * copy of 1 GiB (bytes read + written per second: the HBM rate a plain kernel reaches), 5 = the
- * densification passes of the short-read sketch kernel with nothing but their LDS traffic and exit
- * test (one wavefront per sketch, 8 per CU, two proposals + two read-backs per lane and pass: the
- * LDS round-trip ceiling of src/niqki_index.cpp:313-331 on this device).
- * *rate = adds / multiplies / k-mers / instructions / bytes / passes per second over ~ms milliseconds. */
-int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,321 @@
+// nq_api_stage.hip -- raw file bytes in (Index::Biogetline and the read loops around it, src/niqki_index.cpp:383-456,
+// :505-519, :890-941): niqki_stage_raw / _prefetch (copy, packed FASTA back to the files' bytes, framing on the device),
+// the staged batch (sketch / insert / query / read-back), and the host-side packer's entry points.
+#include "nq_handle.h"
+#include "nq_pack.h"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace nqi {
+
+// sketches of the staged entries into their own buffer (once per staged batch; the other
+// entry points keep using ws_sk, so they cannot disturb a staged batch)
+int staged_sketch_ws(niqki_index *ix) {
+  if (!ix->staged.valid) return fail(ix, NIQKI_E_STATE, "no staged batch (niqki_stage_raw first)");
+  if (ix->staged.sketched) return NIQKI_OK;
+  const uint32_t n = ix->staged.n_entry;
+  int rc = ensure(ix, ix->ws_stsk, std::max<size_t>((size_t)n * ix->d.F * 4, 4));
+  if (rc) return rc;
+  rc = sketch_dev(ix, (const uint8_t *)ix->ws_seq.p, (const uint64_t *)ix->ws_recoff.p, ix->staged.n_rec,
+                  ix->staged.entry_rec, n, (int32_t *)ix->ws_stsk.p, ix->staged.seq_bytes);
+  if (rc) return rc;
+  ix->staged.sketched = true;
+  return NIQKI_OK;
+}
+
+}  // namespace nqi
+
+using namespace nqi;
+
+extern "C" {
+
+int niqki_stage_raw_prefetch(niqki_index *ix, const niqki_raw_batch *b) {
+  if (!ix || !b) return NIQKI_E_INVALID;
+  if (!b->file_ptr || !b->file_off) return fail(ix, NIQKI_E_INVALID, "a prefetch takes the file_ptr form of a host batch");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  if (!ix->copy_stream) {
+    NQ_HIP(ix, hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
+    NQ_HIP(ix, hipEventCreateWithFlags(&ix->ev_copy, hipEventDisableTiming));
+  }
+  if (ix->pre.valid) NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream));  // an unused one: its host bytes may go away now
+  ix->pre.valid = false;
+  const uint32_t nf = b->n_files;
+  if (nf == 0) return NIQKI_OK;
+  for (uint32_t f = 0; f < nf; ++f)
+    if (b->file_off[f + 1] < b->file_off[f]) return fail(ix, NIQKI_E_INVALID, "file_off must be non-decreasing");
+  const uint64_t T = b->file_off[nf];
+  int rc = ensure(ix, ix->ws_raw2, (size_t)T + 2 * NIQKI_SEQ_PAD);
+  if (rc) return rc;
+  for (uint32_t f = 0; f < nf; ++f) {
+    const uint64_t n = b->file_off[f + 1] - b->file_off[f];
+    if (n) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_raw2.p + b->file_off[f], b->file_ptr[f], n, hipMemcpyHostToDevice, ix->copy_stream));
+  }
+  NQ_HIP(ix, hipEventRecord(ix->ev_copy, ix->copy_stream));
+  ix->pre.ptr.assign(b->file_ptr, b->file_ptr + nf);
+  ix->pre.off.assign(b->file_off, b->file_off + nf + 1);
+  ix->pre.valid = true;
+  return NIQKI_OK;
+}
+
+int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_stage_info *info,
+                    uint64_t *entry_hdr) {
+  if (!ix || !b || !info) return NIQKI_E_INVALID;
+  if (b->n_files && (!b->file_off || !b->file_type)) return NIQKI_E_INVALID;
+  if (b->lines && b->n_files > 1) return fail(ix, NIQKI_E_INVALID, "lines mode frames one file per call");
+  if (b->lines && b->max_entries == 0) return fail(ix, NIQKI_E_INVALID, "max_entries must be > 0");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  ix->staged.valid = false;
+  ix->staged.sketched = false;
+  *info = niqki_stage_info{0, 0, 0, 0};
+  const uint32_t nf = b->n_files;
+  const uint64_t T = nf ? b->file_off[nf] : 0;   // bytes handed over ("wire" bytes: packed files count as their containers)
+  if (nf && !b->raw && !b->file_ptr && T) return NIQKI_E_INVALID;
+  if (b->file_ptr && mem != NIQKI_MEM_HOST) return fail(ix, NIQKI_E_INVALID, "file_ptr needs the host memory space");
+  // Packed FASTA files (file_type 'a': a container of niqki_pack_fasta): the device writes the file's own bytes back
+  // first (nq::unpack_kernel), so everything from here on sees raw files at their raw offsets.
+  bool any_packed = false;
+  for (uint32_t f = 0; f < nf; ++f) any_packed |= b->file_type[f] == 'a';
+  if (any_packed && (mem != NIQKI_MEM_HOST || !b->file_ptr || b->lines))
+    return fail(ix, NIQKI_E_INVALID, "packed files (type 'a'): host memory, the file_ptr form, whole-file mode");
+  std::vector<uint64_t> roff((size_t)nf + 1, 0);   // raw offsets of the files
+  std::vector<nq::UnpackSeg> segs;
+  uint64_t unpack_blocks = 0;
+  for (uint32_t f = 0; f < nf; ++f) {
+    if (b->file_off[f + 1] < b->file_off[f]) return fail(ix, NIQKI_E_INVALID, "file_off must be non-decreasing");
+    const uint64_t wire_len = b->file_off[f + 1] - b->file_off[f];
+    uint64_t raw_len = wire_len;
+    if (b->file_type[f] == 'a') {
+      const uint8_t *c = b->file_ptr[f];
+      if (!c || !nqp::valid(c, wire_len)) return fail(ix, NIQKI_E_INVALID, "file " + std::to_string(f) + " is not a well-formed packed container");
+      nqp::PackHeader h;
+      std::memcpy(&h, c, sizeof h);
+      raw_len = h.raw_len;
+      for (uint32_t k = 0; k < h.n_seg; ++k) {
+        nqp::PackSeg ps;
+        std::memcpy(&ps, c + sizeof(nqp::PackHeader) + (size_t)k * sizeof(nqp::PackSeg), sizeof ps);
+        segs.push_back(nq::UnpackSeg{roff[f] + ps.raw_off, b->file_off[f] + h.payload_off + ps.pk_off, ps.count, ps.width, (uint32_t)unpack_blocks, 0u});
+        unpack_blocks += (nqp::seg_raw_len(ps) + nq::kUnpackChunk - 1) / nq::kUnpackChunk;
+      }
+    } else if (any_packed && wire_len) {   // a raw file in a batch with packed ones: one raw segment
+      if (wire_len > 0xFFFFFFFFull) return fail(ix, NIQKI_E_INVALID, "a raw file of 4 GiB or more cannot share a batch with packed files");
+      segs.push_back(nq::UnpackSeg{roff[f], b->file_off[f], (uint32_t)wire_len, 0u, (uint32_t)unpack_blocks, 0u});
+      unpack_blocks += (wire_len + nq::kUnpackChunk - 1) / nq::kUnpackChunk;
+    }
+    roff[f + 1] = roff[f] + raw_len;
+  }
+  if (unpack_blocks > 0x7FFFFFFFull) return fail(ix, NIQKI_E_INVALID, "raw batch too large");
+  const uint64_t T_raw = roff[nf];
+  // chunk table: chunks never span two files
+  std::vector<uint8_t> meta((size_t)(nf + 1) * 12 + nf + 16);
+  uint64_t *h_off = (uint64_t *)meta.data();
+  uint32_t *h_first = (uint32_t *)(meta.data() + (size_t)(nf + 1) * 8);
+  uint8_t *h_type = meta.data() + (size_t)(nf + 1) * 12;
+  uint64_t chunks = 0;
+  for (uint32_t f = 0; f < nf; ++f) {
+    const uint8_t ty = b->file_type[f] == 'a' ? (uint8_t)'A' : b->file_type[f];
+    if (ty != 'A' && ty != 'Q') return fail(ix, NIQKI_E_INVALID, "file_type must be 'A', 'Q' or 'a' (packed FASTA)");
+    h_off[f] = roff[f];
+    h_first[f] = (uint32_t)chunks;
+    h_type[f] = ty;
+    chunks += (roff[f + 1] - roff[f] + nq::kIngestChunk - 1) / nq::kIngestChunk;
+  }
+  if (chunks > 0x7FFFFFFFull) return fail(ix, NIQKI_E_INVALID, "raw batch too large");
+  h_off[nf] = T_raw;
+  h_first[nf] = (uint32_t)chunks;
+  int rc;
+  const uint8_t *d_raw = b->raw;
+  bool prefetched = false;
+  if (ix->pre.valid) {  // bytes a niqki_stage_raw_prefetch put on their way: this batch's, or dropped
+    prefetched = mem == NIQKI_MEM_HOST && b->file_ptr && nf == ix->pre.ptr.size() &&
+                 std::equal(ix->pre.ptr.begin(), ix->pre.ptr.end(), b->file_ptr) &&
+                 std::equal(ix->pre.off.begin(), ix->pre.off.end(), b->file_off);
+    ix->pre.valid = false;
+    if (prefetched) {
+      if (!any_packed) std::swap(ix->ws_raw, ix->ws_raw2);   // (packed: ws_raw2 stays the wire buffer, unpacked below)
+      NQ_HIP(ix, hipStreamWaitEvent(ix->stream, ix->ev_copy, 0));
+      d_raw = (const uint8_t *)ix->ws_raw.p;
+    } else {
+      NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream));
+    }
+  }
+  if (any_packed) {
+    if (!prefetched) {   // the containers (and raw files) as they are, into the wire buffer
+      if ((rc = ensure(ix, ix->ws_raw2, (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
+      for (uint32_t f = 0; f < nf; ++f) {
+        const uint64_t n = b->file_off[f + 1] - b->file_off[f];
+        if (n) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_raw2.p + b->file_off[f], b->file_ptr[f], n, hipMemcpyHostToDevice, ix->stream));
+      }
+    }
+    if ((rc = ensure(ix, ix->ws_raw, (size_t)T_raw + 2 * NIQKI_SEQ_PAD))) return rc;
+    if ((rc = ensure(ix, ix->ws_useg, std::max<size_t>(segs.size() * sizeof(nq::UnpackSeg), 32)))) return rc;
+    if (!segs.empty()) {
+      NQ_HIP(ix, hipMemcpyAsync(ix->ws_useg.p, segs.data(), segs.size() * sizeof(nq::UnpackSeg), hipMemcpyHostToDevice, ix->stream));
+      Span sp(ix, NIQKI_KC_INGEST);
+      NQ_HIP(ix, nq::launch_unpack((const nq::UnpackSeg *)ix->ws_useg.p, (uint32_t)segs.size(), (uint32_t)unpack_blocks,
+                                   (const uint8_t *)ix->ws_raw2.p, (uint8_t *)ix->ws_raw.p, ix->stream));
+    }
+    d_raw = (const uint8_t *)ix->ws_raw.p;
+  } else if (prefetched) {
+  } else if (mem == NIQKI_MEM_HOST) {
+    if ((rc = ensure(ix, ix->ws_raw, (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
+    if (b->file_ptr) {
+      for (uint32_t f = 0; f < nf; ++f) {
+        const uint64_t n = b->file_off[f + 1] - b->file_off[f];
+        if (n) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_raw.p + b->file_off[f], b->file_ptr[f], n, hipMemcpyHostToDevice, ix->stream));
+      }
+    } else if (T) {
+      NQ_HIP(ix, hipMemcpyAsync(ix->ws_raw.p, b->raw, T, hipMemcpyHostToDevice, ix->stream));
+    }
+    d_raw = (const uint8_t *)ix->ws_raw.p;
+  } else if ((uintptr_t)d_raw & 3) {
+    return fail(ix, NIQKI_E_INVALID, "device raw bytes must be 4-byte aligned");
+  }
+  if ((rc = ensure(ix, ix->ws_fmeta, meta.size()))) return rc;
+  if ((rc = ensure(ix, ix->ws_summ, std::max<size_t>((size_t)chunks * 20, 4)))) return rc;
+  if ((rc = ensure(ix, ix->ws_chunk, std::max<size_t>((size_t)chunks * 16, 4)))) return rc;
+  if ((rc = ensure(ix, ix->ws_fkept, (size_t)(nf + 1) * 8))) return rc;
+  if ((rc = ensure(ix, ix->ws_fnrec, (size_t)(nf + 1) * 4))) return rc;
+  if ((rc = ensure(ix, ix->ws_misc, 256))) return rc;
+  NQ_HIP(ix, hipMemcpyAsync(ix->ws_fmeta.p, meta.data(), meta.size(), hipMemcpyHostToDevice, ix->stream));
+  nq::IngestArgs a;
+  a.raw = d_raw;
+  a.file_off = (const uint64_t *)ix->ws_fmeta.p;
+  a.chunk_first = (const uint32_t *)((uint8_t *)ix->ws_fmeta.p + (size_t)(nf + 1) * 8);
+  a.file_type = (const uint8_t *)ix->ws_fmeta.p + (size_t)(nf + 1) * 12;
+  a.n_files = nf;
+  a.n_chunks = (uint32_t)chunks;
+  a.summ = (uint32_t *)ix->ws_summ.p;
+  a.chunk_out = (uint32_t *)ix->ws_chunk.p;
+  a.file_kept = (uint64_t *)ix->ws_fkept.p;
+  a.file_nrec = (uint32_t *)ix->ws_fnrec.p;
+  a.totals = (uint64_t *)ix->ws_misc.p;
+  a.seqs = nullptr;
+  a.rec_off = nullptr;
+  a.hdr_pos = nullptr;
+  uint64_t totals[2] = {0, 0};
+  {
+    Span sp(ix, NIQKI_KC_INGEST);
+    NQ_HIP(ix, nq::launch_ingest_scan(a, ix->stream));
+  }
+  NQ_HIP(ix, hipMemcpyAsync(totals, a.totals, 16, hipMemcpyDeviceToHost, ix->stream));
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));  // also: `meta` and the caller's raw bytes are consumed
+  if (totals[0] > 0xFFFFFFF0ull) return fail(ix, NIQKI_E_INVALID, "too many records in one batch");
+  const uint32_t n_rec = (uint32_t)totals[0];
+  const uint64_t kept = totals[1];
+  if ((rc = ensure(ix, ix->ws_recoff, (size_t)(n_rec + 1) * 8))) return rc;
+  if ((rc = ensure(ix, ix->ws_hdrpos, std::max<size_t>((size_t)n_rec * 8, 8)))) return rc;
+  if ((rc = ensure(ix, ix->ws_seq, (size_t)kept + 2 * NIQKI_SEQ_PAD))) return rc;
+  a.seqs = (uint8_t *)ix->ws_seq.p;
+  a.rec_off = (uint64_t *)ix->ws_recoff.p;
+  a.hdr_pos = (uint64_t *)ix->ws_hdrpos.p;
+  {
+    Span sp(ix, NIQKI_KC_INGEST);
+    NQ_HIP(ix, nq::launch_ingest_emit(a, ix->stream));
+  }
+  NQ_HIP(ix, hipMemcpyAsync(a.rec_off + n_rec, a.totals + 1, 8, hipMemcpyDeviceToDevice, ix->stream));
+  NQ_HIP(ix, hipMemsetAsync(a.seqs + kept, 0, NIQKI_SEQ_PAD, ix->stream));
+  uint32_t n_entry = nf;
+  uint64_t consumed = T_raw;
+  const uint32_t *d_entry = a.file_nrec;  // whole mode: entry f = the records of file f
+  if (b->lines) {
+    const uint32_t n_use = b->final ? n_rec : (n_rec ? n_rec - 1 : 0);
+    if ((rc = ensure(ix, ix->ws_entry, (size_t)(b->max_entries + 1) * 4))) return rc;
+    if ((rc = ensure(ix, ix->ws_ehdr, (size_t)b->max_entries * 8))) return rc;
+    uint32_t *d_res = (uint32_t *)((uint8_t *)ix->ws_misc.p + 64);
+    NQ_HIP(ix, nq::launch_ingest_entries(a.rec_off, a.hdr_pos, n_use, ix->d.K, b->max_entries,
+                                         (uint32_t *)ix->ws_entry.p, (uint64_t *)ix->ws_ehdr.p, d_res, ix->stream));
+    uint32_t res[2] = {0, 0};
+    NQ_HIP(ix, hipMemcpyAsync(res, d_res, 8, hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    n_entry = res[0];
+    if (res[1] < n_rec)
+      NQ_HIP(ix, hipMemcpyAsync(&consumed, a.hdr_pos + res[1], 8, hipMemcpyDeviceToHost, ix->stream));
+    if (entry_hdr && n_entry)
+      NQ_HIP(ix, hipMemcpyAsync(entry_hdr, ix->ws_ehdr.p, (size_t)n_entry * 8, hipMemcpyDeviceToHost, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+    d_entry = (const uint32_t *)ix->ws_entry.p;
+  }
+  ix->staged.valid = true;
+  ix->staged.n_entry = n_entry;
+  ix->staged.n_rec = n_rec;
+  ix->staged.seq_bytes = kept;
+  ix->staged.entry_rec = d_entry;
+  info->n_entry = n_entry;
+  info->n_rec = n_rec;
+  info->consumed = consumed;
+  info->seq_bytes = kept;
+  return NIQKI_OK;
+}
+
+int niqki_staged_sketch(niqki_index *ix, int32_t *sketches, int mem) {
+  if (!ix) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = staged_sketch_ws(ix);
+  if (rc) return rc;
+  const size_t bytes = (size_t)ix->staged.n_entry * ix->d.F * 4;
+  if (!bytes) return NIQKI_OK;
+  if (!sketches) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipMemcpyAsync(sketches, ix->ws_stsk.p, bytes,
+                            mem == NIQKI_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ix->stream));
+  if (mem == NIQKI_MEM_HOST) NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  return NIQKI_OK;
+}
+
+int niqki_staged_insert(niqki_index *ix) {
+  if (!ix) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = staged_sketch_ws(ix);
+  if (rc) return rc;
+  return niqki_insert(ix, (const int32_t *)ix->ws_stsk.p, ix->staged.n_entry, NIQKI_MEM_DEVICE);
+}
+
+int niqki_staged_query(niqki_index *ix, uint64_t *hit_off, uint32_t *hit_counts, uint32_t *hit_gids,
+                       uint64_t capacity, int mem) {
+  if (!ix || !hit_off) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  int rc = staged_sketch_ws(ix);
+  if (rc) return rc;
+  if (mem == NIQKI_MEM_DEVICE)
+    return niqki_query(ix, (const int32_t *)ix->ws_stsk.p, ix->staged.n_entry, hit_off, hit_counts, hit_gids,
+                       capacity, NIQKI_MEM_DEVICE);
+  if ((rc = build_if_needed(ix))) return rc;
+  return query_to_host(ix, (const int32_t *)ix->ws_stsk.p, true, ix->staged.n_entry, hit_off, hit_counts,
+                       hit_gids, capacity);
+}
+
+int niqki_staged_records(niqki_index *ix, uint64_t *rec_off, uint8_t *seqs, uint32_t *entry_rec,
+                         uint64_t *hdr_pos) {
+  if (!ix) return NIQKI_E_INVALID;
+  if (!ix->staged.valid) return fail(ix, NIQKI_E_STATE, "no staged batch (niqki_stage_raw first)");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  const auto &st = ix->staged;
+  if (rec_off) NQ_HIP(ix, hipMemcpyAsync(rec_off, ix->ws_recoff.p, (size_t)(st.n_rec + 1) * 8, hipMemcpyDeviceToHost, ix->stream));
+  if (seqs && st.seq_bytes) NQ_HIP(ix, hipMemcpyAsync(seqs, ix->ws_seq.p, st.seq_bytes, hipMemcpyDeviceToHost, ix->stream));
+  if (entry_rec) NQ_HIP(ix, hipMemcpyAsync(entry_rec, st.entry_rec, (size_t)(st.n_entry + 1) * 4, hipMemcpyDeviceToHost, ix->stream));
+  if (hdr_pos && st.n_rec) NQ_HIP(ix, hipMemcpyAsync(hdr_pos, ix->ws_hdrpos.p, (size_t)st.n_rec * 8, hipMemcpyDeviceToHost, ix->stream));
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  return NIQKI_OK;
+}
+
+// ---- packed FASTA (nq_pack.h): host code, no device needed ----
+size_t niqki_pack_bound(size_t n) { return nqp::pack_bound(n); }
+
+size_t niqki_pack_fasta(const uint8_t *raw, size_t n, uint8_t *out, size_t capacity) {
+  if (!raw || !out) return 0;
+  return nqp::pack(raw, n, out, capacity);
+}
+
+int niqki_unpack_fasta(const uint8_t *container, size_t len, uint8_t *raw, size_t capacity, size_t *raw_len) {
+  if (!container || !nqp::valid(container, len)) return NIQKI_E_INVALID;
+  nqp::PackHeader h;
+  std::memcpy(&h, container, sizeof h);
+  if (raw_len) *raw_len = (size_t)h.raw_len;
+  if (!raw) return NIQKI_OK;
+  if (h.raw_len > capacity) return NIQKI_E_CAPACITY;
+  return nqp::unpack(container, len, raw, capacity) ? NIQKI_OK : NIQKI_E_INVALID;
+}
+
+}  // extern "C"

@@ -3,6 +3,7 @@
 // Private to libniqki_hip.so.
 #pragma once
 #include "../../include/niqki_hip.h"
+#include "../../include/niqki_hip_bench.h"
 #include "nq_kernels.h"
 
 #include <string>
@@ -137,10 +138,35 @@ struct niqki_index {
 
 namespace nqi {
 
+// ---- nq_api.hip: the handle ----
 int fail(niqki_index *ix, int code, const std::string &msg);
 int ensure(niqki_index *ix, Buf &b, size_t bytes);   // device scratch of at least `bytes`
 nq::IndexView view(const niqki_index *ix);
+std::string &create_error();   // thread-local: why the last niqki_create / niqki_import_* of the calling thread failed
+int derive(const niqki_params &p, nq::Derived &d, std::string &why);
+int collect_spans(niqki_index *ix);
+// more than 2^15 slots on the handle (whole-range S = 16): counts reach 2^16, two counter planes (nq_kernels.h, kPassSlots)
+bool two_planes(const niqki_index *ix);
+// first slot of the handle in a whole sketch row (while a page is resident d.slot_begin is the page's)
+uint32_t first_slot(const niqki_index *ix);
+// ---- nq_api_build.hip: sketch store, sketching, index segments ----
+int reserve_store(niqki_index *ix, uint64_t want);
+int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, uint32_t n_rec, const uint32_t *entry_rec,
+               uint32_t n_entry, int32_t *sketches, uint64_t total_bytes);
+void swap_segment(niqki_index *ix);   // flat index members <-> alt ("Delta segment" above)
+int build_range(niqki_index *ix, uint32_t g_base, uint32_t N);
 int build_if_needed(niqki_index *ix);
+int build_single(niqki_index *ix);    // ONE index over all genomes (dump export, per-bucket statistics)
+// ---- nq_api_query.hip: counters and hits ----
+uint32_t page_slots(const niqki_index *ix);
+int load_page(niqki_index *ix, uint32_t s0, uint32_t s1);
+int counts_resident(niqki_index *ix, const int32_t *sketches, uint32_t q_stride, uint32_t q_off, uint32_t nq, uint16_t *counts,
+                    uint64_t stride, bool accumulate, uint16_t *counts2 = nullptr, const nq::CandOut *co = nullptr);
+int query_hits_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16_t *c1, uint16_t *c2, uint64_t stride,
+                   unsigned long long *hit_off, uint32_t *hc, uint32_t *hg, uint64_t capacity, bool check_capacity,
+                   uint64_t *total_out);
+int query_to_host(niqki_index *ix, const int32_t *sketches, bool sk_dev, uint32_t nq, uint64_t *hit_off, uint32_t *hit_counts,
+                  uint32_t *hit_gids, uint64_t capacity);
 // hit counters of nq device-resident sketches (rows q_stride apart, this shard's slots at q_off)
 // counts2: the second counter plane of a whole-range S = 16 handle (nq_kernels.h, kPassSlots), else nullptr
 // co: also the candidate lists of the rows (nq_kernels.h CandOut; presets them itself), not on paged or S = 16 handles

@@ -199,7 +199,12 @@ void read_file_bytes(const std::string &path, PinnedBuf &out, bool want_pack = f
       if (n == 0) break;
       out.size += (size_t)n;
     }
+    // a stream that ends inside a member gives what it has and then 0: zlib only says so through gzerror
+    // (the reference's zstr reader throws on such a file, src/zstr.hpp)
+    int zerr = Z_OK;
+    (void)gzerror(g, &zerr);
     gzclose(g);
+    if (zerr != Z_OK && zerr != Z_STREAM_END) throw std::runtime_error("'" + path + "': gzip stream is damaged or truncated");
     return;
   }
   out.reserve(std::max<size_t>((size_t)st.st_size, 64));
@@ -809,7 +814,7 @@ void Index::stream_lines(const std::string &filestr, bool insert) {
         pc->last = false;
         pc->buf.size = 0;
         pc->buf.reserve(std::max(target, carry.size()) + (size_t(1) << 16));
-        std::memcpy(pc->buf.p, carry.data(), carry.size());
+        if (!carry.empty()) std::memcpy(pc->buf.p, carry.data(), carry.size());   // (an empty vector's data() may be null)
         pc->buf.size = carry.size();
         carry.clear();
         size_t cut = 0;

@@ -21,6 +21,7 @@
 // bucket vectors from the file, and the first bound call rebuilds the GPU index from them (bound_of).
 #include "niqki_index.h"          // the reference's header: -I/root/reference/src
 #include "../include/niqki_hip.h"
+#include "../include/niqki_hip_bench.h"   // (niqki_shared_stats: the report line of NIQKI_REF_GPU_REPORT)
 
 #include <cstdio>
 #include <cstdlib>

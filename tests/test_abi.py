@@ -8,10 +8,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "niqki_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(niqki_[A-Za-z0-9_]+)\s*\(", text)))
+HEADERS = ("niqki_hip.h", "niqki_hip_bench.h")     # the drop-in boundary; measurement / diagnosis / test support
+
+
+def declared_symbols(header=None):
+    out = set()
+    for h in ((header,) if header else HEADERS):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(niqki_[A-Za-z0-9_]+)\s*\(", text))
+    return sorted(out)
 
 
 def test_header_symbols_all_exported(native):
@@ -19,6 +25,16 @@ def test_header_symbols_all_exported(native):
     L = ctypes.CDLL(native.lib_path())
     syms = declared_symbols()
     assert len(syms) >= 30
+    # the two headers do not overlap, and what a host program needs -- the reference's operators, files, dump / load,
+    # groups -- is all in the first one: the bench header holds no create / sketch / insert / query / stage / dump call
+    main, extra = set(declared_symbols("niqki_hip.h")), set(declared_symbols("niqki_hip_bench.h"))
+    assert not (main & extra) and len(extra) <= 20
+    for need in ("niqki_create", "niqki_sketch", "niqki_insert", "niqki_query", "niqki_query_sequences", "niqki_matrix_range",
+                 "niqki_stage_raw", "niqki_staged_insert", "niqki_staged_query", "niqki_export_dump", "niqki_import_dump",
+                 "niqki_group_create", "niqki_group_query", "niqki_sketch_shared", "niqki_pack_fasta", "niqki_select_best_H"):
+        assert need in main, need
+    for tool in ("niqki_synth_genomes", "niqki_measure_alu", "niqki_profile_read", "niqki_query_survivors"):
+        assert tool in extra, tool
     for s in syms:
         assert hasattr(L, s), "libniqki_hip.so lacks %s" % s
     # the ctypes table covers the whole header too
