@@ -6,10 +6,20 @@
 #    path's kernels (tools/pmc_bench.sh: FETCH_SIZE, WRITE_SIZE, TCC_EA0_RDREQ[_128B], SQ_*;
 #    MI355X_MICROARCH.md: on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so it is doubled)
 # 4) the same with the look-ups inside the gather kernel (pre-pass off), the 8-way shard emulation, the world-1 RCCL run
+# Two parts (a gpurun call is limited to 20 minutes):  tools/profile_round.sh r05 line   |   tools/profile_round.sh r05 rest
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r03}
+PART=${2:-all}
 cd $R; mkdir -p gpurun_out
-timeout -k 10 900 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err || { tail -5 gpurun_out/${TAG}_bench_n1.err; exit 1; }
+if [ "$PART" = "line" ] || [ "$PART" = "all" ]; then
+timeout -k 10 1000 python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err || { tail -5 gpurun_out/${TAG}_bench_n1.err; exit 1; }
+python3 -c "
+import json
+j=json.load(open('gpurun_out/${TAG}_bench_n1.json'))
+print('value %.0f ms/step %.2f gather %.3f frac %.3f (algorithmic %.3f, layout min %.3f)' % (j['value'], j['ms_per_step'], j['roofline']['avg_launch_ms'], j['roofline']['frac'], j['roofline']['frac_algorithmic'], j['roofline']['frac_layout_min']))
+print(json.dumps(j['cpu_baseline'])[:1500])"
+[ "$PART" = "line" ] && exit 0
+fi
 cd /tmp; export TMPDIR=/tmp
 # the traced command runs ONLY the index build, the warm-up and the timed steps (--no-legs): a kernel's median in the
 # summary is the median of the launches roofline.avg_launch_ms averages
@@ -39,15 +49,17 @@ NIQKI_FORCE_DIST=1 timeout -k 10 600 python3 bench.py --no-cpu --no-extra > gpur
 # the walk's access pattern alone, and which instruction kinds issue side by side (built by hand into tools/bin/)
 [ -x tools/bin/ubench_lines ] && timeout -k 10 60 tools/bin/ubench_lines > gpurun_out/${TAG}_ubench_lines.txt 2>&1
 [ -x tools/bin/ubench_mix ] && timeout -k 10 60 stdbuf -oL tools/bin/ubench_mix > gpurun_out/${TAG}_ubench_mix.txt 2>&1
+# round 5: the short-read path's kernels, a 500 000-genome index, (the file path on 2048 files is part of the bench line's cli_files)
+bash tools/profile_reads4.sh ${TAG} > /dev/null 2>&1
+timeout -k 10 600 python3 bench.py --genomes 500000 --no-legs --steps 6 --warmup 2 > gpurun_out/${TAG}_bench_500k_genomes.json 2> gpurun_out/${TAG}_bench_500k.err
 # LAST (it rebuilds the library of this scratch copy with clock reads in the gather kernel): phase clocks of a gather workgroup
 touch niqki_amd/csrc/nq_query.hip && make -C niqki_amd/csrc HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DNQ_GATHER_CLOCK" > gpurun_out/${TAG}_clock_build.log 2>&1 && {
   timeout -k 10 300 python3 tools/gather_clock.py --shard-of 8 --no-cpu --no-extra --steps 3 2>&1 | grep -v "^{\|amdgpu.ids" > gpurun_out/${TAG}_gather_phase_clocks_shard_of_8.txt
   timeout -k 10 300 python3 tools/gather_clock.py --no-cpu --no-extra --steps 3 2>&1 | grep -v "^{\|amdgpu.ids" > gpurun_out/${TAG}_gather_phase_clocks_whole_range.txt
 }
-cd $R; head -14 gpurun_out/${TAG}_bench_kernel_trace_summary.txt | cut -c1-170
-python3 -c "
+cd $R
+head -14 gpurun_out/${TAG}_bench_kernel_trace_summary.txt | cut -c1-170
+[ -f gpurun_out/${TAG}_bench_under_rocprof.json ] && python3 -c "
 import json
-j=json.load(open('gpurun_out/${TAG}_bench_n1.json'))
-print('value %.0f ms/step %.2f gather %.3f frac %.3f (algorithmic %.3f, layout min %.3f)' % (j['value'], j['ms_per_step'], j['roofline']['avg_launch_ms'], j['roofline']['frac'], j['roofline']['frac_algorithmic'], j['roofline']['frac_layout_min']))
-print(json.dumps(j['cpu_baseline']))
-print(json.dumps(j['sketch_kernel']))"
+j=json.load(open('gpurun_out/${TAG}_bench_under_rocprof.json'))
+print('traced run: value %.0f ms/step %.2f gather %.3f' % (j['value'], j['ms_per_step'], j['roofline']['avg_launch_ms']))"
