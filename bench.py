@@ -39,176 +39,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-
-
-BENCH_K = 31   # the bench's k-mer length (BASELINE.json: K=31 S=15 W=12)
-
-def log(*a):
-    print(*a, file=sys.stderr, flush=True)
-
-
-def genome_spec(g, n_fam, fam_size):
-    """Indexed genome g: family g // fam_size, member g % fam_size; member 0 is the
-    ancestor, the others carry substitution rates spread geometrically over
-    0.1 % .. 5 % so that in-family Jaccard spans ~0.05 .. 0.95."""
-    fam = g // fam_size
-    mem = g % fam_size
-    rate = np.where(mem == 0, 0, np.round(16 * (820 / 16) ** ((mem - 1) / max(fam_size - 2, 1)))).astype(np.uint32)
-    return fam.astype(np.uint32), mem.astype(np.uint32), rate
-
-
-def query_spec(q, n_fam):
-    """Query q: a fresh mutant (member id >= 2^20) of a pseudo-random indexed
-    family; every 10th query comes from a family that is not indexed."""
-    h = (q.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(33)
-    fam = (h % np.uint64(n_fam)).astype(np.uint32)
-    fam = np.where(q % 10 == 9, n_fam + q, fam).astype(np.uint32)
-    mem = ((1 << 20) + q).astype(np.uint32)
-    rate = (16 + (h >> np.uint64(8)) % np.uint64(400)).astype(np.uint32)
-    return fam, mem, rate
-
-
-def measure_counters(args):
-    """Hardware counters of a short run of this same command under rocprofv3 (one --pmc pass per counter, no
-    trace flags, child processes started before this process touches the GPU):
-      * HBM-side bytes per gather launch (gather kernel + look-up pre-pass + locality probe):
-        2 x FETCH_SIZE (gfx950 tallies 128-byte requests at 64 bytes, MI355X_MICROARCH.md) + WRITE_SIZE, in KB;
-      * vector instructions per k-mer of the sketch kernel: SQ_INSTS_VALU (wave instructions, all XCDs)
-        x 64 lanes over the k-mers its launches of that run rolled.
-    None if anything goes wrong."""
-    import csv
-    import glob
-    import re
-    import shutil
-    import signal
-    import subprocess
-    import tempfile
-    if shutil.which("rocprofv3") is None:
-        return None
-    rx = re.compile(r"gather_kernel<|lookup(_rows)?_kernel<|probe_kernel<")
-    # not under another profiler: the nested rocprofv3 would inherit its preload / tool variables
-    if ("ROCP_TOOL_LIBRARIES" in os.environ or any(k.startswith("ROCPROF_") for k in os.environ)
-            or "rocprof" in os.environ.get("LD_PRELOAD", "")):
-        return None
-    kb = {}
-    launches = None
-    valu = None
-    c_steps, c_warm = 2, 1
-    t0 = time.time()
-    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
-        out = tempfile.mkdtemp(prefix="niqki_pmc_", dir="/tmp")
-        try:
-            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", str(c_steps), "--warmup", str(c_warm),
-                   "--genomes", str(args.genomes), "--batch", str(args.batch), "--len", str(args.len),
-                   "--family", str(args.family), "--seed", str(args.seed), "--ring", str(args.ring)]
-            env = dict(os.environ, TMPDIR="/tmp")
-            # a session of its own: on a timeout the whole group goes (rocprofv3 AND the bench under it)
-            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                                  start_new_session=True)
-            try:
-                rc = pr.wait(timeout=240)
-            except subprocess.TimeoutExpired:
-                try:
-                    os.killpg(pr.pid, signal.SIGKILL)
-                except OSError:
-                    pass
-                pr.wait()
-                return None
-            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            if rc != 0 or not files:
-                if counter == "SQ_INSTS_VALU":
-                    break                  # (the traffic passes stand on their own)
-                return None
-            total, n_gather, v_sum, v_n = 0.0, 0, 0.0, 0
-            with open(files[0], newline="") as f:
-                for row in csv.DictReader(f):
-                    name = row.get("Kernel_Name", "")
-                    if row.get("Counter_Name") != counter:
-                        continue
-                    if counter == "SQ_INSTS_VALU":
-                        if "sketch_kernel<" in name:
-                            v_sum += float(row["Counter_Value"])
-                            v_n += 1
-                    elif rx.search(name):
-                        total += float(row["Counter_Value"])
-                        n_gather += "gather_kernel<" in name
-            if counter == "SQ_INSTS_VALU":
-                # every sketch launch of the child: the index build (all genomes) and its warm-up + timed query batches
-                # (K = 31: the bench's only k-mer length -- config.K below; a launch of `len` bases rolls len - K k-mers,
-                # src/niqki_index.cpp:342.  The child runs --no-legs, so its sketch launches are exactly these; the
-                # exact re-run of a genome whose filtered pass left a slot empty, 1 in ~20 000, is inside the
-                # numerator and not the denominator: < 0.01 %.)
-                kmers = (args.genomes + (c_steps + c_warm) * args.batch) * max(args.len - BENCH_K, 0)
-                if v_n and kmers:
-                    valu = {"valu_per_kmer": v_sum * 64.0 / kmers, "launches": v_n}
-                continue
-            if n_gather == 0:
-                return None
-            kb[counter] = total / n_gather
-            launches = n_gather
-        except (OSError, subprocess.SubprocessError, KeyError, ValueError):
-            return None
-        finally:
-            shutil.rmtree(out, ignore_errors=True)
-    log("[bench] HBM traffic of the gather path: FETCH_SIZE %.0f KB, WRITE_SIZE %.0f KB per launch (%d launches); sketch kernel %s "
-        "vector instructions per k-mer (%.0f s)" % (kb["FETCH_SIZE"], kb["WRITE_SIZE"], launches,
-                                                    ("%.2f" % valu["valu_per_kmer"]) if valu else "n/a", time.time() - t0))
-    return {"bytes_per_launch": (2 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024,
-            "fetch_kb": kb["FETCH_SIZE"], "write_kb": kb["WRITE_SIZE"],
-            "valu": valu,
-            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes over %d launches of this same command, run by "
-                      "bench.py before its timed run: 2 x FETCH_SIZE (gfx950) + WRITE_SIZE of gather_kernel, the look-up "
-                      "pre-pass and the locality probe" % launches}
-
-
-def launch_ranks(n):
-    """`python bench.py --gpus N` without a launcher: start N ranks of this same command under
-    torch.distributed.run as a CHILD process (a session of its own, killed as a group on a time-out), relay
-    its stdout -- the one JSON line of rank 0 -- and return its exit code.  Called before this process has
-    imported torch or made any HIP call: a process that has initialised the GPU must not be replaced or
-    forked into a launcher on this pool."""
-    import signal
-    import socket
-    import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL and the ipc transport need on this driver
-    env.setdefault("OMP_NUM_THREADS", "1")
-    limit = float(os.environ.get("NIQKI_BENCH_LAUNCH_TIMEOUT", "3000"))
-    log("[bench] --gpus %d without a launcher: starting %s" % (n, " ".join(cmd[1:10]) + " ..."))
-    pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
-    try:
-        out, _ = pr.communicate(timeout=limit)
-    except subprocess.TimeoutExpired:
-        try:
-            os.killpg(pr.pid, signal.SIGKILL)
-        except OSError:
-            pass
-        pr.wait()
-        log("[bench] the %d ranks did not finish within %.0f s: killed" % (n, limit))
-        return 124
-    except KeyboardInterrupt:
-        try:
-            os.killpg(pr.pid, signal.SIGTERM)
-        except OSError:
-            pass
-        pr.wait()
-        return 130
-    lines = [ln for ln in out.decode(errors="replace").splitlines() if ln.startswith("{")]
-    if lines:
-        sys.stdout.write(lines[-1] + "\n")
-        sys.stdout.flush()
-    elif pr.returncode == 0:
-        log("[bench] the ranks exited 0 without a JSON line")
-        return 1
-    return pr.returncode
-
+from bench_support import (BENCH_K, HBM_PEAK_GBS, genome_spec, host_cpu_info, launch_ranks, log, measure_counters,  # noqa: E402,F401
+                           query_spec, roofline_record)
 
 def main():
     ap = argparse.ArgumentParser()
@@ -922,95 +754,6 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_record(achieved_alg, traffic, traffic_source, live, gather_ms, launches, alg_bytes, layout_min, copy_gbs, measured_in,
-                    T, n_q_local, pipeline):
-    """The `roofline` object of the line.  `frac` is what the memory system moved (PMC counters, per launch) over the
-    launch time over the spec peak -- bytes that really crossed the L2's memory side (only a working set that the 256 MB
-    Infinity Cache serves could push it past 1: not this 17 GB index); without a counter measurement for this shape, the bytes
-    the layout cannot avoid stand in (a lower bound of the traffic).  SURVEY.md 8(d)'s algorithmic figure (4-byte ids,
-    every query's lines counted for itself) is `achieved` / `frac_algorithmic`: the layout stores 2-byte ids and an
-    XCD's L2 serves lines that neighbouring queries share, so that one can pass 1.  `achieved` is the same basis as
-    `frac` in GB/s (so frac = achieved / peak); the algorithmic rate is `achieved_algorithmic`."""
-    n = max(1, launches)
-    t_launch = gather_ms / n * 1e-3
-    alg_l, lay_l = alg_bytes / n, layout_min / n
-    real_gbs = traffic / t_launch / 1e9 if (traffic and t_launch) else None
-    lay_gbs = lay_l / t_launch / 1e9 if t_launch else None
-    basis_gbs = real_gbs if real_gbs is not None else lay_gbs
-    rec = {
-        "kernel": "nq::gather_kernel (gather-histogram, rank 0's slot shard) incl. its look-up pre-pass and probe / order passes",
-        # achieved = what the memory system moved per second (frac = achieved / peak); SURVEY.md 8(d)'s formula, which
-        # counts 4 bytes per id and can pass the peak, is achieved_algorithmic / frac_algorithmic
-        "bound": "hbm", "achieved": basis_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": (basis_gbs / HBM_PEAK_GBS) if basis_gbs else None,
-        "achieved_algorithmic": achieved_alg,
-        "frac_basis": ("traffic: (2 x FETCH_SIZE + WRITE_SIZE) per launch / avg_launch_ms / peak" if real_gbs is not None
-                       else "layout_min_bytes_per_launch / avg_launch_ms / peak (no counter measurement for this shape in this run: "
-                            "a lower bound of the bytes moved)"),
-        "achieved_measured": real_gbs,
-        "frac_algorithmic": achieved_alg / HBM_PEAK_GBS,
-        "frac_layout_min": (lay_gbs / HBM_PEAK_GBS) if lay_gbs else None,
-        "traffic": traffic, "traffic_source": traffic_source,
-        "traffic_over_layout_min": (traffic / lay_l) if (traffic and lay_l) else None,
-        "traffic_fetch_kb": live["fetch_kb"] if live else None, "traffic_write_kb": live["write_kb"] if live else None,
-        "copy_gbs": copy_gbs,
-        "copy_ceiling_frac": (real_gbs / copy_gbs) if (real_gbs and copy_gbs) else None,
-        "note": ("achieved_algorithmic / frac_algorithmic count the ALGORITHMIC bytes of SURVEY.md 8d (4 bytes per id as the reference stores "
-                 "them, bucket lines that neighbouring queries share counted for each): the layout moves 2-byte ids and an XCD's "
-                 "L2 serves shared lines, so that figure can pass 1.  achieved / frac are the counter traffic; FETCH_SIZE counts requests that "
-                 "leave the L2, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM section), so frac is an UPPER bound of the "
-                 "HBM-proper fraction.  traffic_over_layout_min: bytes moved over the bytes this layout cannot avoid (half-empty "
-                 "128-byte bucket lines are the difference)"
-                 + ("; with the next batch's sketch kernel beside the gather the two share the CUs, the gather launch time here "
-                    "is not a roofline figure" if pipeline else "")),
-        "algorithmic_bytes_per_launch": alg_l,
-        "layout_min_bytes_per_launch": lay_l,
-        "launches": launches, "avg_launch_ms": gather_ms / n,
-        "measured_in": measured_in or "the timed steps",
-        "gathered_ids_per_query": T / max(1, n_q_local),
-    }
-    return rec
-
-
-def host_cpu_info():
-    """What this process may use of the host: logical CPUs, physical cores, the affinity mask and the cgroup's CPU
-    quota (a container is often handed a share of the node: more threads than that only take turns)."""
-    phys = set()
-    try:
-        pid = cid = None
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("physical id"):
-                pid = line.split(":")[1].strip()
-            elif line.startswith("core id"):
-                cid = line.split(":")[1].strip()
-            elif not line.strip():
-                if pid is not None and cid is not None:
-                    phys.add((pid, cid))
-                pid = cid = None
-    except OSError:
-        pass
-    quota = None
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    quota = float(txt[0]) / float(txt[1])
-            else:
-                q = float(txt[0])
-                if q > 0:
-                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
-            break
-        except (OSError, ValueError, IndexError):
-            continue
-    try:
-        aff = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        aff = os.cpu_count()
-    return {"logical_cpus": os.cpu_count(), "physical_cores": len(phys) or None, "affinity_cpus": aff,
-            "cgroup_cpu_quota": quota}
-
-
 def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, prm):
     """The oracle (port of the reference CPU path) on this host, on a bounded
     sample of the same workload; also the in-run parity check (sketches, dense counters and the
@@ -1446,9 +1189,11 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
     sk_s = kprof["sketch"] * 1e-3
     sk_pass_rate = NR * passes_per_read / sk_s if sk_s else 0.0
     T4 = float(e.gathered_dev(rsk, RB).sum()) / RB        # ids gathered per read (last batch)
-    g_bytes = NR * (4 * F4 + 2 * N4 + 4 * T4 + 8 * T4)
+    lists = int(e.stat("last_hits_form")) == 1       # the hits left the gather kernel as ordered lists: no counter rows
+    hpr = float(th_.sum()) / NR
+    g_bytes = NR * (4 * F4 + 4 * T4 + 8 * T4 + (4 * hpr + 4 if lists else 2 * N4))
     g_s = kprof["gather"] * 1e-3
-    h_bytes = NR * (2 * N4) + 8 * float(th_.sum())
+    h_bytes = NR * ((4 + 12 + 4 * hpr) if lists else 2 * N4) + 8 * float(th_.sum())
     h_s = kprof["hits"] * 1e-3
     ceilings = {
         "sketch": {"bound": "lds round trips of the densification passes", "passes_per_read": passes_per_read,
@@ -1458,14 +1203,20 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
                            "proposals + two read-backs per lane and pass) with nothing but its LDS traffic and exit test, measured "
                            "in this run; achieved = reads/s of the sketch kernel x the passes the oracle's serial loop takes for "
                            "64 of these reads (k-mer hashing and the entry list are inside the kernel's time, outside the peak)"},
-        "gather": {"bound": "hbm", "algorithmic_bytes_per_read": 4 * F4 + 2 * N4 + 12 * T4, "gathered_ids_per_read": T4,
+        "gather": {"bound": "hbm", "algorithmic_bytes_per_read": g_bytes / NR, "gathered_ids_per_read": T4,
                    "achieved": g_bytes / g_s / 1e9 if g_s else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": g_bytes / g_s / 1e9 / HBM_PEAK_GBS if g_s else None,
                    "class_mask": int(e.stat("class_mask")),
-                   "note": "per read: its 2^S-cell sketch in, its 2N-byte counter row out, and the entries and ids of the buckets "
-                           "it touches; with the per-slot class mask the 2^S table look-ups of a read are not memory traffic any more"},
-        "hits": {"bound": "hbm", "achieved": h_bytes / h_s / 1e9 if h_s else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": h_bytes / h_s / 1e9 / HBM_PEAK_GBS if h_s else None},
+                   "hit_lists": lists,
+                   "note": "per read: its 2^S-cell sketch in, the entries and ids of the buckets it touches, and its ordered hit list "
+                           "out (4 bytes per hit; a 2N-byte counter row only for a read with more than hit_list_cap hits, or with "
+                           "option hit_lists = 0); with the per-slot class mask the 2^S table look-ups of a read are not memory "
+                           "traffic any more.  The kernel is bound by the latency of a read's dependent steps at 5 workgroups per "
+                           "CU, not by these bytes"},
+        "hits": {"bound": "launch latency of three small kernels (sizes -> offsets, lists -> places, overflowing lists ordered)",
+                 "bytes_per_read": h_bytes / NR, "achieved": h_bytes / h_s / 1e9 if h_s else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": h_bytes / h_s / 1e9 / HBM_PEAK_GBS if h_s else None,
+                 "ms_per_batch": kprof["hits"] / (NR // RB)},
     }
     out["configs4_reads_vs_10k_index"] = {
         "workload": "%d distinct 150-base reads (1 %% substitutions, generated on the device) against a 10000-genome index, "
