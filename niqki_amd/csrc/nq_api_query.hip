@@ -247,6 +247,13 @@ int hits_dev(niqki_index *ix, const uint16_t *counts, uint32_t nq, uint64_t stri
   return NIQKI_OK;
 }
 
+// the built index takes the hit-list form of query_hits_dev (one small tile, one segment, resident, one plane)
+static bool hit_lists_apply(const niqki_index *ix) {
+  const uint32_t N = ix->built_n;
+  return ix->hit_lists && N && !ix->resident_bytes && !two_planes(ix) && ix->n_tiles == 1 && ix->delta_n == 0 &&
+         ix->tile <= nq::kHitListMaxTile && ix->g_base == 0 && N <= 65536u;
+}
+
 // Index::query_sketch (src/niqki_index.cpp:633-687) for nq device-resident whole sketches into device buffers: counters,
 // threshold, order.  c1 / c2: counter planes of nq rows (c2 only on a two-plane handle).  On a single-tile, single-
 // segment index with a small tile -- the short-read shape -- the hits leave the gather kernel as ordered lists and no
@@ -257,8 +264,7 @@ int query_hits_dev(niqki_index *ix, const int32_t *sketches, uint32_t nq, uint16
   int rc = build_if_needed(ix);
   if (rc) return rc;
   const uint32_t N = ix->built_n;
-  const bool lists = ix->hit_lists && nq && N && !ix->resident_bytes && !two_planes(ix) && ix->n_tiles == 1 && ix->delta_n == 0 &&
-                     ix->tile <= nq::kHitListMaxTile && ix->g_base == 0 && N <= 65536u;
+  const bool lists = nq && hit_lists_apply(ix);
   ix->last_hits_form = lists ? 1u : 0u;
   if (!lists) {
     if ((rc = counts_dev(ix, sketches, ix->d.F, first_slot(ix), nq, c1, stride, c2))) return rc;
@@ -314,9 +320,13 @@ int query_to_host(niqki_index *ix, const int32_t *sketches, bool sk_dev, uint32_
   uint64_t base = 0;
   bool overflow = false;
   hit_off[0] = 0;
-  const uint32_t qb = ix->query_batch;
+  // queries per round of launches: option "query_batch" bounds the counter rows (2N bytes per query); an index that
+  // takes the hit-list form writes rows only for the rare overflowing query and is small (<= 12 288 genomes), so a
+  // whole staged batch of short reads goes through in one round (64 rounds of 1024 cost the lines-mode host path
+  // twice its kernels' time)
+  const uint32_t qb = hit_lists_apply(ix) ? std::max<uint32_t>(ix->query_batch, 65536u) : ix->query_batch;
   const size_t planes = two_planes(ix) ? 2 : 1;
-  std::vector<unsigned long long> off(qb + 1);
+  std::vector<unsigned long long> off(std::min(qb, nq) + 1);
   for (uint32_t q0 = 0; q0 < nq; q0 += qb) {
     const uint32_t n = std::min(qb, nq - q0);
     if (!sk_dev && (rc = ensure(ix, ix->ws_sk, (size_t)n * ix->d.F * 4))) return rc;

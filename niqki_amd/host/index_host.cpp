@@ -9,6 +9,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -780,6 +781,7 @@ struct Piece {
   PinnedBuf buf;
   bool last = false;
   std::string err;
+  std::atomic<int> refs{0};   // the GPU thread while it works on the piece + every batch of hits whose names still lie in it
 };
 
 }  // namespace
@@ -796,7 +798,7 @@ void Index::stream_lines(const std::string &filestr, bool insert) {
   const uint8_t type_u8 = (uint8_t)type;
   // sketches of one call stay below 2 GB
   const uint32_t max_entries = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(1024, (uint64_t(2) << 30) / ((uint64_t)F * 4)));
-  constexpr size_t kPieces = 3;
+  constexpr size_t kPieces = 6;   // one being read, one on the GPU, up to four whose header lines the writer still needs
   std::deque<Piece> pieces(kPieces);
   Channel<Piece *> free_q, ready_q;
   for (auto &pc : pieces) free_q.push(&pc);
@@ -846,20 +848,43 @@ void Index::stream_lines(const std::string &filestr, bool insert) {
   std::deque<Hits> results(4);
   for (auto &r : results) out_free.push(&r);
   std::string writer_err;
+  auto drop_ref = [&](Piece *pc) {
+    if (pc->refs.fetch_sub(1) == 1) free_q.push(pc);   // the last user hands the piece back to the reader
+  };
   std::thread writer([&] {
     for (;;) {
       Hits *h = out_q.pop();
       if (!h) return;
-      try { if (writer_err.empty()) write_hits(*h); } catch (const std::exception &e) { writer_err = e.what(); }
+      try {
+        if (h->keep) {   // the names: the header lines of the entries, cut out here instead of on the GPU thread
+          h->names.clear();
+          h->names.reserve(h->name_at.size());
+          for (uint64_t at : h->name_at) {
+            const uint8_t *b = h->name_base + at;
+            const uint8_t *nl = (const uint8_t *)memchr(b, '\n', h->name_room - at);
+            h->names.emplace_back((const char *)b, nl ? (size_t)(nl - b) : (size_t)(h->name_room - at));
+          }
+        }
+        if (writer_err.empty()) write_hits(*h);
+      } catch (const std::exception &e) { writer_err = e.what(); }
+      if (h->keep) {
+        Piece *pc = (Piece *)h->keep;
+        h->keep = nullptr;
+        drop_ref(pc);
+      }
       out_free.push(h);
     }
   });
 
   std::string err;
   std::vector<uint64_t> hdr(max_entries);
+  double t_piece = 0, t_frame = 0, t_names = 0, t_engine = 0, t_slot = 0;   // NIQKI_HOST_TIMING: where this thread's time goes
   try {
     for (bool last = false; !last;) {
+      Lap lap;
       Piece *pc = ready_q.pop();
+      pc->refs.store(1);
+      lap.to(t_piece);
       last = pc->last;
       if (!pc->err.empty()) throw std::runtime_error(pc->err);
       size_t at = 0;
@@ -931,32 +956,41 @@ void Index::stream_lines(const std::string &filestr, bool insert) {
         rb.final = 1;  // pieces hold whole records
         rb.max_entries = max_entries;
         niqki_stage_info info{};
+        Lap lap2;
         check(niqki_stage_raw(h_, &rb, NIQKI_MEM_HOST, &info, hdr.data()), "niqki_stage_raw");
+        lap2.to(t_frame);
         n_entries_total += info.n_entry;
         if (info.n_entry) {
           Hits *h = insert ? nullptr : out_free.pop();
-          std::vector<std::string> local;
-          std::vector<std::string> &names = h ? h->names : local;
-          names.clear();
+          lap2.to(t_slot);
           const uint8_t *base = pc->buf.p + at;
           const size_t left = pc->buf.size - at;
-          for (uint32_t e = 0; e < info.n_entry; ++e) {
-            const uint8_t *b = base + hdr[e];
-            const uint8_t *nl = (const uint8_t *)memchr(b, '\n', left - hdr[e]);
-            names.emplace_back((const char *)b, nl ? (size_t)(nl - b) : (size_t)(left - hdr[e]));
-          }
           if (insert) {
+            for (uint32_t e = 0; e < info.n_entry; ++e) {
+              const uint8_t *b = base + hdr[e];
+              const uint8_t *nl = (const uint8_t *)memchr(b, '\n', left - hdr[e]);
+              filenames.emplace_back((const char *)b, nl ? (size_t)(nl - b) : (size_t)(left - hdr[e]));
+            }
+            lap2.to(t_names);
             check(niqki_staged_insert(h_), "niqki_staged_insert");
-            for (auto &nm : names) filenames.push_back(nm);
           } else {
-            try { query_staged(info.n_entry, *h); } catch (...) { out_free.push(h); throw; }
+            // the writer thread cuts the names out of the piece (it stays alive until then: Piece::refs)
+            h->names.clear();
+            h->name_base = base;
+            h->name_room = left;
+            h->name_at.assign(hdr.begin(), hdr.begin() + info.n_entry);
+            h->keep = pc;
+            pc->refs.fetch_add(1);
+            lap2.to(t_names);
+            try { query_staged(info.n_entry, *h); } catch (...) { h->keep = nullptr; pc->refs.fetch_sub(1); out_free.push(h); throw; }
             out_q.push(h);
           }
+          lap2.to(t_engine);
         }
         if (info.consumed == 0 && info.n_entry == 0) break;  // nothing but a header without end
         at += info.consumed;
       } while (at < pc->buf.size);
-      free_q.push(pc);
+      drop_ref(pc);
     }
   } catch (const std::exception &e) {
     err = e.what();
@@ -969,7 +1003,9 @@ void Index::stream_lines(const std::string &filestr, bool insert) {
   if (!writer_err.empty()) throw std::runtime_error(writer_err);
   if (std::getenv("NIQKI_HOST_TIMING"))
     std::cerr << "[niqki timing] lines mode: " << n_entries_total << " entries in "
-              << std::chrono::duration<double>(clk::now() - t_begin).count() << " s" << std::endl;
+              << std::chrono::duration<double>(clk::now() - t_begin).count() << " s (this thread: waiting for file bytes " << t_piece
+              << ", copy + frame " << t_frame << ", names " << t_names << ", sketch + insert/query " << t_engine
+              << ", waiting for the writer " << t_slot << ")" << std::endl;
 }
 
 void Index::insert_file_lines(const std::string &filestr) { stream_lines(filestr, true); }

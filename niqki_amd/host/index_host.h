@@ -68,6 +68,12 @@ class Index {
     std::vector<std::string> names;
     std::vector<uint64_t> off;
     std::vector<uint32_t> hc, hg;
+    // lines mode: the names are header lines of a piece of the input that stays alive until the WRITER thread has
+    // taken them (name e = the line at name_base + name_at[e]); `keep` is that piece
+    const uint8_t *name_base = nullptr;
+    size_t name_room = 0;
+    std::vector<uint64_t> name_at;
+    void *keep = nullptr;
   };
   void query_staged(size_t n, Hits &h);
   void write_hits(const Hits &h);
