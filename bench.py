@@ -1242,7 +1242,7 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
         if gz:
             cmd.append("--gz")
         else:
-            cmd += ["--reference", "128"]
+            cmd += ["--reference", "128", "--reads", "4000000"]
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
             j = json.loads(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else None
@@ -1257,6 +1257,10 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
                         "packed_fasta": "plain FASTA files travel as 2 bits per base in full A/C/G/T lines (niqki_pack_fasta, "
                                         "made by the reader threads while they read); the device restores the files' bytes" if not gz else None,
                         "query_phase_split_s": j.get("query_phase_split_s")}
+            if j.get("reads_per_s"):
+                # BASELINE configs[4] as FILES: `niqki -I fof -l reads.fa -S 12 -W 10` (--querylines: one entry per record),
+                # 4 M 150-base reads in a FASTA file in the page cache, the lines phase's own clock
+                cli[tag]["lines_mode_reads_per_s"] = j["reads_per_s"]
             if j.get("reference_program"):
                 # the reference's OWN program on the first files: its CPU path, and the same binary with its three
                 # operators bound to the C ABI (oracle/ref_gpu_ops.cpp) -- what INTEGRATION.md's minimal patch gives
