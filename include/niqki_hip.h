@@ -71,7 +71,9 @@ enum niqki_status {
   NIQKI_E_HIP = 3,         /* a HIP runtime call failed; see niqki_last_error */
   NIQKI_E_CAPACITY = 4,    /* caller buffer too small; sizes were still reported */
   NIQKI_E_STATE = 5,       /* call not valid in the handle's current state */
-  NIQKI_E_NODEVICE = 6     /* no usable gfx950 device */
+  NIQKI_E_NODEVICE = 6,    /* no usable gfx950 device */
+  NIQKI_E_GZIP = 7         /* niqki_stage_raw: a file flagged NIQKI_FILE_GZIP is not a plain intact gzip file of the
+                              size its trailer states (see niqki_raw_batch.file_status); nothing was staged */
 };
 
 enum niqki_mem { NIQKI_MEM_HOST = 0, NIQKI_MEM_DEVICE = 1 };
@@ -303,14 +305,30 @@ typedef struct niqki_raw_batch {
   const uint8_t *file_type;  /* HOST array, n_files: 'A' FASTA / 'Q' FASTQ (get_data_type, :944-952); 'a' = a FASTA
                                 file handed over as the container niqki_pack_fasta made of it (host memory space, the
                                 file_ptr form, whole mode): 2 bits per base across PCIe, the device writes the file's
-                                own bytes back before it frames them -- same results as 'A' on the file itself */
+                                own bytes back before it frames them -- same results as 'A' on the file itself;
+                                'A' | NIQKI_FILE_GZIP, 'Q' | NIQKI_FILE_GZIP = the file as it lies on disk, gzip'd (host
+                                memory space, the file_ptr form, whole mode): inflated on the device, see below */
   uint32_t n_files;
   uint32_t lines;            /* 0: one sketch per file (whole mode); 1: one sketch per record longer
                                 than K (lines mode, n_files must be 1) */
   uint32_t final;            /* lines mode: raw reaches the end of the file; otherwise the last
                                 (possibly incomplete) record is left for the next call */
   uint32_t max_entries;      /* lines mode: stop after this many sketches */
+  uint8_t *file_status;      /* optional HOST array, n_files, written when the call returns NIQKI_E_GZIP: 0, or why the
+                                device would not inflate gzip file f (1..13, nq_kernels.h InflateJob) */
 } niqki_raw_batch;
+
+/* Gzip files inflated on the device.  The reference reads every input through zstr::ifstream (src/zstr.hpp:190-203,
+ * :236-239: gzip by magic, zlib member after member); a file flagged NIQKI_FILE_GZIP crosses PCIe as it lies on disk
+ * (a quarter of its FASTA bytes) and one wavefront per file writes its bytes where the framing expects them.  The
+ * device takes what is plainly a gzip file: members that inflate without any irregularity, CRC-32 and ISIZE of every
+ * member right, the whole file exactly as long as its last four bytes say (so: one member, the usual case, or
+ * several whose sizes add up to the last one's -- never).  For anything else -- damaged or truncated streams,
+ * concatenated members, bytes behind the last member, sizes of 2 GiB and more -- niqki_stage_raw stages nothing,
+ * returns NIQKI_E_GZIP and names the files in file_status; the caller inflates those itself (zlib decides what they
+ * yield, as before) and hands them over as 'A' / 'Q'.  The kernel is at least as strict as zlib's inflate, so a file
+ * it accepts has zlib's bytes. */
+#define NIQKI_FILE_GZIP 0x80
 
 typedef struct niqki_stage_info {
   uint32_t n_entry;    /* sketches the staged batch produces */

@@ -106,7 +106,8 @@ enum niqki_kernel_class {
   NIQKI_KC_BUILD = 4,    /* insert transpose + CSR build */
   NIQKI_KC_INGEST = 5,   /* FASTA / FASTQ framing */
   NIQKI_KC_EXCHANGE = 6, /* slot-shard exchange: slice packing, candidate kernels, collectives */
-  NIQKI_KC_COUNT = 7
+  NIQKI_KC_INFLATE = 7,  /* gzip members inflated on the device */
+  NIQKI_KC_COUNT = 8
 };
 
 /* When enabled, every launch of the classes above is bracketed by HIP events
@@ -147,6 +148,15 @@ int niqki_synth_reads(niqki_index *ix, uint64_t seed, const uint32_t *family, co
  * LDS round-trip ceiling of src/niqki_index.cpp:313-331 on this device).
  * *rate = adds / multiplies / k-mers / instructions / bytes / passes per second over ~ms milliseconds. */
 int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate);
+
+/* The device inflate alone (what niqki_stage_raw does with NIQKI_FILE_GZIP files; nq_inflate.hip), for tests and
+ * rates: gzip file f = HOST bytes gz[gz_off[f], gz_off[f+1]); its bytes are expected to be exactly
+ * raw_off[f+1] - raw_off[f] long and come back in HOST raw[raw_off[f] ..) (raw == NULL: they stay on the device).
+ * status[f] = 0 or why the file was not taken (1..12, nq_kernels.h InflateJob), produced[f] = bytes written (never
+ * more than expected), members[f] = members completed; the three may be NULL.  *outside (may be NULL) = bytes of the
+ * output buffer outside the files' own ranges that differ from the pattern it was filled with (must be 0). */
+int niqki_gunzip(niqki_index *ix, const uint8_t *gz, const uint64_t *gz_off, uint32_t n_files, const uint64_t *raw_off,
+                 uint8_t *raw, uint32_t *status, uint64_t *produced, uint32_t *members, uint64_t *outside);
 
 
 #ifdef __cplusplus

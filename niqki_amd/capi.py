@@ -14,7 +14,9 @@ _LIB = os.path.join(_HERE, "lib", "libniqki_hip.so")
 
 MEM_HOST, MEM_DEVICE = 0, 1
 SEQ_PAD = 64
-KC_SKETCH, KC_DENSIFY, KC_GATHER, KC_HITS, KC_BUILD, KC_INGEST, KC_EXCHANGE = 0, 1, 2, 3, 4, 5, 6
+KC_SKETCH, KC_DENSIFY, KC_GATHER, KC_HITS, KC_BUILD, KC_INGEST, KC_EXCHANGE, KC_INFLATE = 0, 1, 2, 3, 4, 5, 6, 7
+E_GZIP = 7
+FILE_GZIP = 0x80
 GROUP_ID_BYTES = 128
 E_CAPACITY = 4
 
@@ -35,7 +37,7 @@ class Params(C.Structure):
 class RawBatch(C.Structure):
     _fields_ = [("raw", C.c_void_p), ("file_ptr", C.c_void_p), ("file_off", C.c_void_p), ("file_type", C.c_void_p),
                 ("n_files", C.c_uint32), ("lines", C.c_uint32), ("final", C.c_uint32),
-                ("max_entries", C.c_uint32)]
+                ("max_entries", C.c_uint32), ("file_status", C.c_void_p)]
 
 
 class GroupPlan(C.Structure):
@@ -142,6 +144,7 @@ ABI = [
     ("niqki_synth_genome_host", None, [_u64, _u32, _u32, _u32, _u64, _vp]),
     ("niqki_synth_reads", _int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _vp, _int]),
     ("niqki_measure_alu", _int, [_vp, _int, _dbl, C.POINTER(_dbl)]),
+    ("niqki_gunzip", _int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
 ]
 
 _lib = None
@@ -439,9 +442,10 @@ class Engine:
         off = np.zeros(len(blobs) + 1, dtype=np.uint64)
         off[1:] = np.cumsum([b.size for b in blobs], dtype=np.uint64)
         raw = np.concatenate(blobs + [np.zeros(0, np.uint8)]) if blobs else np.zeros(0, np.uint8)
-        ty = np.frombuffer(("".join(types) if types else "A" * len(blobs)).encode(), dtype=np.uint8).copy()
+        ty = np.array([ord(t) if isinstance(t, str) else int(t) for t in (types if types else "A" * len(blobs))], dtype=np.uint8)
         if ty.size == 0:
             ty = np.zeros(1, np.uint8)
+        self.file_status = np.zeros(max(len(blobs), 1), dtype=np.uint8)   # (why a gzip file was refused, after E_GZIP)
         ptrs = None
         if prefetch == "take":      # the buffers an earlier prefetch="only" call handed over
             keep, ptrs, off, ty = self._pre_keep
@@ -449,7 +453,7 @@ class Engine:
             keep = [np.ascontiguousarray(x).copy() for x in blobs]
             ptrs = (C.c_void_p * max(len(keep), 1))(*[k.ctypes.data for k in keep])
         b = RawBatch(None if scattered or not raw.size else _p(raw), C.cast(ptrs, C.c_void_p) if scattered else None,
-                     _p(off), _p(ty), len(blobs), int(bool(lines)), int(bool(final)), max_entries)
+                     _p(off), _p(ty), len(blobs), int(bool(lines)), int(bool(final)), max_entries, _p(self.file_status))
         info = StageInfo()
         hdr = np.zeros(max(max_entries, 1), dtype=np.uint64)
         if prefetch in ("this", "only"):
@@ -460,6 +464,24 @@ class Engine:
         self._ck(self.L.niqki_stage_raw(self.h, C.byref(b), MEM_HOST, C.byref(info), _p(hdr) if lines else None))
         self._staged = info
         return info, hdr[:info.n_entry] if lines else None
+
+    def gunzip(self, files, sizes, check_outside=True):
+        """The device inflate alone (niqki_gunzip): files = gzip files as bytes, sizes = the length each is expected
+        to inflate to.  Returns (list of bytes, status, produced, members, outside)."""
+        blobs = [np.frombuffer(bytes(f), dtype=np.uint8) for f in files]
+        goff = np.zeros(len(blobs) + 1, dtype=np.uint64)
+        goff[1:] = np.cumsum([b.size for b in blobs], dtype=np.uint64)
+        roff = np.zeros(len(blobs) + 1, dtype=np.uint64)
+        roff[1:] = np.cumsum(list(sizes), dtype=np.uint64)
+        gz = np.concatenate(blobs + [np.zeros(8, np.uint8)])
+        raw = np.zeros(int(roff[-1]) + 8, dtype=np.uint8)
+        n = len(blobs)
+        status, produced, members = np.zeros(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint32)
+        outside = C.c_uint64(0)
+        self._ck(self.L.niqki_gunzip(self.h, _p(gz), _p(goff), n, _p(roff), _p(raw), _p(status), _p(produced), _p(members),
+                                     C.byref(outside) if check_outside else None))
+        out = [raw[int(roff[i]):int(roff[i]) + int(min(produced[i], roff[i + 1] - roff[i]))].tobytes() for i in range(n)]
+        return out, status[:n], produced[:n], members[:n], int(outside.value)
 
     def staged_records(self):
         """(records as list of bytes, entry_rec, hdr_pos) of the staged batch."""

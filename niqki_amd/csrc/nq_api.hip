@@ -181,6 +181,7 @@ const char *niqki_status_string(int s) {
     case NIQKI_E_CAPACITY: return "output capacity too small";
     case NIQKI_E_STATE: return "invalid state";
     case NIQKI_E_NODEVICE: return "no gfx950 device";
+    case NIQKI_E_GZIP: return "gzip file not taken by the device inflate";
     default: return "unknown status";
   }
 }
@@ -270,7 +271,7 @@ void niqki_destroy(niqki_index *ix) {
   for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
                  &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash,
                  &ix->ws_raw, &ix->ws_raw2, &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
-                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order, &ix->ws_pre, &ix->ws_hl, &ix->ws_useg})
+                 &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order, &ix->ws_pre, &ix->ws_hl, &ix->ws_useg, &ix->ws_ijob, &ix->ws_xtab})
     if (b->p) (void)hipFree(b->p);
   for (Buf *b : {&ix->pg_store, &ix->pg_stage})
     if (b->p) (void)hipFree(b->p);

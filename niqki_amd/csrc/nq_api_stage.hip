@@ -26,6 +26,30 @@ int staged_sketch_ws(niqki_index *ix) {
   return NIQKI_OK;
 }
 
+// The gzip files of a batch through the device inflate (nq_inflate.hip): job j reads d_wire[src, src + src_len) and
+// writes d_raw[dst, dst + cap).  Asynchronous on ix->stream; the results (nq::InflateOut per job) lie in ix->ws_ijob
+// behind the jobs.
+int inflate_launch(niqki_index *ix, const std::vector<nq::InflateJob> &jobs, const uint8_t *d_wire, uint64_t wire_bytes,
+                   uint8_t *d_raw) {
+  if (jobs.empty()) return NIQKI_OK;
+  int rc;
+  if (!ix->xtab_ok) {
+    if ((rc = ensure(ix, ix->ws_xtab, nq::kInflateXtabWords * 4))) return rc;
+    uint32_t t[nq::kInflateXtabWords];
+    nq::inflate_xtab(t);
+    NQ_HIP(ix, hipMemcpyAsync(ix->ws_xtab.p, t, sizeof t, hipMemcpyHostToDevice, ix->stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->stream));   // (t is a local)
+    ix->xtab_ok = true;
+  }
+  const size_t n = jobs.size();
+  if ((rc = ensure(ix, ix->ws_ijob, n * (sizeof(nq::InflateJob) + sizeof(nq::InflateOut))))) return rc;
+  NQ_HIP(ix, hipMemcpyAsync(ix->ws_ijob.p, jobs.data(), n * sizeof(nq::InflateJob), hipMemcpyHostToDevice, ix->stream));
+  Span sp(ix, NIQKI_KC_INFLATE);
+  NQ_HIP(ix, nq::launch_inflate((const nq::InflateJob *)ix->ws_ijob.p, (uint32_t)n, d_wire, wire_bytes, d_raw,
+                                (const uint32_t *)ix->ws_xtab.p, (nq::InflateOut *)((nq::InflateJob *)ix->ws_ijob.p + n), ix->stream));
+  return NIQKI_OK;
+}
+
 }  // namespace nqi
 
 using namespace nqi;
@@ -76,10 +100,19 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   if (b->file_ptr && mem != NIQKI_MEM_HOST) return fail(ix, NIQKI_E_INVALID, "file_ptr needs the host memory space");
   // Packed FASTA files (file_type 'a': a container of niqki_pack_fasta): the device writes the file's own bytes back
   // first (nq::unpack_kernel), so everything from here on sees raw files at their raw offsets.
-  bool any_packed = false;
-  for (uint32_t f = 0; f < nf; ++f) any_packed |= b->file_type[f] == 'a';
-  if (any_packed && (mem != NIQKI_MEM_HOST || !b->file_ptr || b->lines))
-    return fail(ix, NIQKI_E_INVALID, "packed files (type 'a'): host memory, the file_ptr form, whole-file mode");
+  // Gzip files (NIQKI_FILE_GZIP): the device inflates them (nq::inflate_kernel) to the size their trailers announce.
+  bool any_packed = false, any_gz = false;
+  for (uint32_t f = 0; f < nf; ++f) {
+    any_packed |= b->file_type[f] == 'a';
+    any_gz |= (b->file_type[f] & NIQKI_FILE_GZIP) != 0;
+  }
+  const bool any_wire = any_packed || any_gz;   // some files' bytes are not what crosses PCIe
+  if (any_wire && (mem != NIQKI_MEM_HOST || !b->file_ptr || b->lines))
+    return fail(ix, NIQKI_E_INVALID, "packed (type 'a') and gzip (NIQKI_FILE_GZIP) files: host memory, the file_ptr form, whole-file mode");
+  std::vector<nq::InflateJob> jobs;
+  std::vector<uint32_t> job_file;
+  bool gz_refused = false;
+  if (any_gz && b->file_status) std::memset(b->file_status, 0, nf);
   std::vector<uint64_t> roff((size_t)nf + 1, 0);   // raw offsets of the files
   std::vector<nq::UnpackSeg> segs;
   uint64_t unpack_blocks = 0;
@@ -99,7 +132,22 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
         segs.push_back(nq::UnpackSeg{roff[f] + ps.raw_off, b->file_off[f] + h.payload_off + ps.pk_off, ps.count, ps.width, (uint32_t)unpack_blocks, 0u});
         unpack_blocks += (nqp::seg_raw_len(ps) + nq::kUnpackChunk - 1) / nq::kUnpackChunk;
       }
-    } else if (any_packed && wire_len) {   // a raw file in a batch with packed ones: one raw segment
+    } else if (b->file_type[f] & NIQKI_FILE_GZIP) {
+      // the size the file announces: its last four bytes (ISIZE of the last member, RFC 1952)
+      const uint8_t *c = b->file_ptr[f];
+      uint64_t isize = 0;
+      if (c && wire_len >= 18) isize = (uint64_t)c[wire_len - 4] | (uint64_t)c[wire_len - 3] << 8 | (uint64_t)c[wire_len - 2] << 16 | (uint64_t)c[wire_len - 1] << 24;
+      // not plausibly one plain member (DEFLATE cannot exceed 1032 : 1; FASTA and FASTQ stay below 10 : 1): the host's turn
+      if (!c || wire_len < 18 || wire_len > 0x7FFF0000ull || isize > 0x7FFF0000ull || isize > wire_len * 64u || isize * 4096u < wire_len) {
+        if (b->file_status) b->file_status[f] = 13;
+        gz_refused = true;
+        isize = 0;
+      } else {
+        jobs.push_back(nq::InflateJob{b->file_off[f], wire_len, roff[f], isize});
+        job_file.push_back(f);
+      }
+      raw_len = isize;
+    } else if (any_wire && wire_len) {   // a raw file in a batch with packed or gzip'd ones: one raw segment
       if (wire_len > 0xFFFFFFFFull) return fail(ix, NIQKI_E_INVALID, "a raw file of 4 GiB or more cannot share a batch with packed files");
       segs.push_back(nq::UnpackSeg{roff[f], b->file_off[f], (uint32_t)wire_len, 0u, (uint32_t)unpack_blocks, 0u});
       unpack_blocks += (wire_len + nq::kUnpackChunk - 1) / nq::kUnpackChunk;
@@ -107,6 +155,7 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
     roff[f + 1] = roff[f] + raw_len;
   }
   if (unpack_blocks > 0x7FFFFFFFull) return fail(ix, NIQKI_E_INVALID, "raw batch too large");
+  if (gz_refused) return fail(ix, NIQKI_E_GZIP, "gzip files whose trailers do not announce a plausible size (file_status)");
   const uint64_t T_raw = roff[nf];
   // chunk table: chunks never span two files
   std::vector<uint8_t> meta((size_t)(nf + 1) * 12 + nf + 16);
@@ -115,8 +164,8 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   uint8_t *h_type = meta.data() + (size_t)(nf + 1) * 12;
   uint64_t chunks = 0;
   for (uint32_t f = 0; f < nf; ++f) {
-    const uint8_t ty = b->file_type[f] == 'a' ? (uint8_t)'A' : b->file_type[f];
-    if (ty != 'A' && ty != 'Q') return fail(ix, NIQKI_E_INVALID, "file_type must be 'A', 'Q' or 'a' (packed FASTA)");
+    const uint8_t ty = b->file_type[f] == 'a' ? (uint8_t)'A' : (uint8_t)(b->file_type[f] & ~NIQKI_FILE_GZIP);
+    if (ty != 'A' && ty != 'Q') return fail(ix, NIQKI_E_INVALID, "file_type must be 'A', 'Q', 'a' (packed FASTA) or one of the first two | NIQKI_FILE_GZIP");
     h_off[f] = roff[f];
     h_first[f] = (uint32_t)chunks;
     h_type[f] = ty;
@@ -134,14 +183,14 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
                  std::equal(ix->pre.off.begin(), ix->pre.off.end(), b->file_off);
     ix->pre.valid = false;
     if (prefetched) {
-      if (!any_packed) std::swap(ix->ws_raw, ix->ws_raw2);   // (packed: ws_raw2 stays the wire buffer, unpacked below)
+      if (!any_wire) std::swap(ix->ws_raw, ix->ws_raw2);   // (packed / gzip: ws_raw2 stays the wire buffer, unpacked below)
       NQ_HIP(ix, hipStreamWaitEvent(ix->stream, ix->ev_copy, 0));
       d_raw = (const uint8_t *)ix->ws_raw.p;
     } else {
       NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream));
     }
   }
-  if (any_packed) {
+  if (any_wire) {
     if (!prefetched) {   // the containers (and raw files) as they are, into the wire buffer
       if ((rc = ensure(ix, ix->ws_raw2, (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
       for (uint32_t f = 0; f < nf; ++f) {
@@ -157,6 +206,7 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
       NQ_HIP(ix, nq::launch_unpack((const nq::UnpackSeg *)ix->ws_useg.p, (uint32_t)segs.size(), (uint32_t)unpack_blocks,
                                    (const uint8_t *)ix->ws_raw2.p, (uint8_t *)ix->ws_raw.p, ix->stream));
     }
+    if ((rc = inflate_launch(ix, jobs, (const uint8_t *)ix->ws_raw2.p, (uint64_t)ix->ws_raw2.n & ~(uint64_t)3, (uint8_t *)ix->ws_raw.p))) return rc;
     d_raw = (const uint8_t *)ix->ws_raw.p;
   } else if (prefetched) {
   } else if (mem == NIQKI_MEM_HOST) {
@@ -201,7 +251,20 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
     NQ_HIP(ix, nq::launch_ingest_scan(a, ix->stream));
   }
   NQ_HIP(ix, hipMemcpyAsync(totals, a.totals, 16, hipMemcpyDeviceToHost, ix->stream));
+  std::vector<nq::InflateOut> iout(jobs.size());
+  if (!jobs.empty())
+    NQ_HIP(ix, hipMemcpyAsync(iout.data(), (const nq::InflateJob *)ix->ws_ijob.p + jobs.size(), jobs.size() * sizeof(nq::InflateOut),
+                              hipMemcpyDeviceToHost, ix->stream));
   NQ_HIP(ix, hipStreamSynchronize(ix->stream));  // also: `meta` and the caller's raw bytes are consumed
+  {
+    uint32_t bad = 0;
+    for (size_t j = 0; j < jobs.size(); ++j)
+      if (iout[j].status) {
+        if (b->file_status) b->file_status[job_file[j]] = (uint8_t)iout[j].status;
+        ++bad;
+      }
+    if (bad) return fail(ix, NIQKI_E_GZIP, std::to_string(bad) + " gzip file(s) not taken by the device inflate (file_status)");
+  }
   if (totals[0] > 0xFFFFFFF0ull) return fail(ix, NIQKI_E_INVALID, "too many records in one batch");
   const uint32_t n_rec = (uint32_t)totals[0];
   const uint64_t kept = totals[1];
@@ -297,6 +360,59 @@ int niqki_staged_records(niqki_index *ix, uint64_t *rec_off, uint8_t *seqs, uint
   if (entry_rec) NQ_HIP(ix, hipMemcpyAsync(entry_rec, st.entry_rec, (size_t)(st.n_entry + 1) * 4, hipMemcpyDeviceToHost, ix->stream));
   if (hdr_pos && st.n_rec) NQ_HIP(ix, hipMemcpyAsync(hdr_pos, ix->ws_hdrpos.p, (size_t)st.n_rec * 8, hipMemcpyDeviceToHost, ix->stream));
   NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  return NIQKI_OK;
+}
+
+int niqki_gunzip(niqki_index *ix, const uint8_t *gz, const uint64_t *gz_off, uint32_t n_files, const uint64_t *raw_off,
+                 uint8_t *raw, uint32_t *status, uint64_t *produced, uint32_t *members, uint64_t *outside) {
+  if (!ix || !gz || !gz_off || !raw_off) return NIQKI_E_INVALID;
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  ix->staged.valid = false;   // (shares the staging buffers)
+  if (ix->pre.valid) { NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream)); ix->pre.valid = false; }
+  if (n_files == 0) return NIQKI_OK;
+  std::vector<nq::InflateJob> jobs(n_files);
+  for (uint32_t f = 0; f < n_files; ++f) {
+    if (gz_off[f + 1] < gz_off[f] || raw_off[f + 1] < raw_off[f]) return fail(ix, NIQKI_E_INVALID, "offsets must be non-decreasing");
+    jobs[f] = nq::InflateJob{gz_off[f], gz_off[f + 1] - gz_off[f], raw_off[f], raw_off[f + 1] - raw_off[f]};
+  }
+  const uint64_t T = gz_off[n_files], T_raw = raw_off[n_files];
+  int rc;
+  if ((rc = ensure(ix, ix->ws_raw2, (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
+  if ((rc = ensure(ix, ix->ws_raw, (size_t)T_raw + 2 * NIQKI_SEQ_PAD))) return rc;
+  if (T > gz_off[0]) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_raw2.p + gz_off[0], gz + gz_off[0], T - gz_off[0], hipMemcpyHostToDevice, ix->stream));
+  NQ_HIP(ix, hipMemsetAsync(ix->ws_raw.p, 0xEE, (size_t)T_raw + 2 * NIQKI_SEQ_PAD, ix->stream));
+  if ((rc = inflate_launch(ix, jobs, (const uint8_t *)ix->ws_raw2.p, (uint64_t)ix->ws_raw2.n & ~(uint64_t)3, (uint8_t *)ix->ws_raw.p))) return rc;
+  std::vector<nq::InflateOut> out(n_files);
+  NQ_HIP(ix, hipMemcpyAsync(out.data(), (const nq::InflateJob *)ix->ws_ijob.p + n_files, (size_t)n_files * sizeof(nq::InflateOut),
+                            hipMemcpyDeviceToHost, ix->stream));
+  std::vector<uint8_t> whole;
+  if (outside) {
+    whole.resize((size_t)T_raw + 2 * NIQKI_SEQ_PAD);
+    NQ_HIP(ix, hipMemcpyAsync(whole.data(), ix->ws_raw.p, whole.size(), hipMemcpyDeviceToHost, ix->stream));
+  } else if (raw && T_raw > raw_off[0]) {
+    NQ_HIP(ix, hipMemcpyAsync(raw + raw_off[0], (const uint8_t *)ix->ws_raw.p + raw_off[0], T_raw - raw_off[0], hipMemcpyDeviceToHost, ix->stream));
+  }
+  NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  if (outside) {
+    // a file may only have written the first `produced` bytes of its own range
+    uint64_t diff = 0, at = 0;
+    for (uint32_t f = 0; f <= n_files; ++f) {
+      const uint64_t lo = f < n_files ? raw_off[f] : whole.size();
+      for (uint64_t i = at; i < lo; ++i) diff += whole[i] != 0xEE;
+      if (f < n_files) {
+        const uint64_t made = std::min<uint64_t>(out[f].produced, raw_off[f + 1] - raw_off[f]);
+        for (uint64_t i = raw_off[f] + made; i < raw_off[f + 1]; ++i) diff += whole[i] != 0xEE;
+        at = raw_off[f + 1];
+      }
+    }
+    *outside = diff;
+    if (raw && T_raw > raw_off[0]) std::memcpy(raw + raw_off[0], whole.data() + raw_off[0], T_raw - raw_off[0]);
+  }
+  for (uint32_t f = 0; f < n_files; ++f) {
+    if (status) status[f] = out[f].status;
+    if (produced) produced[f] = out[f].produced;
+    if (members) members[f] = out[f].members;
+  }
   return NIQKI_OK;
 }
 

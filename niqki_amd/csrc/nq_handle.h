@@ -108,7 +108,8 @@ struct niqki_index {
   nqi::Buf ws_seq, ws_recoff, ws_entry, ws_sk, ws_counts, ws_blk, ws_hitoff, ws_hc, ws_hg, ws_tc, ws_tg,
       ws_misc, ws_stash, ws_hl;
   // staged batch (niqki_stage_raw): framing results live in ws_seq / ws_recoff / ws_entry
-  nqi::Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk, ws_order, ws_pre, ws_useg;
+  nqi::Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk, ws_order, ws_pre, ws_useg, ws_ijob, ws_xtab;
+  bool xtab_ok = false;   // ws_xtab holds the CRC folding constants of the inflate kernel
   struct {
     bool valid = false, sketched = false;
     uint32_t n_entry = 0, n_rec = 0;

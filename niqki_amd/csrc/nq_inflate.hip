@@ -1,0 +1,584 @@
+// nq_inflate.hip -- gzip members inflated on the GPU, one wavefront per file.
+//
+// The reference opens every input through zstr::ifstream (src/zstr.hpp:190-203, :236-239: gzip is detected by its
+// magic and inflated by zlib, member after member) before Index::Biogetline frames the lines
+// (src/niqki_index.cpp:890-941); its example data (resources/*.fa.gz) and the genome collections it is run on are
+// gzip'd FASTA.  With the framing on the device (nq_ingest.hip) the inflate was the last per-byte stage left on the
+// host's cores; here a gzip file crosses PCIe as it is and this kernel writes its bytes where niqki_stage_raw's
+// framing kernels expect them.
+//
+// DEFLATE (RFC 1951) decodes one symbol after the other, so a file is a serial job: the parallelism is over the
+// files of a batch (one 64-lane wavefront each, four per CU) and, inside a wavefront, over the bytes of a match copy,
+// of a flush and of the table builds.  Everything the serial part touches is in LDS:
+//   ring      the 32 KB window; a byte leaves for HBM when its 4 KB page is complete (16-byte stores, CRC-32 of the
+//             page on the way: 64 lanes x 64 bytes, folded with the x^(8n) mod P operators of xtab)
+//   lit / dist tables   one look-up of 10 / 8 bits per symbol (codes that are longer take the canonical walk)
+// The decoder state (bit buffer, positions) is wave-uniform and lives in scalar registers; the next 256 input bytes
+// wait in one vector register (lane i = dword i, taken by v_readlane), the block after them is on its way.
+//
+// What is not a plain, intact gzip file of the announced size is not decided here: any irregularity ends the file's
+// job with a status != 0 and the caller (niqki_stage_raw) reports the file, which the host then reads through zlib
+// as before -- the kernel is at least as strict as zlib's inflate (RFC 1951 + zlib's inflate_table rules), so a file
+// it accepts has exactly zlib's bytes.  Every loop consumes input bits or ends; every store lies inside the job's
+// [dst, dst + cap) and every load inside the wire buffer, whatever the bytes say.
+#include "nq_kernels.h"
+
+namespace nq {
+
+namespace {
+
+constexpr uint32_t kRing = 32768, kRingMask = kRing - 1u;
+constexpr uint32_t kLitP = 10, kDistP = 8, kClP = 7;
+constexpr uint32_t kPage = 4096;
+constexpr uint32_t kKindLit = 0, kKindLen = 1, kKindEob = 2, kKindSlow = 3;
+constexpr uint32_t kSlow = kKindSlow << 5;
+
+__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// Table entries (0 = no such code):
+//   literal/length  bits 0-4 code length, 5-6 kind; literal: 8-15 the byte; length: 8-16 base, 17-19 extra bits
+//   distance        bits 0-4 code length, 5-6 kind (0 or slow); 8-22 base, 24-27 extra bits
+//   code lengths    bits 0-4 code length, 8-12 the symbol
+__device__ __forceinline__ uint32_t lit_entry(uint32_t sym, uint32_t l) {
+  if (sym < 256u) return l | (kKindLit << 5) | (sym << 8);
+  if (sym == 256u) return l | (kKindEob << 5);
+  if (sym < 286u) return l | (kKindLen << 5) | ((uint32_t)c_len_base[sym - 257u] << 8) | ((uint32_t)c_len_extra[sym - 257u] << 17);
+  return 0u;   // 286, 287: in the fixed code, never valid
+}
+__device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t l) {
+  if (sym < 30u) return l | ((uint32_t)c_dist_base[sym] << 8) | ((uint32_t)c_dist_extra[sym] << 24);
+  return 0u;   // 30, 31
+}
+template <int WHICH>
+__device__ __forceinline__ uint32_t make_entry(uint32_t sym, uint32_t l) {
+  return WHICH == 0 ? lit_entry(sym, l) : WHICH == 1 ? dist_entry(sym, l) : (l | (sym << 8));
+}
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// all LDS traffic of the wave so far is done and the compiler keeps the accesses on either side apart (one wave
+// per workgroup: the LDS serves its instructions in order)
+__device__ __forceinline__ void lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// a(x) * b(x) mod P in the reflected representation of CRC-32 (bit 31 = x^0), as zlib's multmodp
+__device__ __forceinline__ uint32_t mulmod(uint32_t a, uint32_t b) {
+  uint32_t p = 0;
+#pragma unroll 4
+  for (int i = 0; i < 32; ++i) {
+    p ^= (a & 0x80000000u) ? b : 0u;
+    a <<= 1;
+    b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
+  }
+  return p;
+}
+
+// Code lengths L[0..n) -> canonical-Huffman decoding data: cnt / first / offs per length, the symbols ordered by
+// (length, symbol) in `sorted`, and the table of 2^P entries indexed by the next P stream bits.  false: the lengths
+// are over-subscribed, or incomplete in a way zlib's inflate_table refuses.
+template <int WHICH, uint32_t P>
+__device__ bool build_table(const uint8_t *L, uint32_t n, uint32_t *tab, uint16_t *sorted, uint32_t *cnt, uint32_t *first,
+                            uint32_t *offs, uint32_t *run, uint32_t lane) {
+  if (lane < 16u) cnt[lane] = 0u;
+  lds_fence();
+  for (uint32_t s = lane; s < n; s += 64u) {
+    const uint32_t l = L[s];
+    if (l) atomicAdd(&cnt[l], 1u);
+  }
+  lds_fence();
+  // (every lane walks the 15 lengths: the same values everywhere)
+  uint32_t code = 0, at = 0, maxl = 0;
+  int32_t left = 1;
+  bool over = false;
+  for (uint32_t l = 1; l <= 15u; ++l) {
+    const uint32_t c = cnt[l];
+    code <<= 1;
+    left <<= 1;
+    left -= (int32_t)c;
+    over |= left < 0;
+    if (lane == 0u) { first[l] = code; offs[l] = at; run[l] = at; }
+    code += c;
+    at += c;
+    if (c) maxl = l;
+  }
+  if (over) return false;
+  if (left > 0 && (WHICH == 2 || maxl != 1u)) return false;   // zlib: an incomplete set only as one 1-bit code
+  if (WHICH == 2 && maxl == 0u) return false;
+  lds_fence();
+  // symbols in (length, symbol) order: rank among the symbols of the same length by ballots
+  for (uint32_t s0 = 0; s0 < n; s0 += 64u) {
+    const uint32_t s = s0 + lane;
+    const uint32_t l = s < n ? L[s] : 0u;
+    uint64_t pending = __ballot(l != 0u);
+    while (pending) {
+      const uint32_t src = (uint32_t)__builtin_ctzll(pending);
+      const uint32_t ll = (uint32_t)__builtin_amdgcn_readlane((int)l, (int)src);
+      const uint64_t m = __ballot(l == ll);
+      const uint32_t base = run[ll];
+      if (l == ll) sorted[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)s;
+      lds_fence();
+      if (lane == 0u) run[ll] = base + (uint32_t)__popcll(m);
+      lds_fence();
+      pending &= ~m;
+    }
+  }
+  // the table, one entry per lane and round: the canonical walk over the entry's own index bits
+  for (uint32_t i = lane; i < (1u << P); i += 64u) {
+    uint32_t e = kSlow, c2 = 0;
+    for (uint32_t l = 1; l <= P; ++l) {
+      c2 = (c2 << 1) | ((i >> (l - 1u)) & 1u);
+      const uint32_t idx = c2 - first[l];
+      if (idx < cnt[l]) {
+        e = make_entry<WHICH>(sorted[offs[l] + idx], l);
+        break;
+      }
+    }
+    tab[i] = e;
+  }
+  lds_fence();
+  return true;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, const uint8_t *wire, uint64_t wire_bytes,
+                                                     uint8_t *raw, const uint32_t *xtab, InflateOut *outs) {
+  __shared__ __align__(16) uint8_t ring[kRing];
+  __shared__ uint32_t lit_tab[1u << kLitP];
+  __shared__ uint32_t dist_tab[1u << kDistP];
+  __shared__ uint32_t crc_tab[256];
+  __shared__ uint16_t lit_sorted[288];
+  __shared__ uint16_t dist_sorted[32];
+  __shared__ uint8_t lens[320];
+  __shared__ uint8_t cl_lens[32];
+  __shared__ uint32_t hc[2][3][16];   // [lit, dist][cnt, first, offs]
+  __shared__ uint32_t run[16];
+
+  const uint32_t lane = threadIdx.x;
+  const InflateJob job = jobs[blockIdx.x];
+  InflateOut res;
+  res.status = 0; res.members = 0; res.produced = 0; res.consumed = 0;
+
+  // CRC-32 byte table (reflected, polynomial 0xEDB88320)
+  for (uint32_t i = lane; i < 256u; i += 64u) {
+    uint32_t c = i;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
+    crc_tab[i] = c;
+  }
+  lds_fence();
+
+  // ---- input: dwords from the wire buffer, 64 at a time in a vector register; the next 160 bits in five scalars ----
+  const uint64_t in_addr = job.src;                           // byte offset of the file in `wire`
+  const uint32_t skip = (uint32_t)(in_addr & 3u);             // bytes of the first dword that precede the file
+  const uint32_t *in_base = (const uint32_t *)(wire + (in_addr - skip));
+  const uint64_t last_dword = ((wire_bytes + 3u) >> 2) - 1u - ((in_addr - skip) >> 2);   // last loadable dword, from in_base
+  const uint64_t n_words = (skip + job.src_len + 3u) >> 2;    // dwords that hold bytes of the file
+  const uint64_t total_bits = (skip + job.src_len) * 8u;
+  uint32_t err = 0;
+  uint32_t cur, nxt;
+  uint64_t blk = 0;       // 64-dword block held in cur
+  uint32_t wi = 0;        // next dword of cur
+  uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0;   // the window: the stream's next bit is bit `bo` of w0
+  uint32_t bo = 0;        // 0..31
+  auto load_blk = [&](uint64_t b) -> uint32_t {
+    uint64_t w = b * 64u + lane;
+    w = w > last_dword ? last_dword : w;
+    return in_base[w];
+  };
+  auto take32 = [&]() -> uint32_t {
+    if (blk * 64u + wi > n_words + 8u) { err = err ? err : 8u; return 0u; }   // far past the file: truncated
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)wi);
+    if (++wi == 64u) {
+      cur = nxt;
+      ++blk;
+      nxt = load_blk(blk + 1u);
+      wi = 0;
+    }
+    return w;
+  };
+  auto drop = [&](uint32_t n) {   // n <= 64
+    bo += n;
+    while (bo >= 32u) {
+      w0 = w1; w1 = w2; w2 = w3; w3 = w4;
+      w4 = take32();
+      bo -= 32u;
+    }
+  };
+  auto peek64 = [&]() -> uint64_t {
+    const uint64_t lo = (((uint64_t)w1 << 32) | w0) >> bo;
+    const uint64_t hi = ((uint64_t)w2 << 32) << (32u - bo);   // (bo = 0: shifted out entirely)
+    return lo | (bo ? hi : 0ull);
+  };
+  auto getbits = [&](uint32_t n) -> uint32_t {   // n <= 32
+    const uint32_t v = (uint32_t)(peek64() & ((1ull << n) - 1ull));
+    drop(n);
+    return v;
+  };
+  auto consumed_bits = [&]() -> uint64_t { return (blk * 64u + wi) * 32u - 160u + bo; };
+  auto seek_byte = [&](uint64_t byte_from_base) {   // (re)start the reader at a byte position counted from in_base
+    blk = byte_from_base >> 8;
+    cur = load_blk(blk);
+    nxt = load_blk(blk + 1u);
+    wi = (uint32_t)(byte_from_base & 255u) >> 2;
+    w0 = take32(); w1 = take32(); w2 = take32(); w3 = take32(); w4 = take32();
+    bo = 8u * (uint32_t)(byte_from_base & 3u);
+  };
+
+  // ---- output: positions count from pos0 = (dst & 15), so that ring index and HBM address agree modulo 16 ----
+  const uint32_t pos0 = (uint32_t)(job.dst & 15u);
+  uint8_t *out_al = raw + (job.dst - pos0);
+  const uint32_t cap_end = pos0 + (uint32_t)job.cap;
+  uint32_t pos = pos0, flushed = pos0, member_start = pos0;
+  uint32_t crc = 0;   // CRC-32 of the member's bytes below `flushed`
+
+  // bytes [lo, hi) of one 4 KB page of positions leave the ring: HBM stores, and the member's CRC moves on
+  auto flush = [&](uint32_t lo, uint32_t hi) {
+    lds_fence();
+    const uint32_t win = lo & ~(kPage - 1u);
+    const uint32_t b0 = win + lane * 64u;
+    const uint32_t a = lo > b0 ? lo : b0, b = hi < b0 + 64u ? hi : b0 + 64u;
+    uint32_t c = 0;
+    if (a < b) {
+      c = 0xFFFFFFFFu;
+      if (b - a == 64u) {
+        const uint4 *rp = (const uint4 *)(ring + (b0 & kRingMask));
+        uint4 *gp = (uint4 *)(out_al + b0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint4 v = rp[k];
+          gp[k] = v;
+          const uint32_t w4v[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            c ^= w4v[j];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) c = crc_tab[c & 0xFFu] ^ (c >> 8);
+          }
+        }
+      } else {
+        for (uint32_t p = a; p < b; ++p) {
+          const uint32_t v = ring[p & kRingMask];
+          out_al[p] = (uint8_t)v;
+          c = crc_tab[(c ^ v) & 0xFFu] ^ (c >> 8);
+        }
+      }
+      c = ~c;
+    }
+    // crc(A || B) = x^(8|B|) * crc(A) + crc(B): the lanes' pieces, then the member's running value
+    const uint32_t first_blk = (lo - win) >> 6, last_blk = (hi - 1u - win) >> 6;
+    const uint32_t tail = hi - (win + last_blk * 64u);   // bytes of the last piece, 1..64
+    uint32_t t = 0;
+    if (lane >= first_blk && lane < last_blk) t = mulmod(xtab[65u + (last_blk - lane - 1u)], c);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) t ^= (uint32_t)__shfl_xor((int)t, d, 64);
+    const uint32_t c_last = (uint32_t)__builtin_amdgcn_readlane((int)c, (int)last_blk);
+    const uint32_t chunk = mulmod(xtab[tail], uni(t)) ^ c_last;
+    const uint32_t n = hi - lo;
+    crc = uni(mulmod(mulmod(xtab[65u + (n >> 6)], xtab[n & 63u]), crc) ^ chunk);
+  };
+  auto flush_pages = [&]() {   // after `pos` moved: every completed page
+    while ((flushed ^ pos) & ~(kPage - 1u)) {
+      const uint32_t hi = (flushed & ~(kPage - 1u)) + kPage;
+      flush(flushed, hi);
+      flushed = hi;
+    }
+  };
+
+  seek_byte(skip);
+  if (job.src_len < 18u || job.cap > 0x7FFF0000ull) err = 1u;
+
+  // ---- members ----
+  while (!err) {
+    // header (RFC 1952)
+    const uint32_t id = getbits(16), cm = getbits(8), flg = getbits(8);
+    (void)getbits(32);          // MTIME
+    (void)getbits(16);          // XFL, OS
+    if (id != 0x8B1Fu || cm != 8u || (flg & 0xE0u)) { err = err ? err : 1u; break; }
+    if (flg & 4u) {             // FEXTRA
+      uint32_t xlen = getbits(16);
+      while (xlen && !err) { (void)getbits(8); --xlen; }
+    }
+    if (flg & 8u) while (!err && getbits(8) != 0u) {}    // FNAME
+    if (flg & 16u) while (!err && getbits(8) != 0u) {}   // FCOMMENT
+    if (flg & 2u) (void)getbits(16);                     // FHCRC (not verified, as zlib's gzread)
+    if (err) break;
+    crc = 0;
+    member_start = pos;
+
+    // ---- blocks (RFC 1951) ----
+    uint32_t bfinal = 0;
+    while (!err && !bfinal) {
+      bfinal = getbits(1);
+      const uint32_t btype = getbits(2);
+      if (btype == 0u) {
+        // stored: LEN bytes behind the next byte boundary
+        drop((8u - (bo & 7u)) & 7u);
+        const uint32_t len = getbits(16), nlen = getbits(16);
+        if ((len ^ nlen) != 0xFFFFu) { err = err ? err : 3u; break; }
+        if (err) break;
+        uint64_t at = consumed_bits() >> 3;   // byte position from in_base
+        if (at + len > skip + job.src_len) { err = 8u; break; }
+        if (pos + len > cap_end) { err = 7u; break; }
+        const uint8_t *sb = (const uint8_t *)in_base;
+        uint32_t left = len;
+        while (left) {
+          const uint32_t room = kPage - (pos & (kPage - 1u));
+          const uint32_t n = left < room ? left : room;
+          for (uint32_t i = lane; i < n; i += 64u) ring[(pos + i) & kRingMask] = sb[at + i];
+          pos += n; at += n; left -= n;
+          flush_pages();
+        }
+        seek_byte(at);
+        continue;
+      }
+      if (btype == 3u) { err = 2u; break; }
+      if (btype == 1u) {
+        // fixed code: lengths 8 / 9 / 7 / 8 for the 288 literal/length symbols, 5 for the 32 distances
+        for (uint32_t s = lane; s < 288u; s += 64u) lens[s] = (uint8_t)(s < 144u ? 8u : s < 256u ? 9u : s < 280u ? 7u : 8u);
+        if (lane < 32u) lens[288u + lane] = 5u;
+        lds_fence();
+        build_table<0, kLitP>(lens, 288u, lit_tab, lit_sorted, hc[0][0], hc[0][1], hc[0][2], run, lane);
+        build_table<1, kDistP>(lens + 288, 32u, dist_tab, dist_sorted, hc[1][0], hc[1][1], hc[1][2], run, lane);
+      } else {
+        const uint32_t hlit = getbits(5) + 257u, hdist = getbits(5) + 1u, hclen = getbits(4) + 4u;
+        if (hlit > 286u || hdist > 30u) { err = err ? err : 4u; break; }
+        if (lane < 19u) cl_lens[lane] = 0u;
+        lds_fence();
+        for (uint32_t i = 0; i < hclen; ++i) {
+          const uint32_t v = getbits(3);
+          cl_lens[c_cl_order[i]] = (uint8_t)v;   // (all lanes: the same byte)
+        }
+        lds_fence();
+        if (err) break;
+        // the code-length code's table and order share the literal table's memory, which is built after its last use
+        if (!build_table<2, kClP>(cl_lens, 19u, lit_tab, lit_sorted, hc[0][0], hc[0][1], hc[0][2], run, lane)) { err = 4u; break; }
+        const uint32_t total = hlit + hdist;
+        uint32_t i = 0, prev = 0;
+        while (i < total && !err) {
+          const uint32_t e = uni(lit_tab[(uint32_t)peek64() & ((1u << kClP) - 1u)]);
+          const uint32_t l = e & 31u;
+          if (l == 0u || (e & kSlow)) { err = 4u; break; }   // (code lengths are at most 7 bits: never slow)
+          drop(l);
+          const uint32_t sym = e >> 8;
+          if (sym < 16u) {
+            lens[i++] = (uint8_t)sym;
+            prev = sym;
+            continue;
+          }
+          uint32_t rep, val = 0;
+          if (sym == 16u) {
+            if (i == 0u) { err = 4u; break; }
+            rep = 3u + getbits(2);
+            val = prev;
+          } else if (sym == 17u) {
+            rep = 3u + getbits(3);
+          } else {
+            rep = 11u + getbits(7);
+          }
+          if (i + rep > total) { err = 4u; break; }
+          for (uint32_t k = lane; k < rep; k += 64u) lens[i + k] = (uint8_t)val;
+          i += rep;
+          prev = val;
+        }
+        lds_fence();
+        if (err) break;
+        if (lens[256] == 0u) { err = 4u; break; }   // zlib: "missing end-of-block"
+        if (!build_table<0, kLitP>(lens, hlit, lit_tab, lit_sorted, hc[0][0], hc[0][1], hc[0][2], run, lane)) { err = 4u; break; }
+        if (!build_table<1, kDistP>(lens + hlit, hdist, dist_tab, dist_sorted, hc[1][0], hc[1][1], hc[1][2], run, lane)) { err = 4u; break; }
+      }
+
+      // ---- symbols ----
+      for (;;) {
+        if (err) break;
+        // A ROUND: lane i decodes the token that would start at bit i of the window -- literal, or length + distance
+        // with their extra bits -- as if it were the next one; the chain of real tokens (0, its length, ...) is then
+        // walked through the lanes' results, and the bytes of all tokens of the round (up to 64) are written in one
+        // LDS gather + scatter.  The round ends before a token that is not plain (end of block, a code behind the
+        // tables, a match that overlaps the round's own bytes, more than 64 bytes): the serial step below takes that one.
+        uint32_t v_info, v_tokv;
+        {
+          const uint32_t q = bo + lane;
+          const uint32_t k = q >> 5, sh = q & 31u;
+          const uint32_t d0 = k == 0u ? w0 : k == 1u ? w1 : w2;
+          const uint32_t d1 = k == 0u ? w1 : k == 1u ? w2 : w3;
+          const uint32_t d2 = k == 0u ? w2 : k == 1u ? w3 : w4;
+          const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sh), x1 = __builtin_amdgcn_alignbit(d2, d1, sh);
+          const uint32_t e = lit_tab[x0 & ((1u << kLitP) - 1u)];
+          const uint32_t l = e & 31u, kind = (e >> 5) & 3u;
+          const uint32_t xl = (e >> 17) & 7u;
+          const uint32_t t0 = __builtin_amdgcn_alignbit(x1, x0, l);
+          const uint32_t mlen = ((e >> 8) & 511u) + (t0 & ((1u << xl) - 1u));
+          const uint32_t a = l + xl;
+          const uint32_t y = __builtin_amdgcn_alignbit(x1, x0, a);
+          const uint32_t d = dist_tab[y & ((1u << kDistP) - 1u)];
+          const uint32_t dl = d & 31u, xd = (d >> 24) & 15u;
+          const uint32_t dist = ((d >> 8) & 0x7FFFu) + ((y >> dl) & ((1u << xd) - 1u));
+          const bool lit = kind == kKindLit, mat = kind == kKindLen;
+          const bool stop = l == 0u || !(lit || (mat && dl != 0u && (d & 0x60u) == 0u));
+          const uint32_t tot = lit ? l : a + dl + xd;
+          v_info = tot | ((lit ? 1u : mlen) << 6) | (stop ? 0x8000u : 0u);
+          v_tokv = lit ? (0x10000u | ((e >> 8) & 0xFFu)) : dist;
+        }
+        uint32_t p = 0, outb = 0, v_tok = 0;
+        const uint32_t room = cap_end - pos;
+        while (p < 64u) {
+          const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)v_info, (int)p);
+          if (info & 0x8000u) break;
+          const uint32_t tv = (uint32_t)__builtin_amdgcn_readlane((int)v_tokv, (int)p);
+          const uint32_t olen = (info >> 6) & 511u;
+          if (outb + olen > 64u || outb + olen > room) break;
+          if (!(tv >> 16) && (tv < outb + olen || tv > pos + outb - member_start)) break;   // overlaps the round / too far back
+          v_tok = lane >= outb ? tv : v_tok;
+          outb += olen;
+          p += info & 63u;
+        }
+        if (outb) {
+          if (lane < outb) {
+            const uint32_t b = ring[(pos + lane - (v_tok & 0xFFFFu)) & kRingMask];
+            ring[(pos + lane) & kRingMask] = (uint8_t)((v_tok >> 16) ? v_tok : b);
+          }
+          const uint32_t before = pos;
+          pos += outb;
+          drop(p);
+          if ((before ^ pos) & ~(kPage - 1u)) flush_pages();
+          continue;
+        }
+        // ---- one token, serially ----
+        uint64_t bb = peek64();
+        uint32_t e = uni(lit_tab[(uint32_t)bb & ((1u << kLitP) - 1u)]);
+        if ((e & 0x60u) == kSlow) {
+          // a code of more than kLitP bits (or none at all): the canonical walk, bit by bit
+          uint32_t c2 = 0, found = 0;
+          for (uint32_t l = 1; l <= 15u; ++l) {
+            c2 = (c2 << 1) | ((uint32_t)(bb >> (l - 1u)) & 1u);
+            const uint32_t idx = c2 - uni(hc[0][1][l]);
+            if (idx < uni(hc[0][0][l])) {
+              e = lit_entry(uni((uint32_t)lit_sorted[uni(hc[0][2][l]) + idx]), l);
+              found = 1;
+              break;
+            }
+          }
+          if (!found) e = 0;
+        }
+        const uint32_t l = e & 31u;
+        if (l == 0u) { err = 5u; break; }
+        bb >>= l;
+        uint32_t used = l;
+        const uint32_t kind = (e >> 5) & 3u;
+        if (kind == kKindLit) {
+          if (pos >= cap_end) { err = 7u; break; }
+          ring[pos & kRingMask] = (uint8_t)(e >> 8);
+          ++pos;
+          drop(used);
+          if ((pos & (kPage - 1u)) == 0u) flush_pages();
+          continue;
+        }
+        if (kind == kKindEob) { drop(used); break; }
+        // a match: length, then distance (at most 15 + 5 + 15 + 13 = 48 bits in all)
+        const uint32_t xl = (e >> 17) & 7u;
+        const uint32_t mlen = ((e >> 8) & 511u) + ((uint32_t)bb & ((1u << xl) - 1u));
+        bb >>= xl;
+        used += xl;
+        uint32_t d = uni(dist_tab[(uint32_t)bb & ((1u << kDistP) - 1u)]);
+        if ((d & 0x60u) == kSlow) {
+          uint32_t c2 = 0, found = 0;
+          for (uint32_t dl = 1; dl <= 15u; ++dl) {
+            c2 = (c2 << 1) | ((uint32_t)(bb >> (dl - 1u)) & 1u);
+            const uint32_t idx = c2 - uni(hc[1][1][dl]);
+            if (idx < uni(hc[1][0][dl])) {
+              d = dist_entry(uni((uint32_t)dist_sorted[uni(hc[1][2][dl]) + idx]), dl);
+              found = 1;
+              break;
+            }
+          }
+          if (!found) d = 0;
+        }
+        const uint32_t dl = d & 31u;
+        if (dl == 0u) { err = 5u; break; }
+        bb >>= dl;
+        const uint32_t xd = (d >> 24) & 15u;
+        const uint32_t dist = ((d >> 8) & 0x7FFFu) + ((uint32_t)bb & ((1u << xd) - 1u));
+        used += dl + xd;
+        drop(used);
+        if (dist > pos - member_start) { err = 6u; break; }   // zlib: "invalid distance too far back"
+        if (pos + mlen > cap_end) { err = 7u; break; }
+        const uint32_t src0 = pos - dist;
+        if (dist >= 64u || dist >= mlen) {
+          // 64 bytes at a time: a chunk's sources lie before the chunk, and the LDS serves the wave in order
+          for (uint32_t o = 0; o < mlen; o += 64u) {
+            const uint32_t i = o + lane;
+            if (i < mlen) ring[(pos + i) & kRingMask] = ring[(src0 + i) & kRingMask];
+          }
+        } else {
+          // a pattern of `dist` bytes repeated: every source byte was written before the match
+          for (uint32_t o = 0; o < mlen; o += 64u) {
+            const uint32_t i = o + lane;
+            if (i < mlen) ring[(pos + i) & kRingMask] = ring[(src0 + i % dist) & kRingMask];
+          }
+        }
+        const uint32_t before = pos;
+        pos += mlen;
+        if ((before ^ pos) & ~(kPage - 1u)) flush_pages();
+      }
+    }
+    if (err) break;
+    // trailer: CRC-32 and ISIZE behind the next byte boundary
+    drop((8u - (bo & 7u)) & 7u);
+    const uint32_t want_crc = getbits(32), want_size = getbits(32);
+    if (err) break;
+    if (pos != flushed) { flush(flushed, pos); flushed = pos; }
+    if (crc != want_crc) { err = 9u; break; }
+    if (want_size != pos - member_start) { err = 10u; break; }
+    ++res.members;
+    const uint64_t used = (consumed_bits() >> 3) - skip;   // bytes of the file consumed
+    if (used > job.src_len) { err = 8u; break; }
+    if (used == job.src_len) break;
+    if (job.src_len - used < 18u) { err = 11u; break; }
+    // (the next member's magic is checked by its header parse; anything else ends with status 1 -> the host decides)
+  }
+  if (!err) {
+    if (consumed_bits() > total_bits) err = 8u;
+    else if (pos != cap_end) err = 12u;
+  }
+  res.status = err;
+  res.produced = pos - pos0;
+  res.consumed = (consumed_bits() >> 3) >= skip ? (consumed_bits() >> 3) - skip : 0u;
+  if (lane == 0u) outs[blockIdx.x] = res;
+}
+
+// x^(8k) and x^(512k) mod P, k = 0..64 (host side of the kernel's CRC folding): 130 words
+void inflate_xtab(uint32_t *t) {
+  auto mul = [](uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 0; i < 32; ++i) {
+      if (a & 0x80000000u) p ^= b;
+      a <<= 1;
+      b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
+    }
+    return p;
+  };
+  uint32_t x8 = 0x80000000u;
+  for (int i = 0; i < 8; ++i) x8 = mul(x8, 0x40000000u);   // x^8
+  t[0] = 0x80000000u;
+  for (int k = 1; k <= 64; ++k) t[k] = mul(t[k - 1], x8);
+  t[65] = 0x80000000u;
+  for (int k = 1; k <= 64; ++k) t[65 + k] = mul(t[65 + k - 1], t[64]);
+}
+
+hipError_t launch_inflate(const InflateJob *jobs, uint32_t n_jobs, const uint8_t *wire, uint64_t wire_bytes, uint8_t *raw,
+                          const uint32_t *xtab, InflateOut *outs, hipStream_t stream) {
+  if (n_jobs == 0) return hipSuccess;
+  hipLaunchKernelGGL(inflate_kernel, dim3(n_jobs), dim3(64), 0, stream, jobs, wire, wire_bytes, raw, xtab, outs);
+  return hipGetLastError();
+}
+
+}  // namespace nq

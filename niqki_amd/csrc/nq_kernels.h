@@ -255,6 +255,25 @@ struct UnpackSeg {
 };
 hipError_t launch_unpack(const UnpackSeg *segs, uint32_t n_seg, uint32_t n_blocks, const uint8_t *wire, uint8_t *raw, hipStream_t stream);
 
+// ---- gzip members inflated on the device (nq_inflate.hip) ------------------------------------------
+// One job per gzip file: its bytes wire[src, src + src_len) become raw[dst, dst + cap), cap = the size the file's
+// trailer announces.  status 0: every member decoded, CRC-32 and sizes agree, exactly cap bytes were written.  Any
+// other status (1 header, 2 block type, 3 stored length, 4 code lengths, 5 symbol, 6 distance too far back, 7 more
+// than cap bytes, 8 input ends early, 9 CRC, 10 member size, 11 bytes behind the last member, 12 fewer than cap
+// bytes): the file is to be read some other way -- nothing was written outside [dst, dst + cap).
+struct InflateJob {
+  uint64_t src, src_len, dst, cap;
+};
+struct InflateOut {
+  uint32_t status, members;
+  uint64_t produced, consumed;
+};
+constexpr uint32_t kInflateXtabWords = 130;
+void inflate_xtab(uint32_t *t);   // host: the CRC folding constants the kernel reads (kInflateXtabWords words)
+// wire_bytes: readable bytes of `wire` (the kernel loads whole dwords up to there); raw: 16-byte aligned
+hipError_t launch_inflate(const InflateJob *jobs, uint32_t n_jobs, const uint8_t *wire, uint64_t wire_bytes, uint8_t *raw,
+                          const uint32_t *xtab, InflateOut *outs, hipStream_t stream);
+
 // ---- synthetic genomes (nq_synth.hip) ----------------------------------------
 hipError_t launch_synth(uint64_t seed, const uint32_t *family, const uint32_t *member,
                         const uint32_t *rate14, uint32_t n, uint64_t len, uint64_t stride,
