@@ -145,6 +145,7 @@ ABI = [
     ("niqki_synth_reads", _int, [_vp, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u64, _vp, _int]),
     ("niqki_measure_alu", _int, [_vp, _int, _dbl, C.POINTER(_dbl)]),
     ("niqki_gunzip", _int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, C.POINTER(_u64)]),
+    ("niqki_gunzip_stats", _int, [_vp, _vp]),
 ]
 
 _lib = None
@@ -482,6 +483,12 @@ class Engine:
                                      C.byref(outside) if check_outside else None))
         out = [raw[int(roff[i]):int(roff[i]) + int(min(produced[i], roff[i + 1] - roff[i]))].tobytes() for i in range(n)]
         return out, status[:n], produced[:n], members[:n], int(outside.value)
+
+    def gunzip_stats(self):
+        """{rounds, round_tokens, serial_tokens, blocks} of the last device inflate (summed over its files)"""
+        o = np.zeros(4, dtype=np.uint64)
+        self._ck(self.L.niqki_gunzip_stats(self.h, _p(o)))
+        return dict(zip(("rounds", "round_tokens", "serial_tokens", "blocks"), (int(x) for x in o)))
 
     def staged_records(self):
         """(records as list of bytes, entry_rec, hdr_pos) of the staged batch."""

@@ -5,6 +5,7 @@
 #include "nq_pack.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -258,6 +259,11 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   NQ_HIP(ix, hipStreamSynchronize(ix->stream));  // also: `meta` and the caller's raw bytes are consumed
   {
     uint32_t bad = 0;
+    for (int i = 0; i < 4; ++i) ix->inflate_stats[i] = 0;
+    for (size_t j = 0; j < jobs.size(); ++j) {
+      ix->inflate_stats[0] += iout[j].rounds; ix->inflate_stats[1] += iout[j].round_tokens;
+      ix->inflate_stats[2] += iout[j].serial_tokens; ix->inflate_stats[3] += iout[j].blocks;
+    }
     for (size_t j = 0; j < jobs.size(); ++j)
       if (iout[j].status) {
         if (b->file_status) b->file_status[job_file[j]] = (uint8_t)iout[j].status;
@@ -408,11 +414,25 @@ int niqki_gunzip(niqki_index *ix, const uint8_t *gz, const uint64_t *gz_off, uin
     *outside = diff;
     if (raw && T_raw > raw_off[0]) std::memcpy(raw + raw_off[0], whole.data() + raw_off[0], T_raw - raw_off[0]);
   }
+  for (int i = 0; i < 4; ++i) ix->inflate_stats[i] = 0;
+#ifdef NQ_INFLATE_CLOCK
+  fprintf(stderr, "inflate clocks of file 0 (outside, decode, walk, copy, reader, flush):");
+  for (int i = 0; i < 6; ++i) fprintf(stderr, " %llu", (unsigned long long)out[0].clk[i]);
+  fprintf(stderr, "\n");
+#endif
   for (uint32_t f = 0; f < n_files; ++f) {
+    ix->inflate_stats[0] += out[f].rounds; ix->inflate_stats[1] += out[f].round_tokens;
+    ix->inflate_stats[2] += out[f].serial_tokens; ix->inflate_stats[3] += out[f].blocks;
     if (status) status[f] = out[f].status;
     if (produced) produced[f] = out[f].produced;
     if (members) members[f] = out[f].members;
   }
+  return NIQKI_OK;
+}
+
+int niqki_gunzip_stats(niqki_index *ix, uint64_t out[4]) {
+  if (!ix || !out) return NIQKI_E_INVALID;
+  for (int i = 0; i < 4; ++i) out[i] = ix->inflate_stats[i];
   return NIQKI_OK;
 }
 

@@ -33,10 +33,6 @@ constexpr uint32_t kPage = 4096;
 constexpr uint32_t kKindLit = 0, kKindLen = 1, kKindEob = 2, kKindSlow = 3;
 constexpr uint32_t kSlow = kKindSlow << 5;
 
-__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // Table entries (0 = no such code):
@@ -46,11 +42,22 @@ __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 
 __device__ __forceinline__ uint32_t lit_entry(uint32_t sym, uint32_t l) {
   if (sym < 256u) return l | (kKindLit << 5) | (sym << 8);
   if (sym == 256u) return l | (kKindEob << 5);
-  if (sym < 286u) return l | (kKindLen << 5) | ((uint32_t)c_len_base[sym - 257u] << 8) | ((uint32_t)c_len_extra[sym - 257u] << 17);
+  if (sym < 286u) {
+    // RFC 1951 3.2.5 in closed form: codes 257..264 are lengths 3..10; then four codes per extra bit; 285 is 258
+    const uint32_t i = sym - 257u;
+    const uint32_t x = i < 8u || i == 28u ? 0u : (i >> 2) - 1u;
+    const uint32_t base = i < 8u ? 3u + i : i == 28u ? 258u : 3u + ((4u + (i & 3u)) << x);
+    return l | (kKindLen << 5) | (base << 8) | (x << 17);
+  }
   return 0u;   // 286, 287: in the fixed code, never valid
 }
 __device__ __forceinline__ uint32_t dist_entry(uint32_t sym, uint32_t l) {
-  if (sym < 30u) return l | ((uint32_t)c_dist_base[sym] << 8) | ((uint32_t)c_dist_extra[sym] << 24);
+  if (sym < 30u) {
+    // codes 0..3 are distances 1..4; then two codes per extra bit
+    const uint32_t x = sym < 4u ? 0u : (sym >> 1) - 1u;
+    const uint32_t base = sym < 4u ? 1u + sym : 1u + ((2u + (sym & 1u)) << x);
+    return l | (base << 8) | (x << 24);
+  }
   return 0u;   // 30, 31
 }
 template <int WHICH>
@@ -59,6 +66,12 @@ __device__ __forceinline__ uint32_t make_entry(uint32_t sym, uint32_t l) {
 }
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+#ifdef NQ_INFLATE_CLOCK
+#define NQ_CLK(i) do { const uint64_t t_ = __builtin_readcyclecounter(); res.clk[i] += t_ - clk_last; clk_last = t_; } while (0)
+#else
+#define NQ_CLK(i) do {} while (0)
+#endif
 
 // all LDS traffic of the wave so far is done and the compiler keeps the accesses on either side apart (one wave
 // per workgroup: the LDS serves its instructions in order)
@@ -132,16 +145,13 @@ __device__ bool build_table(const uint8_t *L, uint32_t n, uint32_t *tab, uint16_
   }
   // the table, one entry per lane and round: the canonical walk over the entry's own index bits
   for (uint32_t i = lane; i < (1u << P); i += 64u) {
-    uint32_t e = kSlow, c2 = 0;
+    uint32_t c2 = 0, at_l = 0, at_i = 0;
     for (uint32_t l = 1; l <= P; ++l) {
       c2 = (c2 << 1) | ((i >> (l - 1u)) & 1u);
       const uint32_t idx = c2 - first[l];
-      if (idx < cnt[l]) {
-        e = make_entry<WHICH>(sorted[offs[l] + idx], l);
-        break;
-      }
+      if (at_l == 0u && idx < cnt[l]) { at_l = l; at_i = offs[l] + idx; }
     }
-    tab[i] = e;
+    tab[i] = at_l ? make_entry<WHICH>(sorted[at_i], at_l) : kSlow;
   }
   lds_fence();
   return true;
@@ -166,6 +176,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
   const InflateJob job = jobs[blockIdx.x];
   InflateOut res;
   res.status = 0; res.members = 0; res.produced = 0; res.consumed = 0;
+  res.rounds = 0; res.round_tokens = 0; res.serial_tokens = 0; res.blocks = 0;
+#ifdef NQ_INFLATE_CLOCK
+  for (int i = 0; i < 8; ++i) res.clk[i] = 0;
+  uint64_t clk_last = __builtin_readcyclecounter();
+#endif
 
   // CRC-32 byte table (reflected, polynomial 0xEDB88320)
   for (uint32_t i = lane; i < 256u; i += 64u) {
@@ -180,57 +195,52 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
   const uint64_t in_addr = job.src;                           // byte offset of the file in `wire`
   const uint32_t skip = (uint32_t)(in_addr & 3u);             // bytes of the first dword that precede the file
   const uint32_t *in_base = (const uint32_t *)(wire + (in_addr - skip));
-  const uint64_t last_dword = ((wire_bytes + 3u) >> 2) - 1u - ((in_addr - skip) >> 2);   // last loadable dword, from in_base
-  const uint64_t n_words = (skip + job.src_len + 3u) >> 2;    // dwords that hold bytes of the file
+  const uint64_t last_dword64 = ((wire_bytes + 3u) >> 2) - 1u - ((in_addr - skip) >> 2);   // last loadable dword, from in_base
+  const uint32_t last_dword = last_dword64 > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)last_dword64;
+  const uint32_t n_words = (uint32_t)((skip + job.src_len + 3u) >> 2);   // dwords that hold bytes of the file (< 2^29)
   const uint64_t total_bits = (skip + job.src_len) * 8u;
   uint32_t err = 0;
-  uint32_t cur, nxt;
-  uint64_t blk = 0;       // 64-dword block held in cur
-  uint32_t wi = 0;        // next dword of cur
-  uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0;   // the window: the stream's next bit is bit `bo` of w0
-  uint32_t bo = 0;        // 0..31
-  auto load_blk = [&](uint64_t b) -> uint32_t {
-    uint64_t w = b * 64u + lane;
+  uint32_t cur, nxt;      // lane i: dword 64 * bblk + i of the input / the block behind it
+  uint32_t bblk = 0;      // which 64-dword block `cur` holds
+  uint32_t bitpos = 0;    // the stream's next bit, counted from the start of `cur`; < 2048 between tokens
+  auto load_blk = [&](uint32_t b) -> uint32_t {
+    uint32_t w = b * 64u + lane;
     w = w > last_dword ? last_dword : w;
     return in_base[w];
   };
-  auto take32 = [&]() -> uint32_t {
-    if (blk * 64u + wi > n_words + 8u) { err = err ? err : 8u; return 0u; }   // far past the file: truncated
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)wi);
-    if (++wi == 64u) {
-      cur = nxt;
-      ++blk;
-      nxt = load_blk(blk + 1u);
-      wi = 0;
-    }
-    return w;
+  auto s_dword = [&](uint32_t i) -> uint32_t {   // dword i (< 128) behind the start of `cur`, wave-uniform
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i & 63u));
+    const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)(i & 63u));
+    return i < 64u ? a : b;
   };
-  auto drop = [&](uint32_t n) {   // n <= 64
-    bo += n;
-    while (bo >= 32u) {
-      w0 = w1; w1 = w2; w2 = w3; w3 = w4;
-      w4 = take32();
-      bo -= 32u;
+  auto drop = [&](uint32_t n) {   // n < 2048
+    bitpos += n;
+    if (bitpos >= 2048u) {
+      cur = nxt;
+      ++bblk;
+      nxt = load_blk(bblk + 1u);
+      bitpos -= 2048u;
+      if (bblk * 64u > n_words + 64u) err = err ? err : 8u;   // far past the file: truncated
     }
   };
   auto peek64 = [&]() -> uint64_t {
-    const uint64_t lo = (((uint64_t)w1 << 32) | w0) >> bo;
-    const uint64_t hi = ((uint64_t)w2 << 32) << (32u - bo);   // (bo = 0: shifted out entirely)
-    return lo | (bo ? hi : 0ull);
+    const uint32_t i = bitpos >> 5, sh = bitpos & 31u;
+    const uint32_t d0 = s_dword(i), d1 = s_dword(i + 1u), d2 = s_dword(i + 2u);
+    const uint64_t lo = (((uint64_t)d1 << 32) | d0) >> sh;
+    const uint64_t hi = ((uint64_t)d2 << 32) << (32u - sh);   // (sh = 0: shifted out entirely)
+    return lo | (sh ? hi : 0ull);
   };
   auto getbits = [&](uint32_t n) -> uint32_t {   // n <= 32
     const uint32_t v = (uint32_t)(peek64() & ((1ull << n) - 1ull));
     drop(n);
     return v;
   };
-  auto consumed_bits = [&]() -> uint64_t { return (blk * 64u + wi) * 32u - 160u + bo; };
+  auto consumed_bits = [&]() -> uint64_t { return (uint64_t)bblk * 2048u + bitpos; };
   auto seek_byte = [&](uint64_t byte_from_base) {   // (re)start the reader at a byte position counted from in_base
-    blk = byte_from_base >> 8;
-    cur = load_blk(blk);
-    nxt = load_blk(blk + 1u);
-    wi = (uint32_t)(byte_from_base & 255u) >> 2;
-    w0 = take32(); w1 = take32(); w2 = take32(); w3 = take32(); w4 = take32();
-    bo = 8u * (uint32_t)(byte_from_base & 3u);
+    bblk = (uint32_t)(byte_from_base >> 8);
+    cur = load_blk(bblk);
+    nxt = load_blk(bblk + 1u);
+    bitpos = 8u * (uint32_t)(byte_from_base & 255u);
   };
 
   // ---- output: positions count from pos0 = (dst & 15), so that ring index and HBM address agree modulo 16 ----
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
   };
 
   seek_byte(skip);
-  if (job.src_len < 18u || job.cap > 0x7FFF0000ull) err = 1u;
+  if (job.src_len < 18u || job.src_len > 0x7FFF0000ull || job.cap > 0x7FFF0000ull) err = 1u;
 
   // ---- members ----
   while (!err) {
@@ -319,9 +329,10 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
     while (!err && !bfinal) {
       bfinal = getbits(1);
       const uint32_t btype = getbits(2);
+      ++res.blocks;
       if (btype == 0u) {
         // stored: LEN bytes behind the next byte boundary
-        drop((8u - (bo & 7u)) & 7u);
+        drop((8u - (bitpos & 7u)) & 7u);
         const uint32_t len = getbits(16), nlen = getbits(16);
         if ((len ^ nlen) != 0xFFFFu) { err = err ? err : 3u; break; }
         if (err) break;
@@ -404,8 +415,21 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
         // walked through the lanes' results, and the bytes of all tokens of the round (up to 64) are written in one
         // LDS gather + scatter.  The round ends before a token that is not plain (end of block, a code behind the
         // tables, a match that overlaps the round's own bytes, more than 64 bytes): the serial step below takes that one.
+        NQ_CLK(0);   // everything outside the rounds: headers, tables, serial tokens
         uint32_t v_info, v_tokv;
         {
+          // the five dwords the 64 offsets reach into, wave-uniform
+          const uint32_t i0 = bitpos >> 5, bo = bitpos & 31u;
+          uint32_t w0, w1, w2, w3, w4;
+          if (i0 < 60u) {
+            w0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)i0);
+            w1 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i0 + 1u));
+            w2 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i0 + 2u));
+            w3 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i0 + 3u));
+            w4 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i0 + 4u));
+          } else {
+            w0 = s_dword(i0); w1 = s_dword(i0 + 1u); w2 = s_dword(i0 + 2u); w3 = s_dword(i0 + 3u); w4 = s_dword(i0 + 4u);
+          }
           const uint32_t q = bo + lane;
           const uint32_t k = q >> 5, sh = q & 31u;
           const uint32_t d0 = k == 0u ? w0 : k == 1u ? w1 : w2;
@@ -423,24 +447,62 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
           const uint32_t dl = d & 31u, xd = (d >> 24) & 15u;
           const uint32_t dist = ((d >> 8) & 0x7FFFu) + ((y >> dl) & ((1u << xd) - 1u));
           const bool lit = kind == kKindLit, mat = kind == kKindLen;
-          const bool stop = l == 0u || !(lit || (mat && dl != 0u && (d & 0x60u) == 0u));
+          // a token the round may take: a literal, or a match through both tables that reaches back no further than
+          // the member's start (as seen from the round's start; a little strict near the start of a member)
+          const bool plain = l != 0u && (lit || (mat && dl != 0u && (d & 0x60u) == 0u && dist <= pos - member_start));
           const uint32_t tot = lit ? l : a + dl + xd;
-          v_info = tot | ((lit ? 1u : mlen) << 6) | (stop ? 0x8000u : 0u);
+          const uint32_t olen = lit ? 1u : mlen;
+          // where the round's output may end with this token in it: 64 bytes, the output's capacity, and -- a match
+          // copies from before the round's first byte -- its distance
+          uint32_t lim = cap_end - pos;
+          lim = lim < 64u ? lim : 64u;
+          lim = (lit || dist >= lim) ? lim : dist;
+          v_info = plain ? (tot | (olen << 6) | (lim << 15)) : (1u << 6);   // tot 6 bits, olen 9, lim 7; no token here: a byte that never fits
           v_tokv = lit ? (0x10000u | ((e >> 8) & 0xFFu)) : dist;
         }
-        uint32_t p = 0, outb = 0, v_tok = 0;
-        const uint32_t room = cap_end - pos;
-        while (p < 64u) {
-          const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)v_info, (int)p);
-          if (info & 0x8000u) break;
-          const uint32_t tv = (uint32_t)__builtin_amdgcn_readlane((int)v_tokv, (int)p);
-          const uint32_t olen = (info >> 6) & 511u;
-          if (outb + olen > 64u || outb + olen > room) break;
-          if (!(tv >> 16) && (tv < outb + olen || tv > pos + outb - member_start)) break;   // overlaps the round / too far back
-          v_tok = lane >= outb ? tv : v_tok;
-          outb += olen;
-          p += info & 63u;
+        uint32_t p, outb, v_tok, ntok;
+#ifdef NQ_INFLATE_CLOCK
+        asm volatile("s_nop 0" :: "v"(v_info), "v"(v_tokv));
+        NQ_CLK(1);   // the lanes' decode
+#endif
+        // The chain of tokens through the lanes' results: token at bit p takes the round's bytes [outb, end) when
+        // end <= its lim; the lanes of those bytes remember its tokv.  Written out by hand: the compiler turns the
+        // loop's exits into flag arithmetic and two taken branches per token; this is 16 instructions and one.
+        // (Every adjacent producer / consumer pair below also occurs in compiler-emitted code for gfx950; the s_nop
+        // covers the lanes' last vector writes of v_info / v_tokv ahead of the first v_readlane.)
+        {
+          uint32_t s_info, s_tv, s_end, s_lim, v_tmp;
+          asm volatile(
+              "s_nop 1\n\t"
+              "s_mov_b32 %[p], 0\n\t"
+              "s_mov_b32 %[outb], 0\n\t"
+              "s_mov_b32 %[ntok], 0\n\t"
+              "v_mov_b32 %[vtok], 0\n"
+              ".Lnq_walk_%=:\n\t"
+              "v_readlane_b32 %[info], %[vinfo], %[p]\n\t"
+              "v_readlane_b32 %[tv], %[vtokv], %[p]\n\t"
+              "s_bfe_u32 %[end], %[info], 0x90006\n\t"
+              "s_add_u32 %[end], %[end], %[outb]\n\t"
+              "s_lshr_b32 %[lim], %[info], 15\n\t"
+              "s_cmp_gt_u32 %[end], %[lim]\n\t"
+              "s_cbranch_scc1 .Lnq_walk_done_%=\n\t"
+              "v_mov_b32 %[vtmp], %[tv]\n\t"
+              "v_cmp_gt_u32 vcc, %[outb], %[lane]\n\t"
+              "s_and_b32 %[info], %[info], 63\n\t"
+              "s_add_u32 %[p], %[p], %[info]\n\t"
+              "v_cndmask_b32 %[vtok], %[vtmp], %[vtok], vcc\n\t"
+              "s_mov_b32 %[outb], %[end]\n\t"
+              "s_add_u32 %[ntok], %[ntok], 1\n\t"
+              "s_cmp_lt_u32 %[p], 64\n\t"
+              "s_cbranch_scc1 .Lnq_walk_%=\n"
+              ".Lnq_walk_done_%=:\n\t"
+              "s_nop 0"
+              : [p] "=&s"(p), [outb] "=&s"(outb), [ntok] "=&s"(ntok), [vtok] "=&v"(v_tok), [vtmp] "=&v"(v_tmp), [info] "=&s"(s_info), [tv] "=&s"(s_tv),
+                [end] "=&s"(s_end), [lim] "=&s"(s_lim)
+              : [vinfo] "v"(v_info), [vtokv] "v"(v_tokv), [lane] "v"(lane)
+              : "vcc", "scc");
         }
+        NQ_CLK(2);   // the walk
         if (outb) {
           if (lane < outb) {
             const uint32_t b = ring[(pos + lane - (v_tok & 0xFFFFu)) & kRingMask];
@@ -448,11 +510,16 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
           }
           const uint32_t before = pos;
           pos += outb;
+          ++res.rounds;
+          res.round_tokens += ntok;
+          NQ_CLK(3);   // the copy
           drop(p);
-          if ((before ^ pos) & ~(kPage - 1u)) flush_pages();
+          NQ_CLK(4);   // the reader moving on
+          if ((before ^ pos) & ~(kPage - 1u)) { flush_pages(); NQ_CLK(5); }
           continue;
         }
         // ---- one token, serially ----
+        ++res.serial_tokens;
         uint64_t bb = peek64();
         uint32_t e = uni(lit_tab[(uint32_t)bb & ((1u << kLitP) - 1u)]);
         if ((e & 0x60u) == kSlow) {
@@ -532,7 +599,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
     }
     if (err) break;
     // trailer: CRC-32 and ISIZE behind the next byte boundary
-    drop((8u - (bo & 7u)) & 7u);
+    drop((8u - (bitpos & 7u)) & 7u);
     const uint32_t want_crc = getbits(32), want_size = getbits(32);
     if (err) break;
     if (pos != flushed) { flush(flushed, pos); flushed = pos; }

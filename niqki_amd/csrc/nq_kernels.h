@@ -267,6 +267,10 @@ struct InflateJob {
 struct InflateOut {
   uint32_t status, members;
   uint64_t produced, consumed;
+  uint32_t rounds, round_tokens, serial_tokens, blocks;   // how the file was decoded (nq_inflate.hip)
+#ifdef NQ_INFLATE_CLOCK
+  uint64_t clk[8];   // shader cycles by phase (diagnosis build only)
+#endif
 };
 constexpr uint32_t kInflateXtabWords = 130;
 void inflate_xtab(uint32_t *t);   // host: the CRC folding constants the kernel reads (kInflateXtabWords words)

@@ -52,7 +52,8 @@ def main():
     print(json.dumps({"files": a.files, "genome_bp": a.len, "gzip_level": a.level, "kernel_ms": round(best, 3),
                       "files_per_s": round(a.files / (best / 1e3), 1), "raw_GBps": round(raw / best / 1e6, 2),
                       "wire_GBps": round(wire / best / 1e6, 2), "ratio": round(raw / wire, 3),
-                      "zlib_one_thread_files_per_s": round(1 / t_cpu, 2), "make_inputs_s": round(t_make, 1)}))
+                      "zlib_one_thread_files_per_s": round(1 / t_cpu, 2), "make_inputs_s": round(t_make, 1),
+                      "per_file": {k: v // a.files for k, v in e.gunzip_stats().items()}}))
     e.close()
 
 
