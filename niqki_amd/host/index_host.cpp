@@ -144,9 +144,14 @@ bool gunzip_whole(int fd, size_t file_bytes, PinnedBuf &out) {
 // want_pack: a plain (not gzipped) regular FASTA file may be handed over as its packed container
 // (nq_pack.h, what niqki_pack_fasta makes: 2 bits per base in full A/C/G/T lines, everything else verbatim; the device
 // restores the file's exact bytes) -- *packed says whether it was.
-void read_file_bytes(const std::string &path, PinnedBuf &out, bool want_pack = false, bool *packed = nullptr) {
+// want_gz: a gzip'd regular file may be handed over as it lies on disk (*gz says whether it was): the device inflates it
+// (niqki_stage_raw, NIQKI_FILE_GZIP).  Only what the device will plausibly take -- one member whose trailer states a
+// size in keeping with the file's (the library's own test) -- everything else is inflated here, as before.
+void read_file_bytes(const std::string &path, PinnedBuf &out, bool want_pack = false, bool *packed = nullptr,
+                     bool want_gz = false, bool *gz = nullptr) {
   out.size = 0;
   if (packed) *packed = false;
+  if (gz) *gz = false;
   const int fd = ::open(path.c_str(), O_RDONLY);
   if (fd < 0) throw std::runtime_error("cannot open '" + path + "'");
   struct stat st;
@@ -187,6 +192,26 @@ void read_file_bytes(const std::string &path, PinnedBuf &out, bool want_pack = f
     // not worth packing (or the file changed under us): its bytes as they are, below
   }
   if (m == 2 && magic[0] == 0x1F && magic[1] == 0x8B) {
+    if (want_gz && gz && S_ISREG(st.st_mode) && st.st_size >= 18 && (uint64_t)st.st_size <= 0x7FFF0000ull) {
+      const size_t n = (size_t)st.st_size;
+      out.reserve(n + 64);
+      size_t got = 0;
+      while (got < n) {
+        const ssize_t r = pread(fd, out.p + got, n - got, (off_t)got);
+        if (r <= 0) break;
+        got += (size_t)r;
+      }
+      if (got == n) {
+        const uint64_t isize = (uint64_t)out.p[n - 4] | (uint64_t)out.p[n - 3] << 8 | (uint64_t)out.p[n - 2] << 16 | (uint64_t)out.p[n - 1] << 24;
+        if (isize <= 0x7FFF0000ull && isize <= (uint64_t)n * 64u && isize * 4096u >= (uint64_t)n) {
+          out.size = n;
+          *gz = true;
+          ::close(fd);
+          return;
+        }
+      }
+      out.size = 0;   // (several members, a huge or an empty file, a short read: inflated here)
+    }
     if (S_ISREG(st.st_mode) && gunzip_whole(fd, (size_t)st.st_size, out)) { ::close(fd); return; }
     out.size = 0;
     gzFile g = gzdopen(fd, "rb");  // owns fd from here
@@ -256,6 +281,7 @@ class OrderedFileReader {
     PinnedBuf buf;
     std::string err;
     bool packed = false;   // buf holds the file's packed container (niqki_pack_fasta), not its bytes
+    bool gz = false;       // buf holds the gzip file as it lies on disk: the device inflates it (NIQKI_FILE_GZIP)
   };
   // The page-locked buffers are shared by all readers of the process (index phase, then
   // query phase) and never freed: locking and unlocking 1.5 GB of pages costs more than
@@ -266,7 +292,8 @@ class OrderedFileReader {
     return *p;
   }
   OrderedFileReader(const std::vector<std::string> &paths, unsigned threads, size_t n_bufs)
-      : paths_(paths), bufs_(pool(n_bufs)), ready_(paths.size(), nullptr), pack_(std::getenv("NIQKI_HOST_NO_PACK") == nullptr) {
+      : paths_(paths), bufs_(pool(n_bufs)), ready_(paths.size(), nullptr), pack_(std::getenv("NIQKI_HOST_NO_PACK") == nullptr),
+        gz_(std::getenv("NIQKI_HOST_NO_GPU_INFLATE") == nullptr) {
     for (size_t i = 0; i < n_bufs; ++i) free_.push_back(&bufs_[n_bufs - 1 - i]);  // LIFO: low indices first
     threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(paths.size(), 1));
     for (unsigned t = 0; t < threads; ++t) pool_.emplace_back([this] { work(); });
@@ -311,9 +338,10 @@ class OrderedFileReader {
       }
       f->err.clear();
       f->packed = false;
+      f->gz = false;
       try {
-        read_file_bytes(paths_[idx], f->buf, pack_ && data_type(paths_[idx]) == 'A', &f->packed);
-      } catch (const std::exception &e) { f->err = e.what(); f->buf.size = 0; f->packed = false; }
+        read_file_bytes(paths_[idx], f->buf, pack_ && data_type(paths_[idx]) == 'A', &f->packed, gz_, &f->gz);
+      } catch (const std::exception &e) { f->err = e.what(); f->buf.size = 0; f->packed = false; f->gz = false; }
       {
         std::lock_guard<std::mutex> g(mu_);
         ready_[idx] = f;
@@ -330,18 +358,27 @@ class OrderedFileReader {
   size_t issued_ = 0, taken_ = 0;
   bool stop_ = false;
   const bool pack_;   // plain FASTA files travel as packed containers (NIQKI_HOST_NO_PACK: as their bytes)
+  const bool gz_;     // gzip files travel as they are and are inflated on the device (NIQKI_HOST_NO_GPU_INFLATE: here)
 };
 
 constexpr size_t kWholeBatchFiles = 64;                // files per GPU call (whole-file mode)
 constexpr size_t kWholeBatchBytes = size_t(3) << 29;   // ... or 1.5 GB
 constexpr size_t kReaderBufs = 2 * kWholeBatchFiles + 32;
+// Gzip files inflated on the device: a file is one wavefront's serial job there and the device runs 1024 of them at
+// once (four per CU), so a batch takes as long as its longest file whatever it holds -- batches of up to 1024 files
+// (their bytes are a quarter of the plain ones'), or 6 GB of inflated bytes.
+constexpr size_t kGzBatchFiles = 1024;
+constexpr size_t kGzBatchRawBytes = size_t(6) << 30;
+constexpr size_t kGzReaderBufs = 2 * kGzBatchFiles + 64;
 }  // namespace
 
 // Files of one GPU call (whole-file mode): one sketch per file.
 struct Index::Batch {
   std::vector<OrderedFileReader::File *> files;
   std::vector<std::string> names;
-  size_t bytes = 0;
+  size_t bytes = 0;       // bytes that cross PCIe
+  size_t raw_bytes = 0;   // bytes the device holds once packed / gzip'd files are their own bytes again (gzip: as announced)
+  size_t n_gz = 0;
 };
 
 void Index::check(int rc, const char *what) const {
@@ -496,22 +533,41 @@ static void rank_share(size_t n, size_t per, size_t r, size_t &lo, size_t &hi) {
 // that follows for the same batch takes those bytes
 void Index::stage_batch(Batch &b, bool prefetch) {
   auto stage = [&](niqki_index *h, size_t lo, size_t hi) {
-    std::vector<const uint8_t *> ptr(hi - lo);
-    std::vector<uint64_t> off(hi - lo + 1, 0);
-    std::vector<uint8_t> type(hi - lo);
-    for (size_t i = lo; i < hi; ++i) {
-      ptr[i - lo] = b.files[i]->buf.p;
-      off[i - lo + 1] = off[i - lo] + b.files[i]->buf.size;
-      type[i - lo] = b.files[i]->packed ? (uint8_t)'a' : (uint8_t)data_type(b.names[i]);
+    for (;;) {
+      std::vector<const uint8_t *> ptr(hi - lo);
+      std::vector<uint64_t> off(hi - lo + 1, 0);
+      std::vector<uint8_t> type(hi - lo), status(hi - lo, 0);
+      for (size_t i = lo; i < hi; ++i) {
+        ptr[i - lo] = b.files[i]->buf.p;
+        off[i - lo + 1] = off[i - lo] + b.files[i]->buf.size;
+        type[i - lo] = b.files[i]->packed ? (uint8_t)'a'
+                       : b.files[i]->gz   ? (uint8_t)(data_type(b.names[i]) | NIQKI_FILE_GZIP)
+                                          : (uint8_t)data_type(b.names[i]);
+      }
+      niqki_raw_batch rb{};
+      rb.file_ptr = ptr.data();
+      rb.file_off = off.data();
+      rb.file_type = type.data();
+      rb.n_files = (uint32_t)(hi - lo);
+      rb.file_status = status.data();
+      niqki_stage_info info{};
+      const int rc = prefetch ? niqki_stage_raw_prefetch(h, &rb) : niqki_stage_raw(h, &rb, NIQKI_MEM_HOST, &info, nullptr);
+      if (rc == NIQKI_E_GZIP) {
+        // files the device would not inflate (damaged, several members, ...): through zlib here -- which decides what
+        // they yield, or throws, exactly as for a run without the device inflate -- and the batch again (every pass
+        // leaves fewer gzip files, so this ends)
+        size_t redone = 0;
+        for (size_t i = lo; i < hi; ++i)
+          if (status[i - lo] && b.files[i]->gz) {
+            read_file_bytes(b.names[i], b.files[i]->buf);
+            b.files[i]->gz = false;
+            ++redone;
+          }
+        if (redone) continue;
+      }
+      if (rc) throw std::runtime_error(std::string("niqki_stage_raw: ") + niqki_status_string(rc) + " (" + niqki_last_error(h) + ")");
+      return;
     }
-    niqki_raw_batch rb{};
-    rb.file_ptr = ptr.data();
-    rb.file_off = off.data();
-    rb.file_type = type.data();
-    rb.n_files = (uint32_t)(hi - lo);
-    niqki_stage_info info{};
-    const int rc = prefetch ? niqki_stage_raw_prefetch(h, &rb) : niqki_stage_raw(h, &rb, NIQKI_MEM_HOST, &info, nullptr);
-    if (rc) throw std::runtime_error(std::string("niqki_stage_raw: ") + niqki_status_string(rc) + " (" + niqki_last_error(h) + ")");
   };
   if (!grp_) {
     stage(h_, 0, b.files.size());
@@ -652,19 +708,31 @@ void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*
   double t_wait = 0, t_gpu = 0;
   t_stage_ = t_dev_ = t_out_ = 0;
   const auto t_begin = clk::now();
-  OrderedFileReader rd(paths, host_threads(), kReaderBufs);
+  // a list of mostly gzip'd files (by their names) runs in the large batches the device inflate wants
+  size_t n_gz_names = 0;
+  for (const auto &p : paths) n_gz_names += p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0;
+  const bool gz_list = std::getenv("NIQKI_HOST_NO_GPU_INFLATE") == nullptr && 2 * n_gz_names > paths.size();
+  OrderedFileReader rd(paths, host_threads(), gz_list ? std::min(kGzReaderBufs, 2 * paths.size() + 64) : kReaderBufs);
   size_t i = 0, n_batches = 0;
   auto assemble = [&](Batch &b) {
     const auto t0 = clk::now();
-    // the first batches are small (16, 32, 64 files): the GPU and the copy engine start while the reader threads are
-    // still page-locking their buffers and filling the pipeline
-    const size_t limit = std::min<size_t>(kWholeBatchFiles, size_t(16) << std::min<size_t>(n_batches++, 8));
-    while (b.files.size() < limit && b.bytes < kWholeBatchBytes) {
+    // the first batches are small (16, 32, 64 files; gzip lists 128, 256 .. 1024): the GPU and the copy engine start
+    // while the reader threads are still page-locking their buffers and filling the pipeline
+    const size_t limit = gz_list ? std::min<size_t>(kGzBatchFiles, size_t(128) << std::min<size_t>(n_batches++, 8))
+                                 : std::min<size_t>(kWholeBatchFiles, size_t(16) << std::min<size_t>(n_batches++, 8));
+    while (b.files.size() < limit && b.bytes < kWholeBatchBytes && b.raw_bytes < kGzBatchRawBytes) {
       auto *f = rd.next();
       if (!f) break;
       b.files.push_back(f);
       b.names.push_back(paths[i++]);
       b.bytes += f->buf.size;
+      size_t raw = f->buf.size;
+      if (f->gz) {   // (the reader checked the trailer: at least 18 bytes, a plausible size)
+        const uint8_t *e = f->buf.p + f->buf.size - 4;
+        raw = (size_t)e[0] | (size_t)e[1] << 8 | (size_t)e[2] << 16 | (size_t)e[3] << 24;
+        ++b.n_gz;
+      }
+      b.raw_bytes += raw;
     }
     t_wait += std::chrono::duration<double>(clk::now() - t0).count();
   };

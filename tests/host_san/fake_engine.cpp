@@ -16,6 +16,8 @@
 #include "../../niqki_amd/csrc/nq_pack.h"
 #include "../../oracle/niqki_oracle.h"
 
+#include <zlib.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -33,6 +35,7 @@ struct niqki_index {
   std::vector<int32_t> staged;    // sketches of the staged batch
   uint32_t staged_n = 0;
   bool staged_ok = false;
+  uint64_t gz_seen = 0;   // NIQKI_FILE_GZIP files shown so far
   std::vector<uint8_t> dump;      // export cache / import accumulation
   uint32_t dump_n = 0xFFFFFFFFu;
   std::vector<uint64_t> dump_slot;   // byte position of every slot's first bucket (header excluded), F + 1
@@ -149,6 +152,7 @@ const char *niqki_status_string(int s) {
     case NIQKI_E_CAPACITY: return "output capacity too small";
     case NIQKI_E_STATE: return "invalid state";
     case NIQKI_E_NODEVICE: return "no gfx950 device";
+    case NIQKI_E_GZIP: return "gzip file not taken by the device inflate";
     default: return "unknown status";
   }
 }
@@ -263,6 +267,18 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   *info = niqki_stage_info{0, 0, 0, 0};
   if (b->lines && b->n_files > 1) return fail(ix, NIQKI_E_INVALID, "lines mode frames one file per call");
   std::vector<uint8_t> unpacked;
+  // NIQKI_FILE_GZIP files: this stand-in refuses every third one it is shown (so that the host program's way back
+  // through zlib runs under the sanitizers too) and inflates the others with zlib, as strict about them as the device
+  bool refused = false;
+  for (uint32_t f = 0; f < b->n_files; ++f) {
+    if (b->file_status) b->file_status[f] = 0;
+    if ((b->file_type[f] & NIQKI_FILE_GZIP) && (!b->file_ptr || b->lines)) return fail(ix, NIQKI_E_INVALID, "gzip files: file_ptr form, whole mode");
+    if ((b->file_type[f] & NIQKI_FILE_GZIP) && (ix->gz_seen++ % 3) == 2) {
+      if (b->file_status) b->file_status[f] = 5;
+      refused = true;
+    }
+  }
+  if (refused) return fail(ix, NIQKI_E_GZIP, "gzip files refused (file_status)");
   std::vector<Rec> recs;
   std::vector<size_t> file_first(b->n_files + 1, 0);
   uint64_t raw_total = 0;
@@ -281,6 +297,29 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
       d = unpacked.data();
       n = h.raw_len;
       type = 'A';
+    } else if (b->file_type[f] & NIQKI_FILE_GZIP) {
+      type = (char)(b->file_type[f] & ~NIQKI_FILE_GZIP);
+      if (type != 'A' && type != 'Q') return fail(ix, NIQKI_E_INVALID, "bad gzip file type");
+      uint64_t isize = 0;
+      if (wire >= 18) isize = (uint64_t)d[wire - 4] | (uint64_t)d[wire - 3] << 8 | (uint64_t)d[wire - 2] << 16 | (uint64_t)d[wire - 1] << 24;
+      unpacked.assign((size_t)isize + 1, 0);
+      z_stream z{};
+      bool ok = wire >= 18 && inflateInit2(&z, 15 + 16) == Z_OK;
+      if (ok) {
+        z.next_in = const_cast<Bytef *>(d);
+        z.avail_in = (uInt)wire;
+        z.next_out = unpacked.data();
+        z.avail_out = (uInt)unpacked.size();
+        const int r = inflate(&z, Z_FINISH);
+        ok = r == Z_STREAM_END && z.avail_in == 0 && z.total_out == isize;
+        inflateEnd(&z);
+      }
+      if (!ok) {
+        if (b->file_status) b->file_status[f] = 12;
+        return fail(ix, NIQKI_E_GZIP, "gzip file refused (file_status)");
+      }
+      d = unpacked.data();
+      n = isize;
     } else if (type != 'A' && type != 'Q') {
       return fail(ix, NIQKI_E_INVALID, "file_type must be 'A', 'Q' or 'a'");
     }

@@ -124,6 +124,25 @@ def test_gzip_inputs_and_many_files(workdir, gold):
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, NIQKI_HOST_ZLIB_ONLY="1"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert gunzip(workdir / "big_zlib.gz") == gunzip(workdir / "big.gz")
+    # gzip files cross PCIe as they are and are inflated on the device (nq_inflate.hip; the multi-member ones come back
+    # refused and go through zlib here): inflating everything on the host gives the same text
+    r = subprocess.run([BIN, "-I", "big.txt", "-Q", "fof.txt", "-S", "10", "-J", "0.1", "-O", "big_host.gz"], cwd=workdir,
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, NIQKI_HOST_NO_GPU_INFLATE="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert gunzip(workdir / "big_host.gz") == gunzip(workdir / "big.gz")
+    # a damaged file (a flipped byte in the middle of the stream; a cut one) ends the run the same way either way
+    raw = bytearray((workdir / big[0]).read_bytes())
+    raw[len(raw) // 2] ^= 0x10
+    (workdir / "damaged.fa.gz").write_bytes(bytes(raw))
+    (workdir / "cut.fa.gz").write_bytes((workdir / big[2]).read_bytes()[:-40])
+    for victim in ("damaged.fa.gz", "cut.fa.gz"):
+        (workdir / "bad.txt").write_text("\n".join(big[:40] + [victim] + big[40:80]) + "\n")
+        outs = []
+        for env in ({}, {"NIQKI_HOST_NO_GPU_INFLATE": "1"}):
+            r = subprocess.run([BIN, "-I", "bad.txt", "-S", "10", "-J", "0.1", "-O", "bad.gz"], cwd=workdir,
+                               capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+            outs.append((r.returncode, r.stderr.strip().splitlines()[-1:]))
+        assert outs[0] == outs[1] and outs[0][0] != 0 and victim in outs[0][1][0], outs
     # three shards, each staging (and prefetching) its share of every batch: the same text
     r = subprocess.run([BIN, "--gpus", "3", "-I", "big.txt", "-Q", "fof.txt", "-S", "10", "-J", "0.1", "-O", "big_mg.gz"], cwd=workdir,
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, NIQKI_SHARDS_ON_ONE_DEVICE="1"))
