@@ -158,7 +158,7 @@ int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate);
 int niqki_gunzip(niqki_index *ix, const uint8_t *gz, const uint64_t *gz_off, uint32_t n_files, const uint64_t *raw_off,
                  uint8_t *raw, uint32_t *status, uint64_t *produced, uint32_t *members, uint64_t *outside);
 /* how the files of the last niqki_gunzip / niqki_stage_raw were decoded, summed over them: out[0] speculative
- * rounds, [1] tokens they took, [2] tokens taken one by one, [3] DEFLATE blocks */
+ * rounds, [1] bytes they produced, [2] tokens taken one by one, [3] DEFLATE blocks */
 int niqki_gunzip_stats(niqki_index *ix, uint64_t out[4]);
 
 

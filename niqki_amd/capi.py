@@ -485,10 +485,10 @@ class Engine:
         return out, status[:n], produced[:n], members[:n], int(outside.value)
 
     def gunzip_stats(self):
-        """{rounds, round_tokens, serial_tokens, blocks} of the last device inflate (summed over its files)"""
+        """{rounds, round_bytes, serial_tokens, blocks} of the last device inflate (summed over its files)"""
         o = np.zeros(4, dtype=np.uint64)
         self._ck(self.L.niqki_gunzip_stats(self.h, _p(o)))
-        return dict(zip(("rounds", "round_tokens", "serial_tokens", "blocks"), (int(x) for x in o)))
+        return dict(zip(("rounds", "round_bytes", "serial_tokens", "blocks"), (int(x) for x in o)))
 
     def staged_records(self):
         """(records as list of bytes, entry_rec, hdr_pos) of the staged batch."""

@@ -261,7 +261,7 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
     uint32_t bad = 0;
     for (int i = 0; i < 4; ++i) ix->inflate_stats[i] = 0;
     for (size_t j = 0; j < jobs.size(); ++j) {
-      ix->inflate_stats[0] += iout[j].rounds; ix->inflate_stats[1] += iout[j].round_tokens;
+      ix->inflate_stats[0] += iout[j].rounds; ix->inflate_stats[1] += iout[j].round_bytes;
       ix->inflate_stats[2] += iout[j].serial_tokens; ix->inflate_stats[3] += iout[j].blocks;
     }
     for (size_t j = 0; j < jobs.size(); ++j)
@@ -416,12 +416,12 @@ int niqki_gunzip(niqki_index *ix, const uint8_t *gz, const uint64_t *gz_off, uin
   }
   for (int i = 0; i < 4; ++i) ix->inflate_stats[i] = 0;
 #ifdef NQ_INFLATE_CLOCK
-  fprintf(stderr, "inflate clocks of file 0 (outside, decode, walk, copy, reader, flush):");
-  for (int i = 0; i < 6; ++i) fprintf(stderr, " %llu", (unsigned long long)out[0].clk[i]);
+  fprintf(stderr, "inflate clocks of file 0 (outside, decode, walk, copy, reader, flush, tables, serial matches):");
+  for (int i = 0; i < 8; ++i) fprintf(stderr, " %llu", (unsigned long long)out[0].clk[i]);
   fprintf(stderr, "\n");
 #endif
   for (uint32_t f = 0; f < n_files; ++f) {
-    ix->inflate_stats[0] += out[f].rounds; ix->inflate_stats[1] += out[f].round_tokens;
+    ix->inflate_stats[0] += out[f].rounds; ix->inflate_stats[1] += out[f].round_bytes;
     ix->inflate_stats[2] += out[f].serial_tokens; ix->inflate_stats[3] += out[f].blocks;
     if (status) status[f] = out[f].status;
     if (produced) produced[f] = out[f].produced;

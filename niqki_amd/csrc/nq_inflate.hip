@@ -171,12 +171,13 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
   __shared__ uint8_t cl_lens[32];
   __shared__ uint32_t hc[2][3][16];   // [lit, dist][cnt, first, offs]
   __shared__ uint32_t run[16];
+  __shared__ uint32_t inbuf[132];   // the input blocks bblk and bblk + 1 (slot = block & 1), dwords 0..3 once more behind them
 
   const uint32_t lane = threadIdx.x;
   const InflateJob job = jobs[blockIdx.x];
   InflateOut res;
   res.status = 0; res.members = 0; res.produced = 0; res.consumed = 0;
-  res.rounds = 0; res.round_tokens = 0; res.serial_tokens = 0; res.blocks = 0;
+  res.rounds = 0; res.round_bytes = 0; res.serial_tokens = 0; res.blocks = 0;
 #ifdef NQ_INFLATE_CLOCK
   for (int i = 0; i < 8; ++i) res.clk[i] = 0;
   uint64_t clk_last = __builtin_readcyclecounter();
@@ -200,13 +201,20 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
   const uint32_t n_words = (uint32_t)((skip + job.src_len + 3u) >> 2);   // dwords that hold bytes of the file (< 2^29)
   const uint64_t total_bits = (skip + job.src_len) * 8u;
   uint32_t err = 0;
-  uint32_t cur, nxt;      // lane i: dword 64 * bblk + i of the input / the block behind it
+  uint32_t cur, nxt, nn;  // lane i: dword 64 * bblk + i of the input / the blocks behind it (nn: on its way)
   uint32_t bblk = 0;      // which 64-dword block `cur` holds
   uint32_t bitpos = 0;    // the stream's next bit, counted from the start of `cur`; < 2048 between tokens
   auto load_blk = [&](uint32_t b) -> uint32_t {
     uint32_t w = b * 64u + lane;
     w = w > last_dword ? last_dword : w;
     return in_base[w];
+  };
+  // the lanes read the window of a round from LDS: block b lies in slot b & 1, and the first dwords of slot 0 are
+  // repeated behind slot 1, so that three consecutive dwords never wrap
+  auto stage_blk = [&](uint32_t b, uint32_t v) {
+    const uint32_t slot = (b & 1u) << 6;
+    inbuf[slot + lane] = v;
+    if (slot == 0u && lane < 4u) inbuf[128u + lane] = v;
   };
   auto s_dword = [&](uint32_t i) -> uint32_t {   // dword i (< 128) behind the start of `cur`, wave-uniform
     const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i & 63u));
@@ -217,8 +225,10 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
     bitpos += n;
     if (bitpos >= 2048u) {
       cur = nxt;
+      nxt = nn;              // (asked for a whole block of input ago)
       ++bblk;
-      nxt = load_blk(bblk + 1u);
+      stage_blk(bblk + 1u, nxt);
+      nn = load_blk(bblk + 2u);
       bitpos -= 2048u;
       if (bblk * 64u > n_words + 64u) err = err ? err : 8u;   // far past the file: truncated
     }
@@ -240,6 +250,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
     bblk = (uint32_t)(byte_from_base >> 8);
     cur = load_blk(bblk);
     nxt = load_blk(bblk + 1u);
+    nn = load_blk(bblk + 2u);
+    lds_fence();
+    stage_blk(bblk, cur);
+    stage_blk(bblk + 1u, nxt);
+    lds_fence();
     bitpos = 8u * (uint32_t)(byte_from_base & 255u);
   };
 
@@ -327,6 +342,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
     // ---- blocks (RFC 1951) ----
     uint32_t bfinal = 0;
     while (!err && !bfinal) {
+      NQ_CLK(0);
       bfinal = getbits(1);
       const uint32_t btype = getbits(2);
       ++res.blocks;
@@ -407,6 +423,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
         if (!build_table<1, kDistP>(lens + hlit, hdist, dist_tab, dist_sorted, hc[1][0], hc[1][1], hc[1][2], run, lane)) { err = 4u; break; }
       }
 
+      NQ_CLK(6);   // block header and tables
       // ---- symbols ----
       for (;;) {
         if (err) break;
@@ -418,23 +435,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
         NQ_CLK(0);   // everything outside the rounds: headers, tables, serial tokens
         uint32_t v_info, v_tokv;
         {
-          // the five dwords the 64 offsets reach into, wave-uniform
-          const uint32_t i0 = bitpos >> 5, bo = bitpos & 31u;
-          uint32_t w0, w1, w2, w3, w4;
-          if (i0 < 60u) {
-            w0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)i0);
-            w1 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i0 + 1u));
-            w2 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i0 + 2u));
-            w3 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i0 + 3u));
-            w4 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i0 + 4u));
-          } else {
-            w0 = s_dword(i0); w1 = s_dword(i0 + 1u); w2 = s_dword(i0 + 2u); w3 = s_dword(i0 + 3u); w4 = s_dword(i0 + 4u);
-          }
-          const uint32_t q = bo + lane;
-          const uint32_t k = q >> 5, sh = q & 31u;
-          const uint32_t d0 = k == 0u ? w0 : k == 1u ? w1 : w2;
-          const uint32_t d1 = k == 0u ? w1 : k == 1u ? w2 : w3;
-          const uint32_t d2 = k == 0u ? w2 : k == 1u ? w3 : w4;
+          // the 64 bits behind bit `bitpos + lane`: three dwords of the staged input
+          const uint32_t q = bitpos + lane;
+          const uint32_t *wp = inbuf + ((bblk & 1u) << 6) + (q >> 5);
+          const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2];
+          const uint32_t sh = q & 31u;
           const uint32_t x0 = __builtin_amdgcn_alignbit(d1, d0, sh), x1 = __builtin_amdgcn_alignbit(d2, d1, sh);
           const uint32_t e = lit_tab[x0 & ((1u << kLitP) - 1u)];
           const uint32_t l = e & 31u, kind = (e >> 5) & 3u;
@@ -460,45 +465,64 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
           v_info = plain ? (tot | (olen << 6) | (lim << 15)) : (1u << 6);   // tot 6 bits, olen 9, lim 7; no token here: a byte that never fits
           v_tokv = lit ? (0x10000u | ((e >> 8) & 0xFFu)) : dist;
         }
-        uint32_t p, outb, v_tok, ntok;
+        uint32_t p, outb, v_tok;
 #ifdef NQ_INFLATE_CLOCK
         asm volatile("s_nop 0" :: "v"(v_info), "v"(v_tokv));
         NQ_CLK(1);   // the lanes' decode
 #endif
-        // The chain of tokens through the lanes' results: token at bit p takes the round's bytes [outb, end) when
-        // end <= its lim; the lanes of those bytes remember its tokv.  Written out by hand: the compiler turns the
-        // loop's exits into flag arithmetic and two taken branches per token; this is 16 instructions and one.
-        // (Every adjacent producer / consumer pair below also occurs in compiler-emitted code for gfx950; the s_nop
-        // covers the lanes' last vector writes of v_info / v_tokv ahead of the first v_readlane.)
+        // The chain of tokens through the lanes' results: the token at bit p takes the round's bytes [o, end) when
+        // end <= its lim, and the lanes of those bytes remember its tokv.  Written out by hand (the compiler turns the
+        // loop's exits into flag arithmetic and two taken branches per token): two tokens per trip, 14 instructions
+        // each, the running end alternating between two registers.  Every adjacent producer / consumer pair below
+        // also occurs in compiler-emitted code for gfx950; the s_nop covers the lanes' last vector writes of v_info /
+        // v_tokv ahead of the first v_readlane.
         {
-          uint32_t s_info, s_tv, s_end, s_lim, v_tmp;
+          uint32_t s_info, s_tv, s_o0, s_o1, s_lim, v_tmp;
           asm volatile(
               "s_nop 1\n\t"
               "s_mov_b32 %[p], 0\n\t"
-              "s_mov_b32 %[outb], 0\n\t"
-              "s_mov_b32 %[ntok], 0\n\t"
+              "s_mov_b32 %[o0], 0\n\t"
               "v_mov_b32 %[vtok], 0\n"
               ".Lnq_walk_%=:\n\t"
               "v_readlane_b32 %[info], %[vinfo], %[p]\n\t"
               "v_readlane_b32 %[tv], %[vtokv], %[p]\n\t"
-              "s_bfe_u32 %[end], %[info], 0x90006\n\t"
-              "s_add_u32 %[end], %[end], %[outb]\n\t"
+              "s_bfe_u32 %[o1], %[info], 0x90006\n\t"
+              "s_add_u32 %[o1], %[o1], %[o0]\n\t"
               "s_lshr_b32 %[lim], %[info], 15\n\t"
-              "s_cmp_gt_u32 %[end], %[lim]\n\t"
-              "s_cbranch_scc1 .Lnq_walk_done_%=\n\t"
+              "s_cmp_gt_u32 %[o1], %[lim]\n\t"
+              "s_cbranch_scc1 .Lnq_walk_end0_%=\n\t"
               "v_mov_b32 %[vtmp], %[tv]\n\t"
-              "v_cmp_gt_u32 vcc, %[outb], %[lane]\n\t"
+              "v_cmp_gt_u32 vcc, %[o0], %[lane]\n\t"
               "s_and_b32 %[info], %[info], 63\n\t"
               "s_add_u32 %[p], %[p], %[info]\n\t"
               "v_cndmask_b32 %[vtok], %[vtmp], %[vtok], vcc\n\t"
-              "s_mov_b32 %[outb], %[end]\n\t"
-              "s_add_u32 %[ntok], %[ntok], 1\n\t"
               "s_cmp_lt_u32 %[p], 64\n\t"
-              "s_cbranch_scc1 .Lnq_walk_%=\n"
+              "s_cbranch_scc0 .Lnq_walk_end1_%=\n\t"
+              "v_readlane_b32 %[info], %[vinfo], %[p]\n\t"
+              "v_readlane_b32 %[tv], %[vtokv], %[p]\n\t"
+              "s_bfe_u32 %[o0], %[info], 0x90006\n\t"
+              "s_add_u32 %[o0], %[o0], %[o1]\n\t"
+              "s_lshr_b32 %[lim], %[info], 15\n\t"
+              "s_cmp_gt_u32 %[o0], %[lim]\n\t"
+              "s_cbranch_scc1 .Lnq_walk_end1_%=\n\t"
+              "v_mov_b32 %[vtmp], %[tv]\n\t"
+              "v_cmp_gt_u32 vcc, %[o1], %[lane]\n\t"
+              "s_and_b32 %[info], %[info], 63\n\t"
+              "s_add_u32 %[p], %[p], %[info]\n\t"
+              "v_cndmask_b32 %[vtok], %[vtmp], %[vtok], vcc\n\t"
+              "s_cmp_lt_u32 %[p], 64\n\t"
+              "s_cbranch_scc1 .Lnq_walk_%=\n\t"
+              "s_mov_b32 %[outb], %[o0]\n\t"
+              "s_branch .Lnq_walk_done_%=\n"
+              ".Lnq_walk_end0_%=:\n\t"
+              "s_mov_b32 %[outb], %[o0]\n\t"
+              "s_branch .Lnq_walk_done_%=\n"
+              ".Lnq_walk_end1_%=:\n\t"
+              "s_mov_b32 %[outb], %[o1]\n"
               ".Lnq_walk_done_%=:\n\t"
               "s_nop 0"
-              : [p] "=&s"(p), [outb] "=&s"(outb), [ntok] "=&s"(ntok), [vtok] "=&v"(v_tok), [vtmp] "=&v"(v_tmp), [info] "=&s"(s_info), [tv] "=&s"(s_tv),
-                [end] "=&s"(s_end), [lim] "=&s"(s_lim)
+              : [p] "=&s"(p), [outb] "=&s"(outb), [vtok] "=&v"(v_tok), [vtmp] "=&v"(v_tmp), [info] "=&s"(s_info), [tv] "=&s"(s_tv),
+                [o0] "=&s"(s_o0), [o1] "=&s"(s_o1), [lim] "=&s"(s_lim)
               : [vinfo] "v"(v_info), [vtokv] "v"(v_tokv), [lane] "v"(lane)
               : "vcc", "scc");
         }
@@ -511,7 +535,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
           const uint32_t before = pos;
           pos += outb;
           ++res.rounds;
-          res.round_tokens += ntok;
+          res.round_bytes += outb;
           NQ_CLK(3);   // the copy
           drop(p);
           NQ_CLK(4);   // the reader moving on
@@ -519,6 +543,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
           continue;
         }
         // ---- one token, serially ----
+        NQ_CLK(0);
         ++res.serial_tokens;
         uint64_t bb = peek64();
         uint32_t e = uni(lit_tab[(uint32_t)bb & ((1u << kLitP) - 1u)]);
@@ -595,6 +620,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
         const uint32_t before = pos;
         pos += mlen;
         if ((before ^ pos) & ~(kPage - 1u)) flush_pages();
+        NQ_CLK(7);   // a token taken serially
       }
     }
     if (err) break;

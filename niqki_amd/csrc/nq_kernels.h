@@ -267,7 +267,7 @@ struct InflateJob {
 struct InflateOut {
   uint32_t status, members;
   uint64_t produced, consumed;
-  uint32_t rounds, round_tokens, serial_tokens, blocks;   // how the file was decoded (nq_inflate.hip)
+  uint32_t rounds, round_bytes, serial_tokens, blocks;   // how the file was decoded (nq_inflate.hip)
 #ifdef NQ_INFLATE_CLOCK
   uint64_t clk[8];   // shader cycles by phase (diagnosis build only)
 #endif

@@ -22,18 +22,36 @@ sys.path.insert(0, ROOT)
 BIN = os.path.join(ROOT, "niqki_amd", "bin", "niqki")
 
 
-def write_fasta(path, name, seq, gz):
+def write_fasta(path, name, seq, gz, level=1):
     rows = np.frombuffer(seq[: len(seq) // 70 * 70], np.uint8).reshape(-1, 70)
     body = np.concatenate([rows, np.full((rows.shape[0], 1), 10, np.uint8)], axis=1).tobytes()
     tail = bytes(seq[len(seq) // 70 * 70:])
     data = b">" + name.encode() + b"\n" + body + (tail + b"\n" if tail else b"")
     if gz:
-        with gzip.open(path, "wb", compresslevel=1) as f:
+        with gzip.open(path, "wb", compresslevel=level) as f:
             f.write(data)
     else:
         with open(path, "wb") as f:
             f.write(data)
     return len(data)
+
+
+def _write_one(job):
+    g, fn, length, gz, level = job
+    import niqki_amd
+    seq = niqki_amd.synth_genome_host(11, g // 16, g % 16, 0 if g % 16 == 0 else 20 + 40 * (g % 16), length)
+    return write_fasta(fn, "g%05d" % g, seq, gz, level)
+
+
+def cpu_quota():
+    try:
+        threads = len(os.sched_getaffinity(0))
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            threads = max(1, min(threads, int(round(float(q[0]) / float(q[1])))))
+        return threads
+    except (OSError, ValueError, IndexError, AttributeError):
+        return os.cpu_count() or 1
 
 
 def main():
@@ -42,6 +60,9 @@ def main():
     ap.add_argument("--len", type=int, default=5_000_000)
     ap.add_argument("--reads", type=int, default=0)
     ap.add_argument("--gz", action="store_true")
+    ap.add_argument("--gz-level", type=int, default=6, help="gzip level of the input files (gzip's own default is 6)")
+    ap.add_argument("--host-inflate-too", action="store_true",
+                    help="--gz: the index + query run once more with NIQKI_HOST_NO_GPU_INFLATE=1 (every file inflated by the reader threads)")
     ap.add_argument("--dir", default="/dev/shm/niqki_cli_bench")
     ap.add_argument("--extra", default="", help="extra CLI options, space separated")
     ap.add_argument("--reference", type=int, default=0,
@@ -52,22 +73,28 @@ def main():
     shutil.rmtree(args.dir, ignore_errors=True)
     os.makedirs(args.dir)
     try:
-        names, raw_bytes = [], 0
-        for g in range(args.genomes):
-            seq = niqki_amd.synth_genome_host(11, g // 16, g % 16, 0 if g % 16 == 0 else 20 + 40 * (g % 16), args.len)
-            fn = os.path.join(args.dir, "g%05d.fa%s" % (g, ".gz" if args.gz else ""))
-            raw_bytes += write_fasta(fn, "g%05d" % g, seq, args.gz)
-            names.append(fn)
+        names = [os.path.join(args.dir, "g%05d.fa%s" % (g, ".gz" if args.gz else "")) for g in range(args.genomes)]
+        jobs = [(g, fn, args.len, args.gz, args.gz_level) for g, fn in enumerate(names)]
+        if args.gz and args.genomes >= 32:   # (compressing is the slow part of making the inputs)
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(min(16, cpu_quota())) as pool:
+                raw_bytes = sum(pool.map(_write_one, jobs, chunksize=4))
+        else:
+            raw_bytes = sum(_write_one(j) for j in jobs)
         open(os.path.join(args.dir, "fof.txt"), "w").write("\n".join(names) + "\n")
         extra = args.extra.split()
         res = {"genomes": args.genomes, "len": args.len, "gz": args.gz, "fasta_bytes": raw_bytes}
+        if args.gz:
+            res["gz_level"] = args.gz_level
+            res["file_bytes"] = sum(os.path.getsize(n) for n in names)
 
         env = dict(os.environ, NIQKI_HOST_TIMING="1")
         phases = {}
 
-        def run(tag, cli):
+        def run(tag, cli, more_env=None):
             t0 = time.time()
-            r = subprocess.run([BIN] + cli + extra, cwd=args.dir, capture_output=True, text=True, timeout=1800, env=env)
+            r = subprocess.run([BIN] + cli + extra, cwd=args.dir, capture_output=True, text=True, timeout=1800,
+                               env=dict(env, **(more_env or {})))
             dt = time.time() - t0
             # the program's own phase clocks: "[niqki timing] N files: total T s, ..." / "... lines mode: N entries in T s"
             phases[tag] = [float(x.split(" s")[0]) for line in r.stderr.splitlines() if line.startswith("[niqki timing]")
@@ -99,6 +126,11 @@ def main():
             cp, dv, ou = (float(x) for x in m.groups())
             # (copy_and_frame: what the main thread still waits for -- the copy of batch i+1 runs under batch i)
             res["query_phase_split_s"] = {"copy_and_frame": cp, "sketch_and_query": dv, "output": ou}
+        if args.gz and args.host_inflate_too:
+            run("index_query_host_inflate", ["-I", "fof.txt", "-Q", "fof.txt", "-J", "0.1", "-O", "o2h.gz"], {"NIQKI_HOST_NO_GPU_INFLATE": "1"})
+            res["host_inflate"] = {"index_genomes_per_s": round(args.genomes / phases["index_query_host_inflate"][0], 1),
+                                   "query_genomes_per_s": round(args.genomes / phases["index_query_host_inflate"][1], 1),
+                                   "outputs_equal": open(os.path.join(args.dir, "o2.gz"), "rb").read() == open(os.path.join(args.dir, "o2h.gz"), "rb").read()}
         # the REFERENCE's own program on the same files (oracle/_ref, where it travelled with the repo): its CPU path,
         # and the same program with compute_sketch / insert_sketch / query_sketch bound to the C ABI
         # (oracle/ref_gpu_ops.cpp) -- wall time of `-I fof -Q fof` on the first files, threads = the CPUs this job has
@@ -107,13 +139,7 @@ def main():
         if not args.gz and args.reference and os.path.exists(ref_cpu) and os.path.exists(ref_gpu):
             n_ref = min(args.genomes, args.reference)
             open(os.path.join(args.dir, "ref.txt"), "w").write("\n".join(names[:n_ref]) + "\n")
-            try:
-                threads = len(os.sched_getaffinity(0))
-                q = open("/sys/fs/cgroup/cpu.max").read().split()
-                if q[0] != "max":
-                    threads = max(1, min(threads, int(round(float(q[0]) / float(q[1])))))
-            except (OSError, ValueError, IndexError, AttributeError):
-                threads = os.cpu_count() or 1
+            threads = cpu_quota()
             renv = dict(os.environ, OMP_NUM_THREADS=str(threads), NIQKI_REF_GPU_REPORT="1")
             ref = {"files": n_ref, "threads": threads}
             for tag, binary in (("reference_cpu", ref_cpu), ("reference_on_c_abi", ref_gpu)):
