@@ -1236,11 +1236,13 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
     # program's own phase clocks, its start-up reported beside them)
     import subprocess
     cli = {}
-    for tag, n_files, gz in (("plain_fasta", 2048, False), ("gzip_fasta", 64, True)):
+    for tag, n_files, gz in (("plain_fasta", 2048, False), ("gzip_fasta", 2048, True)):
         cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_cli.py"), "--genomes", str(n_files), "--len", str(L),
                "--dir", os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "niqki_bench_cli_%d" % os.getpid())]
         if gz:
-            cmd.append("--gz")
+            # gzip -6 files (gzip's default), crossing PCIe as they are and inflated on the device (nq_inflate.hip); the
+            # same run once more with every file inflated by the reader threads (NIQKI_HOST_NO_GPU_INFLATE=1)
+            cmd += ["--gz", "--host-inflate-too"]
         else:
             cmd += ["--reference", "128", "--reads", "4000000"]
         try:
@@ -1257,6 +1259,12 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
                         "packed_fasta": "plain FASTA files travel as 2 bits per base in full A/C/G/T lines (niqki_pack_fasta, "
                                         "made by the reader threads while they read); the device restores the files' bytes" if not gz else None,
                         "query_phase_split_s": j.get("query_phase_split_s")}
+            if gz:
+                cli[tag]["gzip_level"] = j.get("gz_level")
+                cli[tag]["file_GB"] = round(j.get("file_bytes", 0) / 1e9, 3)
+                cli[tag]["device_inflate"] = ("gzip files cross PCIe as they lie on disk, one wavefront per file inflates them "
+                                              "(batches of 256, then 1024 files; CRC-32 and sizes checked on the device)")
+                cli[tag]["reader_threads_inflate_instead"] = j.get("host_inflate")
             if j.get("reads_per_s"):
                 # BASELINE configs[4] as FILES: `niqki -I fof -l reads.fa -S 12 -W 10` (--querylines: one entry per record),
                 # 4 M 150-base reads in a FASTA file in the page cache, the lines phase's own clock
@@ -1267,6 +1275,22 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
                 cli[tag]["reference_program"] = j["reference_program"]
     out["cli_files"] = {"workload": "niqki -I fof -Q fof -J 0.1 on 5 Mbp FASTA files (70 columns) in the page cache, whole-file mode",
                         **cli} if cli else None
+    # ---- the device inflate alone: 1024 gzip -6 genome files resident in HBM, one launch (tools/bench_inflate.py) ----
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_inflate.py"), "--files", "1024", "--len", str(L),
+                            "--distinct", "8", "--reps", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        j = json.loads(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else None
+    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
+        j = None
+    if j:
+        out["gzip_inflate"] = {
+            "workload": "1024 gzip -6 FASTA files of %d bp inflated in one launch of nq::inflate_kernel (one wavefront per file, four per CU), "
+                        "bytes checked against the files' own" % L,
+            "kernel_ms": j["kernel_ms"], "files_per_s": j["files_per_s"], "inflated_GBps": j["raw_GBps"], "compressed_GBps": j["wire_GBps"],
+            "per_file": j["per_file"],
+            "bound": "the latency of one wavefront's dependent instructions (a DEFLATE stream is serial): every file takes the whole "
+                     "launch, throughput = files in flight / that time",
+            "zlib_one_host_thread_files_per_s": j["zlib_one_thread_files_per_s"]}
     return out
 
 

@@ -46,6 +46,7 @@
  *                           strength (default: chosen per sketch).  Test switches of nq_sketch.hip's launch shapes.
  * The `niqki` host program reads NIQKI_HOST_THREADS (reader threads; default: the CPUs the process may use),
  * NIQKI_HOST_TIMING (phase times on stderr), NIQKI_HOST_NO_PACK (plain FASTA files travel as their bytes),
+ * NIQKI_HOST_NO_GPU_INFLATE (gzip files are inflated by the reader threads instead of the device),
  * NIQKI_HOST_ZLIB_ONLY (no libdeflate), NIQKI_SHARDS_ON_ONE_DEVICE (--gpus N on one device: tests).
  */
 #ifndef NIQKI_HIP_H
@@ -286,7 +287,7 @@ int niqki_query_sequences(niqki_index *ix, const uint8_t *seqs,
  * Index::Biogetline (src/niqki_index.cpp:890-941) and the read loops of
  * insert_file_whole / query_file_whole (:442-456, :505-519) and
  * insert_file_lines / query_file_lines (:383-430): the caller hands over the
- * (gunzipped) bytes of its files, the records are framed on the device and stay
+ * bytes of its files (gzip files as they are, see NIQKI_FILE_GZIP below, or inflated), the records are framed on the device and stay
  * there as the "staged batch" of the handle; niqki_staged_* then sketch, insert
  * or query it.  Framing is the reference's: FASTA = the first line of a file and
  * every line starting with '>' is a header, all other lines are concatenated
