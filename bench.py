@@ -1263,7 +1263,7 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
                 cli[tag]["gzip_level"] = j.get("gz_level")
                 cli[tag]["file_GB"] = round(j.get("file_bytes", 0) / 1e9, 3)
                 cli[tag]["device_inflate"] = ("gzip files cross PCIe as they lie on disk, one wavefront per file inflates them "
-                                              "(batches of 256, then 1024 files; CRC-32 and sizes checked on the device)")
+                                              "(batches of 1024 files; CRC-32 and sizes checked on the device)")
                 cli[tag]["reader_threads_inflate_instead"] = j.get("host_inflate")
             if j.get("reads_per_s"):
                 # BASELINE configs[4] as FILES: `niqki -I fof -l reads.fa -S 12 -W 10` (--querylines: one entry per record),
