@@ -176,7 +176,11 @@ int niqki_synchronize(niqki_index *ix);
  * src/niqki_index.cpp:412-430 -- niqki_query* / niqki_staged_query take a query's thresholded hits out of the gather
  * kernel while its counters are in LDS, already ordered, instead of writing a 2N-byte counter row per query and reading
  * it again; 0 = always through counter rows), "hit_list_cap" (1..2048, default 256: hits per query such a list holds; a
- * query with more -- min_score 0: every genome -- leaves through its counter row and is ordered from there). */
+ * query with more -- min_score 0: every genome -- leaves through its counter row and is ordered from there),
+ * "inflate_window" (-1 = default: a launch of the device inflate, NIQKI_FILE_GZIP below, keeps each file's whole 32 KB
+ * window in LDS -- four files per CU at a time -- unless it holds more files than that runs at once; then only the
+ * window's last 8 KB, ten files per CU, and matches that reach further back read the file's own flushed output;
+ * 0 / 1 = always the first / second form.  Same bytes either way). */
 int niqki_set_option(niqki_index *ix, const char *key, int64_t value);
 
 /* Pre-sizes the sketch store for n_genomes (optional; the store grows). */

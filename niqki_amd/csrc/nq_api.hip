@@ -342,6 +342,11 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
     return NIQKI_OK;
   }
   if (!std::strcmp(key, "hit_lists")) { ix->hit_lists = value != 0; return NIQKI_OK; }
+  if (!std::strcmp(key, "inflate_window")) {
+    if (value < -1 || value > 1) return fail(ix, NIQKI_E_INVALID, "inflate_window: -1 = by the number of files, 0 = whole in LDS, 1 = its last 8 KB in LDS");
+    ix->inflate_window = (int)value;
+    return NIQKI_OK;
+  }
   if (!std::strcmp(key, "hit_list_cap")) {
     if (value < 1 || value > (int64_t)nq::kHitListMaxCap) return fail(ix, NIQKI_E_INVALID, "hit_list_cap must be in 1..2048");
     ix->hit_list_cap = (uint32_t)value;

@@ -47,7 +47,8 @@ int inflate_launch(niqki_index *ix, const std::vector<nq::InflateJob> &jobs, con
   NQ_HIP(ix, hipMemcpyAsync(ix->ws_ijob.p, jobs.data(), n * sizeof(nq::InflateJob), hipMemcpyHostToDevice, ix->stream));
   Span sp(ix, NIQKI_KC_INFLATE);
   NQ_HIP(ix, nq::launch_inflate((const nq::InflateJob *)ix->ws_ijob.p, (uint32_t)n, d_wire, wire_bytes, d_raw,
-                                (const uint32_t *)ix->ws_xtab.p, (nq::InflateOut *)((nq::InflateJob *)ix->ws_ijob.p + n), ix->stream));
+                                (const uint32_t *)ix->ws_xtab.p, (nq::InflateOut *)((nq::InflateJob *)ix->ws_ijob.p + n), ix->stream,
+                                ix->inflate_window));
   return NIQKI_OK;
 }
 

@@ -110,6 +110,7 @@ struct niqki_index {
   // staged batch (niqki_stage_raw): framing results live in ws_seq / ws_recoff / ws_entry
   nqi::Buf ws_raw, ws_fmeta, ws_summ, ws_chunk, ws_fkept, ws_fnrec, ws_hdrpos, ws_ehdr, ws_stsk, ws_order, ws_pre, ws_useg, ws_ijob, ws_xtab;
   uint64_t inflate_stats[4] = {0, 0, 0, 0};   // niqki_gunzip_stats
+  int inflate_window = -1;   // option "inflate_window": which form of the inflate kernel a launch takes
   bool xtab_ok = false;   // ws_xtab holds the CRC folding constants of the inflate kernel
   struct {
     bool valid = false, sketched = false;

@@ -27,7 +27,6 @@ namespace nq {
 
 namespace {
 
-constexpr uint32_t kRing = 32768, kRingMask = kRing - 1u;
 constexpr uint32_t kLitP = 10, kDistP = 8, kClP = 7;
 constexpr uint32_t kPage = 4096;
 constexpr uint32_t kKindLit = 0, kKindLen = 1, kKindEob = 2, kKindSlow = 3;
@@ -159,8 +158,15 @@ __device__ bool build_table(const uint8_t *L, uint32_t n, uint32_t *tab, uint16_
 
 }  // namespace
 
+// kRing: bytes of the window kept in LDS.  32768: all of it (four wavefronts per CU).  8192: the last 8 KB -- ten
+// wavefronts per CU; a match that reaches further back (kNear) reads its bytes from the file's own output in HBM,
+// which the flushes have written by then: a byte is flushed at most 4 KB + one match + one round after it is made.
+template <uint32_t kRing>
 __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, const uint8_t *wire, uint64_t wire_bytes,
                                                      uint8_t *raw, const uint32_t *xtab, InflateOut *outs) {
+  constexpr uint32_t kRingMask = kRing - 1u;
+  constexpr bool kFar = kRing < 32768u;
+  constexpr uint32_t kNear = kFar ? kRing - 512u : 0xFFFFFFFFu;   // distances up to here are served by the ring
   __shared__ __align__(16) uint8_t ring[kRing];
   __shared__ uint32_t lit_tab[1u << kLitP];
   __shared__ uint32_t dist_tab[1u << kDistP];
@@ -265,6 +271,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
   uint32_t pos = pos0, flushed = pos0, member_start = pos0;
   uint32_t crc = 0;   // CRC-32 of the member's bytes below `flushed`
 
+  // a byte of the file's own output that has left the ring (agent scope: past this CU's L1, from the L2 the flushes
+  // wrote through to)
+  auto load_far = [&](uint32_t p) -> uint32_t {
+    return __hip_atomic_load(out_al + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   // bytes [lo, hi) of one 4 KB page of positions leave the ring: HBM stores, and the member's CRC moves on
   auto flush = [&](uint32_t lo, uint32_t hi) {
     lds_fence();
@@ -309,6 +320,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
     const uint32_t chunk = mulmod(xtab[tail], uni(t)) ^ c_last;
     const uint32_t n = hi - lo;
     crc = uni(mulmod(mulmod(xtab[65u + (n >> 6)], xtab[n & 63u]), crc) ^ chunk);
+    if (kFar) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the page's stores are done before any later load_far
   };
   auto flush_pages = [&]() {   // after `pos` moved: every completed page
     while ((flushed ^ pos) & ~(kPage - 1u)) {
@@ -529,7 +541,10 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
         NQ_CLK(2);   // the walk
         if (outb) {
           if (lane < outb) {
-            const uint32_t b = ring[(pos + lane - (v_tok & 0xFFFFu)) & kRingMask];
+            const uint32_t dist = v_tok & 0xFFFFu, src = pos + lane - dist;
+            uint32_t b;
+            if (kFar && !(v_tok >> 16) && dist > kNear) b = load_far(src);
+            else b = ring[src & kRingMask];
             ring[(pos + lane) & kRingMask] = (uint8_t)((v_tok >> 16) ? v_tok : b);
           }
           const uint32_t before = pos;
@@ -604,7 +619,13 @@ __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, con
         if (dist > pos - member_start) { err = 6u; break; }   // zlib: "invalid distance too far back"
         if (pos + mlen > cap_end) { err = 7u; break; }
         const uint32_t src0 = pos - dist;
-        if (dist >= 64u || dist >= mlen) {
+        if (kFar && dist > kNear) {
+          // the whole source has left the ring (it ends kNear - 258 bytes back or more)
+          for (uint32_t o = 0; o < mlen; o += 64u) {
+            const uint32_t i = o + lane;
+            if (i < mlen) ring[(pos + i) & kRingMask] = (uint8_t)load_far(src0 + i);
+          }
+        } else if (dist >= 64u || dist >= mlen) {
           // 64 bytes at a time: a chunk's sources lie before the chunk, and the LDS serves the wave in order
           for (uint32_t o = 0; o < mlen; o += 64u) {
             const uint32_t i = o + lane;
@@ -668,9 +689,15 @@ void inflate_xtab(uint32_t *t) {
 }
 
 hipError_t launch_inflate(const InflateJob *jobs, uint32_t n_jobs, const uint8_t *wire, uint64_t wire_bytes, uint8_t *raw,
-                          const uint32_t *xtab, InflateOut *outs, hipStream_t stream) {
+                          const uint32_t *xtab, InflateOut *outs, hipStream_t stream, int small_ring) {
   if (n_jobs == 0) return hipSuccess;
-  hipLaunchKernelGGL(inflate_kernel, dim3(n_jobs), dim3(64), 0, stream, jobs, wire, wire_bytes, raw, xtab, outs);
+  // more files than the whole window in LDS lets run at once (four per CU): the small ring, ten per CU
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  if (small_ring < 0 ? n_jobs > 4u * (uint32_t)cus : small_ring != 0)
+    hipLaunchKernelGGL(inflate_kernel<8192u>, dim3(n_jobs), dim3(64), 0, stream, jobs, wire, wire_bytes, raw, xtab, outs);
+  else
+    hipLaunchKernelGGL(inflate_kernel<32768u>, dim3(n_jobs), dim3(64), 0, stream, jobs, wire, wire_bytes, raw, xtab, outs);
   return hipGetLastError();
 }
 

@@ -275,8 +275,10 @@ struct InflateOut {
 constexpr uint32_t kInflateXtabWords = 130;
 void inflate_xtab(uint32_t *t);   // host: the CRC folding constants the kernel reads (kInflateXtabWords words)
 // wire_bytes: readable bytes of `wire` (the kernel loads whole dwords up to there); raw: 16-byte aligned
+// small_ring: -1 = choose by the number of files (the whole 32 KB window in LDS, four files per CU at a time, or its
+// last 8 KB with far matches read back from the output, ten per CU), 0 / 1 = force (tests)
 hipError_t launch_inflate(const InflateJob *jobs, uint32_t n_jobs, const uint8_t *wire, uint64_t wire_bytes, uint8_t *raw,
-                          const uint32_t *xtab, InflateOut *outs, hipStream_t stream);
+                          const uint32_t *xtab, InflateOut *outs, hipStream_t stream, int small_ring = -1);
 
 // ---- synthetic genomes (nq_synth.hip) ----------------------------------------
 hipError_t launch_synth(uint64_t seed, const uint32_t *family, const uint32_t *member,

@@ -364,11 +364,13 @@ class OrderedFileReader {
 constexpr size_t kWholeBatchFiles = 64;                // files per GPU call (whole-file mode)
 constexpr size_t kWholeBatchBytes = size_t(3) << 29;   // ... or 1.5 GB
 constexpr size_t kReaderBufs = 2 * kWholeBatchFiles + 32;
-// Gzip files inflated on the device: a file is one wavefront's serial job there and the device runs 1024 of them at
-// once (four per CU), so a batch takes as long as its longest file whatever it holds -- batches of up to 1024 files
-// (their bytes are a quarter of the plain ones'), or 6 GB of inflated bytes.
-constexpr size_t kGzBatchFiles = 1024;
-constexpr size_t kGzBatchRawBytes = size_t(6) << 30;
+// Gzip files inflated on the device: a file is one wavefront's serial job there and the device runs up to 2048 of them
+// at once (eight per CU with the window's last 8 KB in LDS; 1024 with all of it), so a batch takes as long as its
+// longest file whatever it holds -- batches of up to 2048 files (their bytes are a third of the plain ones'), 4 GB
+// of file bytes or 12 GB of inflated ones.
+constexpr size_t kGzBatchFiles = 2048;
+constexpr size_t kGzBatchWireBytes = size_t(4) << 30;
+constexpr size_t kGzBatchRawBytes = size_t(12) << 30;
 constexpr size_t kGzReaderBufs = 2 * kGzBatchFiles + 64;
 }  // namespace
 
@@ -722,7 +724,7 @@ void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*
     // on 2048 files: 256 + 1024 + 768 gives 3.6 k genomes/s, 1024 + 1024 gives 5.1 k.)
     const size_t limit = gz_list ? kGzBatchFiles + 0 * n_batches++
                                  : std::min<size_t>(kWholeBatchFiles, size_t(16) << std::min<size_t>(n_batches++, 8));
-    while (b.files.size() < limit && b.bytes < kWholeBatchBytes && b.raw_bytes < kGzBatchRawBytes) {
+    while (b.files.size() < limit && b.bytes < (gz_list ? kGzBatchWireBytes : kWholeBatchBytes) && b.raw_bytes < kGzBatchRawBytes) {
       auto *f = rd.next();
       if (!f) break;
       b.files.push_back(f);

@@ -129,9 +129,12 @@ def zlib_says(blob):
         return None
 
 
-@pytest.fixture(scope="module")
-def eng(native):
+@pytest.fixture(scope="module", params=["window_in_lds", "last_8k_in_lds"])
+def eng(native, request):
+    """both forms of the kernel: the file's whole 32 KB window in LDS, or its last 8 KB with far matches read back from
+    the file's own output (what launches of more files than the device runs at once take)"""
     e = native.Engine(K=31, S=10, W=10, H=4)
+    e.set_option("inflate_window", 0 if request.param == "window_in_lds" else 1)
     yield e
     e.close()
 

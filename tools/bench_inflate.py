@@ -20,8 +20,10 @@ def main():
     ap.add_argument("--distinct", type=int, default=16)
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--window", type=int, default=-1, help="option inflate_window: -1 by the number of files, 0 whole window in LDS, 1 its last 8 KB")
     a = ap.parse_args()
     e = niqki_amd.Engine(K=31, S=10, W=10, H=4)
+    e.set_option("inflate_window", a.window)
     t0 = time.time()
     plain, zipped = [], []
     for i in range(a.distinct):
@@ -49,7 +51,7 @@ def main():
     assert all(out[i] == plain[i % a.distinct] for i in range(0, a.files, max(1, a.files // 37)))
     raw = float(sum(sizes))
     wire = float(sum(len(f) for f in files))
-    print(json.dumps({"files": a.files, "genome_bp": a.len, "gzip_level": a.level, "kernel_ms": round(best, 3),
+    print(json.dumps({"files": a.files, "inflate_window": a.window, "genome_bp": a.len, "gzip_level": a.level, "kernel_ms": round(best, 3),
                       "files_per_s": round(a.files / (best / 1e3), 1), "raw_GBps": round(raw / best / 1e6, 2),
                       "wire_GBps": round(wire / best / 1e6, 2), "ratio": round(raw / wire, 3),
                       "zlib_one_thread_files_per_s": round(1 / t_cpu, 2), "make_inputs_s": round(t_make, 1),
