@@ -417,6 +417,12 @@ int niqki_get_stat(const niqki_index *ix, const char *key, uint64_t *value) {
   if (!std::strcmp(key, "class_mask")) { *value = (ix->built && ix->hmask_ok) ? 1 : 0; return NIQKI_OK; }
   if (!std::strcmp(key, "last_gather_form")) { *value = ix->last_form; return NIQKI_OK; }
   if (!std::strcmp(key, "last_hits_form")) { *value = ix->last_hits_form; return NIQKI_OK; }
+  if (!std::strcmp(key, "inflate_files_in_flight") || !std::strcmp(key, "inflate_files_in_flight_8k")) {
+    // how many files a launch of the device inflate runs at once (workgroups the device keeps resident), by kernel form
+    (void)hipSetDevice(ix->device);
+    *value = nq::inflate_resident_files(key[23] != 0);
+    return NIQKI_OK;
+  }
   if (!std::strcmp(key, "page_slots")) { *value = ix->resident_bytes ? page_slots(ix) : f_all; return NIQKI_OK; }
   if (!std::strcmp(key, "pages")) {
     const uint32_t ps = ix->resident_bytes ? page_slots(ix) : f_all;

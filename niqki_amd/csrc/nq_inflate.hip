@@ -158,9 +158,13 @@ __device__ bool build_table(const uint8_t *L, uint32_t n, uint32_t *tab, uint16_
 
 }  // namespace
 
-// kRing: bytes of the window kept in LDS.  32768: all of it (four wavefronts per CU).  8192: the last 8 KB -- ten
-// wavefronts per CU; a match that reaches further back (kNear) reads its bytes from the file's own output in HBM,
-// which the flushes have written by then: a byte is flushed at most 4 KB + one match + one round after it is made.
+// kRing: bytes of the window kept in LDS.  32768: all of it (40.9 KB per file: four wavefronts per CU).  8192: the
+// last 8 KB (16.3 KB per file: nine fit a CU, eight -- two per SIMD -- is what a batch of 2048 uses); a match that
+// reaches further back (kNear) reads its bytes from the file's own output in HBM, which the flushes have written by
+// then: a byte is flushed at most 4 KB + one match + one round after it is made.  A wavefront alone on its SIMD issues
+// a dependent instruction every other turn, so two per SIMD run at 0.88 of the speed each (1024 files: 147 ms whole
+// window, 160 ms this form; 2048 files: 180 ms).  (A 9-bit literal table would make it ten per CU: 2560 files in
+// 206 ms, + 9 % -- not worth batches of 2560.)
 template <uint32_t kRing>
 __global__ __launch_bounds__(64) void inflate_kernel(const InflateJob *jobs, const uint8_t *wire, uint64_t wire_bytes,
                                                      uint8_t *raw, const uint32_t *xtab, InflateOut *outs) {
@@ -688,13 +692,20 @@ void inflate_xtab(uint32_t *t) {
   for (int k = 1; k <= 64; ++k) t[65 + k] = mul(t[65 + k - 1], t[64]);
 }
 
+uint32_t inflate_resident_files(bool small_ring) {
+  int dev = 0, cus = 0, per = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  const hipError_t e = small_ring ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, inflate_kernel<8192u>, 64, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, inflate_kernel<32768u>, 64, 0);
+  return e == hipSuccess ? (uint32_t)(per * cus) : 0u;
+}
+
 hipError_t launch_inflate(const InflateJob *jobs, uint32_t n_jobs, const uint8_t *wire, uint64_t wire_bytes, uint8_t *raw,
                           const uint32_t *xtab, InflateOut *outs, hipStream_t stream, int small_ring) {
   if (n_jobs == 0) return hipSuccess;
-  // more files than the whole window in LDS lets run at once (four per CU): the small ring, ten per CU
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-  if (small_ring < 0 ? n_jobs > 4u * (uint32_t)cus : small_ring != 0)
+  // more files than the whole window in LDS lets run at once (four per CU): the small ring, eight per CU
+  static const uint32_t big_form_files = inflate_resident_files(false);
+  if (small_ring < 0 ? n_jobs > (big_form_files ? big_form_files : 1024u) : small_ring != 0)
     hipLaunchKernelGGL(inflate_kernel<8192u>, dim3(n_jobs), dim3(64), 0, stream, jobs, wire, wire_bytes, raw, xtab, outs);
   else
     hipLaunchKernelGGL(inflate_kernel<32768u>, dim3(n_jobs), dim3(64), 0, stream, jobs, wire, wire_bytes, raw, xtab, outs);

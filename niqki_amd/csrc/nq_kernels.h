@@ -273,6 +273,7 @@ struct InflateOut {
 #endif
 };
 constexpr uint32_t kInflateXtabWords = 130;
+uint32_t inflate_resident_files(bool small_ring);   // workgroups of a form of the kernel the current device keeps resident
 void inflate_xtab(uint32_t *t);   // host: the CRC folding constants the kernel reads (kInflateXtabWords words)
 // wire_bytes: readable bytes of `wire` (the kernel loads whole dwords up to there); raw: 16-byte aligned
 // small_ring: -1 = choose by the number of files (the whole 32 KB window in LDS, four files per CU at a time, or its

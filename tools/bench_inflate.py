@@ -51,7 +51,7 @@ def main():
     assert all(out[i] == plain[i % a.distinct] for i in range(0, a.files, max(1, a.files // 37)))
     raw = float(sum(sizes))
     wire = float(sum(len(f) for f in files))
-    print(json.dumps({"files": a.files, "inflate_window": a.window, "genome_bp": a.len, "gzip_level": a.level, "kernel_ms": round(best, 3),
+    print(json.dumps({"files": a.files, "inflate_window": a.window, "files_in_flight": [e.stat("inflate_files_in_flight"), e.stat("inflate_files_in_flight_8k")], "genome_bp": a.len, "gzip_level": a.level, "kernel_ms": round(best, 3),
                       "files_per_s": round(a.files / (best / 1e3), 1), "raw_GBps": round(raw / best / 1e6, 2),
                       "wire_GBps": round(wire / best / 1e6, 2), "ratio": round(raw / wire, 3),
                       "zlib_one_thread_files_per_s": round(1 / t_cpu, 2), "make_inputs_s": round(t_make, 1),
