@@ -13,7 +13,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <sys/mman.h>
+
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 #include <new>
 #include <string>
 #include <vector>
@@ -167,6 +172,84 @@ uint32_t first_slot(const niqki_index *ix) { return ix->resident_bytes ? ix->ful
 }  // namespace nqi
 
 using namespace nqi;
+
+
+// ---- page-locked host memory (niqki_host_alloc) ----------------------------------------------------------------
+// hipHostMalloc page-locks at ~5 GB/s on this platform whatever the size or the number of calling threads
+// (profiles/r05_ubench_pin.txt: the time goes into faulting 4 KB pages in one by one), and a run's reader buffers are
+// gigabytes: its first phase waited for them.  Buffers of 256 KB and more are therefore cut from 256 MB slabs of
+// anonymous memory that asks for transparent huge pages (madvise) and is registered with the runtime as a whole
+// (hipHostRegister: 25 GB/s where huge pages are to be had, the old rate where not); freed pieces are kept by size
+// and handed out again, slabs are never returned (a process has a few, for its lifetime).  Anything that fails falls
+// back to hipHostMalloc.
+namespace nqi {
+namespace {
+constexpr size_t kSlabBytes = size_t(256) << 20, kHuge = size_t(2) << 20, kPieceGran = size_t(64) << 10, kSlabMin = size_t(256) << 10;
+struct Slab {
+  uint8_t *base;
+  size_t size, used;
+};
+std::mutex g_host_mu;
+std::vector<Slab> g_slabs;
+std::multimap<size_t, void *> g_free_pieces;      // size -> piece
+std::unordered_map<void *, size_t> g_piece_size;  // every piece ever cut: its size
+
+uint8_t *new_slab(size_t size) {
+  void *raw = mmap(nullptr, size + kHuge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (raw == MAP_FAILED) return nullptr;
+  uint8_t *base = (uint8_t *)(((uintptr_t)raw + kHuge - 1) & ~(uintptr_t)(kHuge - 1));
+  (void)madvise(base, size, MADV_HUGEPAGE);
+  if (hipHostRegister(base, size, hipHostRegisterPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    munmap(raw, size + kHuge);
+    return nullptr;
+  }
+  return base;
+}
+}  // namespace
+
+void *host_alloc(size_t bytes) {
+  if (bytes >= kSlabMin) {
+    const size_t n = (bytes + kPieceGran - 1) & ~(kPieceGran - 1);
+    std::lock_guard<std::mutex> g(g_host_mu);
+    auto it = g_free_pieces.find(n);
+    if (it != g_free_pieces.end()) {
+      void *p = it->second;
+      g_free_pieces.erase(it);
+      return p;
+    }
+    if (g_slabs.empty() || g_slabs.back().size - g_slabs.back().used < n) {
+      // (32 MB, 64, 128, then 256 MB slabs: a small run does not lock a quarter of a gigabyte)
+      const size_t size = std::max(std::min(kSlabBytes, (size_t(32) << 20) << std::min<size_t>(g_slabs.size(), 3)), (n + kHuge - 1) & ~(kHuge - 1));
+      uint8_t *base = new_slab(size);
+      if (base) g_slabs.push_back(Slab{base, size, 0});
+    }
+    if (!g_slabs.empty() && g_slabs.back().size - g_slabs.back().used >= n) {
+      Slab &sl = g_slabs.back();
+      void *p = sl.base + sl.used;
+      sl.used += n;
+      g_piece_size[p] = n;
+      return p;
+    }
+  }
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void host_free(void *p) {
+  if (!p) return;
+  {
+    std::lock_guard<std::mutex> g(g_host_mu);
+    auto it = g_piece_size.find(p);
+    if (it != g_piece_size.end()) {
+      g_free_pieces.emplace(it->second, p);
+      return;
+    }
+  }
+  (void)hipHostFree(p);
+}
+}  // namespace nqi
 
 extern "C" {
 
@@ -457,14 +540,8 @@ int niqki_profile_read(niqki_index *ix, int kc, double *ms, uint64_t *launches) 
   return rc;
 }
 
-void *niqki_host_alloc(size_t bytes) {
-  void *p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
-  return p;
-}
+void *niqki_host_alloc(size_t bytes) { return nqi::host_alloc(bytes); }
 
-void niqki_host_free(void *p) {
-  if (p) (void)hipHostFree(p);
-}
+void niqki_host_free(void *p) { nqi::host_free(p); }
 
 }  // extern "C"

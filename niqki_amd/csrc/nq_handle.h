@@ -142,6 +142,8 @@ struct niqki_index {
 namespace nqi {
 
 // ---- nq_api.hip: the handle ----
+void *host_alloc(size_t bytes);   // page-locked host memory (niqki_host_alloc): slabs on transparent huge pages
+void host_free(void *p);
 int fail(niqki_index *ix, int code, const std::string &msg);
 int ensure(niqki_index *ix, Buf &b, size_t bytes);   // device scratch of at least `bytes`
 nq::IndexView view(const niqki_index *ix);

@@ -719,11 +719,12 @@ void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*
   auto assemble = [&](Batch &b) {
     const auto t0 = clk::now();
     // the first batches are small (16, 32, 64 files): the GPU and the copy engine start while the reader threads are
-    // still page-locking their buffers and filling the pipeline.  (Gzip lists: 1024, then 2048 -- a launch of the device
-    // inflate takes as long as its longest file however few files it holds, so small batches only cost: on 2048 files
-    // 256 + 1024 + 768 gives 3.6 k genomes/s, 1024 + 1024 5.1 k; one batch of 2048 5.5 k, but the list's first phase,
-    // which page-locks the buffers while it reads, then has nothing to overlap that with: 2.0 k instead of 2.5 k.)
-    const size_t limit = gz_list ? (n_batches++ ? kGzBatchFiles : kGzBatchFiles / 2)
+    // still page-locking their buffers and filling the pipeline.  (Gzip lists: equal batches of at most 2048 -- a launch
+    // of the device inflate takes as long as its longest file however few files it holds, so small batches only cost: on
+    // 2048 files 256 + 1024 + 768 gives 3.6 k genomes/s, 1024 + 1024 5.1 k, one batch 5.5 k; on 4096 files
+    // 1024 + 2048 + 1024 gives 5.3 k.)
+    const size_t gz_batches = (paths.size() + kGzBatchFiles - 1) / kGzBatchFiles;
+    const size_t limit = gz_list ? (paths.size() + gz_batches - 1) / std::max<size_t>(gz_batches, 1)
                                  : std::min<size_t>(kWholeBatchFiles, size_t(16) << std::min<size_t>(n_batches++, 8));
     while (b.files.size() < limit && b.bytes < (gz_list ? kGzBatchWireBytes : kWholeBatchBytes) && b.raw_bytes < kGzBatchRawBytes) {
       auto *f = rd.next();
