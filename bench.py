@@ -1263,7 +1263,7 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
                 cli[tag]["gzip_level"] = j.get("gz_level")
                 cli[tag]["file_GB"] = round(j.get("file_bytes", 0) / 1e9, 3)
                 cli[tag]["device_inflate"] = ("gzip files cross PCIe as they lie on disk, one wavefront per file inflates them "
-                                              "(batches of 1024 files; CRC-32 and sizes checked on the device)")
+                                              "(equal batches of at most 2048 files; CRC-32 and sizes checked on the device)")
                 cli[tag]["reader_threads_inflate_instead"] = j.get("host_inflate")
             if j.get("reads_per_s"):
                 # BASELINE configs[4] as FILES: `niqki -I fof -l reads.fa -S 12 -W 10` (--querylines: one entry per record),
@@ -1277,15 +1277,17 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
                         **cli} if cli else None
     # ---- the device inflate alone: 1024 gzip -6 genome files resident in HBM, one launch (tools/bench_inflate.py) ----
     try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_inflate.py"), "--files", "1024", "--len", str(L),
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_inflate.py"), "--files", "2048", "--len", str(L),
                             "--distinct", "8", "--reps", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
         j = json.loads(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else None
     except (OSError, ValueError, IndexError, subprocess.SubprocessError):
         j = None
     if j:
         out["gzip_inflate"] = {
-            "workload": "1024 gzip -6 FASTA files of %d bp inflated in one launch of nq::inflate_kernel (one wavefront per file, four per CU), "
+            "workload": "2048 gzip -6 FASTA files of %d bp inflated in one launch of nq::inflate_kernel (one wavefront per file, eight per "
+                        "CU: each file's last 8 KB of window in LDS, matches that reach further back read from its flushed output), "
                         "bytes checked against the files' own" % L,
+            "files_in_flight_by_kernel_form": j.get("files_in_flight"),
             "kernel_ms": j["kernel_ms"], "files_per_s": j["files_per_s"], "inflated_GBps": j["raw_GBps"], "compressed_GBps": j["wire_GBps"],
             "per_file": j["per_file"],
             "bound": "the latency of one wavefront's dependent instructions (a DEFLATE stream is serial): every file takes the whole "
