@@ -310,6 +310,24 @@ def test_many_files_one_launch(eng):
     assert all(a == b for a, b in zip(out, datas))
 
 
+def test_launch_form_follows_the_number_of_files(native):
+    """option inflate_window -1: a launch of more files than the device keeps resident with whole windows in LDS takes
+    the form with the window's last 8 KB there (twice as many resident); same bytes"""
+    e = native.Engine(K=31, S=10, W=10, H=4)
+    whole, small = e.stat("inflate_files_in_flight"), e.stat("inflate_files_in_flight_8k")
+    assert whole >= 256 and small >= 2 * whole
+    rng = np.random.default_rng(10)
+    d = fasta(rng, 60000)
+    # far matches: the second half repeats the first at distances of 20 to 30 KB, beyond what the small form keeps in LDS
+    d2 = d[:30000] + d[2000:28000] + d[:30000]
+    for n in (3, int(whole) + 5):
+        blobs = [gz(d2 if i % 2 else d, 6) for i in range(n)]
+        out, status, _, _, outside = e.gunzip(blobs, [len(d2) if i % 2 else len(d) for i in range(n)])
+        assert outside == 0 and not status.any()
+        assert all(o == (d2 if i % 2 else d) for i, o in enumerate(out))
+    e.close()
+
+
 def test_staged_gzip_files_equal_plain_ones(native, po):
     """niqki_stage_raw with NIQKI_FILE_GZIP files: the same records and sketches as the files' own bytes; mixed with
     raw and packed files; a damaged file is reported through file_status and nothing is staged"""
