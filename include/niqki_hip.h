@@ -46,7 +46,8 @@
  *                           strength (default: chosen per sketch).  Test switches of nq_sketch.hip's launch shapes.
  * The `niqki` host program reads NIQKI_HOST_THREADS (reader threads; default: the CPUs the process may use),
  * NIQKI_HOST_TIMING (phase times on stderr), NIQKI_HOST_NO_PACK (plain FASTA files travel as their bytes),
- * NIQKI_HOST_NO_GPU_INFLATE (gzip files are inflated by the reader threads instead of the device),
+ * NIQKI_HOST_NO_GPU_INFLATE (gzip files are always inflated by the reader threads), NIQKI_HOST_GPU_INFLATE_MIN (how many
+ * gzip files a list must hold for the device to inflate them; default 32 per reader thread),
  * NIQKI_HOST_ZLIB_ONLY (no libdeflate), NIQKI_SHARDS_ON_ONE_DEVICE (--gpus N on one device: tests).
  */
 #ifndef NIQKI_HIP_H

@@ -291,9 +291,9 @@ class OrderedFileReader {
     while (p->size() < n) p->emplace_back();
     return *p;
   }
-  OrderedFileReader(const std::vector<std::string> &paths, unsigned threads, size_t n_bufs)
+  OrderedFileReader(const std::vector<std::string> &paths, unsigned threads, size_t n_bufs, bool device_inflate)
       : paths_(paths), bufs_(pool(n_bufs)), ready_(paths.size(), nullptr), pack_(std::getenv("NIQKI_HOST_NO_PACK") == nullptr),
-        gz_(std::getenv("NIQKI_HOST_NO_GPU_INFLATE") == nullptr) {
+        gz_(device_inflate) {
     for (size_t i = 0; i < n_bufs; ++i) free_.push_back(&bufs_[n_bufs - 1 - i]);  // LIFO: low indices first
     threads = (unsigned)std::min<size_t>(threads, std::max<size_t>(paths.size(), 1));
     for (unsigned t = 0; t < threads; ++t) pool_.emplace_back([this] { work(); });
@@ -358,7 +358,7 @@ class OrderedFileReader {
   size_t issued_ = 0, taken_ = 0;
   bool stop_ = false;
   const bool pack_;   // plain FASTA files travel as packed containers (NIQKI_HOST_NO_PACK: as their bytes)
-  const bool gz_;     // gzip files travel as they are and are inflated on the device (NIQKI_HOST_NO_GPU_INFLATE: here)
+  const bool gz_;     // gzip files travel as they are and are inflated on the device (for_each_batch decides per list)
 };
 
 constexpr size_t kWholeBatchFiles = 64;                // files per GPU call (whole-file mode)
@@ -710,11 +710,16 @@ void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*
   double t_wait = 0, t_gpu = 0;
   t_stage_ = t_dev_ = t_out_ = 0;
   const auto t_begin = clk::now();
-  // a list of mostly gzip'd files (by their names) runs in the large batches the device inflate wants
-  size_t n_gz_names = 0;
+  // A list of mostly gzip'd files (by their names) is inflated on the device, in the large batches that wants -- if
+  // it is long enough: a launch of the device inflate takes one file's time (150 ms for a 5 Mbp genome) however few
+  // files it holds, in which a reader thread inflates some 30 files, so below 32 files per reader thread the readers
+  // do it (NIQKI_HOST_GPU_INFLATE_MIN sets that number of files; NIQKI_HOST_NO_GPU_INFLATE: always the readers).
+  const unsigned n_threads = host_threads();
+  size_t n_gz_names = 0, gz_min = size_t(32) * n_threads;
   for (const auto &p : paths) n_gz_names += p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0;
-  const bool gz_list = std::getenv("NIQKI_HOST_NO_GPU_INFLATE") == nullptr && 2 * n_gz_names > paths.size();
-  OrderedFileReader rd(paths, host_threads(), gz_list ? std::min(kGzReaderBufs, 2 * paths.size() + 64) : kReaderBufs);
+  if (const char *v = std::getenv("NIQKI_HOST_GPU_INFLATE_MIN")) gz_min = (size_t)std::max(0, std::atoi(v));
+  const bool gz_list = std::getenv("NIQKI_HOST_NO_GPU_INFLATE") == nullptr && 2 * n_gz_names > paths.size() && n_gz_names >= gz_min;
+  OrderedFileReader rd(paths, n_threads, gz_list ? std::min(kGzReaderBufs, 2 * paths.size() + 64) : kReaderBufs, gz_list);
   size_t i = 0, n_batches = 0;
   auto assemble = [&](Batch &b) {
     const auto t0 = clk::now();

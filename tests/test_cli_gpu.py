@@ -21,6 +21,10 @@ def workdir(tmp_path_factory, native, gold):
     return make_cli_workdir(tmp_path_factory.mktemp("cli"), native, meta)
 
 
+# (lists of gzip files as short as these tests' are inflated by the reader threads unless told otherwise: the device path)
+os.environ["NIQKI_HOST_GPU_INFLATE_MIN"] = "1"
+
+
 def run(td, args):
     assert os.path.exists(BIN), "niqki_amd/bin/niqki missing: run __graft_entry__.build()"
     r = subprocess.run([BIN] + args, cwd=td, capture_output=True, text=True, timeout=600)
