@@ -1292,6 +1292,11 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
             "per_file": j["per_file"],
             "bound": "the latency of one wavefront's dependent instructions (a DEFLATE stream is serial): every file takes the whole "
                      "launch, throughput = files in flight / that time",
+            "hbm_frac": round((j["raw_GBps"] + j["wire_GBps"]) / 8000.0, 4),
+            "cycles_per_file_round": round(j["kernel_ms"] * 1e-3 * 2.4e9 / max(j["per_file"]["rounds"], 1)),
+            "note": "bytes written + read over the 8 TB/s peak: a hundredth -- the kernel is nowhere near memory; a round (64 bit offsets "
+                    "decoded at once, their tokens walked, <= 64 bytes written) is ~190 instructions of one wavefront, two wavefronts per "
+                    "SIMD (profiles/r05_inflate_phase_clocks.txt); cycles_per_file_round at a nominal 2.4 GHz",
             "zlib_one_host_thread_files_per_s": j["zlib_one_thread_files_per_s"]}
     return out
 
