@@ -430,45 +430,73 @@ Index::Index(uint32_t ilF, uint32_t iK, uint32_t iW, uint32_t iH, const std::str
 Index::Index(const std::string &dump_file, bool pretty, const std::string &out_filename, int device, int n_gpus,
              int resident_mib) {
   pretty_printing = pretty;
-  // The dump is streamed: header, then the buckets in groups of whole slots (the
-  // payload of a 100k-genome index is 13.6 GB), then the names.
-  GzReader in(dump_file);
+  // The dump is streamed: header, then the buckets in groups of whole slots (the payload of a 100k-genome index is
+  // 13.6 GB), then the names.  A dump this program wrote is a file of size-tagged gzip members (gzio.h): they are
+  // inflated side by side by the reader threads, a window ahead; any other gzip file (the reference's dumps are one
+  // member) comes through zlib's stream.  Either way the bytes arrive in pieces, and the walk over the buckets' size
+  // words -- the one serial thing about the format -- runs over memory, not over a reader call per bucket.
+  std::unique_ptr<TaggedGzReader> tagged;
+  std::unique_ptr<GzReader> plain;
+  if (TaggedGzReader::probe(dump_file)) tagged.reset(new TaggedGzReader(dump_file, host_threads()));
+  else plain.reset(new GzReader(dump_file));
+  std::vector<uint8_t> buf, piece;
+  size_t p = 0;   // parse position in buf
+  auto more = [&]() -> bool {   // appends the stream's next piece
+    if (tagged) {
+      if (!tagged->next(piece)) return false;
+    } else {
+      piece.resize(size_t(4) << 20);
+      piece.resize(plain->read(piece.data(), piece.size()));
+      if (piece.empty()) return false;
+    }
+    buf.insert(buf.end(), piece.begin(), piece.end());
+    return true;
+  };
+  auto need = [&](size_t n) -> bool {
+    while (buf.size() - p < n)
+      if (!more()) return false;
+    return true;
+  };
+  if (!need(24)) throw std::runtime_error("'" + dump_file + "' is not a niqki dump");
   uint8_t hdr[24];
-  if (in.read(hdr, 24) != 24) throw std::runtime_error("'" + dump_file + "' is not a niqki dump");
-  niqki_params p{};
-  p.resident_mib = resident_mib > 0 ? (uint32_t)resident_mib : 0u;
-  make_shards(p, device, n_gpus, hdr);   // every shard keeps its own slots of the stream
+  std::memcpy(hdr, buf.data(), 24);
+  p = 24;
+  niqki_params prm{};
+  prm.resident_mib = resident_mib > 0 ? (uint32_t)resident_mib : 0u;
+  make_shards(prm, device, n_gpus, hdr);   // every shard keeps its own slots of the stream
   niqki_params q{};
   niqki_get_params(h_, &q);
   K = q.K; W = q.W; H = q.H; lF = q.S; F = 1u << q.S; min_score = q.min_score;
   const uint32_t R = 1u << W;
-  std::vector<uint8_t> chunk;
   uint32_t s0 = 0;
+  size_t g0 = p;   // where the slots not yet handed over start in buf
   auto flush = [&](uint32_t s1) {
     uint64_t used = 0;
-    for (auto *h : sh_) check(niqki_import_slots(h, s0, s1, chunk.data(), chunk.size(), &used), "niqki_import_slots");
-    chunk.clear();
+    for (auto *h : sh_) check(niqki_import_slots(h, s0, s1, buf.data() + g0, p - g0, &used), "niqki_import_slots");
+    buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)p);   // (what is left is less than one piece)
+    p = g0 = 0;
     s0 = s1;
   };
   for (uint32_t s = 0; s < F; ++s) {
     for (uint32_t fp = 0; fp < R; ++fp) {
-      uint32_t size = 0;
-      if (in.read(&size, 4) != 4) throw std::runtime_error("'" + dump_file + "' is truncated");
-      const size_t at = chunk.size();
-      chunk.resize(at + 4 + (size_t)size * 4);
-      std::memcpy(chunk.data() + at, &size, 4);
-      if (size && in.read(chunk.data() + at + 4, (size_t)size * 4) != (size_t)size * 4)
-        throw std::runtime_error("'" + dump_file + "' is truncated");
+      if (!need(4)) throw std::runtime_error("'" + dump_file + "' is truncated");
+      uint32_t size;
+      std::memcpy(&size, buf.data() + p, 4);
+      if (!need(4 + (size_t)size * 4)) throw std::runtime_error("'" + dump_file + "' is truncated");
+      p += 4 + (size_t)size * 4;
     }
-    if (chunk.size() >= kBatchBytes / 8) flush(s + 1);
+    if (p - g0 >= kBatchBytes / 8) flush(s + 1);
   }
   flush(F);
   // genome names, one per line after the buckets (src/niqki_index.cpp:91-95)
+  while (more()) {}
   const uint32_t n = niqki_genome_count(h_);
-  std::string name;
   for (uint32_t i = 0; i < n; ++i) {
-    in.getline(name);
-    filenames.push_back(name);
+    const uint8_t *b0 = buf.data() + p, *e0 = buf.data() + buf.size();
+    const uint8_t *nl = p < buf.size() ? (const uint8_t *)memchr(b0, '\n', (size_t)(e0 - b0)) : nullptr;
+    const uint8_t *end = nl ? nl : e0;
+    filenames.emplace_back(p < buf.size() ? std::string((const char *)b0, (size_t)(end - b0)) : std::string());
+    p = nl ? (size_t)(nl + 1 - buf.data()) : buf.size();
   }
   if (n_gpus > 1) {
     const int rc = niqki_group_create(sh_.data(), (uint32_t)sh_.size(), 0, (uint32_t)sh_.size(), nullptr, &grp_);
@@ -1155,38 +1183,51 @@ void Index::query_matrix() {
 void Index::dump_index_disk(const std::string &filestr) {
   // header + buckets (src/niqki_index.cpp:42-55) exported in groups of whole slots
   // and gzipped in parallel, then the names (:56-58)
-  unsigned threads = std::thread::hardware_concurrency();
-  threads = threads ? std::min(threads, 32u) : 4u;
-  ParallelGzWriter out(filestr, threads);
-  std::vector<uint8_t> block(24);
-  check(niqki_export_dump_header(h_, block.data()), "niqki_export_dump_header");
+  const bool timing = std::getenv("NIQKI_HOST_TIMING") != nullptr;
+  Lap lap;
+  double t_layout = 0, t_alloc = 0, t_export = 0, t_writer = 0;
+  ParallelGzWriter out(filestr, host_threads() + 1);   // (the CPUs this process may use: its cgroup quota counts)
+  {
+    std::vector<uint8_t> hdr(24);
+    check(niqki_export_dump_header(h_, hdr.data()), "niqki_export_dump_header");
+    out.add(hdr);
+  }
   const uint64_t target = uint64_t(32) << 20;
+  uint64_t payload = 0;
   for (size_t r = 0; r < sh_.size(); ++r) {   // the shards' slots in rank order are the whole payload
     uint32_t sb = 0, se = F;
     if (grp_) niqki_group_slot_range((uint32_t)r, (uint32_t)sh_.size(), lF, &sb, &se);
     const uint32_t f_local = se - sb;
     std::vector<uint64_t> slot_bytes((size_t)f_local + 1);
     check(niqki_export_dump_layout(sh_[r], slot_bytes.data()), "niqki_export_dump_layout");
+    lap.to(t_layout);
     uint32_t s0 = 0;
     while (s0 < f_local) {
       uint32_t s1 = s0 + 1;
       while (s1 < f_local && slot_bytes[s1 + 1] - slot_bytes[s0] <= target) ++s1;
-      const size_t at = block.size();
       const uint64_t want = slot_bytes[s1] - slot_bytes[s0];
-      block.resize(at + want);
+      ParallelGzWriter::Block block(want);
+      lap.to(t_alloc);
       uint64_t size = 0;
-      check(niqki_export_dump_slots(sh_[r], s0, s1, block.data() + at, want, &size), "niqki_export_dump_slots");
+      check(niqki_export_dump_slots(sh_[r], s0, s1, block.data(), want, &size), "niqki_export_dump_slots");
+      lap.to(t_export);
+      payload += want;
       out.add(std::move(block));
-      block.clear();
+      lap.to(t_writer);
       s0 = s1;
     }
   }
+  std::vector<uint8_t> names;
   for (const auto &nm : filenames) {
-    block.insert(block.end(), nm.begin(), nm.end());
-    block.push_back('\n');
+    names.insert(names.end(), nm.begin(), nm.end());
+    names.push_back('\n');
   }
-  out.add(std::move(block));
+  out.add(names);
   out.finish();
+  lap.to(t_writer);
+  if (timing)
+    std::cerr << "[niqki timing] dump: " << payload / 1e9 << " GB of buckets: layout " << t_layout << " s, buffers " << t_alloc
+              << ", export (kernel + copy) " << t_export << ", waiting for the gzip writer " << t_writer << std::endl;
 }
 
 }  // namespace nqhost
