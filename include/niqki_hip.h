@@ -328,9 +328,10 @@ typedef struct niqki_raw_batch {
  * :236-239: gzip by magic, zlib member after member); a file flagged NIQKI_FILE_GZIP crosses PCIe as it lies on disk
  * (a quarter of its FASTA bytes) and one wavefront per file writes its bytes where the framing expects them.  The
  * device takes what is plainly a gzip file: members that inflate without any irregularity, CRC-32 and ISIZE of every
- * member right, the whole file exactly as long as its last four bytes say (so: one member, the usual case, or
- * several whose sizes add up to the last one's -- never).  For anything else -- damaged or truncated streams,
- * concatenated members, bytes behind the last member, sizes of 2 GiB and more -- niqki_stage_raw stages nothing,
+ * member right, and either ONE member as long as the file's last four bytes say (the usual case), or a file whose
+ * members all carry their size -- BGZF (bgzip / htslib: the 'B' 'C' extra subfield) or this project's 'N' 'Q' tag --,
+ * which is cut into its members and inflated by one wavefront per member.  For anything else -- damaged or truncated
+ * streams, plainly concatenated members, bytes behind the last member, sizes of 2 GiB and more -- niqki_stage_raw stages nothing,
  * returns NIQKI_E_GZIP and names the files in file_status; the caller inflates those itself (zlib decides what they
  * yield, as before) and hands them over as 'A' / 'Q'.  The kernel is at least as strict as zlib's inflate, so a file
  * it accepts has zlib's bytes. */

@@ -5,6 +5,7 @@
 #include "nq_pack.h"
 
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -25,6 +26,33 @@ int staged_sketch_ws(niqki_index *ix) {
   if (rc) return rc;
   ix->staged.sketched = true;
   return NIQKI_OK;
+}
+
+// A gzip file whose members all say how long they are -- BGZF (the 'B' 'C' subfield of bgzip / htslib: blocks of at most
+// 64 KB) or this project's own 'N' 'Q' tag (niqki_amd/host/gzio.h) -- can be cut into its members without inflating
+// anything: every member becomes a job of its own, so such a file is inflated by as many wavefronts as it has members.
+// members: {offset, bytes, ISIZE} of each; false: not such a file (or not one from end to end).
+static bool tagged_members(const uint8_t *c, uint64_t len, std::vector<std::array<uint64_t, 3>> &members) {
+  members.clear();
+  uint64_t at = 0;
+  while (at < len) {
+    if (len - at < 28 || c[at] != 0x1F || c[at + 1] != 0x8B || c[at + 2] != 8 || !(c[at + 3] & 4)) return false;
+    const uint64_t xlen = (uint64_t)c[at + 10] | (uint64_t)c[at + 11] << 8;
+    if (at + 12 + xlen + 8 > len) return false;
+    uint64_t total = 0;
+    for (uint64_t x = at + 12, xe = at + 12 + xlen; x + 4 <= xe;) {
+      const uint64_t sl = (uint64_t)c[x + 2] | (uint64_t)c[x + 3] << 8;
+      if (x + 4 + sl > xe) return false;
+      if (c[x] == 'B' && c[x + 1] == 'C' && sl == 2) total = ((uint64_t)c[x + 4] | (uint64_t)c[x + 5] << 8) + 1;
+      if (c[x] == 'N' && c[x + 1] == 'Q' && sl == 4) total = (uint64_t)c[x + 4] | (uint64_t)c[x + 5] << 8 | (uint64_t)c[x + 6] << 16 | (uint64_t)c[x + 7] << 24;
+      x += 4 + sl;
+    }
+    if (total < 12 + xlen + 8 + 2 || at + total > len) return false;
+    const uint8_t *t = c + at + total - 4;
+    members.push_back({at, total, (uint64_t)t[0] | (uint64_t)t[1] << 8 | (uint64_t)t[2] << 16 | (uint64_t)t[3] << 24});
+    at += total;
+  }
+  return !members.empty();
 }
 
 // The gzip files of a batch through the device inflate (nq_inflate.hip): job j reads d_wire[src, src + src_len) and
@@ -113,6 +141,7 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
     return fail(ix, NIQKI_E_INVALID, "packed (type 'a') and gzip (NIQKI_FILE_GZIP) files: host memory, the file_ptr form, whole-file mode");
   std::vector<nq::InflateJob> jobs;
   std::vector<uint32_t> job_file;
+  std::vector<std::array<uint64_t, 3>> members;
   bool gz_refused = false;
   if (any_gz && b->file_status) std::memset(b->file_status, 0, nf);
   std::vector<uint64_t> roff((size_t)nf + 1, 0);   // raw offsets of the files
@@ -139,6 +168,22 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
       const uint8_t *c = b->file_ptr[f];
       uint64_t isize = 0;
       if (c && wire_len >= 18) isize = (uint64_t)c[wire_len - 4] | (uint64_t)c[wire_len - 3] << 8 | (uint64_t)c[wire_len - 2] << 16 | (uint64_t)c[wire_len - 1] << 24;
+      // a file of size-tagged members (BGZF ...): one job per member
+      if (c && wire_len <= 0x7FFF0000ull && tagged_members(c, wire_len, members)) {
+        uint64_t sum = 0;
+        for (const auto &m : members) sum += m[2];
+        if (sum <= 0x7FFF0000ull && sum <= wire_len * 64u) {
+          uint64_t at = roff[f];
+          for (const auto &m : members) {
+            jobs.push_back(nq::InflateJob{b->file_off[f] + m[0], m[1], at, m[2]});
+            job_file.push_back(f);
+            at += m[2];
+          }
+          raw_len = sum;
+          roff[f + 1] = roff[f] + raw_len;
+          continue;
+        }
+      }
       // not plausibly one plain member (DEFLATE cannot exceed 1032 : 1; FASTA and FASTQ stay below 10 : 1): the host's turn
       if (!c || wire_len < 18 || wire_len > 0x7FFF0000ull || isize > 0x7FFF0000ull || isize > wire_len * 64u || isize * 4096u < wire_len) {
         if (b->file_status) b->file_status[f] = 13;

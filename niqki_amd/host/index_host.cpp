@@ -203,7 +203,15 @@ void read_file_bytes(const std::string &path, PinnedBuf &out, bool want_pack = f
       }
       if (got == n) {
         const uint64_t isize = (uint64_t)out.p[n - 4] | (uint64_t)out.p[n - 3] << 8 | (uint64_t)out.p[n - 2] << 16 | (uint64_t)out.p[n - 1] << 24;
-        if (isize <= 0x7FFF0000ull && isize <= (uint64_t)n * 64u && isize * 4096u >= (uint64_t)n) {
+        // ... or a file of members that say how long they are (BGZF's 'B' 'C' subfield, this project's 'N' 'Q'): the
+        // library cuts it into its members, one wavefront each
+        bool tagged = false;
+        if (n >= 28 && (out.p[3] & 4)) {
+          const size_t xlen = (size_t)out.p[10] | (size_t)out.p[11] << 8;
+          for (size_t x = 12; x + 4 <= 12 + xlen && x + 4 <= n; x += 4 + ((size_t)out.p[x + 2] | (size_t)out.p[x + 3] << 8))
+            tagged |= (out.p[x] == 'B' && out.p[x + 1] == 'C') || (out.p[x] == 'N' && out.p[x + 1] == 'Q');
+        }
+        if (tagged || (isize <= 0x7FFF0000ull && isize <= (uint64_t)n * 64u && isize * 4096u >= (uint64_t)n)) {
           out.size = n;
           *gz = true;
           ::close(fd);
@@ -769,6 +777,7 @@ void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*
       if (f->gz) {   // (the reader checked the trailer: at least 18 bytes, a plausible size)
         const uint8_t *e = f->buf.p + f->buf.size - 4;
         raw = (size_t)e[0] | (size_t)e[1] << 8 | (size_t)e[2] << 16 | (size_t)e[3] << 24;
+        if (raw < f->buf.size) raw = 4 * f->buf.size;   // (a file of tagged members: the trailer is its last member's)
         ++b.n_gz;
       }
       b.raw_bytes += raw;

@@ -106,6 +106,17 @@ def test_gzip_inputs_and_many_files(workdir, gold):
                 if rep % 5 == 1:     # a multi-member file (what `cat a.gz b.gz` makes), bytes behind the last member
                     cut = len(raw) // 3
                     (workdir / dst).write_bytes(gzip.compress(raw[:cut], 1) + gzip.compress(raw[cut:], 6) + b"\0" * 7)
+                elif rep % 5 == 2:   # BGZF, what bgzip writes: members of <= 64 KB that carry their size, an empty one last
+                    import struct
+                    import zlib
+                    out = bytearray()
+                    for a in list(range(0, len(raw), 65280)) + [len(raw)]:
+                        piece = raw[a:a + 65280] if a < len(raw) else b""
+                        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+                        body = c.compress(piece) + c.flush()
+                        out += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", 18 + len(body) + 8 - 1) + body +
+                                struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece)))
+                    (workdir / dst).write_bytes(bytes(out))
                 else:
                     with gzip.open(workdir / dst, "wb", compresslevel=1) as f:
                         f.write(raw)

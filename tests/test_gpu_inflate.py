@@ -328,6 +328,50 @@ def test_launch_form_follows_the_number_of_files(native):
     e.close()
 
 
+def bgzf(data, block=65280, tag=b"BC"):
+    """what bgzip / htslib write: gzip members of at most 64 KB, each with its size in a 'B' 'C' extra subfield, an
+    empty member at the end (tag = b"NQ": this project's own 4-byte size tag, members of any size)"""
+    out = bytearray()
+    for a in list(range(0, len(data), block)) + [len(data)]:
+        piece = data[a:a + block] if a < len(data) else b""
+        body = raw_deflate(piece, 6)
+        if tag == b"BC":
+            total = 18 + len(body) + 8
+            extra = b"BC" + struct.pack("<HH", 2, total - 1)
+        else:
+            total = 20 + len(body) + 8
+            extra = b"NQ" + struct.pack("<HI", 4, total)
+        out += member(body, piece, extra=extra)
+        assert len(out) and (tag != b"BC" or total <= 65536)
+    return bytes(out)
+
+
+def test_files_of_size_tagged_members(native, po):
+    """BGZF files (and files with this project's own member tag): niqki_stage_raw cuts them into their members, one
+    wavefront each -- same records and sketches as the files' own bytes; a damaged member sends the whole file back"""
+    rng = np.random.default_rng(11)
+    e = native.Engine(K=31, S=10, W=10, H=4)
+    plain = [fasta(rng, 300000 + 7777 * i, name=b"b%d" % i) for i in range(5)]
+    info0, _ = e.stage_raw(plain, ["A"] * 5, scattered=True)
+    recs0, ent0, _ = e.staged_records()
+    sk0 = e.staged_sketch()
+    G = native.capi.FILE_GZIP
+    files = [bgzf(plain[0]), bgzf(plain[1], tag=b"NQ", block=1 << 20), gz(plain[2]), bgzf(plain[3], block=4000), plain[4]]
+    assert all(zlib_says(f) == p for f, p in zip(files[:4], plain[:4]))
+    tys = [ord("A") | G] * 4 + [ord("A")]
+    info, _ = e.stage_raw(files, tys, scattered=True)
+    recs, ent, _ = e.staged_records()
+    assert (info.n_entry, info.n_rec, info.seq_bytes) == (info0.n_entry, info0.n_rec, info0.seq_bytes)
+    assert recs == recs0 and np.array_equal(ent, ent0) and np.array_equal(e.staged_sketch(), sk0)
+    st = e.gunzip_stats()
+    assert st["blocks"] >= len(plain[0]) // 65280 + len(plain[3]) // 4000     # (every member is at least one DEFLATE block)
+    bad = bytearray(files[0]); bad[len(bad) // 3] ^= 0x20
+    with pytest.raises(native.capi.NiqkiError) as ei:
+        e.stage_raw([bytes(bad)] + files[1:], tys, scattered=True)
+    assert ei.value.code == native.capi.E_GZIP and e.file_status[:5].tolist()[1:] == [0] * 4 and e.file_status[0] != 0
+    e.close()
+
+
 def test_staged_gzip_files_equal_plain_ones(native, po):
     """niqki_stage_raw with NIQKI_FILE_GZIP files: the same records and sketches as the files' own bytes; mixed with
     raw and packed files; a damaged file is reported through file_status and nothing is staged"""
