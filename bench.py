@@ -1275,6 +1275,20 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
                 cli[tag]["reference_program"] = j["reference_program"]
     out["cli_files"] = {"workload": "niqki -I fof -Q fof -J 0.1 on 5 Mbp FASTA files (70 columns) in the page cache, whole-file mode",
                         **cli} if cli else None
+    # ---- `niqki -D` / `-L` end to end (tools/bench_dump_cli.py): 8192 genomes, 1.6 GB of buckets ----
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_dump_cli.py"), "--genomes", "8192", "--len", "200000"],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        j = json.loads(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else None
+    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
+        j = None
+    if j:
+        out["dump_load_cli"] = {
+            "workload": "niqki -I fof -D dump.gz, then niqki -L dump.gz -Q q: 8192 synthetic genomes of 200 kbp (K=31 S=15 W=12), the dump a "
+                        "file of size-tagged gzip -1 members written and read side by side by the host's threads",
+            "dump_file_GB": j["dump_file_GB"], "dump_s": j["dump_s"], "load_s": j["load_s"],
+            "hits_after_load_equal_hits_after_index": j["same_hits"],
+            "dump_phase": [l for l in j["timing"].get("index_dump", []) if "dump:" in l][-1:]}
     # ---- the device inflate alone: 1024 gzip -6 genome files resident in HBM, one launch (tools/bench_inflate.py) ----
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_inflate.py"), "--files", "2048", "--len", str(L),
