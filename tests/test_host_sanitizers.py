@@ -50,6 +50,16 @@ def stress_bin(san):
 
 
 @pytest.fixture(scope="module")
+def gzio_bin(san):
+    out = os.path.join(BINDIR, "gzio_stress_" + san)
+    src = [os.path.join(HS, "gzio_stress.cpp"), os.path.join(HOST, "gzio.h")]
+    if not newer(out, src):
+        os.makedirs(BINDIR, exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-pthread"] + FLAGS[san] + [src[0], "-o", out, "-lz", "-ldl"])
+    return out
+
+
+@pytest.fixture(scope="module")
 def niqki_bin(san):
     out = os.path.join(BINDIR, "niqki_fake_" + san)
     src = [os.path.join(HOST, f) for f in ("niqki_main.cpp", "index_host.cpp", "index_host.h", "gzio.h", "seqio.h", "Makefile")] + \
@@ -188,3 +198,13 @@ def test_host_pipeline_many_files_and_streams_under_sanitizer(niqki_bin, san, wo
     assert "Bad usage!!!" in r.stdout
     r = run(niqki_bin, san, workdir, ["--gpus", "2", "-I", "fof.txt", "-S", "10", "-O", "mg.gz"], ok=(1,))   # the fake engine has no groups
     assert "whole-range handles only" in r.stderr          # (an engine error on the way out: message, exit code 1, no hang)
+
+
+
+def test_parallel_gzip_writer_and_reader_under_sanitizer(gzio_bin, san, tmp_path):
+    """The dump files' writer and reader (size-tagged gzip members compressed, written and inflated side by side:
+    niqki_amd/host/gzio.h) on blocks of every size around the 8 MB piece, with libdeflate and with zlib's codec: the
+    same bytes back through the parallel reader and through zlib's gzread; damage is an exception."""
+    for env, size in (({}, "full"), ({"NIQKI_HOST_ZLIB_ONLY": "1"}, "small")):
+        r = subprocess.run([gzio_bin, str(tmp_path), size], capture_output=True, text=True, timeout=900, env=dict(os.environ, **SAN_ENV[san], **env))
+        assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout[-500:] + r.stderr[-3000:]
