@@ -231,7 +231,7 @@ inline void tagged_inflate(const uint8_t *p, size_t total, std::vector<uint8_t> 
 // Gzip writer that compresses in parallel: what it is given is cut into pieces of 8 MB, every piece becomes a gzip
 // member of its own (tagged with its size, above), members are written in order.  Concatenated members are one valid
 // gzip file; the reference's reader (zstr::istreambuf, src/zstr.hpp:236-239) restarts its inflater at every member
-// end, so it reads these files unchanged (tests/test_oracle_golden.py: the real reference loads such a dump).
+// end, so it reads these files unchanged (the CPU test suite lets the real reference load such a dump).
 class ParallelGzWriter {
  public:
   static constexpr size_t kPiece = size_t(8) << 20;
