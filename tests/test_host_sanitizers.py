@@ -62,7 +62,7 @@ def gzio_bin(san):
 @pytest.fixture(scope="module")
 def niqki_bin(san):
     out = os.path.join(BINDIR, "niqki_fake_" + san)
-    src = [os.path.join(HOST, f) for f in ("niqki_main.cpp", "index_host.cpp", "index_host.h", "gzio.h", "seqio.h", "Makefile")] + \
+    src = [os.path.join(HOST, f) for f in ("niqki_main.cpp", "index_host.cpp", "index_host.h", "file_reader.h", "gzio.h", "seqio.h", "Makefile")] + \
           [os.path.join(HS, "fake_engine.cpp"), os.path.join(ROOT, "oracle", "niqki_oracle.c"),
            os.path.join(ROOT, "niqki_amd", "csrc", "nq_pack.h"), os.path.join(ROOT, "include", "niqki_hip.h")]
     if not newer(out, src):
