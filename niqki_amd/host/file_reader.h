@@ -126,11 +126,12 @@ bool gunzip_whole(int fd, size_t file_bytes, PinnedBuf &out) {
 // want_pack: a plain (not gzipped) regular FASTA file may be handed over as its packed container
 // (nq_pack.h, what niqki_pack_fasta makes: 2 bits per base in full A/C/G/T lines, everything else verbatim; the device
 // restores the file's exact bytes) -- *packed says whether it was.
-// want_gz: a gzip'd regular file may be handed over as it lies on disk (*gz says whether it was): the device inflates it
+// want_gz (2: any, 1: only files whose members carry their size -- BGZF, this project's tag: those the library cuts into
+// members, a wavefront each, quick however few files a batch holds): a gzip'd regular file may be handed over as it lies on disk (*gz says whether it was): the device inflates it
 // (niqki_stage_raw, NIQKI_FILE_GZIP).  Only what the device will plausibly take -- one member whose trailer states a
 // size in keeping with the file's (the library's own test) -- everything else is inflated here, as before.
 void read_file_bytes(const std::string &path, PinnedBuf &out, bool want_pack = false, bool *packed = nullptr,
-                     bool want_gz = false, bool *gz = nullptr) {
+                     int want_gz = 0, bool *gz = nullptr) {
   out.size = 0;
   if (packed) *packed = false;
   if (gz) *gz = false;
@@ -174,7 +175,17 @@ void read_file_bytes(const std::string &path, PinnedBuf &out, bool want_pack = f
     // not worth packing (or the file changed under us): its bytes as they are, below
   }
   if (m == 2 && magic[0] == 0x1F && magic[1] == 0x8B) {
-    if (want_gz && gz && S_ISREG(st.st_mode) && st.st_size >= 18 && (uint64_t)st.st_size <= 0x7FFF0000ull) {
+    bool tagged_head = false;   // the first member says how long it is
+    {
+      unsigned char h[64];
+      const ssize_t hn = pread(fd, h, sizeof h, 0);
+      if (hn >= 28 && (h[3] & 4)) {
+        const size_t xlen = (size_t)h[10] | (size_t)h[11] << 8;
+        for (size_t x = 12; x + 4 <= 12 + xlen && x + 4 <= (size_t)hn; x += 4 + ((size_t)h[x + 2] | (size_t)h[x + 3] << 8))
+          tagged_head |= (h[x] == 'B' && h[x + 1] == 'C') || (h[x] == 'N' && h[x + 1] == 'Q');
+      }
+    }
+    if ((want_gz == 2 || (want_gz == 1 && tagged_head)) && gz && S_ISREG(st.st_mode) && st.st_size >= 18 && (uint64_t)st.st_size <= 0x7FFF0000ull) {
       const size_t n = (size_t)st.st_size;
       out.reserve(n + 64);
       size_t got = 0;
@@ -185,15 +196,8 @@ void read_file_bytes(const std::string &path, PinnedBuf &out, bool want_pack = f
       }
       if (got == n) {
         const uint64_t isize = (uint64_t)out.p[n - 4] | (uint64_t)out.p[n - 3] << 8 | (uint64_t)out.p[n - 2] << 16 | (uint64_t)out.p[n - 1] << 24;
-        // ... or a file of members that say how long they are (BGZF's 'B' 'C' subfield, this project's 'N' 'Q'): the
-        // library cuts it into its members, one wavefront each
-        bool tagged = false;
-        if (n >= 28 && (out.p[3] & 4)) {
-          const size_t xlen = (size_t)out.p[10] | (size_t)out.p[11] << 8;
-          for (size_t x = 12; x + 4 <= 12 + xlen && x + 4 <= n; x += 4 + ((size_t)out.p[x + 2] | (size_t)out.p[x + 3] << 8))
-            tagged |= (out.p[x] == 'B' && out.p[x + 1] == 'C') || (out.p[x] == 'N' && out.p[x + 1] == 'Q');
-        }
-        if (tagged || (isize <= 0x7FFF0000ull && isize <= (uint64_t)n * 64u && isize * 4096u >= (uint64_t)n)) {
+        // ... or a file of members that say how long they are: the library cuts it into its members
+        if (tagged_head || (isize <= 0x7FFF0000ull && isize <= (uint64_t)n * 64u && isize * 4096u >= (uint64_t)n)) {
           out.size = n;
           *gz = true;
           ::close(fd);
@@ -281,7 +285,7 @@ class OrderedFileReader {
     while (p->size() < n) p->emplace_back();
     return *p;
   }
-  OrderedFileReader(const std::vector<std::string> &paths, unsigned threads, size_t n_bufs, bool device_inflate)
+  OrderedFileReader(const std::vector<std::string> &paths, unsigned threads, size_t n_bufs, int device_inflate)
       : paths_(paths), bufs_(pool(n_bufs)), ready_(paths.size(), nullptr), pack_(std::getenv("NIQKI_HOST_NO_PACK") == nullptr),
         gz_(device_inflate) {
     for (size_t i = 0; i < n_bufs; ++i) free_.push_back(&bufs_[n_bufs - 1 - i]);  // LIFO: low indices first
@@ -348,7 +352,7 @@ class OrderedFileReader {
   size_t issued_ = 0, taken_ = 0;
   bool stop_ = false;
   const bool pack_;   // plain FASTA files travel as packed containers (NIQKI_HOST_NO_PACK: as their bytes)
-  const bool gz_;     // gzip files travel as they are and are inflated on the device (for_each_batch decides per list)
+  const int gz_;      // which gzip files travel as they are and are inflated on the device (read_file_bytes' want_gz; for_each_batch decides per list)
 };
 
 }  // namespace

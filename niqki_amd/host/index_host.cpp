@@ -431,7 +431,8 @@ void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*
   for (const auto &p : paths) n_gz_names += p.size() > 3 && p.compare(p.size() - 3, 3, ".gz") == 0;
   if (const char *v = std::getenv("NIQKI_HOST_GPU_INFLATE_MIN")) gz_min = (size_t)std::max(0, std::atoi(v));
   const bool gz_list = std::getenv("NIQKI_HOST_NO_GPU_INFLATE") == nullptr && 2 * n_gz_names > paths.size() && n_gz_names >= gz_min;
-  OrderedFileReader rd(paths, n_threads, gz_list ? std::min(kGzReaderBufs, 2 * paths.size() + 64) : kReaderBufs, gz_list);
+  OrderedFileReader rd(paths, n_threads, gz_list ? std::min(kGzReaderBufs, 2 * paths.size() + 64) : kReaderBufs,
+                       std::getenv("NIQKI_HOST_NO_GPU_INFLATE") ? 0 : gz_list ? 2 : 1);
   size_t i = 0, n_batches = 0;
   auto assemble = [&](Batch &b) {
     const auto t0 = clk::now();

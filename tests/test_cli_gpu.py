@@ -145,6 +145,17 @@ def test_gzip_inputs_and_many_files(workdir, gold):
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, NIQKI_HOST_NO_GPU_INFLATE="1"))
     assert r.returncode == 0, r.stdout + r.stderr
     assert gunzip(workdir / "big_host.gz") == gunzip(workdir / "big.gz")
+    # BGZF files go to the device whatever the list's length (their members are a wavefront's job each), other gzip
+    # files of a short list to the reader threads: the default policy, same text
+    (workdir / "bgzf.txt").write_text("\n".join(b for b in big if int(b[1:3]) % 5 in (2, 3)) + "\n")
+    env_default = {k: v for k, v in os.environ.items() if k != "NIQKI_HOST_GPU_INFLATE_MIN"}
+    outs = []
+    for env in (env_default, dict(env_default, NIQKI_HOST_NO_GPU_INFLATE="1")):
+        r = subprocess.run([BIN, "-I", "bgzf.txt", "-Q", "fof.txt", "-S", "10", "-J", "0.1", "-O", "bgzf.gz"], cwd=workdir,
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(gunzip(workdir / "bgzf.gz"))
+    assert outs[0] == outs[1] and len(outs[0]) > 100
     # a damaged file (a flipped byte in the middle of the stream; a cut one) ends the run the same way either way
     raw = bytearray((workdir / big[0]).read_bytes())
     raw[len(raw) // 2] ^= 0x10
