@@ -353,7 +353,7 @@ void niqki_destroy(niqki_index *ix) {
   (void)hipStreamSynchronize(ix->stream);
   for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
                  &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash,
-                 &ix->ws_raw, &ix->ws_raw2, &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
+                 &ix->ws_raw, &ix->ws_wire[0], &ix->ws_wire[1], &ix->ws_fmeta, &ix->ws_summ, &ix->ws_chunk, &ix->ws_fkept, &ix->ws_fnrec,
                  &ix->ws_hdrpos, &ix->ws_ehdr, &ix->ws_stsk, &ix->ws_order, &ix->ws_pre, &ix->ws_hl, &ix->ws_useg, &ix->ws_ijob, &ix->ws_xtab})
     if (b->p) (void)hipFree(b->p);
   for (Buf *b : {&ix->pg_store, &ix->pg_stage})
@@ -371,7 +371,7 @@ void niqki_destroy(niqki_index *ix) {
   for (auto e : ix->ev_pool) (void)hipEventDestroy(e);
   if (ix->aux_stream) { (void)hipStreamSynchronize(ix->aux_stream); (void)hipStreamDestroy(ix->aux_stream); }
   if (ix->copy_stream) { (void)hipStreamSynchronize(ix->copy_stream); (void)hipStreamDestroy(ix->copy_stream); }
-  if (ix->ev_copy) (void)hipEventDestroy(ix->ev_copy);
+  for (auto &pr : ix->pre) if (pr.ev) (void)hipEventDestroy(pr.ev);
   if (ix->ev_fork) (void)hipEventDestroy(ix->ev_fork);
   if (ix->ev_join) (void)hipEventDestroy(ix->ev_join);
   if (ix->own_stream) (void)hipStreamDestroy(ix->stream);

@@ -90,27 +90,28 @@ int niqki_stage_raw_prefetch(niqki_index *ix, const niqki_raw_batch *b) {
   if (!ix || !b) return NIQKI_E_INVALID;
   if (!b->file_ptr || !b->file_off) return fail(ix, NIQKI_E_INVALID, "a prefetch takes the file_ptr form of a host batch");
   NQ_HIP(ix, hipSetDevice(ix->device));
-  if (!ix->copy_stream) {
-    NQ_HIP(ix, hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
-    NQ_HIP(ix, hipEventCreateWithFlags(&ix->ev_copy, hipEventDisableTiming));
-  }
-  if (ix->pre.valid) NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream));  // an unused one: its host bytes may go away now
-  ix->pre.valid = false;
+  if (!ix->copy_stream) NQ_HIP(ix, hipStreamCreateWithFlags(&ix->copy_stream, hipStreamNonBlocking));
+  const uint32_t slot = ix->pre_next;
+  auto &pr = ix->pre[slot];
+  if (!pr.ev) NQ_HIP(ix, hipEventCreateWithFlags(&pr.ev, hipEventDisableTiming));
+  if (pr.valid) NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream));  // an unused one: its host bytes may go away now
+  pr.valid = false;
   const uint32_t nf = b->n_files;
   if (nf == 0) return NIQKI_OK;
   for (uint32_t f = 0; f < nf; ++f)
     if (b->file_off[f + 1] < b->file_off[f]) return fail(ix, NIQKI_E_INVALID, "file_off must be non-decreasing");
   const uint64_t T = b->file_off[nf];
-  int rc = ensure(ix, ix->ws_raw2, (size_t)T + 2 * NIQKI_SEQ_PAD);
+  int rc = ensure(ix, ix->ws_wire[slot], (size_t)T + 2 * NIQKI_SEQ_PAD);
   if (rc) return rc;
   for (uint32_t f = 0; f < nf; ++f) {
     const uint64_t n = b->file_off[f + 1] - b->file_off[f];
-    if (n) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_raw2.p + b->file_off[f], b->file_ptr[f], n, hipMemcpyHostToDevice, ix->copy_stream));
+    if (n) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_wire[slot].p + b->file_off[f], b->file_ptr[f], n, hipMemcpyHostToDevice, ix->copy_stream));
   }
-  NQ_HIP(ix, hipEventRecord(ix->ev_copy, ix->copy_stream));
-  ix->pre.ptr.assign(b->file_ptr, b->file_ptr + nf);
-  ix->pre.off.assign(b->file_off, b->file_off + nf + 1);
-  ix->pre.valid = true;
+  NQ_HIP(ix, hipEventRecord(pr.ev, ix->copy_stream));
+  pr.ptr.assign(b->file_ptr, b->file_ptr + nf);
+  pr.off.assign(b->file_off, b->file_off + nf + 1);
+  pr.valid = true;
+  ix->pre_next = slot ^ 1u;
   return NIQKI_OK;
 }
 
@@ -224,25 +225,37 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   int rc;
   const uint8_t *d_raw = b->raw;
   bool prefetched = false;
-  if (ix->pre.valid) {  // bytes a niqki_stage_raw_prefetch put on their way: this batch's, or dropped
-    prefetched = mem == NIQKI_MEM_HOST && b->file_ptr && nf == ix->pre.ptr.size() &&
-                 std::equal(ix->pre.ptr.begin(), ix->pre.ptr.end(), b->file_ptr) &&
-                 std::equal(ix->pre.off.begin(), ix->pre.off.end(), b->file_off);
-    ix->pre.valid = false;
-    if (prefetched) {
-      if (!any_wire) std::swap(ix->ws_raw, ix->ws_raw2);   // (packed / gzip: ws_raw2 stays the wire buffer, unpacked below)
-      NQ_HIP(ix, hipStreamWaitEvent(ix->stream, ix->ev_copy, 0));
-      d_raw = (const uint8_t *)ix->ws_raw.p;
-    } else {
-      NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream));
+  // bytes a niqki_stage_raw_prefetch put on their way: this batch's (the other slot's, a later batch's, stay on their
+  // way) -- or, when the batch is none of them, all dropped
+  uint32_t wslot = 0;   // the wire buffer of this batch
+  {
+    int hit = -1;
+    for (int sl = 0; sl < 2; ++sl) {
+      const auto &pr = ix->pre[sl];
+      if (pr.valid && mem == NIQKI_MEM_HOST && b->file_ptr && nf == pr.ptr.size() && std::equal(pr.ptr.begin(), pr.ptr.end(), b->file_ptr) &&
+          std::equal(pr.off.begin(), pr.off.end(), b->file_off))
+        hit = sl;
     }
+    if (hit >= 0) {
+      prefetched = true;
+      wslot = (uint32_t)hit;
+      ix->pre[hit].valid = false;
+      if (!any_wire) std::swap(ix->ws_raw, ix->ws_wire[wslot]);   // (packed / gzip: the slot stays the wire buffer, unpacked below)
+      NQ_HIP(ix, hipStreamWaitEvent(ix->stream, ix->pre[hit].ev, 0));
+      d_raw = (const uint8_t *)ix->ws_raw.p;
+    } else if (ix->pre[0].valid || ix->pre[1].valid) {
+      NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream));
+      ix->pre[0].valid = ix->pre[1].valid = false;
+      ix->pre_next = 0;
+    }
+    if (hit < 0) wslot = ix->pre[0].valid ? 1u : 0u;
   }
   if (any_wire) {
     if (!prefetched) {   // the containers (and raw files) as they are, into the wire buffer
-      if ((rc = ensure(ix, ix->ws_raw2, (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
+      if ((rc = ensure(ix, ix->ws_wire[wslot], (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
       for (uint32_t f = 0; f < nf; ++f) {
         const uint64_t n = b->file_off[f + 1] - b->file_off[f];
-        if (n) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_raw2.p + b->file_off[f], b->file_ptr[f], n, hipMemcpyHostToDevice, ix->stream));
+        if (n) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_wire[wslot].p + b->file_off[f], b->file_ptr[f], n, hipMemcpyHostToDevice, ix->stream));
       }
     }
     if ((rc = ensure(ix, ix->ws_raw, (size_t)T_raw + 2 * NIQKI_SEQ_PAD))) return rc;
@@ -251,9 +264,9 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
       NQ_HIP(ix, hipMemcpyAsync(ix->ws_useg.p, segs.data(), segs.size() * sizeof(nq::UnpackSeg), hipMemcpyHostToDevice, ix->stream));
       Span sp(ix, NIQKI_KC_INGEST);
       NQ_HIP(ix, nq::launch_unpack((const nq::UnpackSeg *)ix->ws_useg.p, (uint32_t)segs.size(), (uint32_t)unpack_blocks,
-                                   (const uint8_t *)ix->ws_raw2.p, (uint8_t *)ix->ws_raw.p, ix->stream));
+                                   (const uint8_t *)ix->ws_wire[wslot].p, (uint8_t *)ix->ws_raw.p, ix->stream));
     }
-    if ((rc = inflate_launch(ix, jobs, (const uint8_t *)ix->ws_raw2.p, (uint64_t)ix->ws_raw2.n & ~(uint64_t)3, (uint8_t *)ix->ws_raw.p))) return rc;
+    if ((rc = inflate_launch(ix, jobs, (const uint8_t *)ix->ws_wire[wslot].p, (uint64_t)ix->ws_wire[wslot].n & ~(uint64_t)3, (uint8_t *)ix->ws_raw.p))) return rc;
     d_raw = (const uint8_t *)ix->ws_raw.p;
   } else if (prefetched) {
   } else if (mem == NIQKI_MEM_HOST) {
@@ -420,7 +433,7 @@ int niqki_gunzip(niqki_index *ix, const uint8_t *gz, const uint64_t *gz_off, uin
   if (!ix || !gz || !gz_off || !raw_off) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
   ix->staged.valid = false;   // (shares the staging buffers)
-  if (ix->pre.valid) { NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream)); ix->pre.valid = false; }
+  if (ix->pre[0].valid || ix->pre[1].valid) { NQ_HIP(ix, hipStreamSynchronize(ix->copy_stream)); ix->pre[0].valid = ix->pre[1].valid = false; ix->pre_next = 0; }
   if (n_files == 0) return NIQKI_OK;
   std::vector<nq::InflateJob> jobs(n_files);
   for (uint32_t f = 0; f < n_files; ++f) {
@@ -429,11 +442,11 @@ int niqki_gunzip(niqki_index *ix, const uint8_t *gz, const uint64_t *gz_off, uin
   }
   const uint64_t T = gz_off[n_files], T_raw = raw_off[n_files];
   int rc;
-  if ((rc = ensure(ix, ix->ws_raw2, (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
+  if ((rc = ensure(ix, ix->ws_wire[0], (size_t)T + 2 * NIQKI_SEQ_PAD))) return rc;
   if ((rc = ensure(ix, ix->ws_raw, (size_t)T_raw + 2 * NIQKI_SEQ_PAD))) return rc;
-  if (T > gz_off[0]) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_raw2.p + gz_off[0], gz + gz_off[0], T - gz_off[0], hipMemcpyHostToDevice, ix->stream));
+  if (T > gz_off[0]) NQ_HIP(ix, hipMemcpyAsync((uint8_t *)ix->ws_wire[0].p + gz_off[0], gz + gz_off[0], T - gz_off[0], hipMemcpyHostToDevice, ix->stream));
   NQ_HIP(ix, hipMemsetAsync(ix->ws_raw.p, 0xEE, (size_t)T_raw + 2 * NIQKI_SEQ_PAD, ix->stream));
-  if ((rc = inflate_launch(ix, jobs, (const uint8_t *)ix->ws_raw2.p, (uint64_t)ix->ws_raw2.n & ~(uint64_t)3, (uint8_t *)ix->ws_raw.p))) return rc;
+  if ((rc = inflate_launch(ix, jobs, (const uint8_t *)ix->ws_wire[0].p, (uint64_t)ix->ws_wire[0].n & ~(uint64_t)3, (uint8_t *)ix->ws_raw.p))) return rc;
   std::vector<nq::InflateOut> out(n_files);
   NQ_HIP(ix, hipMemcpyAsync(out.data(), (const nq::InflateJob *)ix->ws_ijob.p + n_files, (size_t)n_files * sizeof(nq::InflateOut),
                             hipMemcpyDeviceToHost, ix->stream));

@@ -118,15 +118,18 @@ struct niqki_index {
     uint64_t seq_bytes = 0;
     const uint32_t *entry_rec = nullptr;  // device, n_entry+1
   } staged;
-  // niqki_stage_raw_prefetch: the next batch's file bytes on their way into ws_raw2 on copy_stream
-  nqi::Buf ws_raw2;
+  // niqki_stage_raw_prefetch: file bytes of coming batches on their way into ws_wire[slot] on copy_stream.  Two
+  // slots, taken in turn: the bytes of batch i + 1 may cross while batch i -- whose own (prefetched) bytes are still
+  // being inflated / unpacked out of the other slot -- is staged.
+  nqi::Buf ws_wire[2];
   hipStream_t copy_stream = nullptr;
-  hipEvent_t ev_copy = nullptr;
   struct {
     bool valid = false;
     std::vector<const uint8_t *> ptr;
     std::vector<uint64_t> off;
-  } pre;
+    hipEvent_t ev = nullptr;
+  } pre[2];
+  uint32_t pre_next = 0;   // the slot the next prefetch takes
 
   bool prof = false;
   double prof_ms[NIQKI_KC_COUNT] = {0};

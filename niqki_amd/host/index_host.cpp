@@ -461,18 +461,29 @@ void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*
     }
     t_wait += std::chrono::duration<double>(clk::now() - t0).count();
   };
+  // The bytes of batch i + 1 cross PCIe while batch i is worked on (the library keeps two prefetch buffers).  Gzip lists
+  // (2048 files, gigabytes a batch, readers far ahead of the device): batch i + 1 is put together and sent on its way
+  // BEFORE batch i is staged, so the copy runs under batch i's inflate kernel.  Other lists (64 files a batch, readers
+  // about as fast as the device): batch i is staged first, so that the readers' buffers are not all spoken for while it
+  // runs -- waiting for batch i + 1 up front cost a third of the rate there.
   Batch cur, nxt;
   assemble(cur);
   if (!cur.files.empty()) stage_batch(cur, true);
   while (!cur.files.empty()) {
+    if (gz_list) {
+      assemble(nxt);
+      if (!nxt.files.empty()) stage_batch(nxt, true);
+    }
     auto t0 = clk::now();
     Lap lap;
     stage_batch(cur, false);
     lap.to(t_stage_);
     t_gpu += std::chrono::duration<double>(clk::now() - t0).count();
-    assemble(nxt);
+    if (!gz_list) {
+      assemble(nxt);
+      if (!nxt.files.empty()) stage_batch(nxt, true);
+    }
     t0 = clk::now();
-    if (!nxt.files.empty()) stage_batch(nxt, true);
     (this->*flush)(cur);
     t_gpu += std::chrono::duration<double>(clk::now() - t0).count();
     for (auto *f : cur.files) rd.release(f);
