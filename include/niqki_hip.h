@@ -352,8 +352,10 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *batch, int mem_space
 /* Starts the host-to-device copy of the NEXT batch's file bytes (file_ptr form, whole mode) on a
  * copy stream of the handle and returns without waiting: the copy runs beside the kernels of the
  * batch staged now (the read loops of :461-500 / :523-540 with the transfer of file i+1 under the
- * work on file i).  The next niqki_stage_raw(NIQKI_MEM_HOST) whose batch names the same file_ptr[]
- * and file_off[] takes these bytes instead of copying; any other niqki_stage_raw drops them.  The
+ * work on file i).  A niqki_stage_raw(NIQKI_MEM_HOST) whose batch names the same file_ptr[] and
+ * file_off[] takes these bytes instead of copying.  Two prefetches may be on their way at a time (the
+ * batch about to be staged and the one behind it: a third takes the older one's place); staging
+ * one of them leaves the other alone, staging any other batch drops both.  The
  * caller keeps the host bytes valid until that call returns (page-locked memory, or the copy is
  * not asynchronous). */
 int niqki_stage_raw_prefetch(niqki_index *ix, const niqki_raw_batch *batch);
