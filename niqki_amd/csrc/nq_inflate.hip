@@ -1,4 +1,4 @@
-// nq_inflate.hip -- gzip members inflated on the GPU, one wavefront per file.
+// nq_inflate.hip -- gzip members inflated on the GPU, one wavefront per file (or per size-tagged member).
 //
 // The reference opens every input through zstr::ifstream (src/zstr.hpp:190-203, :236-239: gzip is detected by its
 // magic and inflated by zlib, member after member) before Index::Biogetline frames the lines
@@ -7,14 +7,21 @@
 // host's cores; here a gzip file crosses PCIe as it is and this kernel writes its bytes where niqki_stage_raw's
 // framing kernels expect them.
 //
-// DEFLATE (RFC 1951) decodes one symbol after the other, so a file is a serial job: the parallelism is over the
-// files of a batch (one 64-lane wavefront each, four per CU) and, inside a wavefront, over the bytes of a match copy,
-// of a flush and of the table builds.  Everything the serial part touches is in LDS:
-//   ring      the 32 KB window; a byte leaves for HBM when its 4 KB page is complete (16-byte stores, CRC-32 of the
-//             page on the way: 64 lanes x 64 bytes, folded with the x^(8n) mod P operators of xtab)
-//   lit / dist tables   one look-up of 10 / 8 bits per symbol (codes that are longer take the canonical walk)
-// The decoder state (bit buffer, positions) is wave-uniform and lives in scalar registers; the next 256 input bytes
-// wait in one vector register (lane i = dword i, taken by v_readlane), the block after them is on its way.
+// DEFLATE (RFC 1951) decodes one symbol after the other, so a job -- a gzip file, or one member of a file whose members
+// say how long they are (BGZF: the caller cuts such a file up) -- is serial: ONE 64-lane wavefront per job.  The
+// parallelism is over the jobs of a launch and, inside the wavefront, over bit offsets and bytes:
+//   a round   lane i decodes the token that WOULD start at bit pos + i of the input (literal, or length + distance with
+//             their extra bits: two table gathers), whatever the real token boundaries are; the chain of real tokens is
+//             walked through the lanes' results by v_readlane; the bytes of all tokens of the round, up to 64, are
+//             written in one LDS gather + scatter.  A token that is not plain (end of block, a code behind the tables,
+//             a match overlapping the round's own bytes) is taken serially from the wave-uniform reader.
+//   ring      the window in LDS (all 32 KB of it, or its last 8 KB with far matches read back from the job's own
+//             flushed output: template parameter); a byte leaves for HBM when its 4 KB page is complete (16-byte
+//             stores, CRC-32 of the page on the way: 64 lanes x 64 bytes, folded with the x^(8n) mod P operators of xtab)
+//   lit / dist tables   10 / 8 bits per look-up (longer codes: the canonical walk), built by the wave per block
+//   inbuf     the two 256-byte input blocks the lanes' windows reach into (the block behind them is on its way)
+// The decoder state (bit position, output position) is wave-uniform and lives in scalar registers.  A wavefront alone
+// on its SIMD issues a dependent instruction every other turn (~10 cycles each here): LDS decides how many run.
 //
 // What is not a plain, intact gzip file of the announced size is not decided here: any irregularity ends the file's
 // job with a status != 0 and the caller (niqki_stage_raw) reports the file, which the host then reads through zlib
