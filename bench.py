@@ -754,6 +754,11 @@ def main():
         dist.destroy_process_group()
 
 
+def torch_index(like, idx):
+    import torch
+    return torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(like.device)
+
+
 def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, prm):
     """The oracle (port of the reference CPU path) on this host, on a bounded
     sample of the same workload; also the in-run parity check (sketches, dense counters and the
@@ -774,8 +779,11 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
     n_s = int(min(per, max(8, 2 * min(omp_max, phys))))
     si = args.warmup + args.steps - 1  # the last timed step: its hits are what hc / hg still hold
     bi = si % qsk.shape[0]
-    seqs = qseq[bi * per * stride_b: bi * per * stride_b + n_s * stride_b].cpu().numpy()
-    rec = np.stack([seqs[i * stride_b:i * stride_b + L] for i in range(n_s)])
+    # the sample: n_s queries spread evenly over the whole batch (launch positions of every 1024-query group of the
+    # look-up pre-pass and of both ends of the locality order), not its first n_s
+    pos = (np.arange(n_s, dtype=np.int64) * per) // n_s + (per // n_s) // 2
+    base = bi * per * stride_b
+    rec = np.stack([qseq[base + int(q) * stride_b: base + int(q) * stride_b + L].cpu().numpy() for q in pos])
     rec_off = (np.arange(n_s + 1) * L).astype(np.uint64)
     # sketch leg at every thread count (each pass sketches all n_s genomes: a few seconds together)
     # the headline runs on the CPUs this job HAS: the cgroup quota where there is one (more threads than that only
@@ -795,15 +803,16 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
         t_sk = time.perf_counter() - t0
         sk_table[quota_threads] = n_s / t_sk
     cores = quota_threads
-    sk_gpu = qsk[bi, :n_s].cpu().numpy()
+    sk_gpu = qsk[bi][torch_index(qsk, pos)].cpu().numpy()
     parity_sketch = bool(np.array_equal(sk_cpu, sk_gpu))
     # gather leg: the oracle's query loop timed on EVERY sub-index of <= 16384 genomes the index is cut into
     # (the seven of them hold all 100 000 genomes: their sum is the whole-index figure, nothing extrapolated);
     # the sub-index' arrays are first touched by the threads that gather from them (nqo_index_spread);
     # parity over ALL columns from the same seven sub-indexes
-    n_par = min(n_s, 8)
+    n_par = min(n_s, 16)
+    par = (np.arange(n_par) * n_s) // n_par          # which of the sample: again evenly spread
     exp_cols = np.zeros((n_par, N), np.uint32)
-    cnt = eng.query_counts(sk_gpu[:n_par])
+    cnt = eng.query_counts(sk_gpu[par])
     t_q, n_sub_ix, q_table, q_threads = 0.0, 0, {}, cores
     for b0 in range(0, N, 16384):
         n_sub = min(16384, N - b0)
@@ -829,7 +838,7 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
         t_q += best
         n_sub_ix += 1
         for i in range(n_par):
-            exp_cols[i, b0:b0 + n_sub] = ix.counts(sk_cpu[i])
+            exp_cols[i, b0:b0 + n_sub] = ix.counts(sk_cpu[par[i]])
         del ix, sub
     parity_counts = bool(np.array_equal(cnt.astype(np.uint32), exp_cols))
     # hit lists of the timed step for these queries: threshold + order of the oracle's columns
@@ -839,7 +848,7 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
     for i in range(n_par):
         gids = np.nonzero(exp_cols[i] >= p.min_score)[0]
         order = np.lexsort((-gids.astype(np.int64), -exp_cols[i, gids].astype(np.int64)))
-        lo, hi = int(off[i]), int(off[i + 1])
+        lo, hi = int(off[pos[par[i]]]), int(off[pos[par[i]] + 1])
         parity_hits &= bool(np.array_equal(g_hc[lo:hi].astype(np.uint32), exp_cols[i, gids][order]) and
                             np.array_equal(g_hg[lo:hi].astype(np.uint32), gids[order].astype(np.uint32)))
     val = n_s / (t_sk + t_q)
@@ -917,8 +926,8 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
             r_off, r_hc, r_hg = r.query_batch(r_sk, threads=cores)
             t_rq = time.perf_counter() - t0
             same = bool(np.array_equal(r_sk, sk_gpu))
-            for i in range(n_par):   # the reference's own hit lists against the GPU's of the timed step
-                lo, hi = int(off[i]), int(off[i + 1])
+            for i in range(n_s):     # the reference's own hit lists against the GPU's of the timed step, the whole sample
+                lo, hi = int(off[pos[i]]), int(off[pos[i] + 1])
                 rl, rh = int(r_off[i]), int(r_off[i + 1])
                 same &= bool(np.array_equal(g_hc[lo:hi].astype(np.uint32), r_hc[rl:rh]) and np.array_equal(g_hg[lo:hi].astype(np.uint32), r_hg[rl:rh]))
             r.close()
@@ -930,7 +939,7 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
                          "sketch_genomes_per_s": n_s / t_rsk, "query_genomes_per_s": n_s / t_rq,
                          "index_build_s": {"constructor": round(t_ctor, 2), "insert_%d_genomes" % N: round(t_ins, 2)},
                          "gpu_hit_lists_equal_the_references": same,
-                         "sample": "%d query genomes of step %d through the reference's own Index (oracle/_ref/libniqki_ref.so, built from "
+                         "sample": "%d query genomes (spread evenly over the batch) of step %d through the reference's own Index (oracle/_ref/libniqki_ref.so, built from "
                                    "/root/reference/src by oracle/Makefile) holding all %d genomes: compute_sketch + query_sketch from %d "
                                    "OpenMP threads, one record per thread at a time like src/niqki_index.cpp:523-540 (%.2f + %.2f s)"
                                    % (n_s, si, N, cores, t_rsk, t_rq)}
@@ -945,13 +954,14 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
         "sketch_genomes_per_s_by_threads": {str(k): v for k, v in sorted(sk_table.items())},
         "gather_queries_per_s_by_threads_first_sub_index": {str(k): v for k, v in sorted(q_table.items())},
         "gather_threads": q_threads,
-        "sample": "%d query genomes of step %d: sketch leg timed in full on %d threads (the CPUs this job has: its cgroup quota, else the "
+        "sample": "%d query genomes of step %d, spread evenly over its %d launch positions: sketch leg timed in full on %d threads (the CPUs this job has: its cgroup quota, else the "
                   "physical cores; %.2f s); gather leg = the oracle's query loop on %d threads timed on each of the %d sub-indexes of "
                   "<= 16384 genomes that together hold all %d genomes, summed (%.2f s); the index arrays first touched by the "
-                  "gathering threads" % (n_s, si, cores, t_sk, q_threads, n_sub_ix, N, t_q),
+                  "gathering threads" % (n_s, si, per, cores, t_sk, q_threads, n_sub_ix, N, t_q),
         "reference_sample": ref,
         "parity": {"sketch_bit_exact": parity_sketch, "counts_bit_exact_all_columns": parity_counts,
-                   "hit_lists_bit_exact": parity_hits, "queries_checked": n_par},
+                   "hit_lists_bit_exact": parity_hits, "queries_checked": n_par,
+                   "launch_positions_checked": [int(pos[i]) for i in par]},
     }
 
 

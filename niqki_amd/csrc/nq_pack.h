@@ -45,7 +45,8 @@ struct PackSeg {
 static_assert(sizeof(PackHeader) == 32 && sizeof(PackSeg) == 24, "container layout");
 
 inline uint64_t seg_raw_len(const PackSeg &s) { return s.width ? (uint64_t)s.count * (s.width + 1ull) : s.count; }
-inline uint64_t seg_pk_len(const PackSeg &s) { return s.width ? (uint64_t)s.count * ((s.width + 3u) / 4u) : s.count; }
+inline uint64_t seg_pk_len(const PackSeg &s) { return s.width ? (uint64_t)s.count * (((uint64_t)s.width + 3u) / 4u) : s.count; }
+constexpr uint32_t kMaxWidth = 0xFFFFFFu;   // the widest line the packer writes as a periodic segment (Packer::feed)
 
 // Packs one line of n bases (no newline) into (n + 3) / 4 bytes; false (nothing useful written) when a byte is not
 // one of A C G T.
@@ -167,7 +168,7 @@ struct Packer {
       if (!nl && !last) break;   // the line goes on in the next piece
       const size_t len = nl ? (size_t)(nl - (raw + i)) : n - i;   // without the newline
       bool packed = false;
-      if (nl && len >= 16 && len <= 0xFFFFFFu) {
+      if (nl && len >= 16 && len <= kMaxWidth) {
         PackSeg *cur = n_seg ? &seg[n_seg - 1] : nullptr;
         const bool extend = cur && cur->width == len && cur->count < 0xFFFFFFFFu;
         if (pack_line(raw + i, len, pay + pk, n - (i + len))) {
@@ -233,9 +234,13 @@ inline bool valid(const uint8_t *buf, size_t len) {
   for (uint32_t k = 0; k < h.n_seg; ++k) {
     PackSeg s;
     memcpy(&s, buf + sizeof(PackHeader) + (size_t)k * sizeof(PackSeg), sizeof s);
-    if (s.raw_off != raw || s.pk_off != pk || s.count == 0) return false;
-    raw += seg_raw_len(s);
-    pk += seg_pk_len(s);
+    // width is bounded by what the packer writes: (width + 3) / 4 and width + 1 are computed in 32 bits on the device
+    // (nq::unpack_kernel), and an unbounded width would let a crafted table index past the wire buffer
+    if (s.raw_off != raw || s.pk_off != pk || s.count == 0 || s.width > kMaxWidth) return false;
+    const uint64_t rl = seg_raw_len(s), pl = seg_pk_len(s);
+    if (pl == 0 || rl > h.raw_len - raw) return false;
+    raw += rl;
+    pk += pl;
     if (pk > h.payload_len) return false;
   }
   return raw == h.raw_len && pk == h.payload_len;

@@ -9,6 +9,11 @@ The oracle cannot sketch 500 Gbp, so the test is anchored in two steps, both bit
     index (the oracle's own insert + CSR), and the oracle's counters of ALL 100 000 columns are
     compared with niqki_query_counts; the oracle's thresholded, ordered hit lists built from
     those columns are compared with niqki_query's.
+
+The checked queries are every 61st of the 4096 of the bench's first batch (68 rows), so that the launch form
+bench.py times -- ONE call of 4096 queries: four 1024-query groups of lookup_rows_kernel, the locality order
+over all 4096 -- is compared with the oracle at launch positions of every group, and so is the
+`--shard-of 8 --batch 32768` form (8 ranks x 4096 queries through the sparse exchange).
 """
 import numpy as np
 import pytest
@@ -20,9 +25,10 @@ pytestmark = pytest.mark.gpu
 N, L, FAMILY, SEED = 100_000, 5_000_000, 100, 20261003
 K, S, W, H, J = 31, 15, 12, 4, 0.1
 F = 1 << S
-NQ = 64            # checked queries (dense columns + hit lists)
-NQ_BIG = 1024      # queries of one call in the launch form bench.py times (>= 1024: streamed table rows + order)
-NQ_SKETCH = 6      # of which re-sketched by the oracle (0.1 s of CPU each)
+NQ_BIG = 4096      # queries of one call: bench.py's --batch, the launch form it times (streamed table rows + order)
+CHECK = np.arange(0, NQ_BIG, 61)   # launch positions compared with the oracle: 17 in each 1024-query group of the pre-pass
+NQ = len(CHECK)    # 68 checked queries (dense columns + hit lists)
+NQ_SKETCH = 6      # queries re-sketched by the oracle (0.1 s of CPU each)
 BLOCK = 16384
 
 
@@ -52,7 +58,7 @@ def big(native):
         e.insert_dev(sk, n)
     e.build()
     # queries 0..NQ_BIG-1 of the bench's first batch (every 10th from a family that is not indexed), sketched in
-    # blocks of GB; the first NQ of them are the ones checked column by column
+    # blocks of GB; rows CHECK of them are the ones checked column by column
     qfam, qmem, qrate = bench.query_spec(np.arange(NQ_BIG), n_fam)
     qsk_big = torch.empty((NQ_BIG, F), dtype=torch.int32, device=dev)
     qseq = None
@@ -65,16 +71,17 @@ def big(native):
     e.synchronize()
     del seq
     BIG["qsk"] = qsk_big
-    yield e, qsk_big[:NQ].cpu().numpy(), qseq, (qfam[:NQ], qmem[:NQ], qrate[:NQ])
+    yield e, qsk_big[torch.from_numpy(CHECK).to(dev)].cpu().numpy(), qseq, (qfam[CHECK], qmem[CHECK], qrate[CHECK])
     BIG.clear()
     e.close()
 
 
 def test_config3_sketches_of_index_and_queries_vs_oracle(native, po, big):
-    e, qsk, qseq, _ = big
+    e, _, qseq, _ = big
     p = po.make_params(K, S, W, H, J)
+    first = BIG["qsk"][:NQ_SKETCH].cpu().numpy()
     for i in range(NQ_SKETCH):
-        assert np.array_equal(qsk[i], po.compute_sketch(p, qseq[i])), i
+        assert np.array_equal(first[i], po.compute_sketch(p, qseq[i])), i
     # indexed genomes: first, last, a family ancestor and a 5 % member, from the host generator
     n_fam = N // FAMILY
     for g in (0, 4_299, 65_471, N - 1):
@@ -102,19 +109,23 @@ def test_config3_all_columns_and_hit_lists_vs_oracle(native, po, big):
     e.set_option("lookup_prepass", 1)
     assert np.array_equal(e.query_counts(qsk), got)
     e.set_option("lookup_prepass", -1)
-    # the launch form bench.py times -- >= 1024 queries in one call: table rows streamed through LDS
-    # (lookup_rows_kernel), locality probe + order, gather_kernel<1024, 32, -1, 0, true> -- on the same
-    # queries: rows 0..NQ-1 of a 1024-query call are the oracle's columns, the hit lists likewise
+    # the launch form bench.py times -- 4096 queries in one call: table rows streamed through LDS
+    # (lookup_rows_kernel, four groups of 1024 queries), locality probe + order over all 4096,
+    # gather_kernel<1024, 32, -1, 0, true>: rows CHECK of that call (every 61st launch position, all four
+    # groups) are the oracle's columns, the hit lists likewise
     import torch
     big_sk = BIG["qsk"]
     dev = big_sk.device
+    d_check = torch.from_numpy(CHECK).to(dev)
     stride = native.row_stride(N)
     d_counts = torch.zeros((NQ_BIG, stride), dtype=torch.int16, device=dev)
     e.query_counts_dev(big_sk, NQ_BIG, d_counts, stride)
     e.synchronize()
     assert e.stat("last_gather_form") == 7                      # pre-pass, its streamed-rows kernel, locality order
-    big_rows = d_counts[:NQ, :N].cpu().numpy().view(np.uint16)
+    big_rows = d_counts[d_check][:, :N].cpu().numpy().view(np.uint16)
     assert np.array_equal(big_rows.astype(np.uint32), exp)
+    for grp_ in range(NQ_BIG // 1024):
+        assert ((CHECK // 1024) == grp_).sum() >= 16
     # ... and rows further back in the batch equal what a small call (look-ups inside the gather kernel) gives
     tail = slice(NQ_BIG - 48, NQ_BIG)
     small = e.query_counts(big_sk[tail].cpu().numpy())
@@ -129,10 +140,9 @@ def test_config3_all_columns_and_hit_lists_vs_oracle(native, po, big):
     b_off, b_hc, b_hg = b_off.cpu().numpy(), b_hc.cpu().numpy().astype(np.uint32), b_hg.cpu().numpy().astype(np.uint32)
     assert int(b_off[NQ_BIG]) <= cap_big
     del d_counts
-    # threshold + order from the oracle's columns: greater<pair<count, gid>>, :662-666, :685
+    # threshold + order from the oracle's columns: greater<pair<count, gid>>, :662-666, :685 -- the small call's
+    # lists AND the lists at launch positions CHECK of the 4096-query call
     off, hc, hg = e.query(qsk)
-    assert np.array_equal(b_off[:NQ + 1], off[:NQ + 1].astype(np.int64))
-    assert np.array_equal(b_hc[:int(off[NQ])], hc) and np.array_equal(b_hg[:int(off[NQ])], hg)
     n_with_hits = 0
     for q in range(NQ):
         gids = np.nonzero(exp[q] >= p.min_score)[0]
@@ -140,6 +150,8 @@ def test_config3_all_columns_and_hit_lists_vs_oracle(native, po, big):
         ec, eg = exp[q, gids][order], gids[order].astype(np.uint32)
         lo, hi = int(off[q]), int(off[q + 1])
         assert np.array_equal(hc[lo:hi], ec) and np.array_equal(hg[lo:hi], eg), q
+        lo, hi = int(b_off[CHECK[q]]), int(b_off[CHECK[q] + 1])
+        assert np.array_equal(b_hc[lo:hi], ec) and np.array_equal(b_hg[lo:hi], eg), ("launch position", int(CHECK[q]))
         n_with_hits += len(gids) > 0
         if qfam[q] < N // FAMILY:                              # mutant of an indexed family: hits stay inside it
             assert len(gids) > 0 and (gids // FAMILY == qfam[q]).all(), q
@@ -148,6 +160,7 @@ def test_config3_all_columns_and_hit_lists_vs_oracle(native, po, big):
     assert n_with_hits >= NQ * 8 // 10
     # the oracle's own threshold/sort (nqo_hits_from_counts) agrees with the numpy restatement
     L_ = po.lib()
+    BIG["hits"] = (b_off, b_hc, b_hg)                         # (checked against the oracle at rows CHECK just above)
     row = np.ascontiguousarray(exp[0])
     oc, og = np.empty(N, np.uint32), np.empty(N, np.uint32)
     k = L_.nqo_hits_from_counts(row.ctypes.data, N, p.min_score, oc.ctypes.data, og.ctypes.data, N)
@@ -197,7 +210,8 @@ def test_config4_eight_slot_shards_at_full_size(native, big):
     import torch
     dev = torch.device("cuda")
     e, qsk, _, _ = big
-    G, per = 8, NQ // 8
+    G, per = 8, 8
+    qsk = qsk[:G * per]
     shards = []
     for r in range(G):
         b, s_end = native.group_slot_range(r, G, S)
@@ -227,6 +241,38 @@ def test_config4_eight_slot_shards_at_full_size(native, big):
                 q = r * per + i
                 lo, hi = int(off[q]), int(off[q + 1])
                 assert np.array_equal(c[int(o[i]):int(o[i + 1])], hc[lo:hi]) and np.array_equal(g_[int(o[i]):int(o[i + 1])], hg[lo:hi]), (mode, q)
+    # the form `bench.py --shard-of 8 --batch 32768` times: every rank brings 4096 queries, each shard's gather sees
+    # 32 768 query slices and leaves candidates + survivors (no counter rows), the sparse exchange makes the hits.
+    # Rank r's queries are the bench batch rotated by 517 r positions, so every rank's slice holds every checked
+    # query at another launch position; each of the 8 x 4096 lists must be the whole-range call's list of that
+    # query (compared with the oracle at rows CHECK in the test above, or right here if that test did not run).
+    big_sk = BIG["qsk"]
+    if "hits" in BIG:
+        w_off, w_hc, w_hg = BIG["hits"]
+    else:
+        cap_big = NQ_BIG * 256
+        t_off = torch.zeros(NQ_BIG + 1, dtype=torch.int64, device=dev)
+        t_hc, t_hg = torch.zeros(cap_big, dtype=torch.int32, device=dev), torch.zeros(cap_big, dtype=torch.int32, device=dev)
+        e.query_dev(big_sk, NQ_BIG, t_off, t_hc, t_hg, cap_big)
+        e.synchronize()
+        w_off, w_hc, w_hg = t_off.cpu().numpy(), t_hc.cpu().numpy().astype(np.uint32), t_hg.cpu().numpy().astype(np.uint32)
+        for i, q in enumerate(CHECK[:G * per]):
+            lo, hi = int(off[i]), int(off[i + 1])
+            assert np.array_equal(w_hc[int(w_off[q]):int(w_off[q + 1])], hc[lo:hi]) and np.array_equal(w_hg[int(w_off[q]):int(w_off[q + 1])], hg[lo:hi])
+    SHIFT = 517
+    loc_big = [torch.roll(big_sk, -SHIFT * r, 0).contiguous() for r in range(G)]      # row i of rank r = query (i + 517 r) mod 4096
+    grp.set_option("exchange", 1)
+    res = grp.query(loc_big, NQ_BIG, capacity=NQ_BIG * 256)
+    w_len = np.diff(w_off)
+    for r in range(G):
+        o, c, g_ = res[r]
+        src = (np.arange(NQ_BIG) + SHIFT * r) % NQ_BIG
+        assert np.array_equal(np.diff(o.astype(np.int64)), w_len[src]), r
+        # the rank's lists back in the whole-range call's query order: one comparison per rank
+        order = np.argsort(src, kind="stable")
+        take = np.concatenate([np.arange(int(o[i]), int(o[i + 1])) for i in order]) if int(o[NQ_BIG]) else np.zeros(0, np.int64)
+        assert np.array_equal(c[take], w_hc[:int(w_off[NQ_BIG])]) and np.array_equal(g_[take], w_hg[:int(w_off[NQ_BIG])]), r
+    del loc_big
     assert grp.stat("overflows") == 0
     grp.close()
     for sh in shards:

@@ -76,3 +76,22 @@ def test_damaged_containers_are_rejected(native):
     for d in bad:
         with pytest.raises(native.NiqkiError):
             native.unpack_fasta(np.frombuffer(d, np.uint8))
+
+
+def test_crafted_widths_are_rejected(native):
+    """A table whose line width makes the 32-bit `(width + 3) / 4` or `width + 1` of the device pass wrap (ADVICE round 5:
+    count = 1, width = 0xFFFFFFFD gave raw_len 4294967294 with an EMPTY payload) must not pass validation: nothing wider
+    than the packer's own limit (0xFFFFFF bases per line) is a container."""
+    for width in (0xFFFFFFFD, 0xFFFFFFFE, 0xFFFFFFFF, 0x1000000):
+        raw_len = width + 1
+        pk_len = ((width + 3) & 0xFFFFFFFF) // 4                       # what 32-bit arithmetic made of it
+        for pay_len in {pk_len, (width + 3) // 4 if width < 0x2000000 else 0}:
+            d = struct.pack("<IIQQQ", 0x4B50514E, 1, raw_len, 64, pay_len) + struct.pack("<QQII", 0, 0, 1, width)
+            d += b"\0" * (64 - len(d)) + b"\0" * min(pay_len, 1 << 23)
+            with pytest.raises(native.NiqkiError):
+                native.unpack_fasta(np.frombuffer(d, np.uint8))
+    # the widest line the packer does write is still a container
+    rng = np.random.default_rng(6)
+    data = fasta(rng, 0xFFFFFF + 40, 0xFFFFFF)
+    c = native.pack_fasta(data)
+    assert c is not None and bytes(native.unpack_fasta(c)) == data
