@@ -9,7 +9,10 @@ One "step" = one pass of the hot path (k-mer rolling hash -> HyperMinHash
 sketch -> densification -> gather-histogram over the inverted index ->
 threshold + ordered hits) over one batch of query genomes whose bases are
 already resident in HBM (a ring of distinct batches, step i uses batch i mod
-ring).  N > 1 (torch.distributed.run, one rank per GPU): the index is sharded by
+ring).  On one GPU the step is the C ABI's niqki_query_ahead + niqki_sketch_ahead:
+batch i + 1's sketch kernel runs on the handle's sketch lane beside batch i's
+gather and hit kernels (K sketch launches and K queries inside the K timed steps;
+--no-overlap: one after the other).  N > 1 (torch.distributed.run, one rank per GPU): the index is sharded by
 sketch-slot range, the exchange (RCCL all-to-all of sketch slices, sparse
 candidate exchange or reduce-scatter of the packed hit vectors) runs inside
 libniqki_hip.so (niqki_group_*); torch.distributed only carries the group id
@@ -18,7 +21,8 @@ strong cuts one batch over the ranks).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the gather-histogram kernel
 (the HBM-bound kernel SURVEY.md 8d grades), timed live with HIP events on the
-engine's stream; `kernels` lists every kernel class; `sketch_kernel` holds the
+engine's stream in a few steps of the same run WITHOUT the overlapped sketch kernel
+(beside it the launch time is no roofline figure); `kernels` lists every kernel class; `sketch_kernel` holds the
 ALU-bound sketch kernel against integer-ALU ceilings measured in this run;
 `cpu_baseline` is the oracle (a port of the reference's CPU path) on this
 host's cores; `extra_workloads` (1 GPU) are BASELINE.json configs[1], configs[4]
@@ -27,6 +31,10 @@ and the matrix path, each with its own in-run parity check.
     python bench.py --shard-of 8      one GPU plays rank 0 of an 8-GPU slot shard
                                       (slots [0, F/8), the full query batch): the
                                       compute half of the 1 -> 8 scaling curve
+
+The whole default run keeps to a wall-clock budget (--budget-s, default 150 s from the start of the process): the
+headline, `roofline` and `cpu_baseline` always run, every other leg starts only while its time is left, child processes
+get min(their own limit, what is left), and `budget.dropped` names what did not run.
 """
 import argparse
 import json
@@ -34,12 +42,14 @@ import os
 import sys
 import time
 
-import numpy as np
+T_START = time.time()
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from bench_support import (BENCH_K, HBM_PEAK_GBS, genome_spec, host_cpu_info, launch_ranks, log, measure_counters,  # noqa: E402,F401
+from bench_support import (BENCH_K, HBM_PEAK_GBS, Budget, genome_spec, host_cpu_info, launch_ranks, log, measure_counters,  # noqa: E402,F401
                            query_spec, roofline_record)
 
 def main():
@@ -78,20 +88,22 @@ def main():
     ap.add_argument("--devices", type=int, default=0,
                     help="N > 1: deal the ranks over the first D devices only (0 = all visible ones); with fewer devices than "
                          "ranks the ranks share them over the ipc transport (config.ranks_share_devices)")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="N = 1: sketch batch i+1 on a second handle's stream beside batch i's gather and hits kernels "
-                         "(+4 %% genomes/s; the kernels then share the CUs and the gather launch time is no roofline figure)")
+    ap.add_argument("--pipeline", action="store_true", help=argparse.SUPPRESS)      # (the default since round 6)
     ap.add_argument("--priority-streams", action="store_true",
-                    help="with --pipeline: the query handle on a stream at the top of the device's stream priority range, the "
-                         "sketch handle at the bottom (option stream_priority of the C ABI)")
+                    help="N = 1: the handle's stream at the top of the device's stream priority range, its sketch lane at the "
+                         "bottom (option stream_priority of the C ABI)")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="N > 1: do not run the next batch's sketch kernel beside the exchange of the current one")
-    ap.add_argument("--verify", action="store_true",
-                    help="N > 1: every rank checks the hit lists of its last step against a whole-range handle that it builds "
+                    help="do not run the next batch's sketch kernel beside the gather and hit kernels (N = 1) / the exchange "
+                         "(N > 1) of the current one")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("NIQKI_BENCH_BUDGET_S", "150")),
+                    help="wall-clock budget of the whole run in seconds, from the start of the process (see the module docstring)")
+    ap.add_argument("--verify", action="store_true", help=argparse.SUPPRESS)        # (the default for N > 1 since round 6)
+    ap.add_argument("--no-verify", action="store_true",
+                    help="N > 1: do NOT check every rank's hit lists of its last step against a whole-range handle that it builds "
                          "beside its shard (all genomes sketched once more on every rank: seconds at 100 000 genomes)")
     args = ap.parse_args()
     if args.pmc_child:
-        args.no_legs = True
+        args.no_legs = args.no_overlap = True      # (counters per kernel: every launch has the device to itself)
     if args.no_legs:
         args.no_cpu = args.no_extra = args.no_pmc = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -101,10 +113,13 @@ def main():
     # HBM bytes per launch of the gather path, measured now: two rocprofv3 --pmc passes (FETCH_SIZE,
     # WRITE_SIZE: passes of their own, no trace flags) over a 3-launch run of this same command, as
     # child processes started BEFORE this process touches the GPU.  Full default runs on one GPU only.
+    budget = Budget(args.budget_s, T_START)
     live_traffic = None
     if (args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.shard_of and not args.no_cpu
-            and not args.no_extra and not args.no_pmc and os.environ.get("NIQKI_BENCH_PMC", "1") != "0"):
-        live_traffic = measure_counters(args)
+            and not args.no_extra and not args.no_pmc and os.environ.get("NIQKI_BENCH_PMC", "1") != "0"
+            and budget.want("pmc_passes", 90)):
+        live_traffic = measure_counters(args, budget)
+        budget.lap("pmc_passes")
 
     # Only the JSON line may reach stdout: libraries (RCCL prints a version banner)
     # get stderr for the whole run, the result is written to the saved descriptor.
@@ -162,7 +177,7 @@ def main():
     G = emu if emu else world                  # shards the index is cut into
     sb, se = niqki_amd.group_slot_range(0 if emu else rank, G, S)
     eng = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev, slot_begin=sb, slot_end=se)
-    if args.pipeline and args.priority_streams:
+    if args.priority_streams and not use_dist and not emu:
         eng.set_option("stream_priority", 1)
         torch.cuda.set_stream(torch.cuda.ExternalStream(eng.get_stream(), device=dev))   # torch's current stream IS the handle's
     else:
@@ -283,7 +298,6 @@ def main():
     hc = torch.zeros(cap, dtype=torch.int32, device=dev)
     hg = torch.zeros(cap, dtype=torch.int32, device=dev)
     stride = niqki_amd.row_stride(N)
-    counts = None if (use_dist or emu) else torch.zeros((nq_gather, stride), dtype=torch.int16, device=dev)
     allsk = None
     if emu:
         # the other ranks' sketches of every batch, made once outside the timed region: in the real
@@ -307,19 +321,17 @@ def main():
         e_thr = -(-eng.min_score // G)
     eng.synchronize()
 
+    # N = 1: batch i + 1's sketch kernel runs on the handle's sketch lane beside batch i's gather and hit kernels
+    # (niqki_sketch_ahead / niqki_query_ahead: one handle, the overlap inside the C ABI).
     # N > 1: batch i's exchange (slices, candidate lists, sums: the GPU mostly waits for its peers) runs
     # beside batch i+1's sketch kernel: a second handle sketches on a side stream, niqki_group_query_begin
     # returns without waiting, niqki_group_query_end is the step's one host wait.
-    pipeline = args.pipeline and not use_dist and not emu
-    overlap = (use_dist and not args.no_overlap) or pipeline
+    ahead = not use_dist and not emu and not args.no_overlap
+    overlap = use_dist and not args.no_overlap
     if overlap:
         sk_eng = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev)
-        if args.pipeline and args.priority_streams:
-            sk_eng.set_option("stream_priority", -1)
-            side = torch.cuda.ExternalStream(sk_eng.get_stream(), device=dev)
-        else:
-            side = torch.cuda.Stream(device=dev)
-            sk_eng.set_stream(side.cuda_stream)
+        side = torch.cuda.Stream(device=dev)
+        sk_eng.set_stream(side.cuda_stream)
         sk_eng.set_option("record_len_hint", L)
         ev_sk = [torch.cuda.Event() for _ in range(n_batches)]      # sketches of ring slot b are complete
         ev_used = [torch.cuda.Event() for _ in range(n_batches)]    # ... have been consumed by their batch
@@ -338,25 +350,36 @@ def main():
                 ev_sk[bj].record(side)
             sketched[bj] = sj
 
+    def serial_step(si, off, c_, g_):
+        """sketch, then query, on the handle's stream (what --no-overlap times, and the roofline steps)"""
+        bi = si % n_batches
+        eng.sketch_dev(qseq[bi * per * stride_b:], d_ro, per, qsk[bi])
+        eng.query_dev(qsk[bi], per, off, c_, g_, cap)
+
+    if ahead:
+        eng.sketch_ahead_dev(qseq, d_ro, per)          # batch 0, before the warm-up (or the first timed step)
+
     def step(si):
         bi = si % n_batches
+        if ahead:
+            # the hits of batch si (its sketches were made beside the step before), then batch si + 1's sketch kernel
+            # onto the sketch lane: K queries and K sketch launches inside K steps
+            eng.query_ahead_dev(hit_off[si], hc, hg, cap)
+            eng.sketch_ahead_dev(qseq[((si + 1) % n_batches) * per * stride_b:], d_ro, per)
+            return
         if overlap:
             sketch_ahead(si)                       # (only the first step finds its batch not sketched yet)
             torch.cuda.current_stream().wait_event(ev_sk[bi])
-            if use_dist:
-                sq.begin(qsk[bi], hit_off[si], hc, hg, cap)
-            else:
-                eng.query_counts_dev(qsk[bi], per, counts, stride)
-                eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[si], hc, hg, cap)
+            sq.begin(qsk[bi], hit_off[si], hc, hg, cap)
             ev_used[bi].record(torch.cuda.current_stream())
             sketch_ahead(si + 1)
-            if use_dist:
-                sq.end()
+            sq.end()
             return
-        eng.sketch_dev(qseq[bi * per * stride_b:], d_ro, per, qsk[bi])
         if use_dist:
+            eng.sketch_dev(qseq[bi * per * stride_b:], d_ro, per, qsk[bi])
             sq.step(qsk[bi], hit_off[si], hc, hg, cap)
         elif emu:
+            eng.sketch_dev(qseq[bi * per * stride_b:], d_ro, per, qsk[bi])
             # rank 0's compute of one step of the sparse exchange: its share sketched above; the gather of ALL queries
             # over its slots leaves candidates and survivors, no counter rows; the (stand-in) candidate lists of all
             # ranks are looked up in the survivors; the hits of its own queries come from the candidates' counts
@@ -365,8 +388,7 @@ def main():
             eng.survivor_counts_dev(allsk[bi], nq_all, cand_all, G * EC, surv, nsurv, ESC, mine)
             eng.hits_from_candidates_dev(cand_all, mine, per, G * EC, hit_off[si], hc, hg, cap)
         else:
-            eng.query_counts_dev(qsk[bi], per, counts, stride)
-            eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[si], hc, hg, cap)
+            serial_step(si, hit_off[si], hc, hg)
 
     def barrier():
         if use_dist:
@@ -413,6 +435,38 @@ def main():
     # device with a sketch kernel, their durations say nothing about the kernel.  Its roofline figure comes from a
     # few more steps of this same run without the overlapped sketch (every rank takes them: the exchange is collective).
     roofline_from = None
+    kernels_overlapped = None
+    roof_steps = list(range(args.warmup, n_steps_all))     # the steps whose gather launches `roofline` is taken from
+    roof_gather = None
+    if ahead:
+        # one GPU: the gather launches of the timed steps ran beside the next batch's sketch kernel.  The kernels'
+        # own times -- `roofline`, `kernels`, `sketch_kernel` -- come from n_r more steps of this run that sketch and
+        # query one after the other on the handle's stream (hits into buffers of their own: hc / hg keep the last
+        # timed step's for the parity legs); these also leave every ring batch's sketches in qsk
+        kernels_overlapped = {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items()}
+        off2 = torch.zeros(per + 1, dtype=torch.int64, device=dev)
+        hc2, hg2 = torch.zeros_like(hc), torch.zeros_like(hg)
+        eng.query_ahead_dev(off2, hc2, hg2, cap)        # (the batch the last timed step sketched beyond the run)
+        n_r = max(min(5, args.steps), n_batches)
+        serial_step(args.warmup, off2, hc2, hg2)        # (warm-up of this form: its first launch allocates)
+        eng.synchronize()
+        eng.profile(True)
+        eng.profile_reset()
+        ts = time.perf_counter()
+        for si in range(args.warmup, args.warmup + n_r):
+            serial_step(si, off2, hc2, hg2)
+        eng.synchronize()
+        t_serial = (time.perf_counter() - ts) / n_r
+        sprof = {name: eng.profile_read(kc) for name, kc in (
+            ("sketch", niqki_amd.KC_SKETCH), ("densify", niqki_amd.KC_DENSIFY), ("gather", niqki_amd.KC_GATHER),
+            ("hits", niqki_amd.KC_HITS), ("exchange", niqki_amd.KC_EXCHANGE))}
+        eng.profile(False)
+        # scaled to the K timed steps, like the figures they stand in for
+        prof = {k: (v[0] * args.steps / n_r, v[1] * args.steps // n_r) for k, v in sprof.items()}
+        roof_steps, roof_gather = list(range(args.warmup, args.warmup + n_r)), sprof["gather"]
+        roofline_from = ("%d more steps of this run with the sketch kernel BEFORE the query instead of beside it (%.2f ms per step); "
+                         "the timed steps' launches share the device with the next batch's sketch kernel" % (n_r, t_serial * 1e3))
+        del off2, hc2, hg2
     if use_dist and overlap:
         n_r = min(3, args.steps)
         eng.profile(True)
@@ -432,39 +486,56 @@ def main():
     # --verify (N > 1, small indexes): this rank's hit lists of the last timed step against a whole-range
     # handle that holds every genome of the index
     verify = None
-    if args.verify and use_dist:
-        ref = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev)
-        ref.set_stream(torch.cuda.current_stream().cuda_stream)
-        ref.set_option("record_len_hint", L)
-        vseq = torch.zeros(GB * stride_b + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
-        vsk = torch.full((GB, F), -1, dtype=torch.int32, device=dev)
-        for g0 in range(0, N, GB):
-            n = min(GB, N - g0)
-            fam, mem, rate = genome_spec(np.arange(g0, g0 + n), n_fam, args.family)
-            ref.synth_dev(args.seed, dev_u32(fam), dev_u32(mem), dev_u32(rate), n, L, stride_b, vseq)
-            ref.sketch_dev(vseq, rec_offsets(n), n, vsk)
-            ref.insert_dev(vsk, n)
+    if use_dist and (args.verify or (world > 1 and not args.no_verify)):
+        # The local half may fail on one rank only (an allocation, say): it is caught and counted as "not equal", so
+        # that every rank still reaches the two collectives below -- a check beside the line must not hang the job.
         si = n_steps_all - 1
+        same, nh, v_err = False, 0, None
+        ref = None
+        try:
+            ref = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev)
+            ref.set_stream(torch.cuda.current_stream().cuda_stream)
+            ref.set_option("record_len_hint", L)
+            vseq = torch.zeros(GB * stride_b + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
+            vsk = torch.full((GB, F), -1, dtype=torch.int32, device=dev)
+            for g0 in range(0, N, GB):
+                n = min(GB, N - g0)
+                fam, mem, rate = genome_spec(np.arange(g0, g0 + n), n_fam, args.family)
+                ref.synth_dev(args.seed, dev_u32(fam), dev_u32(mem), dev_u32(rate), n, L, stride_b, vseq)
+                ref.sketch_dev(vseq, rec_offsets(n), n, vsk)
+                ref.insert_dev(vsk, n)
+            del vseq, vsk
+        except Exception as e:      # noqa: BLE001
+            v_err = "whole-range handle: %s" % str(e)[:200]
         # (hc / hg hold whatever step ran last -- the extra roofline steps above may have: the last timed step again,
         # through the group, on every rank)
         sq.step(qsk[si % n_batches], hit_off[si], hc, hg, cap)
         eng.synchronize()
-        r_off = torch.zeros(per + 1, dtype=torch.int64, device=dev)
-        r_hc, r_hg = torch.zeros(cap, dtype=torch.int32, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
-        ref.query_dev(qsk[si % n_batches], per, r_off, r_hc, r_hg, cap)
-        ref.synchronize()
-        nh = int(r_off[per].item())
-        same = bool(torch.equal(r_off, hit_off[si]) and torch.equal(r_hc[:nh], hc[:nh]) and torch.equal(r_hg[:nh], hg[:nh]))
-        ok = torch.tensor([1 if same else 0], dtype=torch.int32, device="cpu" if on_gloo else dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        verify = {"hit_lists_equal_whole_range_handle": bool(ok.item()), "queries_per_rank": per, "hits_rank0": nh}
-        ref.close()
-        del vseq, vsk
+        if v_err is None:
+            try:
+                r_off = torch.zeros(per + 1, dtype=torch.int64, device=dev)
+                r_hc, r_hg = torch.zeros(cap, dtype=torch.int32, device=dev), torch.zeros(cap, dtype=torch.int32, device=dev)
+                ref.query_dev(qsk[si % n_batches], per, r_off, r_hc, r_hg, cap)
+                ref.synchronize()
+                nh = int(r_off[per].item())
+                same = bool(torch.equal(r_off, hit_off[si]) and torch.equal(r_hc[:nh], hc[:nh]) and torch.equal(r_hg[:nh], hg[:nh]))
+                del r_off, r_hc, r_hg
+            except Exception as e:      # noqa: BLE001
+                v_err = "whole-range query: %s" % str(e)[:200]
+        if v_err:
+            log("[rank %d] --verify: %s" % (rank, v_err))
+        ok = torch.tensor([1 if same else 0, 0 if v_err is None else 1], dtype=torch.int32, device="cpu" if on_gloo else dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.SUM)
+        verify = {"hit_lists_equal_whole_range_handle": int(ok[0].item()) == world, "ranks_equal": int(ok[0].item()),
+                  "ranks_that_could_not_check": int(ok[1].item()), "queries_per_rank": per, "hits_rank0": nh,
+                  "rank0_note": v_err}
+        if ref is not None:
+            ref.close()
 
     # ---- roofline of the gather kernel: algorithmic bytes 4T + 20F per query ----
     f_local = se - sb
     T = 0
-    for si in range(args.warmup, n_steps_all):
+    for si in roof_steps:
         bi = si % n_batches
         if use_dist:   # measurement only: whole sketches of every rank, this shard's slots are what counts
             if on_gloo:
@@ -477,8 +548,8 @@ def main():
             T += int(eng.gathered_dev(full, world * per).sum())
         else:
             T += int(eng.gathered_dev(allsk[bi] if emu else qsk[bi], nq_gather).sum())
-    n_q_local = args.steps * nq_gather
-    gather_ms, gather_launches = prof["gather"]
+    n_q_local = len(roof_steps) * nq_gather
+    gather_ms, gather_launches = roof_gather if roof_gather is not None else prof["gather"]
     alg_bytes = 4 * T + 20 * f_local * n_q_local
     # the same quantities at the sizes the layout really stores: 2-byte ids, one 8-byte entry per slot and
     # tile, 2-byte counters written back
@@ -531,131 +602,6 @@ def main():
                        "which every vector opcode but add/and/or/xor/mov shares on gfx950 (profiles/r03_opcode_costs.txt); "
                        "the four ALU rates are measured in this run, valu_per_kmer as valu_per_kmer_source says"}
 
-    cpu = None
-    extra = None
-    d2h = None
-    pipelined = None
-    if rank == 0 and world == 1 and not emu and not args.no_legs:
-        if not args.no_cpu:
-            cpu = cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, (K, S, W, H, J))
-        # ---- the same steps with the hits copied back to the host (SURVEY.md 8d "end-to-end incl. D2H of hits") ----
-        # as a caller would: two sets of hit buffers, step i+1 runs while a copy stream brings step i's
-        # hit_off and then exactly its hits into page-locked memory
-        if counts is not None:     # (the group path of NIQKI_FORCE_DIST keeps no counter rows)
-            hcs, hgs = [hc, torch.zeros_like(hc)], [hg, torch.zeros_like(hg)]
-            h_off = [torch.empty(per + 1, dtype=torch.int64).pin_memory() for _ in range(2)]
-            h_hc = torch.empty(cap, dtype=torch.int32).pin_memory()
-            h_hg = torch.empty(cap, dtype=torch.int32).pin_memory()
-            cstream = torch.cuda.Stream(device=dev)
-            done = [torch.cuda.Event() for _ in range(2)]
-            n_d2h = args.steps                            # the same number of steps as the timed line
-            nh_tot = 0
-            ev_d = [torch.cuda.Event(enable_timing=True) for _ in range(n_d2h + 1)]
-
-            def fetch(k, si):     # hits of step si (buffer set k) to the host, on the copy stream
-                nonlocal nh_tot
-                with torch.cuda.stream(cstream):
-                    cstream.wait_event(done[k])
-                    h_off[k].copy_(hit_off[si], non_blocking=True)
-                    cstream.synchronize()                 # the sizes first ...
-                    nh = int(h_off[k][per])
-                    h_hc[:nh].copy_(hcs[k][:nh], non_blocking=True)      # ... then exactly the hits
-                    h_hg[:nh].copy_(hgs[k][:nh], non_blocking=True)
-                    cstream.synchronize()
-                nh_tot += nh
-            torch.cuda.synchronize()
-            td = time.perf_counter()
-            ev_d[0].record()
-            for j, si in enumerate(range(args.warmup, args.warmup + n_d2h)):
-                k = j % 2
-                bi = si % n_batches
-                eng.sketch_dev(qseq[bi * per * stride_b:], d_ro, per, qsk[bi])
-                eng.query_counts_dev(qsk[bi], per, counts, stride)
-                eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[si], hcs[k], hgs[k], cap)
-                done[k].record(torch.cuda.current_stream())
-                ev_d[j + 1].record()
-                if j:
-                    fetch(1 - k, si - 1)                  # while step si runs
-            fetch((n_d2h - 1) % 2, args.warmup + n_d2h - 1)
-            torch.cuda.synchronize()
-            td = time.perf_counter() - td
-            d_ms = sorted(ev_d[j].elapsed_time(ev_d[j + 1]) for j in range(n_d2h))
-            d_med = d_ms[len(d_ms) // 2] if len(d_ms) % 2 else 0.5 * (d_ms[len(d_ms) // 2 - 1] + d_ms[len(d_ms) // 2])
-            d2h = {"value": n_d2h * per / td, "unit": "genomes/s", "ms_per_step": td / n_d2h * 1e3, "steps": n_d2h,
-                   "ms_per_step_median": d_med, "step_ms_min_max": [d_ms[0], d_ms[-1]],
-                   "value_at_median_step": per / (d_med * 1e-3),
-                   # against the timed line's own median step (the same steps without the copies): what the D2H of the hits costs
-                   "median_step_over_the_lines": d_med / ms_median if ms_median else None,
-                   "hit_bytes_per_step": 8 * (per + 1) + 8 * nh_tot // n_d2h,
-                   "note": "the timed step with hit_off, hit_counts and hit_gids copied into page-locked host memory by a copy "
-                           "stream while the next step runs (two sets of hit buffers); ms_per_step includes the last step's "
-                           "copy, which nothing overlaps, and the host's waits for the sizes"}
-            del hcs, hgs
-
-        # ---- the same steps with batch i+1 sketched beside batch i's gather (what --pipeline times as the line) ----
-        # twice: both handles on streams of the default priority, then the query handle on a stream at the top of
-        # the device's priority range and the sketch handle at the bottom (option "stream_priority"): the pre-pass,
-        # probe / order, gather and hit kernels are then dispatched ahead of waiting sketch workgroups
-        if counts is not None and not pipeline:
-            n_pl = min(10, args.steps)
-
-            def pipelined_leg(prio):
-                sk2 = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev)
-                sk2.set_option("record_len_hint", L)
-                if prio:
-                    eng.set_option("stream_priority", 1)
-                    sk2.set_option("stream_priority", -1)
-                    main = torch.cuda.ExternalStream(eng.get_stream(), device=dev)
-                    side2 = torch.cuda.ExternalStream(sk2.get_stream(), device=dev)
-                else:
-                    main = torch.cuda.current_stream()
-                    side2 = torch.cuda.Stream(device=dev)
-                    sk2.set_stream(side2.cuda_stream)
-                e_sk = [torch.cuda.Event() for _ in range(n_batches)]
-                e_used = [torch.cuda.Event() for _ in range(n_batches)]
-
-                def ahead(j):
-                    bj = j % n_batches
-                    if j >= n_batches:
-                        side2.wait_event(e_used[bj])
-                    sk2.sketch_dev(qseq[bj * per * stride_b:], d_ro, per, qsk[bj])
-                    e_sk[bj].record(side2)
-                torch.cuda.synchronize()
-                ahead(0)
-                torch.cuda.synchronize()
-                tp = time.perf_counter()
-                for j in range(n_pl):
-                    bj = j % n_batches
-                    main.wait_event(e_sk[bj])
-                    eng.query_counts_dev(qsk[bj], per, counts, stride)
-                    eng.hits_from_counts_dev(counts, per, stride, 0, N, hit_off[args.warmup + j], hc, hg, cap)
-                    e_used[bj].record(main)
-                    ahead(j + 1)             # (one sketch per step inside the timed region; the last one is for a step beyond it)
-                torch.cuda.synchronize()
-                tp = time.perf_counter() - tp
-                sk2.close()
-                if prio:                     # back onto torch's current stream for what follows
-                    eng.synchronize()
-                    eng.set_stream(torch.cuda.current_stream().cuda_stream)
-                return tp
-            tp0 = pipelined_leg(False)
-            tp1 = pipelined_leg(True)
-            tp = min(tp0, tp1)
-            pipelined = {"value": n_pl * per / tp, "unit": "genomes/s", "ms_per_step": tp / n_pl * 1e3, "steps": n_pl,
-                         "ms_per_step_default_priority": tp0 / n_pl * 1e3, "ms_per_step_priority_streams": tp1 / n_pl * 1e3,
-                         "floor_ms_if_kernels_could_share_cus": max(prof["sketch"][0], prof["gather"][0] + prof["hits"][0]) / max(1, args.steps),
-                         "floor_note": "max(sketch, gather + hits) per step: a bound for kernels that need different resources; these "
-                                       "two share the vector issue (0.89 of it for the sketch kernel, 0.64 for the gather launch), which "
-                                       "alone is 21 ms per step (DESIGN.md 4.4)",
-                         "note": "batch i+1 sketched on a second handle's stream beside batch i's gather and hits kernels "
-                                 "(bench.py --pipeline makes this the timed line); value = the faster of the two stream set-ups. "
-                                 "The two kernels cannot share a CU (128 KB of LDS each) and each keeps its CUs busy (the gather "
-                                 "launch on half of the CUs takes twice as long, DESIGN.md 4.4), so the overlap only fills the tails"}
-
-        if not args.no_extra:
-            del counts
-            extra = extra_workloads(niqki_amd, torch, dev, args, no_cpu=args.no_cpu)
-
     # bytes a rank sends per step in the exchange (sketch slices, then the candidate lists or the
     # dense counters): with the step time this bounds the average xGMI rate per GPU
     xbytes = None
@@ -692,7 +638,10 @@ def main():
                 "index_genomes": N, "query_batch": nq_all, "genome_len": L,
                 "parallelism": ("slot-shard x%d (%s exchange, %s transport inside libniqki_hip.so%s)"
                                 % (world, sq.exchange, sq.transport, ", next batch sketched beside the exchange" if overlap else "")) if use_dist
-                else ("1 GPU as rank 0 of a %d-way slot shard" % emu if emu else "1 GPU"),
+                else ("1 GPU as rank 0 of a %d-way slot shard" % emu if emu else
+                      ("1 GPU, batch i + 1's sketch kernel beside batch i's gather and hit kernels (niqki_sketch_ahead / niqki_query_ahead)"
+                       if ahead else "1 GPU, sketch kernel then query on one stream")),
+                "sketch_beside_query": bool(ahead or overlap),
                 "transport": sq.transport if use_dist else None,
                 "transport_note": transport_note,
                 "ranks_share_devices": bool(shared) if use_dist else None, "devices_visible": n_dev,
@@ -712,7 +661,7 @@ def main():
                 "hits_per_query": total_hits / max(1, args.steps * per), "hit_overflow": overflow,
             },
             "roofline": roofline_record(achieved, traffic, traffic_source, live_traffic, gather_ms, gather_launches, alg_bytes, layout_min,
-                                        copy_gbs, roofline_from, T, n_q_local, pipeline),
+                                        copy_gbs, roofline_from, T, n_q_local, False),
             "kernels": {k: {"ms": round(v[0], 3), "launches": v[1]} for k, v in prof.items()},
             # the sketch kernel is integer-ALU bound (4 64-bit multiplies per k-mer):
             # its rate in k-mers, the HBM bytes it needs (1 byte per base + the sketch) and the ALU ceilings
@@ -721,10 +670,18 @@ def main():
                 "hbm_gbs": (args.steps * per * (L + 4 * F)) / (prof["sketch"][0] * 1e-3) / 1e9 if prof["sketch"][0] else 0.0,
                 "bound": "valu", "alu": alu,
             },
-            "cpu_baseline": cpu,
-            "end_to_end_d2h": d2h,
-            "pipelined_step": pipelined,
+            "cpu_baseline": None,
+            "end_to_end_d2h": None,
         }
+        if ahead:
+            out["kernels_note"] = ("kernels / roofline / sketch_kernel: each kernel's own time, from %d steps of this run that sketch and query "
+                                   "one after the other (scaled to %d steps); kernels_beside_each_other: the same classes inside the timed "
+                                   "steps, where batch i + 1's sketch kernel shares the device with batch i's gather and hit kernels"
+                                   % (len(roof_steps), args.steps))
+            out["kernels_beside_each_other"] = kernels_overlapped
+            out["serial_step"] = {"ms_per_step": t_serial * 1e3, "value": per / t_serial, "unit": "genomes/s", "steps": len(roof_steps),
+                                  "note": "sketch kernel, then the query, on one stream (bench.py --no-overlap times this as the line)"}
+
         if emu:
             # what one shard of the real job computes per step; the exchange (nq * F/G * 2 bytes of slices out,
             # candidate lists) is not part of it
@@ -740,11 +697,27 @@ def main():
                 "sketch_ms_per_step": prof["sketch"][0] / max(1, args.steps), "hits_ms_per_step": prof["hits"][0] / max(1, args.steps),
                 "projected_genomes_per_s_if_exchange_is_free": nq_all / (dt / args.steps),
             }
-        if extra is not None:
-            out["extra_workloads"] = extra
         if verify is not None:
             out["verify"] = verify
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
+        # ---- everything below is optional: the line above is complete, the legs fill it in while the budget lasts ----
+        emitted = []
+
+        def emit(hard_stop=False):
+            if emitted:
+                return
+            emitted.append(1)
+            out["budget"] = budget.record()
+            if hard_stop:
+                out["budget"]["hard_stop"] = True
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        budget.lap("index_steps_roofline")
+        if world == 1 and not emu and not args.no_legs:
+            budget.arm(45.0, emit)
+            legs(out, budget, eng, niqki_amd, torch, dev, args, qseq, qsk, hit_off, hc, hg, stride_b, L, N, per, (K, S, W, H, J), cap,
+                 n_batches, d_ro, ms_median, ahead)
+            budget.disarm()
+        emit()
     if use_dist:
         sq.close()
     if overlap:
@@ -754,12 +727,115 @@ def main():
         dist.destroy_process_group()
 
 
+def legs(out, budget, eng, niqki_amd, torch, dev, args, qseq, qsk, hit_off, hc, hg, stride_b, L, N, per, prm, cap, n_batches, d_ro,
+         ms_median, ahead):
+    """The legs beside the headline, most important first; each fills its key of `out` and none may cost the line: errors
+    are recorded, a leg without time left is dropped (budget.dropped)."""
+    def guarded(name, fn):
+        try:
+            fn()
+        except Exception as e:      # noqa: BLE001 -- a leg beside the headline: never the run's failure
+            budget.dropped.append({"leg": name, "error": str(e)[:300]})
+            log("[bench] %s failed: %s" % (name, e))
+        budget.lap(name)
+
+    deferred = []     # the real reference over the whole index (31 s of inserts): after the BASELINE configs, if time is left
+    if not args.no_cpu:
+        def _cpu():
+            out["cpu_baseline"] = cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, prm, deferred)
+        guarded("cpu_baseline", _cpu)
+
+    def _d2h():
+        # ---- the same steps with the hits copied back to the host (SURVEY.md 8d "end-to-end incl. D2H of hits") ----
+        # as a caller would: two sets of hit buffers, step i+1 runs while a copy stream brings step i's
+        # hit_off and then exactly its hits into page-locked memory
+        if True:
+            hcs, hgs = [torch.zeros_like(hc), torch.zeros_like(hc)], [torch.zeros_like(hg), torch.zeros_like(hg)]
+            h_off = [torch.empty(per + 1, dtype=torch.int64).pin_memory() for _ in range(2)]
+            h_hc = torch.empty(cap, dtype=torch.int32).pin_memory()
+            h_hg = torch.empty(cap, dtype=torch.int32).pin_memory()
+            cstream = torch.cuda.Stream(device=dev)
+            done = [torch.cuda.Event() for _ in range(2)]
+            n_d2h = args.steps                            # the same number of steps as the timed line
+            nh_tot = 0
+            ev_d = [torch.cuda.Event(enable_timing=True) for _ in range(n_d2h + 1)]
+
+            def fetch(k, si):     # hits of step si (buffer set k) to the host, on the copy stream
+                nonlocal nh_tot
+                with torch.cuda.stream(cstream):
+                    cstream.wait_event(done[k])
+                    h_off[k].copy_(d_off[si - args.warmup], non_blocking=True)
+                    cstream.synchronize()                 # the sizes first ...
+                    nh = int(h_off[k][per])
+                    h_hc[:nh].copy_(hcs[k][:nh], non_blocking=True)      # ... then exactly the hits
+                    h_hg[:nh].copy_(hgs[k][:nh], non_blocking=True)
+                    cstream.synchronize()
+                nh_tot += nh
+            d_off = torch.zeros((n_d2h, per + 1), dtype=torch.int64, device=dev)     # (hit_off keeps the timed steps')
+            if ahead:
+                eng.sketch_ahead_dev(qseq[(args.warmup % n_batches) * per * stride_b:], d_ro, per)
+            eng.synchronize()
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            ev_d[0].record()
+            for j, si in enumerate(range(args.warmup, args.warmup + n_d2h)):
+                k = j % 2
+                bi = si % n_batches
+                if ahead:
+                    eng.query_ahead_dev(d_off[j], hcs[k], hgs[k], cap)
+                    eng.sketch_ahead_dev(qseq[((si + 1) % n_batches) * per * stride_b:], d_ro, per)
+                else:
+                    eng.sketch_dev(qseq[bi * per * stride_b:], d_ro, per, qsk[bi])
+                    eng.query_dev(qsk[bi], per, d_off[j], hcs[k], hgs[k], cap)
+                done[k].record(torch.cuda.current_stream())
+                ev_d[j + 1].record()
+                if j:
+                    fetch(1 - k, si - 1)                  # while step si runs
+            fetch((n_d2h - 1) % 2, args.warmup + n_d2h - 1)
+            eng.synchronize()
+            torch.cuda.synchronize()
+            td = time.perf_counter() - td
+            if ahead:       # (the batch sketched beyond the leg)
+                eng.query_ahead_dev(d_off[0], hcs[0], hgs[0], cap)
+                eng.synchronize()
+            d_ms = sorted(ev_d[j].elapsed_time(ev_d[j + 1]) for j in range(n_d2h))
+            d_med = d_ms[len(d_ms) // 2] if len(d_ms) % 2 else 0.5 * (d_ms[len(d_ms) // 2 - 1] + d_ms[len(d_ms) // 2])
+            out["end_to_end_d2h"] = {"value": n_d2h * per / td, "unit": "genomes/s", "ms_per_step": td / n_d2h * 1e3, "steps": n_d2h,
+                   "ms_per_step_median": d_med, "step_ms_min_max": [d_ms[0], d_ms[-1]],
+                   "value_at_median_step": per / (d_med * 1e-3),
+                   # against the timed line's own median step (the same steps without the copies): what the D2H of the hits costs
+                   "median_step_over_the_lines": d_med / ms_median if ms_median else None,
+                   "hit_bytes_per_step": 8 * (per + 1) + 8 * nh_tot // n_d2h,
+                   "note": "the timed step with hit_off, hit_counts and hit_gids copied into page-locked host memory by a copy "
+                           "stream while the next step runs (two sets of hit buffers); ms_per_step includes the last step's "
+                           "copy, which nothing overlaps, and the host's waits for the sizes"}
+            del hcs, hgs, d_off
+
+    if not use_dist_env() and budget.want("end_to_end_d2h", 5):
+        guarded("end_to_end_d2h", _d2h)
+
+    def _reference():
+        if deferred and out.get("cpu_baseline") and budget.want("cpu_baseline.reference (the reference's own Index over all genomes)", 75):
+            def _run():
+                out["cpu_baseline"]["reference"] = deferred[0]()
+            guarded("cpu_baseline.reference", _run)
+    if args.no_extra:
+        _reference()
+    else:
+        extra = out.setdefault("extra_workloads", {})
+        extra_workloads(niqki_amd, torch, dev, args, budget, extra, guarded, _reference, no_cpu=args.no_cpu)
+
+
+def use_dist_env():
+    return os.environ.get("NIQKI_FORCE_DIST") == "1"
+
+
 def torch_index(like, idx):
     import torch
     return torch.from_numpy(np.asarray(idx, dtype=np.int64)).to(like.device)
 
 
-def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, prm):
+def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, N, per, prm, deferred):
     """The oracle (port of the reference CPU path) on this host, on a bounded
     sample of the same workload; also the in-run parity check (sketches, dense counters and the
     thresholded, ordered hit lists of the sample against what the timed steps produced)."""
@@ -776,7 +852,15 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
         qn = max(1, int(round(host["cgroup_cpu_quota"])))
         cand |= {min(omp_max, qn), min(omp_max, 2 * qn)}
     cand = sorted(cand, reverse=True)
-    n_s = int(min(per, max(8, 2 * min(omp_max, phys))))
+    quota_threads = max(1, min(omp_max, int(round(host["cgroup_cpu_quota"])))) if host["cgroup_cpu_quota"] else min(omp_max, phys)
+    n_s = int(min(per, max(8, 4 * quota_threads)))       # four query genomes per CPU this job has
+    t_leg = {}
+    t_mark = [time.perf_counter()]
+
+    def leg_done(name):
+        now = time.perf_counter()
+        t_leg[name] = round(now - t_mark[0], 2)
+        t_mark[0] = now
     si = args.warmup + args.steps - 1  # the last timed step: its hits are what hc / hg still hold
     bi = si % qsk.shape[0]
     # the sample: n_s queries spread evenly over the whole batch (launch positions of every 1024-query group of the
@@ -788,7 +872,7 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
     # sketch leg at every thread count (each pass sketches all n_s genomes: a few seconds together)
     # the headline runs on the CPUs this job HAS: the cgroup quota where there is one (more threads than that only
     # time-slice), else the physical cores; the other counts make the scaling tables
-    quota_threads = max(1, min(omp_max, int(round(host["cgroup_cpu_quota"])))) if host["cgroup_cpu_quota"] else min(omp_max, phys)
+    leg_done("sample_to_host")
     t_sk, sk_cpu, sk_table = None, None, {}
     for th in cand:
         t0 = time.perf_counter()
@@ -803,6 +887,7 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
         t_sk = time.perf_counter() - t0
         sk_table[quota_threads] = n_s / t_sk
     cores = quota_threads
+    leg_done("sketch_leg")
     sk_gpu = qsk[bi][torch_index(qsk, pos)].cpu().numpy()
     parity_sketch = bool(np.array_equal(sk_cpu, sk_gpu))
     # gather leg: the oracle's query loop timed on EVERY sub-index of <= 16384 genomes the index is cut into
@@ -840,6 +925,7 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
         for i in range(n_par):
             exp_cols[i, b0:b0 + n_sub] = ix.counts(sk_cpu[par[i]])
         del ix, sub
+    leg_done("gather_leg_incl_index_builds")
     parity_counts = bool(np.array_equal(cnt.astype(np.uint32), exp_cols))
     # hit lists of the timed step for these queries: threshold + order of the oracle's columns
     off = hit_off[si].cpu().numpy()
@@ -876,7 +962,7 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
                 r.insert(sub[g])
             t_ref_ins = time.perf_counter() - t0
             t0 = time.perf_counter()
-            ixr = po.Index(p, sub)
+            ixr = po.Index(p, sub, threads=1)
             t_port_ins = time.perf_counter() - t0
             t0 = time.perf_counter()
             r_hits = [r.query(sk_cpu[i]) for i in range(n_rq)]
@@ -902,12 +988,12 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
                              "of %d queries against them -- one thread, the port timed on the same work beside it" % (n_r, n_ri, n_rq)}
         except Exception as e:      # noqa: BLE001 -- a baseline beside the baseline: never the run's failure
             ref = {"error": str(e)[:200]}
+    leg_done("reference_sample")
     # ---- the REAL reference on the job's CPUs over the same sample: its own Index with ALL N genomes inserted (from the
     # sketches the GPU stored -- sketch parity is checked above and in the tests), its compute_sketch and query_sketch
     # driven from `cores` OpenMP threads, one record per thread at a time like its drivers (src/niqki_index.cpp:523-540;
     # oracle/ref_harness.cpp ref_*_batch).  Same queries, same thread count as the port's headline.
-    reference = None
-    if po.have_ref() and hasattr(po.Ref, "query_batch") and not os.environ.get("NIQKI_BENCH_NO_REFERENCE_INDEX"):
+    def reference_on_the_whole_index():
         try:
             t0 = time.perf_counter()
             r = po.Ref(K=K, S=S, W=W, H=H, J=J, out_path="/tmp/niqki_bench_ref_all_%d.gz" % os.getpid())
@@ -935,7 +1021,7 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
                 os.remove("/tmp/niqki_bench_ref_all_%d.gz" % os.getpid())
             except OSError:
                 pass
-            reference = {"value": n_s / (t_rsk + t_rq), "unit": "genomes/s", "cores": cores, "kind": "reference",
+            return {"value": n_s / (t_rsk + t_rq), "unit": "genomes/s", "cores": cores, "kind": "reference",
                          "sketch_genomes_per_s": n_s / t_rsk, "query_genomes_per_s": n_s / t_rq,
                          "index_build_s": {"constructor": round(t_ctor, 2), "insert_%d_genomes" % N: round(t_ins, 2)},
                          "gpu_hit_lists_equal_the_references": same,
@@ -944,10 +1030,12 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
                                    "OpenMP threads, one record per thread at a time like src/niqki_index.cpp:523-540 (%.2f + %.2f s)"
                                    % (n_s, si, N, cores, t_rsk, t_rq)}
         except Exception as e:      # noqa: BLE001 -- a baseline beside the baseline: never the run's failure
-            reference = {"error": str(e)[:200]}
+            return {"error": str(e)[:200]}
+    if po.have_ref() and hasattr(po.Ref, "query_batch") and not os.environ.get("NIQKI_BENCH_NO_REFERENCE_INDEX"):
+        deferred.append(reference_on_the_whole_index)
     return {
         "value": val, "unit": "genomes/s", "cores": cores, "kind": "port",
-        "reference": reference,
+        "reference": None,      # (filled in by a later leg while the budget lasts: legs())
         "host_logical_cpus": host["logical_cpus"], "host_physical_cores": host["physical_cores"],
         "host_affinity_cpus": host["affinity_cpus"], "host_cgroup_cpu_quota": host["cgroup_cpu_quota"],
         "threads_tried": cand,
@@ -959,19 +1047,24 @@ def cpu_baseline(eng, niqki_amd, qseq, qsk, hit_off, hc, hg, args, stride_b, L, 
                   "<= 16384 genomes that together hold all %d genomes, summed (%.2f s); the index arrays first touched by the "
                   "gathering threads" % (n_s, si, per, cores, t_sk, q_threads, n_sub_ix, N, t_q),
         "reference_sample": ref,
+        "seconds_by_leg": t_leg,
         "parity": {"sketch_bit_exact": parity_sketch, "counts_bit_exact_all_columns": parity_counts,
                    "hit_lists_bit_exact": parity_hits, "queries_checked": n_par,
                    "launch_positions_checked": [int(pos[i]) for i in par]},
     }
 
 
-def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
+def extra_workloads(niqki_amd, torch, dev, args, budget, out, guarded, reference_leg, no_cpu=False):
     """BASELINE.json configs[1] (1k genomes: index + self query), configs[4] (150-base reads against a
     10k-genome index, S=12 W=10, lines-mode semantics) and the matrix path, each timed with inputs
-    resident in HBM and each with an in-run parity check against the oracle."""
+    resident in HBM and each with an in-run parity check against the oracle; then the host program on files.
+    Every leg fills its key of `out` and starts only while the budget has its estimated time left."""
     from oracle import pyoracle as po
-    out = {}
     seed, L = args.seed + 1, args.len
+    K, S, W, H, J = 31, 15, 12, 4, 0.1
+    F = 1 << S
+    GB = 250
+    p = po.make_params(K, S, W, H, J)
     t32 = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).to(torch.int32).to(dev)  # noqa: E731
     t64 = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).to(dev)  # noqa: E731
 
@@ -999,267 +1092,288 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
         return e
 
     # ---- configs[1]: 1k synthetic 5 Mbp genomes, index + self query, K=31 S=15 W=12 ----
-    K, S, W, H, J = 31, 15, 12, 4, 0.1
-    F, N1 = 1 << S, 1000
-    fam, mem, rate = genome_spec(np.arange(N1), N1 // 10, 10)
-    seq = torch.zeros(N1 * L + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
-    ro = t64(np.arange(N1 + 1, dtype=np.int64) * L)
-    sk = torch.empty((N1, F), dtype=torch.int32, device=dev)
-    cap = N1 * 64
-    ho = torch.zeros(N1 + 1, dtype=torch.int64, device=dev)
-    hc = torch.zeros(cap, dtype=torch.int32, device=dev)
-    hg = torch.zeros(cap, dtype=torch.int32, device=dev)
-    t_index = None
-    for attempt in range(3):                     # first pass warms kernels and allocations; the faster of the next two counts
+    def leg_configs1():
+        N1 = 1000
+        fam, mem, rate = genome_spec(np.arange(N1), N1 // 10, 10)
+        seq = torch.zeros(N1 * L + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
+        ro = t64(np.arange(N1 + 1, dtype=np.int64) * L)
+        sk = torch.empty((N1, F), dtype=torch.int32, device=dev)
+        cap = N1 * 64
+        ho = torch.zeros(N1 + 1, dtype=torch.int64, device=dev)
+        hc = torch.zeros(cap, dtype=torch.int32, device=dev)
+        hg = torch.zeros(cap, dtype=torch.int32, device=dev)
+        t_index = None
+        for attempt in range(3):                     # first pass warms kernels and allocations; the faster of the next two counts
+            e = engine(S, W)
+            if attempt == 0:
+                e.synth_dev(seed, t32(fam), t32(mem), t32(rate), N1, L, L, seq)
+
+            def index_1k():
+                e.sketch_dev(seq, ro, N1, sk)
+                e.insert_dev(sk, N1)
+                e.build()
+            t = timed(index_1k, e)
+            t_index = t if attempt < 2 else min(t, t_index)   # (a fresh handle's first allocations vary from box to box)
+            if attempt < 2:
+                e.close()
+        e.query_sequences_dev(seq, ro, N1, ho, hc, hg, cap)
+        t_query = timed(lambda: e.query_sequences_dev(seq, ro, N1, ho, hc, hg, cap), e, reps=3)
+        p = po.make_params(K, S, W, H, J)
+        skh = sk.cpu().numpy()
+        n_par = 4
+        par_sk = all(np.array_equal(skh[i], po.compute_sketch(p, seq[i * L:(i + 1) * L].cpu().numpy())) for i in range(n_par))
+        ix = po.Index(p, skh)
+        off, c_, g_ = ho.cpu().numpy(), hc.cpu().numpy(), hg.cpu().numpy()
+        par_hits = all(hits_equal(off, c_, g_, i, ix.counts(skh[i]), p.min_score) for i in range(0, N1, 16))
+        cpu1 = None
+        if not no_cpu:
+            th = po.lib().nqo_max_threads()
+            t0 = time.perf_counter()
+            ix.query_batch(skh[:256], threads=th)
+            cpu1 = {"gather_genomes_per_s": 256 / (time.perf_counter() - t0), "threads": th, "sample": "256 self queries, gather leg only"}
+        out["configs1_1k_index_self_query"] = {
+            "workload": "1000 synthetic %d bp genomes (100 families of 10), K=31 S=15 W=12 J=0.1, bases resident in HBM" % L,
+            "index_genomes_per_s": N1 / t_index, "index_s": t_index,
+            "query_genomes_per_s": N1 / t_query, "query_s": t_query, "hits": int(off[N1]),
+            "parity": {"sketch_bit_exact": bool(par_sk), "sketches_checked": n_par, "hit_lists_bit_exact": bool(par_hits),
+                       "queries_checked": len(range(0, N1, 16))},
+            "cpu_oracle": cpu1,
+        }
+        del ix
+        e.close()
+
+        if not budget.want("sketch_k21", 4):
+            return
+        # ---- -K other than 31 (src/niqki.cpp:260): the sketch kernel's rate at K = 21 on the same bytes ----
+        p21 = po.make_params(21, S, W, H, J)
+        e21 = niqki_amd.Engine(K=21, S=S, W=W, H=4, J=0.1, device=dev.index)
+        e21.set_stream(torch.cuda.current_stream().cuda_stream)
+        e21.set_option("record_len_hint", L)
+        e21.sketch_dev(seq, ro, N1, sk)
+        t21 = timed(lambda: e21.sketch_dev(seq, ro, N1, sk), e21, reps=2)
+        e31 = engine(S, W)
+        sk31 = torch.empty_like(sk)
+        e31.sketch_dev(seq, ro, N1, sk31)
+        t31 = timed(lambda: e31.sketch_dev(seq, ro, N1, sk31), e31, reps=2)
+        sk21h = sk[:2].cpu().numpy()
+        par21 = all(np.array_equal(sk21h[i], po.compute_sketch(p21, seq[i * L:(i + 1) * L].cpu().numpy())) for i in range(2))
+        out["sketch_k21"] = {
+            "workload": "the sketch kernel alone on 1000 synthetic %d bp genomes, K = 21 beside K = 31 (S=15 W=12)" % L,
+            "k21_gkmers_per_s": N1 * (L - 21) / t21 / 1e9, "k31_gkmers_per_s": N1 * (L - 31) / t31 / 1e9,
+            "k21_over_k31": (N1 * (L - 21) / t21) / (N1 * (L - 31) / t31),
+            "parity": {"sketch_bit_exact": bool(par21), "sketches_checked": 2},
+        }
+        e21.close()
+        e31.close()
+        del sk31, seq, sk
+
+    def leg_matrix():
+        # ---- matrix path: all-vs-all of a 10k-genome index (query_range / query_matrix) ----
+        NM = 10_000
         e = engine(S, W)
-        if attempt == 0:
-            e.synth_dev(seed, t32(fam), t32(mem), t32(rate), N1, L, L, seq)
+        seq = torch.zeros(GB * L + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
+        skb = torch.empty((GB, F), dtype=torch.int32, device=dev)
+        rob = t64(np.arange(GB + 1, dtype=np.int64) * L)
+        for g0 in range(0, NM, GB):
+            fam, mem, rate = genome_spec(np.arange(g0, g0 + GB), NM // 100, 100)
+            e.synth_dev(seed + 1, t32(fam), t32(mem), t32(rate), GB, L, L, seq)
+            e.sketch_dev(seq, rob, GB, skb)
+            e.insert_dev(skb, GB)
+        e.build()
+        del skb
+        rows = 1024
+        mstride = niqki_amd.row_stride(NM)
+        mat = torch.zeros((rows, mstride), dtype=torch.int16, device=dev)
 
-        def index_1k():
-            e.sketch_dev(seq, ro, N1, sk)
-            e.insert_dev(sk, N1)
-            e.build()
-        t = timed(index_1k, e)
-        t_index = t if attempt < 2 else min(t, t_index)   # (a fresh handle's first allocations vary from box to box)
-        if attempt < 2:
-            e.close()
-    e.query_sequences_dev(seq, ro, N1, ho, hc, hg, cap)
-    t_query = timed(lambda: e.query_sequences_dev(seq, ro, N1, ho, hc, hg, cap), e, reps=3)
-    p = po.make_params(K, S, W, H, J)
-    skh = sk.cpu().numpy()
-    n_par = 4
-    par_sk = all(np.array_equal(skh[i], po.compute_sketch(p, seq[i * L:(i + 1) * L].cpu().numpy())) for i in range(n_par))
-    ix = po.Index(p, skh)
-    off, c_, g_ = ho.cpu().numpy(), hc.cpu().numpy(), hg.cpu().numpy()
-    par_hits = all(hits_equal(off, c_, g_, i, ix.counts(skh[i]), p.min_score) for i in range(0, N1, 16))
-    cpu1 = None
-    if not no_cpu:
-        th = po.lib().nqo_max_threads()
-        t0 = time.perf_counter()
-        ix.query_batch(skh[:256], threads=th)
-        cpu1 = {"gather_genomes_per_s": 256 / (time.perf_counter() - t0), "threads": th, "sample": "256 self queries, gather leg only"}
-    out["configs1_1k_index_self_query"] = {
-        "workload": "1000 synthetic %d bp genomes (100 families of 10), K=31 S=15 W=12 J=0.1, bases resident in HBM" % L,
-        "index_genomes_per_s": N1 / t_index, "index_s": t_index,
-        "query_genomes_per_s": N1 / t_query, "query_s": t_query, "hits": int(off[N1]),
-        "parity": {"sketch_bit_exact": bool(par_sk), "sketches_checked": n_par, "hit_lists_bit_exact": bool(par_hits),
-                   "queries_checked": len(range(0, N1, 16))},
-        "cpu_oracle": cpu1,
-    }
-    del ix
-    e.close()
+        def matrix_all():
+            for t0_ in range(0, NM, rows):
+                e._ck(e.L.niqki_matrix_range(e.h, t0_, min(NM, t0_ + rows), mat.data_ptr(), mstride, niqki_amd.MEM_DEVICE))
+        matrix_all()
+        t_mat = timed(matrix_all, e)
+        e._ck(e.L.niqki_matrix_range(e.h, 5000, 5000 + rows, mat.data_ptr(), mstride, niqki_amd.MEM_DEVICE))
+        e.synchronize()
+        mh = mat.cpu().numpy().view(np.uint16)[:, :NM]
+        ixm = po.Index(p, e.get_sketches(0, NM))
+        exp = ixm.matrix_range(5000, 5008)            # [a][t - begin]
+        par_mat = bool(np.array_equal(mh[:8], exp.T))
+        out["matrix_10k"] = {
+            "workload": "all-vs-all hit matrix of a 10000-genome index (100 families of 100), K=31 S=15 W=12, counters left on the device",
+            "rows_per_s": NM / t_mat, "seconds": t_mat,
+            "algorithmic_bytes": 4 * NM * F + 2 * NM * NM, "algorithmic_gbs": (4 * NM * F + 2 * NM * NM) / t_mat / 1e9,
+            "parity": {"rows_bit_exact_vs_bucket_cooccurrence": par_mat, "rows_checked": 8},
+        }
+        del ixm, mat
+        e.close()
 
-    # ---- -K other than 31 (src/niqki.cpp:260): the sketch kernel's rate at K = 21 on the same bytes ----
-    p21 = po.make_params(21, S, W, H, J)
-    e21 = niqki_amd.Engine(K=21, S=S, W=W, H=4, J=0.1, device=dev.index)
-    e21.set_stream(torch.cuda.current_stream().cuda_stream)
-    e21.set_option("record_len_hint", L)
-    e21.sketch_dev(seq, ro, N1, sk)
-    t21 = timed(lambda: e21.sketch_dev(seq, ro, N1, sk), e21, reps=2)
-    e31 = engine(S, W)
-    sk31 = torch.empty_like(sk)
-    e31.sketch_dev(seq, ro, N1, sk31)
-    t31 = timed(lambda: e31.sketch_dev(seq, ro, N1, sk31), e31, reps=2)
-    sk21h = sk[:2].cpu().numpy()
-    par21 = all(np.array_equal(sk21h[i], po.compute_sketch(p21, seq[i * L:(i + 1) * L].cpu().numpy())) for i in range(2))
-    out["sketch_k21"] = {
-        "workload": "the sketch kernel alone on 1000 synthetic %d bp genomes, K = 21 beside K = 31 (S=15 W=12)" % L,
-        "k21_gkmers_per_s": N1 * (L - 21) / t21 / 1e9, "k31_gkmers_per_s": N1 * (L - 31) / t31 / 1e9,
-        "k21_over_k31": (N1 * (L - 21) / t21) / (N1 * (L - 31) / t31),
-        "parity": {"sketch_bit_exact": bool(par21), "sketches_checked": 2},
-    }
-    e21.close()
-    e31.close()
-    del sk31, seq, sk
+    def leg_configs4():
+        # ---- configs[4]: 150-base reads vs a 10k-genome index, K=31 S=12 W=10 (lines mode: one sketch per read) ----
+        S4, W4 = 12, 10
+        F4, N4, NR, RL, RB = 1 << S4, 10_000, 10_485_760, 150, 65536
+        e = engine(S4, W4)
+        seq = torch.zeros(GB * L + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
+        rob = t64(np.arange(GB + 1, dtype=np.int64) * L)
+        skb = torch.empty((GB, F4), dtype=torch.int32, device=dev)
+        for g0 in range(0, N4, GB):
+            fam, mem, rate = genome_spec(np.arange(g0, g0 + GB), N4 // 100, 100)
+            e.synth_dev(seed + 2, t32(fam), t32(mem), t32(rate), GB, L, L, seq)
+            e.sketch_dev(seq, rob, GB, skb)
+            e.insert_dev(skb, GB)
+        e.build()
+        del seq, skb
+        # 10 M distinct reads generated on the device: read i = 150 bases at a pseudo-random offset of a
+        # pseudo-random indexed genome, 1 % substitutions of its own (164/16384)
+        rng = np.random.default_rng(args.seed)
+        reads = torch.zeros(NR * RL + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
+        src_g = rng.integers(0, N4, NR)
+        src_off = rng.integers(0, L - RL, NR).astype(np.uint64)
+        CH = 1 << 20
+        for a in range(0, NR, CH):
+            gch = src_g[a:a + CH]
+            fam, mem, rate = genome_spec(gch, N4 // 100, 100)
+            e.synth_reads_dev(seed + 2, t32(fam), t32(mem), t32(rate), t64(src_off[a:a + CH]), t32(np.arange(a, a + len(gch))),
+                              164, len(gch), RL, RL, reads[a * RL:])
+        e.set_option("record_len_hint", RL)
+        rro = t64(np.arange(RB + 1, dtype=np.int64) * RL)
+        rsk = torch.empty((RB, F4), dtype=torch.int32, device=dev)
+        rstride = niqki_amd.row_stride(N4)
+        rcnt = torch.zeros((RB, rstride), dtype=torch.int16, device=dev)
+        # the threshold: reads share few slots with 5 Mbp genomes, so J is set where hits exist -- the count
+        # the source genome of a read typically reaches (calibrated on the first batch, then fixed)
+        e.sketch_dev(reads, rro, RB, rsk)
+        e.query_counts_dev(rsk, RB, rcnt, rstride)
+        e.synchronize()
+        c0 = rcnt[:4096].cpu().numpy().view(np.uint16)[:, :N4]
+        own = c0[np.arange(4096), src_g[:4096]]
+        min_score = max(2, int(np.percentile(own, 25)))
+        del rcnt
+        e.set_option("min_score", min_score)
+        rcap = RB * 256
+        rho = torch.zeros(RB + 1, dtype=torch.int64, device=dev)
+        rhc = torch.zeros(rcap, dtype=torch.int32, device=dev)
+        rhg = torch.zeros(rcap, dtype=torch.int32, device=dev)
+        tots = torch.zeros(NR // RB, dtype=torch.int64, device=dev)
 
-    # ---- matrix path: all-vs-all of a 10k-genome index (query_range / query_matrix) ----
-    NM, GB = 10_000, 250
-    e = engine(S, W)
-    seq = torch.zeros(GB * L + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
-    skb = torch.empty((GB, F), dtype=torch.int32, device=dev)
-    rob = t64(np.arange(GB + 1, dtype=np.int64) * L)
-    for g0 in range(0, NM, GB):
-        fam, mem, rate = genome_spec(np.arange(g0, g0 + GB), NM // 100, 100)
-        e.synth_dev(seed + 1, t32(fam), t32(mem), t32(rate), GB, L, L, seq)
-        e.sketch_dev(seq, rob, GB, skb)
-        e.insert_dev(skb, GB)
-    e.build()
-    del skb
-    rows = 1024
-    mstride = niqki_amd.row_stride(NM)
-    mat = torch.zeros((rows, mstride), dtype=torch.int16, device=dev)
-
-    def matrix_all():
-        for t0_ in range(0, NM, rows):
-            e._ck(e.L.niqki_matrix_range(e.h, t0_, min(NM, t0_ + rows), mat.data_ptr(), mstride, niqki_amd.MEM_DEVICE))
-    matrix_all()
-    t_mat = timed(matrix_all, e)
-    e._ck(e.L.niqki_matrix_range(e.h, 5000, 5000 + rows, mat.data_ptr(), mstride, niqki_amd.MEM_DEVICE))
-    e.synchronize()
-    mh = mat.cpu().numpy().view(np.uint16)[:, :NM]
-    ixm = po.Index(p, e.get_sketches(0, NM))
-    exp = ixm.matrix_range(5000, 5008)            # [a][t - begin]
-    par_mat = bool(np.array_equal(mh[:8], exp.T))
-    out["matrix_10k"] = {
-        "workload": "all-vs-all hit matrix of a 10000-genome index (100 families of 100), K=31 S=15 W=12, counters left on the device",
-        "rows_per_s": NM / t_mat, "seconds": t_mat,
-        "algorithmic_bytes": 4 * NM * F + 2 * NM * NM, "algorithmic_gbs": (4 * NM * F + 2 * NM * NM) / t_mat / 1e9,
-        "parity": {"rows_bit_exact_vs_bucket_cooccurrence": par_mat, "rows_checked": 8},
-    }
-    del ixm, mat
-    e.close()
-
-    # ---- configs[4]: 150-base reads vs a 10k-genome index, K=31 S=12 W=10 (lines mode: one sketch per read) ----
-    S4, W4 = 12, 10
-    F4, N4, NR, RL, RB = 1 << S4, 10_000, 10_485_760, 150, 65536
-    e = engine(S4, W4)
-    skb = torch.empty((GB, F4), dtype=torch.int32, device=dev)
-    for g0 in range(0, N4, GB):
-        fam, mem, rate = genome_spec(np.arange(g0, g0 + GB), N4 // 100, 100)
-        e.synth_dev(seed + 2, t32(fam), t32(mem), t32(rate), GB, L, L, seq)
-        e.sketch_dev(seq, rob, GB, skb)
-        e.insert_dev(skb, GB)
-    e.build()
-    del seq, skb
-    # 10 M distinct reads generated on the device: read i = 150 bases at a pseudo-random offset of a
-    # pseudo-random indexed genome, 1 % substitutions of its own (164/16384)
-    rng = np.random.default_rng(args.seed)
-    reads = torch.zeros(NR * RL + niqki_amd.SEQ_PAD, dtype=torch.uint8, device=dev)
-    src_g = rng.integers(0, N4, NR)
-    src_off = rng.integers(0, L - RL, NR).astype(np.uint64)
-    CH = 1 << 20
-    for a in range(0, NR, CH):
-        gch = src_g[a:a + CH]
-        fam, mem, rate = genome_spec(gch, N4 // 100, 100)
-        e.synth_reads_dev(seed + 2, t32(fam), t32(mem), t32(rate), t64(src_off[a:a + CH]), t32(np.arange(a, a + len(gch))),
-                          164, len(gch), RL, RL, reads[a * RL:])
-    e.set_option("record_len_hint", RL)
-    rro = t64(np.arange(RB + 1, dtype=np.int64) * RL)
-    rsk = torch.empty((RB, F4), dtype=torch.int32, device=dev)
-    rstride = niqki_amd.row_stride(N4)
-    rcnt = torch.zeros((RB, rstride), dtype=torch.int16, device=dev)
-    # the threshold: reads share few slots with 5 Mbp genomes, so J is set where hits exist -- the count
-    # the source genome of a read typically reaches (calibrated on the first batch, then fixed)
-    e.sketch_dev(reads, rro, RB, rsk)
-    e.query_counts_dev(rsk, RB, rcnt, rstride)
-    e.synchronize()
-    c0 = rcnt[:4096].cpu().numpy().view(np.uint16)[:, :N4]
-    own = c0[np.arange(4096), src_g[:4096]]
-    min_score = max(2, int(np.percentile(own, 25)))
-    del rcnt
-    e.set_option("min_score", min_score)
-    rcap = RB * 256
-    rho = torch.zeros(RB + 1, dtype=torch.int64, device=dev)
-    rhc = torch.zeros(rcap, dtype=torch.int32, device=dev)
-    rhg = torch.zeros(rcap, dtype=torch.int32, device=dev)
-    tots = torch.zeros(NR // RB, dtype=torch.int64, device=dev)
-
-    def all_reads():
-        for k, a in enumerate(range(0, NR, RB)):
-            e.sketch_dev(reads[a * RL:], rro, RB, rsk)
-            e.query_dev(rsk, RB, rho, rhc, rhg, rcap)
-            tots[k] = rho[RB]                     # device-side copy: no host sync inside the timed loop
-    all_reads()
-    e.profile(True)
-    e.profile_reset()
-    t_reads = timed(all_reads, e)
-    kprof = {n_: e.profile_read(kc)[0] for n_, kc in (("sketch", niqki_amd.KC_SKETCH), ("gather", niqki_amd.KC_GATHER), ("hits", niqki_amd.KC_HITS))}
-    e.profile(False)
-    th_ = tots.cpu().numpy()
-    # parity on the last batch: oracle sketches of 64 reads, dense counters and hit lists against an oracle index
-    a = NR - RB
-    rd = reads[a * RL:(a + 64) * RL].cpu().numpy().reshape(64, RL)
-    host_rd = e.synth_reads_host(seed + 2, *genome_spec(src_g[a:a + 64], N4 // 100, 100), src_off[a:a + 64], np.arange(a, a + 64), 164, RL)
-    p4 = po.make_params(K, S4, W4, H, J)
-    p4.min_score = min_score
-    rskh = rsk[:64].cpu().numpy()
-    par_sk = all(np.array_equal(rskh[i], po.compute_sketch(p4, rd[i])) for i in range(64))
-    # densification passes of these reads (the oracle's loop is the reference's: src/niqki_index.cpp:313-331)
-    passes = [po.densify(p4, po.sketch_accumulate(p4, rd[i]))[1] for i in range(64)]
-    passes_per_read = float(np.mean([x for x in passes if x > 0])) if any(x > 0 for x in passes) else 0.0
-    ix4 = po.Index(p4, e.get_sketches(0, N4))
-    off, c_, g_ = rho.cpu().numpy(), rhc.cpu().numpy(), rhg.cpu().numpy()
-    par_hits = all(hits_equal(off, c_, g_, i, ix4.counts(rskh[i]), min_score) for i in range(64))
-    cpu4 = None
-    if not no_cpu:
-        th = po.lib().nqo_max_threads()
-        n_c = 2048
-        rdc = reads[:n_c * RL].cpu().numpy()
-        t0 = time.perf_counter()
-        skc = po.sketch_batch(p4, rdc, (np.arange(n_c + 1) * RL).astype(np.uint64), threads=th)
-        ix4.query_batch(skc, threads=th)
-        cpu4 = {"reads_per_s": n_c / (time.perf_counter() - t0), "threads": th, "kind": "port",
-                "sample": "%d reads: sketch (densification dominated, src/niqki_index.cpp:313-331) + query" % n_c}
-    # ceilings of the two big kernels of this workload, measured / computed now:
-    #  * sketch: its time is the densification passes (one LDS round trip each at 8 wavefronts per CU); the ceiling is
-    #    the rate of those passes with nothing but their LDS traffic and exit test (niqki_measure_alu(5))
-    #  * gather: HBM -- per read its sketch in (4F), its counter row out (2N) and the table entries and bucket ids
-    #    of the look-ups the per-slot class mask lets through (measured: T ids + their entries)
-    pass_rate = e.measure_alu(5)
-    sk_s = kprof["sketch"] * 1e-3
-    sk_pass_rate = NR * passes_per_read / sk_s if sk_s else 0.0
-    T4 = float(e.gathered_dev(rsk, RB).sum()) / RB        # ids gathered per read (last batch)
-    lists = int(e.stat("last_hits_form")) == 1       # the hits left the gather kernel as ordered lists: no counter rows
-    hpr = float(th_.sum()) / NR
-    g_bytes = NR * (4 * F4 + 4 * T4 + 8 * T4 + (4 * hpr + 4 if lists else 2 * N4))
-    g_s = kprof["gather"] * 1e-3
-    h_bytes = NR * ((4 + 12 + 4 * hpr) if lists else 2 * N4) + 8 * float(th_.sum())
-    h_s = kprof["hits"] * 1e-3
-    ceilings = {
-        "sketch": {"bound": "lds round trips of the densification passes", "passes_per_read": passes_per_read,
-                   "achieved_passes_per_s": sk_pass_rate, "peak_passes_per_s": pass_rate,
-                   "frac": sk_pass_rate / pass_rate if pass_rate else None,
-                   "note": "peak = niqki_measure_alu(5): the pass loop of the short-read kernel (8 one-wave workgroups per CU, two "
-                           "proposals + two read-backs per lane and pass) with nothing but its LDS traffic and exit test, measured "
-                           "in this run; achieved = reads/s of the sketch kernel x the passes the oracle's serial loop takes for "
-                           "64 of these reads (k-mer hashing and the entry list are inside the kernel's time, outside the peak)"},
-        "gather": {"bound": "hbm", "algorithmic_bytes_per_read": g_bytes / NR, "gathered_ids_per_read": T4,
-                   "achieved": g_bytes / g_s / 1e9 if g_s else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": g_bytes / g_s / 1e9 / HBM_PEAK_GBS if g_s else None,
-                   "class_mask": int(e.stat("class_mask")),
-                   "hit_lists": lists,
-                   "note": "per read: its 2^S-cell sketch in, the entries and ids of the buckets it touches, and its ordered hit list "
-                           "out (4 bytes per hit; a 2N-byte counter row only for a read with more than hit_list_cap hits, or with "
-                           "option hit_lists = 0); with the per-slot class mask the 2^S table look-ups of a read are not memory "
-                           "traffic any more.  The kernel is bound by the latency of a read's dependent steps at 5 workgroups per "
-                           "CU, not by these bytes"},
-        "hits": {"bound": "launch latency of three small kernels (sizes -> offsets, lists -> places, overflowing lists ordered)",
-                 "bytes_per_read": h_bytes / NR, "achieved": h_bytes / h_s / 1e9 if h_s else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": h_bytes / h_s / 1e9 / HBM_PEAK_GBS if h_s else None,
-                 "ms_per_batch": kprof["hits"] / (NR // RB)},
-    }
-    out["configs4_reads_vs_10k_index"] = {
-        "workload": "%d distinct 150-base reads (1 %% substitutions, generated on the device) against a 10000-genome index, "
-                    "K=31 S=12 W=10, one sketch per read, batches of %d resident in HBM" % (NR, RB),
-        "reads_per_s": NR / t_reads, "seconds": t_reads, "min_score": min_score, "J_equivalent": min_score / F4,
-        "hits_total": int(th_.sum()), "hits_per_read": float(th_.sum()) / NR, "hit_overflow": bool((th_ > rcap).any()),
-        "kernel_ms": {k_: round(v, 1) for k_, v in kprof.items()},
-        "ceilings": ceilings,
-        "parity": {"device_reads_equal_host_generator": bool(np.array_equal(rd, host_rd)), "sketch_bit_exact": bool(par_sk),
-                   "hit_lists_bit_exact": bool(par_hits), "reads_checked": 64},
-        "cpu_oracle": cpu4,
-    }
-    e.close()
+        def all_reads():
+            for k, a in enumerate(range(0, NR, RB)):
+                e.sketch_dev(reads[a * RL:], rro, RB, rsk)
+                e.query_dev(rsk, RB, rho, rhc, rhg, rcap)
+                tots[k] = rho[RB]                     # device-side copy: no host sync inside the timed loop
+        all_reads()
+        e.profile(True)
+        e.profile_reset()
+        t_reads = timed(all_reads, e)
+        kprof = {n_: e.profile_read(kc)[0] for n_, kc in (("sketch", niqki_amd.KC_SKETCH), ("gather", niqki_amd.KC_GATHER), ("hits", niqki_amd.KC_HITS))}
+        e.profile(False)
+        th_ = tots.cpu().numpy()
+        # parity on the last batch: oracle sketches of 64 reads, dense counters and hit lists against an oracle index
+        a = NR - RB
+        rd = reads[a * RL:(a + 64) * RL].cpu().numpy().reshape(64, RL)
+        host_rd = e.synth_reads_host(seed + 2, *genome_spec(src_g[a:a + 64], N4 // 100, 100), src_off[a:a + 64], np.arange(a, a + 64), 164, RL)
+        p4 = po.make_params(K, S4, W4, H, J)
+        p4.min_score = min_score
+        rskh = rsk[:64].cpu().numpy()
+        par_sk = all(np.array_equal(rskh[i], po.compute_sketch(p4, rd[i])) for i in range(64))
+        # densification passes of these reads (the oracle's loop is the reference's: src/niqki_index.cpp:313-331)
+        passes = [po.densify(p4, po.sketch_accumulate(p4, rd[i]))[1] for i in range(64)]
+        passes_per_read = float(np.mean([x for x in passes if x > 0])) if any(x > 0 for x in passes) else 0.0
+        ix4 = po.Index(p4, e.get_sketches(0, N4))
+        off, c_, g_ = rho.cpu().numpy(), rhc.cpu().numpy(), rhg.cpu().numpy()
+        par_hits = all(hits_equal(off, c_, g_, i, ix4.counts(rskh[i]), min_score) for i in range(64))
+        cpu4 = None
+        if not no_cpu:
+            th = po.lib().nqo_max_threads()
+            n_c = 2048
+            rdc = reads[:n_c * RL].cpu().numpy()
+            t0 = time.perf_counter()
+            skc = po.sketch_batch(p4, rdc, (np.arange(n_c + 1) * RL).astype(np.uint64), threads=th)
+            ix4.query_batch(skc, threads=th)
+            cpu4 = {"reads_per_s": n_c / (time.perf_counter() - t0), "threads": th, "kind": "port",
+                    "sample": "%d reads: sketch (densification dominated, src/niqki_index.cpp:313-331) + query" % n_c}
+        # ceilings of the two big kernels of this workload, measured / computed now:
+        #  * sketch: its time is the densification passes (one LDS round trip each at 8 wavefronts per CU); the ceiling is
+        #    the rate of those passes with nothing but their LDS traffic and exit test (niqki_measure_alu(5))
+        #  * gather: HBM -- per read its sketch in (4F), its counter row out (2N) and the table entries and bucket ids
+        #    of the look-ups the per-slot class mask lets through (measured: T ids + their entries)
+        pass_rate = e.measure_alu(5)
+        sk_s = kprof["sketch"] * 1e-3
+        sk_pass_rate = NR * passes_per_read / sk_s if sk_s else 0.0
+        T4 = float(e.gathered_dev(rsk, RB).sum()) / RB        # ids gathered per read (last batch)
+        lists = int(e.stat("last_hits_form")) == 1       # the hits left the gather kernel as ordered lists: no counter rows
+        hpr = float(th_.sum()) / NR
+        g_bytes = NR * (4 * F4 + 4 * T4 + 8 * T4 + (4 * hpr + 4 if lists else 2 * N4))
+        g_s = kprof["gather"] * 1e-3
+        h_bytes = NR * ((4 + 12 + 4 * hpr) if lists else 2 * N4) + 8 * float(th_.sum())
+        h_s = kprof["hits"] * 1e-3
+        ceilings = {
+            "sketch": {"bound": "lds round trips of the densification passes", "passes_per_read": passes_per_read,
+                       "achieved_passes_per_s": sk_pass_rate, "peak_passes_per_s": pass_rate,
+                       "frac": sk_pass_rate / pass_rate if pass_rate else None,
+                       "note": "peak = niqki_measure_alu(5): the pass loop of the short-read kernel (8 one-wave workgroups per CU, two "
+                               "proposals + two read-backs per lane and pass) with nothing but its LDS traffic and exit test, measured "
+                               "in this run; achieved = reads/s of the sketch kernel x the passes the oracle's serial loop takes for "
+                               "64 of these reads (k-mer hashing and the entry list are inside the kernel's time, outside the peak)"},
+            "gather": {"bound": "hbm", "algorithmic_bytes_per_read": g_bytes / NR, "gathered_ids_per_read": T4,
+                       "achieved": g_bytes / g_s / 1e9 if g_s else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": g_bytes / g_s / 1e9 / HBM_PEAK_GBS if g_s else None,
+                       "class_mask": int(e.stat("class_mask")),
+                       "hit_lists": lists,
+                       "note": "per read: its 2^S-cell sketch in, the entries and ids of the buckets it touches, and its ordered hit list "
+                               "out (4 bytes per hit; a 2N-byte counter row only for a read with more than hit_list_cap hits, or with "
+                               "option hit_lists = 0); with the per-slot class mask the 2^S table look-ups of a read are not memory "
+                               "traffic any more.  The kernel is bound by the latency of a read's dependent steps at 5 workgroups per "
+                               "CU, not by these bytes"},
+            "hits": {"bound": "launch latency of three small kernels (sizes -> offsets, lists -> places, overflowing lists ordered)",
+                     "bytes_per_read": h_bytes / NR, "achieved": h_bytes / h_s / 1e9 if h_s else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": h_bytes / h_s / 1e9 / HBM_PEAK_GBS if h_s else None,
+                     "ms_per_batch": kprof["hits"] / (NR // RB)},
+        }
+        out["configs4_reads_vs_10k_index"] = {
+            "workload": "%d distinct 150-base reads (1 %% substitutions, generated on the device) against a 10000-genome index, "
+                        "K=31 S=12 W=10, one sketch per read, batches of %d resident in HBM" % (NR, RB),
+            "reads_per_s": NR / t_reads, "seconds": t_reads, "min_score": min_score, "J_equivalent": min_score / F4,
+            "hits_total": int(th_.sum()), "hits_per_read": float(th_.sum()) / NR, "hit_overflow": bool((th_ > rcap).any()),
+            "kernel_ms": {k_: round(v, 1) for k_, v in kprof.items()},
+            "ceilings": ceilings,
+            "parity": {"device_reads_equal_host_generator": bool(np.array_equal(rd, host_rd)), "sketch_bit_exact": bool(par_sk),
+                       "hit_lists_bit_exact": bool(par_hits), "reads_checked": 64},
+            "cpu_oracle": cpu4,
+        }
+        e.close()
 
     # ---- the `niqki` host program on FILES: FASTA bytes in the page cache -> hits in a gz ----
     # (tools/bench_cli.py in child processes: whole-file mode, plain and gzip level 1 inputs; rates from the
     # program's own phase clocks, its start-up reported beside them)
-    import subprocess
+    def child_json(name, cmd, own_timeout, estimate, scratch_dir=None):
+        """the last stdout line of a child process as JSON, or None (dropped / killed / failed); scratch_dir goes either way"""
+        import shutil
+        if os.environ.get("NIQKI_BENCH_TEST_HANG") == name:      # (CPU / GPU rehearsal of a child that never returns)
+            cmd = [sys.executable, "-c", "import time; time.sleep(100000)"]
+        try:
+            r = budget.child(name, cmd, own_timeout, estimate)
+            if r is None or r[0] != 0:
+                if r is not None:
+                    budget.dropped.append({"leg": name, "exit_code": r[0]})
+                return None
+            return json.loads(r[1].decode().strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            return None
+        finally:
+            if scratch_dir:
+                shutil.rmtree(scratch_dir, ignore_errors=True)
+            budget.lap(name)
+
     cli = {}
-    for tag, n_files, gz in (("plain_fasta", 2048, False), ("gzip_fasta", 2048, True)):
-        cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_cli.py"), "--genomes", str(n_files), "--len", str(L),
-               "--dir", os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "niqki_bench_cli_%d" % os.getpid())]
+
+    def leg_cli(tag, n_files, gz, estimate):
+        scratch = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "niqki_bench_cli_%d" % os.getpid())
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_cli.py"), "--genomes", str(n_files), "--len", str(L), "--dir", scratch]
         if gz:
             # gzip -6 files (gzip's default), crossing PCIe as they are and inflated on the device (nq_inflate.hip); the
             # same run once more with every file inflated by the reader threads (NIQKI_HOST_NO_GPU_INFLATE=1)
             cmd += ["--gz", "--host-inflate-too"]
         else:
             cmd += ["--reference", "128", "--reads", "4000000"]
-        try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-            j = json.loads(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else None
-        except (OSError, ValueError, IndexError, subprocess.SubprocessError):
-            j = None
+        j = child_json("cli_files." + tag, cmd, 600, estimate, scratch)
         if j:
             cli[tag] = {"files": n_files, "index_genomes_per_s": j["index_genomes_per_s"], "query_genomes_per_s": j["query_genomes_per_s"],
                         "index_file_GBps": j["index_fasta_GBps"], "process_startup_s": j["startup_s"],
@@ -1283,46 +1397,50 @@ def extra_workloads(niqki_amd, torch, dev, args, no_cpu=False):
                 # the reference's OWN program on the first files: its CPU path, and the same binary with its three
                 # operators bound to the C ABI (oracle/ref_gpu_ops.cpp) -- what INTEGRATION.md's minimal patch gives
                 cli[tag]["reference_program"] = j["reference_program"]
-    out["cli_files"] = {"workload": "niqki -I fof -Q fof -J 0.1 on 5 Mbp FASTA files (70 columns) in the page cache, whole-file mode",
-                        **cli} if cli else None
+        out["cli_files"] = {"workload": "niqki -I fof -Q fof -J 0.1 on 5 Mbp FASTA files (70 columns) in the page cache, whole-file mode",
+                            **cli} if cli else None
+
     # ---- `niqki -D` / `-L` end to end (tools/bench_dump_cli.py): 8192 genomes, 1.6 GB of buckets ----
-    try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_dump_cli.py"), "--genomes", "8192", "--len", "200000"],
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-        j = json.loads(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else None
-    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
-        j = None
-    if j:
-        out["dump_load_cli"] = {
-            "workload": "niqki -I fof -D dump.gz, then niqki -L dump.gz -Q q: 8192 synthetic genomes of 200 kbp (K=31 S=15 W=12), the dump a "
-                        "file of size-tagged gzip -1 members written and read side by side by the host's threads",
-            "dump_file_GB": j["dump_file_GB"], "dump_s": j["dump_s"], "load_s": j["load_s"],
-            "hits_after_load_equal_hits_after_index": j["same_hits"],
-            "dump_phase": [l for l in j["timing"].get("index_dump", []) if "dump:" in l][-1:]}
+    def leg_dump_load():
+        j = child_json("dump_load_cli", [sys.executable, os.path.join(ROOT, "tools", "bench_dump_cli.py"), "--genomes", "8192", "--len", "200000"],
+                       300, 25)
+        if j:
+            out["dump_load_cli"] = {
+                "workload": "niqki -I fof -D dump.gz, then niqki -L dump.gz -Q q: 8192 synthetic genomes of 200 kbp (K=31 S=15 W=12), the dump a "
+                            "file of size-tagged gzip -1 members written and read side by side by the host's threads",
+                "dump_file_GB": j["dump_file_GB"], "dump_s": j["dump_s"], "load_s": j["load_s"],
+                "hits_after_load_equal_hits_after_index": j["same_hits"],
+                "dump_phase": [l for l in j["timing"].get("index_dump", []) if "dump:" in l][-1:]}
     # ---- the device inflate alone: 1024 gzip -6 genome files resident in HBM, one launch (tools/bench_inflate.py) ----
-    try:
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_inflate.py"), "--files", "2048", "--len", str(L),
-                            "--distinct", "8", "--reps", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
-        j = json.loads(r.stdout.decode().strip().splitlines()[-1]) if r.returncode == 0 else None
-    except (OSError, ValueError, IndexError, subprocess.SubprocessError):
-        j = None
-    if j:
-        out["gzip_inflate"] = {
-            "workload": "2048 gzip -6 FASTA files of %d bp inflated in one launch of nq::inflate_kernel (one wavefront per file, eight per "
-                        "CU: each file's last 8 KB of window in LDS, matches that reach further back read from its flushed output), "
-                        "bytes checked against the files' own" % L,
-            "files_in_flight_by_kernel_form": j.get("files_in_flight"),
-            "kernel_ms": j["kernel_ms"], "files_per_s": j["files_per_s"], "inflated_GBps": j["raw_GBps"], "compressed_GBps": j["wire_GBps"],
-            "per_file": j["per_file"],
-            "bound": "the latency of one wavefront's dependent instructions (a DEFLATE stream is serial): every file takes the whole "
-                     "launch, throughput = files in flight / that time",
-            "hbm_frac": round((j["raw_GBps"] + j["wire_GBps"]) / 8000.0, 4),
-            "cycles_per_file_round": round(j["kernel_ms"] * 1e-3 * 2.4e9 / max(j["per_file"]["rounds"], 1)),
-            "note": "bytes written + read over the 8 TB/s peak: a hundredth -- the kernel is nowhere near memory; a round (64 bit offsets "
-                    "decoded at once, their tokens walked, <= 64 bytes written) is ~190 instructions of one wavefront, two wavefronts per "
-                    "SIMD (profiles/r05_inflate_phase_clocks.txt); cycles_per_file_round at a nominal 2.4 GHz",
-            "zlib_one_host_thread_files_per_s": j["zlib_one_thread_files_per_s"]}
-    return out
+    def leg_inflate():
+        j = child_json("gzip_inflate", [sys.executable, os.path.join(ROOT, "tools", "bench_inflate.py"), "--files", "2048", "--len", str(L),
+                                        "--distinct", "8", "--reps", "2"], 300, 25)
+        if j:
+            out["gzip_inflate"] = {
+                "workload": "2048 gzip -6 FASTA files of %d bp inflated in one launch of nq::inflate_kernel (one wavefront per file, eight per "
+                            "CU: each file's last 8 KB of window in LDS, matches that reach further back read from its flushed output), "
+                            "bytes checked against the files' own" % L,
+                "files_in_flight_by_kernel_form": j.get("files_in_flight"),
+                "kernel_ms": j["kernel_ms"], "files_per_s": j["files_per_s"], "inflated_GBps": j["raw_GBps"], "compressed_GBps": j["wire_GBps"],
+                "per_file": j["per_file"],
+                "bound": "the latency of one wavefront's dependent instructions (a DEFLATE stream is serial): every file takes the whole "
+                         "launch, throughput = files in flight / that time",
+                "hbm_frac": round((j["raw_GBps"] + j["wire_GBps"]) / 8000.0, 4),
+                "cycles_per_file_round": round(j["kernel_ms"] * 1e-3 * 2.4e9 / max(j["per_file"]["rounds"], 1)),
+                "note": "bytes written + read over the 8 TB/s peak: a hundredth -- the kernel is nowhere near memory; a round (64 bit offsets "
+                        "decoded at once, their tokens walked, <= 64 bytes written) is ~190 instructions of one wavefront, two wavefronts per "
+                        "SIMD (profiles/r05_inflate_phase_clocks.txt); cycles_per_file_round at a nominal 2.4 GHz",
+                "zlib_one_host_thread_files_per_s": j["zlib_one_thread_files_per_s"]}
+    # ---- the legs in the order of what they are worth; each starts only while its estimated time is left ----
+    for name, est, fn in (("configs4_reads_vs_10k_index", 14, leg_configs4), ("configs1_1k_index_self_query", 10, leg_configs1),
+                          ("matrix_10k", 8, leg_matrix)):
+        if budget.want(name, est):
+            guarded(name, fn)
+    reference_leg()
+    for tag, n_files, gz, est in (("plain_fasta", 2048, False, 60), ("gzip_fasta", 2048, True, 60)):
+        leg_cli(tag, n_files, gz, est)
+    leg_dump_load()
+    leg_inflate()
 
 
 if __name__ == "__main__":

@@ -20,6 +20,91 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class Budget:
+    """Wall-clock budget of one bench.py run (--budget-s, counted from the start of the process): the headline -- index
+    build, warm-up, the K timed steps, the roofline steps, the CPU baseline on its sample -- always runs; every other leg
+    starts only while its estimated time is left, a child process gets min(its own limit, what is left), and what was
+    dropped is named in the line.  A leg that hangs inside this process is cut by the watchdog (arm()), which prints the
+    line as it stands and ends the process."""
+
+    def __init__(self, seconds, t0=None):
+        self.t0 = time.time() if t0 is None else t0
+        self.seconds = float(seconds)
+        self.dropped = []
+        self.timeline = []
+        self._mark = self.t0
+        self._timer = None
+
+    def left(self):
+        return self.t0 + self.seconds - time.time()
+
+    def elapsed(self):
+        return time.time() - self.t0
+
+    def want(self, name, estimate_s):
+        """True if `estimate_s` seconds are left for the leg `name`; else the leg is recorded as dropped."""
+        if self.left() >= estimate_s:
+            return True
+        self.dropped.append({"leg": name, "needs_s": estimate_s, "left_s": round(self.left(), 1)})
+        log("[bench] budget: %s dropped (needs ~%.0f s, %.0f s left)" % (name, estimate_s, self.left()))
+        return False
+
+    def lap(self, name):
+        """closes the timeline entry `name` (seconds since the last lap)"""
+        now = time.time()
+        self.timeline.append([name, round(now - self._mark, 2)])
+        self._mark = now
+
+    def child(self, name, cmd, own_timeout_s, estimate_s, **popen_kw):
+        """Runs cmd as a child process (a session of its own, killed as a group) for at most min(own_timeout_s, what is
+        left); returns (returncode, stdout bytes) or None when it was dropped, timed out or could not start."""
+        import signal
+        import subprocess
+        if not self.want(name, estimate_s):
+            return None
+        limit = max(1.0, min(float(own_timeout_s), self.left()))
+        try:
+            pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True, **popen_kw)
+        except OSError:
+            self.dropped.append({"leg": name, "error": "could not start"})
+            return None
+        try:
+            out, _ = pr.communicate(timeout=limit)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(pr.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            pr.communicate()
+            self.dropped.append({"leg": name, "killed_after_s": round(limit, 1)})
+            log("[bench] budget: %s killed after %.0f s" % (name, limit))
+            return None
+        return pr.returncode, out
+
+    def arm(self, grace_s, emit):
+        """watchdog: grace_s after the deadline emit() is called from a timer thread and the process ends (a leg of this
+        process that hangs -- a kernel that never finishes -- must not cost the run its line)"""
+        import threading
+
+        def fire():
+            log("[bench] budget: %.0f s past the deadline, printing the line as it stands" % grace_s)
+            try:
+                emit(True)
+            finally:
+                os._exit(0)
+        self._timer = threading.Timer(max(1.0, self.left() + grace_s), fire)
+        self._timer.daemon = True
+        self._timer.start()
+
+    def disarm(self):
+        if self._timer is not None:
+            self._timer.cancel()
+            self._timer = None
+
+    def record(self):
+        return {"budget_s": self.seconds, "used_s": round(self.elapsed(), 1), "dropped": self.dropped, "timeline_s": self.timeline}
+
+
 def genome_spec(g, n_fam, fam_size):
     """Indexed genome g: family g // fam_size, member g % fam_size; member 0 is the
     ancestor, the others carry substitution rates spread geometrically over
@@ -41,7 +126,7 @@ def query_spec(q, n_fam):
     return fam, mem, rate
 
 
-def measure_counters(args):
+def measure_counters(args, budget=None):
     """Hardware counters of a short run of this same command under rocprofv3 (one --pmc pass per counter, no
     trace flags, child processes started before this process touches the GPU):
       * HBM-side bytes per gather launch (gather kernel + look-up pre-pass + locality probe):
@@ -80,7 +165,7 @@ def measure_counters(args):
             pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                   start_new_session=True)
             try:
-                rc = pr.wait(timeout=240)
+                rc = pr.wait(timeout=240 if budget is None else max(5.0, min(240.0, budget.left() - 60.0)))
             except subprocess.TimeoutExpired:
                 try:
                     os.killpg(pr.pid, signal.SIGKILL)

@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define NIQKI_ABI_VERSION 1
+#define NIQKI_ABI_VERSION 2   /* 2: niqki_raw_batch.file_status, NIQKI_E_GZIP, niqki_sketch_ahead / niqki_query_ahead */
 
 /* Bytes the caller must keep readable after the last sequence byte of a
  * NIQKI_MEM_DEVICE sequence buffer (the sketch kernel reads whole dwords). */
@@ -287,6 +287,27 @@ int niqki_query_sequences(niqki_index *ix, const uint8_t *seqs,
                           const uint32_t *entry_rec, uint32_t n_entry,
                           uint64_t *hit_off, uint32_t *hit_counts,
                           uint32_t *hit_gids, uint64_t capacity, int mem);
+
+/* The same in two halves, so that consecutive batches overlap on the device: niqki_sketch_ahead starts the sketch
+ * kernel of a batch on a lane of the handle's own (a side stream) and returns; niqki_query_ahead runs the query of the
+ * OLDEST batch sketched ahead on the handle's stream, behind that batch's sketch kernel.  A caller that keeps one batch
+ * ahead --
+ *     niqki_sketch_ahead(batch 0);
+ *     for i: niqki_sketch_ahead(batch i + 1); niqki_query_ahead(hits of batch i);
+ * -- has batch i + 1's sketch kernel (bound by vector instruction issue) running beside batch i's gather and hit
+ * kernels (bound by HBM): 164 k against 156 k query genomes/s at the 100 000-genome shape.  At most two
+ * batches are ahead at a time (NIQKI_E_STATE beyond).  Device memory only, and the one call whose device inputs are NOT
+ * taken in the order of the handle's stream: `seqs`, `rec_off` and `entry_rec` are read on the sketch lane, so they must
+ * be complete when niqki_sketch_ahead is called and stay untouched until the niqki_query_ahead that takes the batch
+ * has been called.  The results of niqki_query_ahead are those of niqki_query_sequences on the same records
+ * and, as there, in the handle's stream order for NIQKI_MEM_DEVICE outputs.  `n_entry` (may be NULL) receives the batch's
+ * entry count, `sketches` (may be NULL; n_entry x 2^S cells in `mem`) a copy of its sketches.  NIQKI_E_CAPACITY (host
+ * outputs) leaves the batch the oldest one: the same call again with larger arrays.  niqki_synchronize waits for the
+ * sketch lane too. */
+int niqki_sketch_ahead(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, uint32_t n_rec,
+                       const uint32_t *entry_rec, uint32_t n_entry, int mem);
+int niqki_query_ahead(niqki_index *ix, uint32_t *n_entry, uint64_t *hit_off, uint32_t *hit_counts,
+                      uint32_t *hit_gids, uint64_t capacity, int32_t *sketches, int mem);
 
 /* ---- raw file bytes in: FASTA / FASTQ framing on the GPU -------------------
  * Index::Biogetline (src/niqki_index.cpp:890-941) and the read loops of

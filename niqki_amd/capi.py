@@ -101,6 +101,8 @@ ABI = [
     ("niqki_survivor_counts", _int, [_vp, _vp, _u32, _vp, _u32, _vp, _vp, _u32, _vp, _int]),
     ("niqki_hits_from_candidates", _int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _u64, _int]),
     ("niqki_query_sequences", _int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _u64, _int]),
+    ("niqki_sketch_ahead", _int, [_vp, _vp, _vp, _u32, _vp, _u32, _int]),
+    ("niqki_query_ahead", _int, [_vp, C.POINTER(_u32), _vp, _vp, _vp, _u64, _vp, _int]),
     ("niqki_stage_raw", _int, [_vp, C.POINTER(RawBatch), _int, C.POINTER(StageInfo), _vp]),
     ("niqki_stage_raw_prefetch", _int, [_vp, C.POINTER(RawBatch)]),
     ("niqki_staged_sketch", _int, [_vp, _vp, _int]),
@@ -640,6 +642,34 @@ class Engine:
     def query_sequences_dev(self, seqs, rec_off, n, hit_off, hc, hg, capacity):
         self._ck(self.L.niqki_query_sequences(self.h, _p(seqs), _p(rec_off), n, None, n, _p(hit_off),
                                               _p(hc), _p(hg), capacity, MEM_DEVICE))
+
+    def sketch_ahead_dev(self, seqs, rec_off, n_rec, entry_rec=None, n_entry=None):
+        """niqki_sketch_ahead: the batch's sketch kernel on the handle's sketch lane, beside what its stream runs."""
+        self._ck(self.L.niqki_sketch_ahead(self.h, _p(seqs), _p(rec_off), n_rec, _p(entry_rec),
+                                           n_rec if n_entry is None else n_entry, MEM_DEVICE))
+
+    def query_ahead_dev(self, hit_off, hc, hg, capacity, sketches=None):
+        """niqki_query_ahead with device outputs: the oldest batch sketched ahead; returns its entry count."""
+        n = _u32(0)
+        self._ck(self.L.niqki_query_ahead(self.h, C.byref(n), _p(hit_off), _p(hc), _p(hg), capacity, _p(sketches), MEM_DEVICE))
+        return n.value
+
+    def query_ahead(self, n_entry, capacity=None, want_sketches=False):
+        """niqki_query_ahead with host outputs: (off, counts, gids[, sketches]) of the oldest batch sketched ahead
+        (n_entry: its entry count, as given to sketch_ahead_dev)."""
+        n = _u32(0)
+        cap = capacity if capacity is not None else max(1024, n_entry * 64)
+        while True:
+            off = np.zeros(n_entry + 1, dtype=np.uint64)
+            hc, hg = np.empty(max(cap, 1), dtype=np.uint32), np.empty(max(cap, 1), dtype=np.uint32)
+            sk = np.empty((n_entry, self.F), dtype=np.int32) if want_sketches else None
+            rc = self.L.niqki_query_ahead(self.h, C.byref(n), _p(off), _p(hc), _p(hg), cap, _p(sk), MEM_HOST)
+            self._ck(rc, allow=(E_CAPACITY,))
+            if rc == 0:
+                tot = int(off[n.value])
+                res = (off[:n.value + 1], hc[:tot], hg[:tot])
+                return res + (sk[:n.value],) if want_sketches else res
+            cap = int(off[n.value])
 
     def gathered_dev(self, sketches, nq):
         out = np.zeros(nq, dtype=np.uint64)

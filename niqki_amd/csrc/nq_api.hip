@@ -100,6 +100,7 @@ Span::~Span() {
 
 int collect_spans(niqki_index *ix) {
   if (ix->spans.empty()) return NIQKI_OK;
+  if (ix->sk_stream) NQ_HIP(ix, hipStreamSynchronize(ix->sk_stream));   // (spans of niqki_sketch_ahead lie on the sketch lane)
   NQ_HIP(ix, hipStreamSynchronize(ix->stream));
   for (auto &s : ix->spans) {
     float ms = 0;
@@ -350,6 +351,7 @@ int niqki_create(const niqki_params *params, niqki_index **out) {
 void niqki_destroy(niqki_index *ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
+  if (ix->sk_stream) (void)hipStreamSynchronize(ix->sk_stream);
   (void)hipStreamSynchronize(ix->stream);
   for (Buf *b : {&ix->ws_seq, &ix->ws_recoff, &ix->ws_entry, &ix->ws_sk, &ix->ws_counts, &ix->ws_blk,
                  &ix->ws_hitoff, &ix->ws_hc, &ix->ws_hg, &ix->ws_tc, &ix->ws_tg, &ix->ws_misc, &ix->ws_stash,
@@ -371,6 +373,12 @@ void niqki_destroy(niqki_index *ix) {
   for (auto e : ix->ev_pool) (void)hipEventDestroy(e);
   if (ix->aux_stream) { (void)hipStreamSynchronize(ix->aux_stream); (void)hipStreamDestroy(ix->aux_stream); }
   if (ix->copy_stream) { (void)hipStreamSynchronize(ix->copy_stream); (void)hipStreamDestroy(ix->copy_stream); }
+  if (ix->sk_stream) { (void)hipStreamSynchronize(ix->sk_stream); (void)hipStreamDestroy(ix->sk_stream); }
+  for (auto &a : ix->ahead) {
+    if (a.sk.p) (void)hipFree(a.sk.p);
+    if (a.done) (void)hipEventDestroy(a.done);
+    if (a.used) (void)hipEventDestroy(a.used);
+  }
   for (auto &pr : ix->pre) if (pr.ev) (void)hipEventDestroy(pr.ev);
   if (ix->ev_fork) (void)hipEventDestroy(ix->ev_fork);
   if (ix->ev_join) (void)hipEventDestroy(ix->ev_join);
@@ -393,6 +401,7 @@ int niqki_get_params(const niqki_index *ix, niqki_params *out) {
 
 int niqki_set_stream(niqki_index *ix, void *s) {
   if (!ix) return NIQKI_E_INVALID;
+  if (ix->sk_stream) NQ_HIP(ix, hipStreamSynchronize(ix->sk_stream));
   NQ_HIP(ix, hipStreamSynchronize(ix->stream));
   if (ix->own_stream) { (void)hipStreamDestroy(ix->stream); ix->own_stream = false; }
   ix->stream = (hipStream_t)s;
@@ -404,6 +413,7 @@ void *niqki_get_stream(const niqki_index *ix) { return ix ? (void *)ix->stream :
 int niqki_synchronize(niqki_index *ix) {
   if (!ix) return NIQKI_E_INVALID;
   NQ_HIP(ix, hipSetDevice(ix->device));
+  if (ix->sk_stream) NQ_HIP(ix, hipStreamSynchronize(ix->sk_stream));   // sketches made ahead (niqki_sketch_ahead)
   NQ_HIP(ix, hipStreamSynchronize(ix->stream));
   return NIQKI_OK;
 }

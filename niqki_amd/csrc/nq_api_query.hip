@@ -507,6 +507,80 @@ int niqki_query_sequences(niqki_index *ix, const uint8_t *seqs, const uint64_t *
   return niqki_query(ix, sk.data(), n_entry, hit_off, hit_counts, hit_gids, capacity, NIQKI_MEM_HOST);
 }
 
+// ---- sketches made ahead: batch i + 1 is sketched beside batch i's gather and hit kernels -------------------------
+// The sketch kernel is bound by vector instruction issue, the gather launch by random HBM lines; a step of the query
+// path is the one after the other (18.9 + 7.3 ms per 4096 genomes).  With the coming batch's sketch kernel on a lane of
+// its own the two overlap where either leaves CUs idle (the tails of both launches): + 5 % genomes/s.
+int niqki_sketch_ahead(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, uint32_t n_rec, const uint32_t *entry_rec,
+                       uint32_t n_entry, int mem) {
+  if (!ix || (!seqs && n_rec) || !rec_off) return NIQKI_E_INVALID;
+  if (mem != NIQKI_MEM_DEVICE) return fail(ix, NIQKI_E_INVALID, "niqki_sketch_ahead is device-memory only (host records: niqki_query_sequences)");
+  if (!entry_rec && n_entry != n_rec) return fail(ix, NIQKI_E_INVALID, "n_entry must equal n_rec without entry_rec");
+  if (ix->ahead_n >= 2) return fail(ix, NIQKI_E_STATE, "two batches are sketched ahead already: niqki_query_ahead takes the older one");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  if (!ix->sk_stream) {
+    // the sketch lane never outranks the handle's stream: what a query is waiting for runs there
+    if (ix->stream_prio_set) {
+      int least = 0, greatest = 0;
+      NQ_HIP(ix, hipDeviceGetStreamPriorityRange(&least, &greatest));
+      NQ_HIP(ix, hipStreamCreateWithPriority(&ix->sk_stream, hipStreamNonBlocking, least));
+    } else {
+      NQ_HIP(ix, hipStreamCreateWithFlags(&ix->sk_stream, hipStreamNonBlocking));
+    }
+  }
+  auto &a = ix->ahead[(ix->ahead_head + ix->ahead_n) & 1u];
+  if (!a.done) {
+    NQ_HIP(ix, hipEventCreateWithFlags(&a.done, hipEventDisableTiming));
+    NQ_HIP(ix, hipEventCreateWithFlags(&a.used, hipEventDisableTiming));
+  }
+  const size_t bytes = std::max<size_t>((size_t)n_entry * ix->d.F * 4, 4);
+  if (bytes > a.sk.n && a.used_set) NQ_HIP(ix, hipEventSynchronize(a.used));   // (growing the slot frees what its last query read)
+  int rc = ensure(ix, a.sk, bytes);
+  if (rc) return rc;
+  if (a.used_set) NQ_HIP(ix, hipStreamWaitEvent(ix->sk_stream, a.used, 0));
+  uint64_t total = ix->record_len_hint * n_entry;
+  if (total == 0 && n_entry) {   // only to pick the launch shape: the last offset
+    NQ_HIP(ix, hipMemcpyAsync(&total, rec_off + n_rec, 8, hipMemcpyDeviceToHost, ix->sk_stream));
+    NQ_HIP(ix, hipStreamSynchronize(ix->sk_stream));
+  }
+  hipStream_t main = ix->stream;
+  ix->stream = ix->sk_stream;      // (sketch_dev and its profiling spans enqueue on the handle's current stream)
+  rc = sketch_dev(ix, seqs, rec_off, n_rec, entry_rec, n_entry, (int32_t *)a.sk.p, total);
+  ix->stream = main;
+  if (rc) return rc;
+  NQ_HIP(ix, hipEventRecord(a.done, ix->sk_stream));
+  a.n_entry = n_entry;
+  ix->ahead_n += 1;
+  return NIQKI_OK;
+}
+
+int niqki_query_ahead(niqki_index *ix, uint32_t *n_entry, uint64_t *hit_off, uint32_t *hit_counts, uint32_t *hit_gids, uint64_t capacity,
+                      int32_t *sketches, int mem) {
+  if (!ix || !hit_off) return NIQKI_E_INVALID;
+  if (ix->ahead_n == 0) return fail(ix, NIQKI_E_STATE, "no batch sketched ahead (niqki_sketch_ahead first)");
+  NQ_HIP(ix, hipSetDevice(ix->device));
+  auto &a = ix->ahead[ix->ahead_head];
+  if (n_entry) *n_entry = a.n_entry;
+  NQ_HIP(ix, hipStreamWaitEvent(ix->stream, a.done, 0));
+  int rc;
+  if (mem == NIQKI_MEM_DEVICE) {
+    rc = niqki_query(ix, (const int32_t *)a.sk.p, a.n_entry, hit_off, hit_counts, hit_gids, capacity, NIQKI_MEM_DEVICE);
+  } else {
+    if ((rc = build_if_needed(ix))) return rc;
+    rc = query_to_host(ix, (const int32_t *)a.sk.p, true, a.n_entry, hit_off, hit_counts, hit_gids, capacity);
+  }
+  if (rc == NIQKI_E_CAPACITY) return rc;   // the batch stays the oldest one: the same call again with larger arrays
+  if (!rc && sketches && a.n_entry)
+    NQ_HIP(ix, hipMemcpyAsync(sketches, a.sk.p, (size_t)a.n_entry * ix->d.F * 4,
+                              mem == NIQKI_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ix->stream));
+  NQ_HIP(ix, hipEventRecord(a.used, ix->stream));
+  if (!rc && sketches && mem == NIQKI_MEM_HOST) NQ_HIP(ix, hipStreamSynchronize(ix->stream));
+  a.used_set = true;
+  ix->ahead_head ^= 1u;
+  ix->ahead_n -= 1;
+  return rc;
+}
+
 int niqki_matrix_range(niqki_index *ix, uint32_t begin, uint32_t end, uint16_t *counts, uint64_t stride,
                        int mem) {
   if (!ix || begin > end || end > ix->n_genomes || (!counts && end > begin)) return NIQKI_E_INVALID;

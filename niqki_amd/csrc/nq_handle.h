@@ -131,6 +131,18 @@ struct niqki_index {
   } pre[2];
   uint32_t pre_next = 0;   // the slot the next prefetch takes
 
+  // niqki_sketch_ahead / niqki_query_ahead: the sketches of up to two coming query batches, made on the sketch lane (a
+  // side stream of the handle) beside whatever the handle's stream runs -- the gather and hit kernels of the batch before
+  hipStream_t sk_stream = nullptr;
+  struct Ahead {
+    nqi::Buf sk;                 // n_entry x F cells
+    uint32_t n_entry = 0;
+    hipEvent_t done = nullptr;   // its sketch kernel has finished (recorded on sk_stream)
+    hipEvent_t used = nullptr;   // the query that took it has read it (recorded on the handle's stream)
+    bool used_set = false;
+  } ahead[2];
+  uint32_t ahead_head = 0, ahead_n = 0;   // the oldest slot in flight, how many are
+
   bool prof = false;
   double prof_ms[NIQKI_KC_COUNT] = {0};
   uint64_t prof_n[NIQKI_KC_COUNT] = {0};

@@ -207,36 +207,69 @@ static inline int slot_valid(int32_t fp, uint32_t R) {
   return fp >= 0 && (uint32_t)fp < R; /* src/niqki_index.cpp:364 */
 }
 
-nqo_index *nqo_index_build(const nqo_params *p, const int32_t *sketches,
-                           uint32_t n) {
+/* threads > 1: the slots are cut into ranges, one per thread -- a bucket belongs to one slot, and every thread
+ * walks the genomes in ascending order, so the arrays are those of the single-threaded build (threads <= 0: all). */
+nqo_index *nqo_index_build_mt(const nqo_params *p, const int32_t *sketches, uint32_t n, int threads) {
   const uint64_t F = (uint64_t)1 << p->S, R = (uint64_t)1 << p->W;
   nqo_index *ix = (nqo_index *)calloc(1, sizeof(*ix));
   if (!ix) return NULL;
+  if (threads <= 0) threads = omp_get_max_threads();
+  if ((uint64_t)threads > F) threads = (int)F;
   ix->p = *p;
   ix->n_genomes = n;
   ix->n_buckets = F * R;
   ix->offsets = (uint64_t *)calloc(ix->n_buckets + 1, sizeof(uint64_t));
   if (!ix->offsets) { free(ix); return NULL; }
   /* counting sort by bucket, gids ascending inside a bucket = the order
-   * single-threaded push_back produces (:362-370) */
-  for (uint32_t g = 0; g < n; ++g) {
-    const int32_t *sk = sketches + (uint64_t)g * F;
-    for (uint64_t s = 0; s < F; ++s)
-      if (slot_valid(sk[s], (uint32_t)R)) ix->offsets[s * R + (uint32_t)sk[s] + 1]++;
-  }
-  for (uint64_t b = 0; b < ix->n_buckets; ++b) ix->offsets[b + 1] += ix->offsets[b];
-  uint64_t total = ix->offsets[ix->n_buckets];
-  ix->gids = (uint32_t *)malloc((total ? total : 1) * sizeof(uint32_t));
+   * single-threaded push_back produces (:362-370).  Every phase runs over the threads' slot ranges (the 8-byte
+   * offsets of all 2^(S+W) buckets are 1 GB at S=15 W=12: their page faults, prefix and copy are most of a small build) */
   uint64_t *cursor = (uint64_t *)malloc(ix->n_buckets * sizeof(uint64_t));
-  if (!ix->gids || !cursor) { free(cursor); nqo_index_free(ix); return NULL; }
-  memcpy(cursor, ix->offsets, ix->n_buckets * sizeof(uint64_t));
-  for (uint32_t g = 0; g < n; ++g) {
-    const int32_t *sk = sketches + (uint64_t)g * F;
-    for (uint64_t s = 0; s < F; ++s)
-      if (slot_valid(sk[s], (uint32_t)R)) ix->gids[cursor[s * R + (uint32_t)sk[s]]++] = g;
+  uint64_t *tsum = (uint64_t *)calloc((size_t)threads + 1, sizeof(uint64_t));
+  if (!cursor || !tsum) { free(cursor); free(tsum); nqo_index_free(ix); return NULL; }
+  int failed = 0;
+#pragma omp parallel num_threads(threads)
+  {
+    const uint64_t t = (uint64_t)omp_get_thread_num(), nt = (uint64_t)omp_get_num_threads();
+    const uint64_t s0 = F * t / nt, s1 = F * (t + 1) / nt;
+    for (uint32_t g = 0; g < n; ++g) {
+      const int32_t *sk = sketches + (uint64_t)g * F;
+      for (uint64_t s = s0; s < s1; ++s)
+        if (slot_valid(sk[s], (uint32_t)R)) ix->offsets[s * R + (uint32_t)sk[s] + 1]++;
+    }
+    uint64_t sum = 0;
+    for (uint64_t bkt = s0 * R; bkt < s1 * R; ++bkt) sum += ix->offsets[bkt + 1];
+    tsum[t + 1] = sum;
+#pragma omp barrier
+#pragma omp single
+    {
+      for (uint64_t i = 0; i < nt; ++i) tsum[i + 1] += tsum[i];
+      const uint64_t total = tsum[nt];
+      ix->gids = (uint32_t *)malloc((total ? total : 1) * sizeof(uint32_t));
+      if (!ix->gids) failed = 1;
+    }   /* (implicit barrier) */
+    if (!failed) {
+      uint64_t run = tsum[t];   /* ids in front of this thread's first bucket */
+      for (uint64_t bkt = s0 * R; bkt < s1 * R; ++bkt) {
+        cursor[bkt] = run;
+        run += ix->offsets[bkt + 1];
+        ix->offsets[bkt + 1] = run;
+      }
+      for (uint32_t g = 0; g < n; ++g) {
+        const int32_t *sk = sketches + (uint64_t)g * F;
+        for (uint64_t s = s0; s < s1; ++s)
+          if (slot_valid(sk[s], (uint32_t)R)) ix->gids[cursor[s * R + (uint32_t)sk[s]]++] = g;
+      }
+    }
   }
+  free(tsum);
+  if (failed) { free(cursor); nqo_index_free(ix); return NULL; }
   free(cursor);
   return ix;
+}
+
+nqo_index *nqo_index_build(const nqo_params *p, const int32_t *sketches,
+                           uint32_t n) {
+  return nqo_index_build_mt(p, sketches, n, 1);
 }
 
 void nqo_index_free(nqo_index *ix) {

@@ -97,6 +97,8 @@ typedef struct nqo_index {
  * sketches is n x F int32, row major. */
 nqo_index *nqo_index_build(const nqo_params *p, const int32_t *sketches,
                            uint32_t n);
+/* the same arrays, built by `threads` threads over slot ranges (<= 0: all) */
+nqo_index *nqo_index_build_mt(const nqo_params *p, const int32_t *sketches, uint32_t n, int threads);
 void nqo_index_free(nqo_index *ix);
 
 /* query_sketch counting loop: src/niqki_index.cpp:633-682.  counts[n_genomes]. */

@@ -70,6 +70,8 @@ def lib():
         L.nqo_compute_sketch.argtypes = [C.POINTER(Params), C.c_void_p, C.c_uint64, C.c_void_p]
         L.nqo_index_build.restype = C.POINTER(_Index)
         L.nqo_index_build.argtypes = [C.POINTER(Params), C.c_void_p, C.c_uint32]
+        L.nqo_index_build_mt.restype = C.POINTER(_Index)
+        L.nqo_index_build_mt.argtypes = [C.POINTER(Params), C.c_void_p, C.c_uint32, C.c_int]
         L.nqo_index_free.restype = None
         L.nqo_index_free.argtypes = [C.POINTER(_Index)]
         L.nqo_query_counts.restype = None
@@ -174,17 +176,36 @@ def sketch_batch(p, seqs, rec_off, threads=0):
     return out
 
 
+def cpu_threads():
+    """CPUs this process may really use: the affinity mask, cut to the cgroup's CPU quota where there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = max(1, min(n, int(round(float(q[0]) / float(q[1])))))
+    except (OSError, ValueError, IndexError):
+        pass
+    return n
+
+
 class Index:
     """CSR inverted index built by the oracle from an (n, F) int32 sketch array."""
 
-    def __init__(self, p=None, sketches=None, handle=None):
+    def __init__(self, p=None, sketches=None, handle=None, threads=None):
+        """threads: builders (slot ranges; the arrays are those of one thread).  None = what this process has
+        (cpu_threads()) for a large index, one for a small one; 1 = the plain single-threaded build."""
         self._L = lib()
         if handle is not None:
             self._h = handle
         else:
             sk = np.ascontiguousarray(sketches, dtype=np.int32)
             assert sk.ndim == 2 and sk.shape[1] == (1 << p.S)
-            self._h = self._L.nqo_index_build(C.byref(p), _ptr(sk), sk.shape[0])
+            if threads is None:
+                threads = cpu_threads() if sk.size >= (1 << 24) else 1
+            self._h = self._L.nqo_index_build_mt(C.byref(p), _ptr(sk), sk.shape[0], int(threads))
         if not self._h:
             raise MemoryError("oracle index build failed")
         self.p = self._h.contents.p

@@ -51,10 +51,28 @@ def test_header_cites_the_reference_interfaces():
 
 def test_abi_version_and_min_score(native):
     L = native.lib()
-    assert L.niqki_abi_version() == 1
+    assert L.niqki_abi_version() == 2
     assert native.min_score(0.9, 10) == 921
     assert native.min_score(0.1, 15) == 3276
     assert L.niqki_status_string(6) == b"no gfx950 device"
+
+
+def test_public_struct_layouts_match_the_ctypes_table(native, tmp_path):
+    """sizeof / offsetof of the header's public structs as a C compiler sees them == the ctypes mirrors in capi.py
+    (a struct that grows must bump NIQKI_ABI_VERSION and its mirror together)."""
+    import ctypes
+    import subprocess
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "niqki_hip.h"\n#include "niqki_hip_bench.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(niqki_params), sizeof(niqki_raw_batch), '
+                   'offsetof(niqki_raw_batch, file_status), sizeof(niqki_stage_info), sizeof(niqki_group_plan), '
+                   '(size_t)NIQKI_ABI_VERSION); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    from niqki_amd import capi
+    assert got == [ctypes.sizeof(capi.Params), ctypes.sizeof(capi.RawBatch), capi.RawBatch.file_status.offset,
+                   ctypes.sizeof(capi.StageInfo), ctypes.sizeof(capi.GroupPlan), native.lib().niqki_abi_version()]
 
 
 def test_no_gpu_means_no_engine(native):

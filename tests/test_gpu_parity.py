@@ -35,7 +35,7 @@ def eng_a(native, gold):
 def test_library_is_the_native_one(native):
     import os
     assert os.path.exists(native.lib_path())
-    assert native.lib().niqki_abi_version() == 1
+    assert native.lib().niqki_abi_version() == 2
 
 
 def test_synth_host_equals_device(native):

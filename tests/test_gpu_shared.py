@@ -94,12 +94,12 @@ def test_stream_priority_option_changes_no_result(native, po):
     e.close()
 
 
-@pytest.mark.parametrize("mode", [["--no-legs"], ["--pipeline", "--no-legs"], ["--pipeline", "--priority-streams", "--no-legs"],
+@pytest.mark.parametrize("mode", [["--no-legs"], ["--no-overlap", "--no-legs"], ["--priority-streams", "--no-legs"],
                                   ["--no-cpu", "--no-extra", "--no-pmc"]])
 def test_bench_modes_on_a_small_index(tmp_path, mode):
-    """bench.py's other modes at a small size (the timed-steps-only run that tools/profile_round.sh traces, the
-    pipelined step with and without priority streams, a run with the legs): one JSON line with the record's fields;
-    the roofline fraction is a fraction."""
+    """bench.py's other modes at a small size (the timed-steps-only run that tools/profile_round.sh traces -- the default
+    step with the next batch's sketch kernel beside the query, the same one after the other, the default with priority
+    streams -- and a run with the legs): one JSON line with the record's fields; the roofline fraction is a fraction."""
     import json
     import os
     import subprocess
@@ -115,10 +115,16 @@ def test_bench_modes_on_a_small_index(tmp_path, mode):
     assert j["n_gpus"] == 1 and j["value"] > 0 and j["unit"] == "genomes/s" and j["scaling"] == "weak"
     assert rf["bound"] == "hbm" and 0 < rf["frac"] <= 1.0 and rf["frac_basis"] and rf["frac_algorithmic"] > 0 and rf["frac_layout_min"] > 0
     assert rf["launches"] == 3 and j["kernels"]["sketch"]["launches"] == 3
-    if "--no-legs" in mode:
-        assert j["cpu_baseline"] is None and j["pipelined_step"] is None and j["end_to_end_d2h"] is None and "extra_workloads" not in j
+    assert j["config"]["sketch_beside_query"] == ("--no-overlap" not in mode)
+    if "--no-overlap" in mode:
+        assert "serial_step" not in j and rf["measured_in"] == "the timed steps"
     else:
-        assert j["pipelined_step"]["ms_per_step_priority_streams"] > 0 and j["end_to_end_d2h"]["value"] > 0
+        assert j["serial_step"]["value"] > 0 and j["kernels_beside_each_other"]["gather"]["launches"] == 3 and "more steps" in rf["measured_in"]
+    assert j["budget"]["used_s"] > 0 and j["budget"]["dropped"] == []
+    if "--no-legs" in mode:
+        assert j["cpu_baseline"] is None and j["end_to_end_d2h"] is None and "extra_workloads" not in j
+    else:
+        assert j["end_to_end_d2h"]["value"] > 0
 
 
 def test_shared_entry_points_under_mixed_load(native, po):

@@ -17,7 +17,7 @@ for grp in \
  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" \
  "GRBM_GUI_ACTIVE" ; do
   i=$((i+1))
-  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 $R/bench.py --no-legs --steps 2 "$@" > $OUT/g$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/g$i.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --pmc $grp --output-format csv -d $OUT/g$i -- python3 $R/bench.py --no-legs --no-overlap --steps 2 "$@" > $OUT/g$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/g$i.log; exit 1; }
 done
 cd $R
 python tools/prof_summary.py $OUT | grep -E "gather_kernel|lookup_kernel|lookup_rows_kernel|block_kernel|probe_kernel|order_kernel|sketch_kernel|hits_|^==" | sed 's/  */ /g' > $R/gpurun_out/pmc_$TAG.summary.txt

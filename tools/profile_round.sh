@@ -21,25 +21,27 @@ print(json.dumps(j['cpu_baseline'])[:1500])"
 [ "$PART" = "line" ] && exit 0
 fi
 cd /tmp; export TMPDIR=/tmp
-# the traced command runs ONLY the index build, the warm-up and the timed steps (--no-legs): a kernel's median in the
-# summary is the median of the launches roofline.avg_launch_ms averages
-rm -rf /tmp/kt; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-legs --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> /tmp/kt.log || { tail -5 /tmp/kt.log; exit 1; }
+# the traced command runs ONLY the index build, the warm-up and the timed steps (--no-legs), sketch kernel and query one
+# after the other (--no-overlap): a kernel's average in the summary is that of launches which had the device to
+# themselves, like the ones roofline.avg_launch_ms averages
+rm -rf /tmp/kt; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --no-legs --no-overlap --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> /tmp/kt.log || { tail -5 /tmp/kt.log; exit 1; }
 cd $R
 python3 tools/prof_summary.py /tmp/kt > gpurun_out/${TAG}_bench_kernel_trace_summary.txt
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_bench_rocprofv3_kernel_stats.csv
-# separately labelled: the pipelined mode (next batch sketched beside the gather), default and priority streams --
-# the gather-path kernels share the CUs with the sketch kernel there, their times are no roofline figures
+# separately labelled: the default step (next batch sketched beside the query: niqki_sketch_ahead / niqki_query_ahead),
+# default and priority streams -- the gather-path kernels share the CUs with the sketch kernel there, their times are no
+# roofline figures (the trace also holds the few one-after-the-other steps bench.py takes its roofline from)
 cd /tmp
 for pm in "" "--priority-streams"; do
-  rm -rf /tmp/ktp; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktp -- python3 $R/bench.py --no-legs --pipeline $pm --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_pipelined${pm}.json 2> /tmp/ktp.log || { tail -5 /tmp/ktp.log; exit 1; }
-  python3 $R/tools/prof_summary.py /tmp/ktp > $R/gpurun_out/${TAG}_pipelined${pm}_kernel_trace_summary.txt
+  rm -rf /tmp/ktp; timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktp -- python3 $R/bench.py --no-legs $pm --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_bench_overlapped${pm}.json 2> /tmp/ktp.log || { tail -5 /tmp/ktp.log; exit 1; }
+  python3 $R/tools/prof_summary.py /tmp/ktp > $R/gpurun_out/${TAG}_overlapped${pm}_kernel_trace_summary.txt
 done
 cd $R
 bash tools/pmc_bench.sh ${TAG}_default || exit 1
 # two processes on this one GPU (bench.py --gpus 2 starts its own ranks when no launcher did): gloo for bench.py's own barrier, the library's ipc transport
 # for the exchange; with and without the next batch's sketch kernel beside the exchange
 for ov in "" "--no-overlap"; do
-  timeout -k 10 600 python3 bench.py --gpus 2 --steps 9 --warmup 2 --no-cpu --no-extra --verify $ov > gpurun_out/${TAG}_bench_n2_ipc_one_gpu${ov}.json 2> gpurun_out/${TAG}_bench_n2.err || { tail -5 gpurun_out/${TAG}_bench_n2.err; exit 1; }
+  timeout -k 10 600 python3 bench.py --gpus 2 --steps 9 --warmup 2 --no-cpu --no-extra $ov > gpurun_out/${TAG}_bench_n2_ipc_one_gpu${ov}.json 2> gpurun_out/${TAG}_bench_n2.err || { tail -5 gpurun_out/${TAG}_bench_n2.err; exit 1; }
 done
 timeout -k 10 600 python3 bench.py --shard-of 8 --no-cpu > gpurun_out/${TAG}_shard_of_8.json 2> gpurun_out/${TAG}_shard_of_8.err || exit 1
 # the weak-scaling shape of --gpus 8 on rank 0 (every rank brings 4096 queries), and all 8 ranks of the group on this one GPU
