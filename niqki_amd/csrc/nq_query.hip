@@ -137,6 +137,61 @@ struct PairWalk {
       __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   }
+#ifdef NQ_ABLATION
+  // COST MODEL of a one-tile walk (measurement only, wrong counters): per id what byte counters for
+  // 100 000 genomes in one tile would cost on top of the same lines -- a half-select by the id's position in its line
+  // (ids stay 16 bits: a bucket as [ids below the split | ids above]), the byte's increment 1 << 8 (id & 3) as a
+  // RETURNING ds_add, and the test whether the byte just wrapped (its old value 0xFF: the carry has to be logged).
+  uint32_t sa[L], sb[L];   // the chunks' split positions (stand-in: their lengths, fetched with the positions)
+  __device__ __forceinline__ void fetch_model(uint32_t (&g)[L], uint32_t (&sp)[L], const Item *items, uint32_t j0) {
+    const Item *mine = items + half;
+    uint32_t pos[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) { const Item it = mine[j0 + 2 * k]; pos[k] = it.pos; sp[k] = it.len; }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      uint64_t addr;
+      asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(addr) : "v"(pos[k]), "s"(128u), "v"((uint64_t)lane_base) : "vcc");
+      g[k] = *(const __attribute__((address_space(1))) uint32_t *)addr;
+    }
+  }
+  template <int PARTS>   // 3: all of it; 1: returning add + wrap test only; 2: half-select only (plain ds_add on the byte)
+  __device__ __forceinline__ bool apply_model(uint32_t (&g)[L], uint32_t (&sp)[L], uint32_t p0) {
+    bool carry = false;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t id = h ? g[k] >> 16 : g[k];                          // (the low id needs no mask: the and below drops the rest)
+        const uint32_t off = (PARTS & 2) ? ((p0 + (uint32_t)h >= sp[k]) ? 0x8000u : 0u) : 0u;   // which half of the genomes (model: an offset that stays inside the counters)
+        const uint32_t addr = (id & 0xFFFCu) | off;
+        const uint32_t sh = (id << 3) & 31u;
+        if (PARTS & 1) {
+          const uint32_t old = __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)addr, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          carry |= ((old >> sh) & 0xFFu) == 0xFFu;
+        } else {
+          __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)addr, 1u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    }
+    return carry;
+  }
+  template <int PARTS>
+  __device__ __forceinline__ bool batch_model(const Item *items, uint32_t p0) {
+    constexpr int R = 64 / UNROLL;
+    bool carry = false;
+    fetch_model(ga, sa, items, 0);
+#pragma unroll
+    for (int r = 0; r < R; r += 2) {
+      fetch_model(gb, sb, items, (r + 1) * UNROLL);
+      carry |= apply_model<PARTS>(ga, sa, p0);
+      if (r + 2 < R) fetch_model(ga, sa, items, (r + 2) * UNROLL);
+      carry |= apply_model<PARTS>(gb, sb, p0);
+    }
+    return carry;
+  }
+#endif
   // 64 chunks: items[0 .. 64) of the wave's queue; all their lines in flight before the first id is counted
   // (keeping a round in flight across batches, over the cutting of the next buckets, gained nothing: measured)
   __device__ __forceinline__ void batch(const Item *items) {
@@ -186,7 +241,7 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
   const uint32_t *my_units = v.slot_units + (uint64_t)t * (v.f_local + 1);
   Item *wq = queue + wave * kQueue;
   uint32_t q_head = 0, q_count = 0;  // wave-uniform
-  constexpr bool PAIR = PAD && MODE == 0 && (UNROLL == 16 || UNROLL == 32);
+  constexpr bool PAIR = PAD && (MODE == 0 || MODE == 9 || MODE == 10 || MODE == 11) && (UNROLL == 16 || UNROLL == 32);
   uint32_t prio_turn = wave >> 2;   // the four waves of a SIMD take turns at the issue arbiter's top priority (PAIR)
   PairWalk<PAIR ? UNROLL : 32> pw;
   pw.init(gl, lane);
@@ -234,6 +289,12 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
         else if (prio_turn == 1) __builtin_amdgcn_s_setprio(1);
         else if (prio_turn == 2) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(3);
+#ifdef NQ_ABLATION
+        if constexpr (MODE == 9 || MODE == 10 || MODE == 11) {
+          // (a wrapped byte would be logged: one append to a per-query list in global memory, by the lanes that saw one)
+          if (__any(pw.template batch_model<MODE == 9 ? 3 : MODE == 10 ? 1 : 2>(wq + q_head, 2u * (lane & 31u)))) sink += 1u;
+        } else
+#endif
         pw.batch(wq + q_head);             // (q_head is a multiple of 64: a batch never wraps; a wave's LDS traffic is in order)
         q_head = (q_head + 64) & (kQueue - 1);
         q_count -= 64;
@@ -1054,7 +1115,7 @@ hipError_t launch_order(const IndexView &v, const int32_t *sketches, uint32_t nq
 
 bool gather_variant_valid(int variant) {
 #ifdef NQ_ABLATION
-  if (variant == 11 || variant == 12 || variant == 16 || variant == 17 || variant == 18) return true;
+  if (variant == 11 || variant == 12 || variant == 16 || variant == 17 || variant == 18 || variant == 19 || variant == 20 || variant == 21) return true;
 #endif
   return variant >= 0 && variant <= 5;
 }
@@ -1113,6 +1174,9 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     case 16: NQ_BY_TILES(1024, 16, 6); break;
     case 17: NQ_BY_TILES(1024, 16, 7, true); break;
     case 18: NQ_BY_TILES(1024, 16, 8, true); break;
+    case 19: NQ_BY_TILES(1024, 32, 9, true); break;   // the one-tile walk's per-id cost on the same lines (PairWalk::apply_model)
+    case 20: NQ_BY_TILES(1024, 32, 10, true); break;  // ... its returning byte add + wrap test alone
+    case 21: NQ_BY_TILES(1024, 32, 11, true); break;  // ... its half-select alone (plain ds_add on the byte)
 #endif
     default:
       // small tiles (short-read indexes): counters of <= 24 KB leave room for several
