@@ -156,6 +156,66 @@ struct PairWalk {
       g[k] = *(const __attribute__((address_space(1))) uint32_t *)addr;
     }
   }
+  // PARTS 4 / 5 / 6 take the SHIPPED walk apart instead: 4 = its loads and vector work without the LDS atomics (the ids
+  // are folded into a register), 5 = one of its two atomics per dword, 6 = the chunks' positions by v_readlane from one
+  // queue read per batch instead of a ds_read_b32 per load.
+  __device__ __forceinline__ bool apply_part(uint32_t (&g)[L], int part) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      uint32_t even, addr, odd, inc, hi;
+      asm("v_and_b32 %0, 0xfffe, %1" : "=v"(even) : "v"(g[k]));
+      asm("v_add_u32 %0, %1, %1" : "=v"(addr) : "v"(even));
+      asm("v_and_b32 %0, 1, %1" : "=v"(odd) : "v"(g[k]));
+      asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc) : "v"(odd), "s"(0xFFFFu));
+      if (part == 4) acc ^= addr + inc;
+      else __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm("v_lshrrev_b32 %0, 16, %1" : "=v"(hi) : "v"(g[k]));
+      asm("v_and_b32 %0, 0xfffe, %1" : "=v"(even) : "v"(hi));
+      asm("v_add_u32 %0, %1, %1" : "=v"(addr) : "v"(even));
+      asm("v_and_b32 %0, 1, %1" : "=v"(odd) : "v"(hi));
+      asm("v_mad_u32_u24 %0, %1, %2, 1" : "=v"(inc) : "v"(odd), "s"(0xFFFFu));
+      if (part == 4 || part == 5) acc ^= addr + inc;
+      else __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)addr, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return acc == 0x12345u;
+  }
+  __device__ __forceinline__ void fetch_readlane(uint32_t (&g)[L], uint32_t posreg, uint32_t j0) {
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+      const uint32_t pa = __builtin_amdgcn_readlane(posreg, j0 + 2 * k), pb = __builtin_amdgcn_readlane(posreg, j0 + 2 * k + 1);
+      const uint32_t pos = half ? pb : pa;
+      uint64_t addr;
+      asm("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(addr) : "v"(pos), "s"(128u), "v"((uint64_t)lane_base) : "vcc");
+      g[k] = *(const __attribute__((address_space(1))) uint32_t *)addr;
+    }
+  }
+  template <int PART>
+  __device__ __forceinline__ bool batch_part(const Item *items, uint32_t lane) {
+    constexpr int R = 64 / UNROLL;
+    bool x = false;
+    if (PART == 6) {
+      const uint32_t posreg = items[lane].pos;
+      fetch_readlane(ga, posreg, 0);
+#pragma unroll
+      for (int r = 0; r < R; r += 2) {
+        fetch_readlane(gb, posreg, (r + 1) * UNROLL);
+        apply(ga);
+        if (r + 2 < R) fetch_readlane(ga, posreg, (r + 2) * UNROLL);
+        apply(gb);
+      }
+      return false;
+    }
+    fetch(ga, items, 0);
+#pragma unroll
+    for (int r = 0; r < R; r += 2) {
+      fetch(gb, items, (r + 1) * UNROLL);
+      x |= apply_part(ga, PART);
+      if (r + 2 < R) fetch(ga, items, (r + 2) * UNROLL);
+      x |= apply_part(gb, PART);
+    }
+    return x;
+  }
   template <int PARTS>   // 3: all of it; 1: returning add + wrap test only; 2: half-select only (plain ds_add on the byte)
   __device__ __forceinline__ bool apply_model(uint32_t (&g)[L], uint32_t (&sp)[L], uint32_t p0) {
     bool carry = false;
@@ -241,7 +301,7 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
   const uint32_t *my_units = v.slot_units + (uint64_t)t * (v.f_local + 1);
   Item *wq = queue + wave * kQueue;
   uint32_t q_head = 0, q_count = 0;  // wave-uniform
-  constexpr bool PAIR = PAD && (MODE == 0 || MODE == 9 || MODE == 10 || MODE == 11) && (UNROLL == 16 || UNROLL == 32);
+  constexpr bool PAIR = PAD && (MODE == 0 || (MODE >= 9 && MODE <= 14)) && (UNROLL == 16 || UNROLL == 32);
   uint32_t prio_turn = wave >> 2;   // the four waves of a SIMD take turns at the issue arbiter's top priority (PAIR)
   PairWalk<PAIR ? UNROLL : 32> pw;
   pw.init(gl, lane);
@@ -290,7 +350,9 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
         else if (prio_turn == 2) __builtin_amdgcn_s_setprio(2);
         else __builtin_amdgcn_s_setprio(3);
 #ifdef NQ_ABLATION
-        if constexpr (MODE == 9 || MODE == 10 || MODE == 11) {
+        if constexpr (MODE == 12 || MODE == 13 || MODE == 14) {
+          if (__any(pw.template batch_part<MODE == 12 ? 4 : MODE == 13 ? 5 : 6>(wq + q_head, lane))) sink += 1u;
+        } else if constexpr (MODE == 9 || MODE == 10 || MODE == 11) {
           // (a wrapped byte would be logged: one append to a per-query list in global memory, by the lanes that saw one)
           if (__any(pw.template batch_model<MODE == 9 ? 3 : MODE == 10 ? 1 : 2>(wq + q_head, 2u * (lane & 31u)))) sink += 1u;
         } else
@@ -1115,7 +1177,7 @@ hipError_t launch_order(const IndexView &v, const int32_t *sketches, uint32_t nq
 
 bool gather_variant_valid(int variant) {
 #ifdef NQ_ABLATION
-  if (variant == 11 || variant == 12 || variant == 16 || variant == 17 || variant == 18 || variant == 19 || variant == 20 || variant == 21) return true;
+  if (variant == 11 || variant == 12 || variant == 16 || variant == 17 || variant == 18 || (variant >= 19 && variant <= 24)) return true;
 #endif
   return variant >= 0 && variant <= 5;
 }
@@ -1177,6 +1239,9 @@ hipError_t launch_gather(const IndexView &v, const int32_t *sketches, uint32_t n
     case 19: NQ_BY_TILES(1024, 32, 9, true); break;   // the one-tile walk's per-id cost on the same lines (PairWalk::apply_model)
     case 20: NQ_BY_TILES(1024, 32, 10, true); break;  // ... its returning byte add + wrap test alone
     case 21: NQ_BY_TILES(1024, 32, 11, true); break;  // ... its half-select alone (plain ds_add on the byte)
+    case 22: NQ_BY_TILES(1024, 32, 12, true); break;  // the shipped walk without its LDS atomics
+    case 23: NQ_BY_TILES(1024, 32, 13, true); break;  // ... with one of the two atomics per dword
+    case 24: NQ_BY_TILES(1024, 32, 14, true); break;  // ... with the chunks' positions by v_readlane (no ds_read per load); counters exact
 #endif
     default:
       // small tiles (short-read indexes): counters of <= 24 KB leave room for several
