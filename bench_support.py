@@ -269,43 +269,43 @@ def launch_ranks(n):
 
 def roofline_record(achieved_alg, traffic, traffic_source, live, gather_ms, launches, alg_bytes, layout_min, copy_gbs, measured_in,
                     T, n_q_local, pipeline):
-    """The `roofline` object of the line.  `frac` is what the memory system moved (PMC counters, per launch) over the
-    launch time over the spec peak -- bytes that really crossed the L2's memory side (only a working set that the 256 MB
-    Infinity Cache serves could push it past 1: not this 17 GB index); without a counter measurement for this shape, the bytes
-    the layout cannot avoid stand in (a lower bound of the traffic).  SURVEY.md 8(d)'s algorithmic figure (4-byte ids,
-    every query's lines counted for itself) is `achieved` / `frac_algorithmic`: the layout stores 2-byte ids and an
-    XCD's L2 serves lines that neighbouring queries share, so that one can pass 1.  `achieved` is the same basis as
-    `frac` in GB/s (so frac = achieved / peak); the algorithmic rate is `achieved_algorithmic`."""
+    """The `roofline` object of the line.  Three byte counts per launch over the same launch time:
+      * `achieved` / `frac`: the bytes this layout CANNOT avoid (2-byte ids of the touched buckets, one 8-byte table entry per
+        slot and tile, the sketch in, the 2-byte counter row out) -- a lower bound of what HBM moved, so a fraction that can
+        never flatter the kernel (VERDICT r5 item 6);
+      * `achieved_algorithmic` / `frac_algorithmic`: SURVEY.md 8(d)'s formula 4T + 20F, which counts 4 bytes per id as the
+        reference stores them and every query's lines for itself: it can pass 1 (the layout stores 2-byte ids);
+      * `traffic` / `traffic_frac`: what the L2s requested from the fabric (rocprofv3 --pmc: 2 x FETCH_SIZE + WRITE_SIZE,
+        MI355X_MICROARCH.md HBM section) -- Infinity-Cache hits and lines that several XCDs fetch are inside, so an UPPER
+        bound of the HBM-proper fraction; `copy_ceiling_frac` holds it against the streaming copy measured in the run.
+    No counter of this device separates the Infinity Cache's hits from HBM reads (TCC_EA0_RDREQ_DRAM counts requests
+    "destined for DRAM", cache or not: profiles/r06_bench_pmc_dram_counters.txt), so the truth lies between `frac` and
+    `traffic_frac`."""
     n = max(1, launches)
     t_launch = gather_ms / n * 1e-3
     alg_l, lay_l = alg_bytes / n, layout_min / n
     real_gbs = traffic / t_launch / 1e9 if (traffic and t_launch) else None
     lay_gbs = lay_l / t_launch / 1e9 if t_launch else None
-    basis_gbs = real_gbs if real_gbs is not None else lay_gbs
     rec = {
         "kernel": "nq::gather_kernel (gather-histogram, rank 0's slot shard) incl. its look-up pre-pass and probe / order passes",
-        # achieved = what the memory system moved per second (frac = achieved / peak); SURVEY.md 8(d)'s formula, which
-        # counts 4 bytes per id and can pass the peak, is achieved_algorithmic / frac_algorithmic
-        "bound": "hbm", "achieved": basis_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": (basis_gbs / HBM_PEAK_GBS) if basis_gbs else None,
+        "bound": "hbm", "achieved": lay_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": (lay_gbs / HBM_PEAK_GBS) if lay_gbs else None,
+        "frac_basis": "layout_min_bytes_per_launch / avg_launch_ms / peak: the bytes this layout cannot avoid (a lower bound of what HBM moved)",
         "achieved_algorithmic": achieved_alg,
-        "frac_basis": ("traffic: (2 x FETCH_SIZE + WRITE_SIZE) per launch / avg_launch_ms / peak" if real_gbs is not None
-                       else "layout_min_bytes_per_launch / avg_launch_ms / peak (no counter measurement for this shape in this run: "
-                            "a lower bound of the bytes moved)"),
-        "achieved_measured": real_gbs,
         "frac_algorithmic": achieved_alg / HBM_PEAK_GBS,
         "frac_layout_min": (lay_gbs / HBM_PEAK_GBS) if lay_gbs else None,
         "traffic": traffic, "traffic_source": traffic_source,
+        "traffic_gbs": real_gbs,
+        "traffic_frac": (real_gbs / HBM_PEAK_GBS) if real_gbs else None,
         "traffic_over_layout_min": (traffic / lay_l) if (traffic and lay_l) else None,
         "traffic_fetch_kb": live["fetch_kb"] if live else None, "traffic_write_kb": live["write_kb"] if live else None,
         "copy_gbs": copy_gbs,
         "copy_ceiling_frac": (real_gbs / copy_gbs) if (real_gbs and copy_gbs) else None,
-        "note": ("achieved_algorithmic / frac_algorithmic count the ALGORITHMIC bytes of SURVEY.md 8d (4 bytes per id as the reference stores "
-                 "them, bucket lines that neighbouring queries share counted for each): the layout moves 2-byte ids and an XCD's "
-                 "L2 serves shared lines, so that figure can pass 1.  achieved / frac are the counter traffic; FETCH_SIZE counts requests that "
-                 "leave the L2, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM section), so frac is an UPPER bound of the "
-                 "HBM-proper fraction.  traffic_over_layout_min: bytes moved over the bytes this layout cannot avoid (half-empty "
-                 "128-byte bucket lines are the difference)"
+        "note": ("frac counts only bytes the layout must move; frac_algorithmic counts SURVEY.md 8d's 4T + 20F (4-byte ids, shared lines "
+                 "counted per query) and can pass 1; traffic_frac is what the L2s requested from the fabric, Infinity-Cache hits "
+                 "included (an upper bound of the HBM fraction; it can pass copy_ceiling).  traffic_over_layout_min: half-empty 128-byte "
+                 "bucket lines are the difference.  What bounds the launch: the lines it fetches -- without any of its LDS atomics it "
+                 "is 3 % faster (profiles/r06_one_tile_cost_model.txt)"
                  + ("; with the next batch's sketch kernel beside the gather the two share the CUs, the gather launch time here "
                     "is not a roofline figure" if pipeline else "")),
         "algorithmic_bytes_per_launch": alg_l,

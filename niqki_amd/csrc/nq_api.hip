@@ -209,17 +209,40 @@ uint8_t *new_slab(size_t size) {
 }
 }  // namespace
 
+// Piece sizes come in classes (2^k and 1.5 x 2^k, in units of kPieceGran): a reader's buffers grow with their files,
+// and with exact sizes a freed piece was all but never asked for again -- page-locked memory that is registered once and
+// never returned piled up to several times the live buffers on a long list.
+static size_t piece_class(size_t bytes) {
+  const size_t n = (bytes + kPieceGran - 1) & ~(kPieceGran - 1);
+  size_t p = kPieceGran;
+  while (p * 2 <= n) p *= 2;
+  if (n == p) return p;
+  const size_t mid = (p + p / 2 + kPieceGran - 1) & ~(kPieceGran - 1);
+  return n <= mid ? mid : 2 * p;
+}
+
 void *host_alloc(size_t bytes) {
   if (bytes >= kSlabMin) {
-    const size_t n = (bytes + kPieceGran - 1) & ~(kPieceGran - 1);
+    const size_t n = piece_class(bytes);
     std::lock_guard<std::mutex> g(g_host_mu);
-    auto it = g_free_pieces.find(n);
-    if (it != g_free_pieces.end()) {
+    // the smallest free piece that holds the request, if it is not more than twice its class
+    auto it = g_free_pieces.lower_bound(n);
+    if (it != g_free_pieces.end() && it->first <= 2 * n) {
       void *p = it->second;
       g_free_pieces.erase(it);
       return p;
     }
     if (g_slabs.empty() || g_slabs.back().size - g_slabs.back().used < n) {
+      if (!g_slabs.empty()) {   // what is left of the slab before becomes a free piece instead of being abandoned
+        Slab &old = g_slabs.back();
+        const size_t tail = (old.size - old.used) & ~(kPieceGran - 1);
+        if (tail >= kSlabMin) {
+          void *tp = old.base + old.used;
+          old.used += tail;
+          g_piece_size[tp] = tail;
+          g_free_pieces.emplace(tail, tp);
+        }
+      }
       // (32 MB, 64, 128, then 256 MB slabs: a small run does not lock a quarter of a gigabyte)
       const size_t size = std::max(std::min(kSlabBytes, (size_t(32) << 20) << std::min<size_t>(g_slabs.size(), 3)), (n + kHuge - 1) & ~(kHuge - 1));
       uint8_t *base = new_slab(size);

@@ -203,7 +203,20 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
     roff[f + 1] = roff[f] + raw_len;
   }
   if (unpack_blocks > 0x7FFFFFFFull) return fail(ix, NIQKI_E_INVALID, "raw batch too large");
-  if (gz_refused) return fail(ix, NIQKI_E_GZIP, "gzip files whose trailers do not announce a plausible size (file_status)");
+  if (gz_refused) {
+    // The caller reads the refused files again (into the same buffers, as a rule) and stages the batch once more.  If
+    // this batch's bytes are on their way from a niqki_stage_raw_prefetch, that copy must have finished with the
+    // buffers first; only its slot is given up, a later batch's prefetch stays on its way.
+    for (int sl = 0; sl < 2; ++sl) {
+      auto &pr = ix->pre[sl];
+      if (pr.valid && mem == NIQKI_MEM_HOST && b->file_ptr && nf == pr.ptr.size() && std::equal(pr.ptr.begin(), pr.ptr.end(), b->file_ptr) &&
+          std::equal(pr.off.begin(), pr.off.end(), b->file_off)) {
+        NQ_HIP(ix, hipEventSynchronize(pr.ev));
+        pr.valid = false;
+      }
+    }
+    return fail(ix, NIQKI_E_GZIP, "gzip files whose trailers do not announce a plausible size (file_status)");
+  }
   const uint64_t T_raw = roff[nf];
   // chunk table: chunks never span two files
   std::vector<uint8_t> meta((size_t)(nf + 1) * 12 + nf + 16);

@@ -206,6 +206,9 @@ inline size_t tagged_size(const uint8_t *p, size_t avail) {
 }
 inline void tagged_inflate(const uint8_t *p, size_t total, std::vector<uint8_t> &out) {
   const size_t n = get_u32(p + total - 4), body = total - kTaggedHeader - 8;
+  // ISIZE comes from the file: before it sizes a buffer it must be what DEFLATE can make of the member's body at all
+  // (1032 : 1) and no more than a few of the writer's pieces -- a damaged trailer must not allocate gigabytes per member
+  if (n > 1032 * body + 64 || n > (size_t(64) << 20)) throw std::runtime_error("gzip stream is damaged");
   out.resize(n);
   const LibDeflate &ld = LibDeflate::get();
   bool ok;

@@ -121,8 +121,12 @@ Index::Index(const std::string &dump_file, bool pretty, const std::string &out_f
   // words -- the one serial thing about the format -- runs over memory, not over a reader call per bucket.
   std::unique_ptr<TaggedGzReader> tagged;
   std::unique_ptr<GzReader> plain;
-  if (TaggedGzReader::probe(dump_file)) tagged.reset(new TaggedGzReader(dump_file, host_threads()));
-  else plain.reset(new GzReader(dump_file));
+  if (TaggedGzReader::probe(dump_file)) {
+    // (a file that starts like one of ours but does not go on that way -- another gzip file appended, a member re-written
+    // by some tool -- is still a gzip file: zlib's stream reads it, as the reference's zstr would)
+    try { tagged.reset(new TaggedGzReader(dump_file, host_threads())); } catch (const std::exception &) { tagged.reset(); }
+  }
+  if (!tagged) plain.reset(new GzReader(dump_file));
   std::vector<uint8_t> buf, piece;
   size_t p = 0;   // parse position in buf
   auto more = [&]() -> bool {   // appends the stream's next piece

@@ -74,13 +74,15 @@ int main(int argc, char **argv) {
       if (z != all) { fprintf(stderr, "zlib read-back differs\n"); return 1; }
     }
   }
-  // damage: a flipped byte inside a member's payload, a cut file, a tag that overstates its member
+  // damage: a flipped byte inside a member's payload, a cut file, a tag that overstates its member, a trailer that
+  // announces gigabytes (must be refused before anything of that size is allocated)
   const std::vector<uint8_t> good = read_all(path);
-  for (int what = 0; what < 3; ++what) {
+  for (int what = 0; what < 4; ++what) {
     std::vector<uint8_t> bad = good;
     if (what == 0) bad[bad.size() / 2] ^= 0x40;
     if (what == 1) bad.resize(bad.size() - 100);
     if (what == 2) bad[16] ^= 0x10;
+    if (what == 3) { bad[bad.size() - 1] = 0xF0; bad[bad.size() - 2] = 0xFF; }   // ISIZE of the last member: ~4 GB
     write_all(path, bad);
     std::vector<uint8_t> back;
     std::string err;
