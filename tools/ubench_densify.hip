@@ -8,6 +8,10 @@
 //   form 3: U passes per round trip: U x R ds_min, U x R ds_read, wait, compares      (same LDS work, 1/U of the waits)
 //   form 4: as 0, but the addresses are lane-linear (no bank conflicts)
 //   form 5: as 0 without the ballots / popcounts (one OR-reduced compare per pass)
+//   form 6: 16-bit cells (half the LDS footprint: 16 waves per CU), no atomics: R ds_read_u16 of the targets, and only
+//           where a lane found its target empty (never here: the tail) a write / read-back / winner write
+//   form 7: the same with a third of the lanes finding an empty target every pass (the dense phase): R ds_read_u16,
+//           R masked ds_write_b16, R masked ds_read_u16, compares
 // Prints SIMD cycles per pass and wave (wall clock x 2.4 GHz) and passes per microsecond and CU.
 // Build: hipcc -O3 --offload-arch=gfx950 tools/ubench_densify.hip -o tools/bin/ubench_densify
 // Measurement aid for DESIGN.md 4.2; not part of the product.
@@ -40,7 +44,40 @@ __global__ __launch_bounds__(64) void pass_kernel(uint32_t iters, uint32_t *sink
     mk[k] = 0x80000000u | ((lane * R + (uint32_t)k) & Fm);
   }
   uint32_t tot = 0;
-  if (FORM == 3) {
+  if (FORM == 6 || FORM == 7) {
+    uint16_t *c16 = (uint16_t *)smem;
+    for (uint32_t it = 0; it < iters; ++it) {
+      uint32_t pre[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) pre[k] = c16[T[k] & Fm];
+      wave_lds_order();
+      bool prop[R], any = false;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        prop[k] = FORM == 7 ? ((pre[k] + it + lane) % 3u == 0u) : pre[k] == 0xFFFFu;
+        any |= prop[k];
+      }
+      if (__any(any)) {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+          if (prop[k]) c16[T[k] & Fm] = (uint16_t)(0x8000u | (mk[k] & 0xFFFu));
+        wave_lds_order();
+        uint32_t back[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) back[k] = prop[k] ? c16[T[k] & Fm] : 0u;
+        wave_lds_order();
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const bool won = prop[k] && back[k] == (0x8000u | (mk[k] & 0xFFFu));
+          if (won) c16[T[k] & Fm] = (uint16_t)(mk[k] & 0x3FFu);
+          tot += (uint32_t)__popcll(__ballot(won));
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < R; ++k) T[k] += B[k];
+      if (tot == 0xFFFFFFFFu) break;
+    }
+  } else if (FORM == 3) {
     for (uint32_t it = 0; it < iters; it += U) {
       uint32_t t[R];
 #pragma unroll
@@ -133,6 +170,10 @@ int main() {
   run<0, 2, 1>("0: the kernel's pass at 4 waves per CU", sink, lds4, 4);
   run<0, 2, 1>("0: the kernel's pass at 16 waves per CU", sink, lds16, 16);
   run<3, 2, 8>("3: U = 8 at 16 waves per CU", sink, lds16, 16);
+  run<6, 2, 1>("6: 16-bit cells, targets read, nothing empty (the tail), 16 waves per CU", sink, lds16, 16);
+  run<7, 2, 1>("7: 16-bit cells, a third of the lanes write / read back every pass, 16 waves per CU", sink, lds16, 16);
+  run<6, 2, 1>("6: the same tail pass at 8 waves per CU", sink, lds, 8);
+  run<7, 2, 1>("7: the same dense pass at 8 waves per CU", sink, lds, 8);
   run<0, 1, 1>("0: one entry per lane", sink, lds, 8);
   run<0, 4, 1>("0: four entries per lane", sink, lds, 8);
   hipFree(sink);
