@@ -279,7 +279,7 @@ def roofline_record(achieved_alg, traffic, traffic_source, live, gather_ms, laun
         MI355X_MICROARCH.md HBM section) -- Infinity-Cache hits and lines that several XCDs fetch are inside, so an UPPER
         bound of the HBM-proper fraction; `copy_ceiling_frac` holds it against the streaming copy measured in the run.
     No counter of this device separates the Infinity Cache's hits from HBM reads (TCC_EA0_RDREQ_DRAM counts requests
-    "destined for DRAM", cache or not: profiles/r06_bench_pmc_dram_counters.txt), so the truth lies between `frac` and
+    "destined for DRAM", cache or not: profiles/r06_bench_pmc_default_summary.txt), so the truth lies between `frac` and
     `traffic_frac`."""
     n = max(1, launches)
     t_launch = gather_ms / n * 1e-3
