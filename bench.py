@@ -1403,7 +1403,7 @@ def extra_workloads(niqki_amd, torch, dev, args, budget, out, guarded, reference
     # ---- `niqki -D` / `-L` end to end (tools/bench_dump_cli.py): 8192 genomes, 1.6 GB of buckets ----
     def leg_dump_load():
         j = child_json("dump_load_cli", [sys.executable, os.path.join(ROOT, "tools", "bench_dump_cli.py"), "--genomes", "8192", "--len", "200000"],
-                       300, 25)
+                       300, 10)
         if j:
             out["dump_load_cli"] = {
                 "workload": "niqki -I fof -D dump.gz, then niqki -L dump.gz -Q q: 8192 synthetic genomes of 200 kbp (K=31 S=15 W=12), the dump a "
@@ -1414,7 +1414,7 @@ def extra_workloads(niqki_amd, torch, dev, args, budget, out, guarded, reference
     # ---- the device inflate alone: 1024 gzip -6 genome files resident in HBM, one launch (tools/bench_inflate.py) ----
     def leg_inflate():
         j = child_json("gzip_inflate", [sys.executable, os.path.join(ROOT, "tools", "bench_inflate.py"), "--files", "2048", "--len", str(L),
-                                        "--distinct", "8", "--reps", "2"], 300, 25)
+                                        "--distinct", "8", "--reps", "2"], 300, 15)
         if j:
             out["gzip_inflate"] = {
                 "workload": "2048 gzip -6 FASTA files of %d bp inflated in one launch of nq::inflate_kernel (one wavefront per file, eight per "
@@ -1437,7 +1437,7 @@ def extra_workloads(niqki_amd, torch, dev, args, budget, out, guarded, reference
         if budget.want(name, est):
             guarded(name, fn)
     reference_leg()
-    for tag, n_files, gz, est in (("plain_fasta", 2048, False, 60), ("gzip_fasta", 2048, True, 60)):
+    for tag, n_files, gz, est in (("plain_fasta", 2048, False, 32), ("gzip_fasta", 2048, True, 58)):
         leg_cli(tag, n_files, gz, est)
     leg_dump_load()
     leg_inflate()

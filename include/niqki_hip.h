@@ -44,6 +44,8 @@
  *   NIQKI_SKETCH_WAVE=0     short records take the workgroup sketch kernel instead of the one-wavefront one;
  *   NIQKI_SKETCH_FILTER     0 = long records are sketched without the candidate filter, n >= 2 = with a fixed filter
  *                           strength (default: chosen per sketch).  Test switches of nq_sketch.hip's launch shapes.
+ *   NIQKI_DENSIFY_WINDOW=0  the one-wavefront kernel's densification passes propose from every entry in every pass
+ *                           instead of reading their targets a window ahead (the A/B figure in profiles/)
  * The `niqki` host program reads NIQKI_HOST_THREADS (reader threads; default: the CPUs the process may use),
  * NIQKI_HOST_TIMING (phase times on stderr), NIQKI_HOST_NO_PACK (plain FASTA files travel as their bytes),
  * NIQKI_HOST_NO_GPU_INFLATE (gzip files are always inflated by the reader threads), NIQKI_HOST_GPU_INFLATE_MIN (how many

@@ -19,6 +19,7 @@ struct SketchArgs {
   uint32_t densify;           // run densification before the store (splits == 1 only)
   uint32_t distinct;          // set by launch_sketch: densify over distinct values (short-read path)
   uint32_t filter;            // set by launch_sketch: candidate filter for long inputs
+  uint32_t window;            // set by launch_sketch: the short-read kernel's passes read their targets a window ahead
 };
 // avg_len: average input bytes per sketch (picks the launch shape)
 hipError_t launch_sketch(const SketchArgs &a, uint32_t n_entry, uint64_t avg_len,

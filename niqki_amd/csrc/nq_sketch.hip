@@ -812,7 +812,93 @@ __device__ __forceinline__ void wave_lds_order() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// The passes over R register entries per lane (entry e = k*64 + lane of elist).
+// The passes over R register entries per lane (entry e = k*64 + lane of elist), targets read a window ahead.
+//
+// A pass of the reference's loop (src/niqki_index.cpp:313-331) changes a cell only where an entry's target is EMPTY,
+// and in the coupon-collector tail (half of a read's ~420 passes run with fewer than 256 of the 4096 cells empty)
+// almost no target is.  So the targets of the next U passes are read first -- U x R plain LDS reads per lane in ONE
+// round trip -- and a pass then costs LDS traffic only for the entries whose target was empty in that window read:
+// they alone propose (ds_min), read back and, where they won, write; a pass without such an entry anywhere in the
+// wave costs one ballot.  The window read may be stale for the later passes of its window in one direction only: a
+// cell it saw empty may have been filled by an earlier pass of the window (cells never go back to empty); the
+// proposal that follows is then a ds_min on an occupied cell, which changes nothing, and its read-back is not the
+// proposer's own word.  Exactly the passes of the plain loop below; 1.05 x its speed on 150- and 300-base reads
+// (profiles/r06_densify_forms.txt, form a: the passes are paid in LDS instructions, and this form issues fewer only
+// where no lane proposes).
+template <int R, int U>
+__device__ __forceinline__ void densify_wave_entries_window(uint32_t *sk, const uint32_t *elist, uint32_t n_ent,
+                                                            uint32_t F, uint32_t empty) {
+  const uint32_t lane = threadIdx.x, Fm = F - 1u;
+  uint32_t T[R], B[R], mk[R], V[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const uint32_t e = (uint32_t)k * 64u + lane;
+    const bool valid = e < n_ent;
+    const uint32_t v = valid ? elist[2 * e + 1] : 0u;
+    V[k] = v;
+    mk[k] = valid ? (0x80000000u | elist[2 * e]) : kEmpty32;
+    T[k] = (uint32_t)unrev64(v);
+    B[k] = (uint32_t)rev64(v);
+  }
+  uint32_t idle = 0;
+  for (;;) {
+    uint32_t pre[U][R];
+    {
+      uint32_t t[R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) t[k] = T[k];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          pre[u][k] = sk[t[k] & Fm];
+          t[k] += B[k];
+        }
+    }
+    wave_lds_order();
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bool prop[R], any = false;
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        prop[k] = pre[u][k] == kEmpty32 && mk[k] != kEmpty32;   // (lanes without an entry never propose)
+        any |= prop[k];
+      }
+      uint32_t tot = 0;
+      if (__any(any)) {   // wave uniform
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+          if (prop[k]) atomicMin(&sk[T[k] & Fm], mk[k]);
+        wave_lds_order();
+        // all proposals of the wave are issued before any read-back: a read sees the surviving proposal of its cell
+        // (which names exactly one entry), or a value -- another pass's or, behind its winner's write, this pass's
+        uint32_t back[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) back[k] = prop[k] ? sk[T[k] & Fm] : 0u;
+        wave_lds_order();
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const uint32_t t = T[k] & Fm;
+          const bool won = prop[k] && back[k] == mk[k];
+          if (won) {
+            sk[t] = V[k];
+            const uint32_t m = 0x80000000u | t;
+            mk[k] = m < mk[k] ? m : mk[k];
+          }
+          tot += (uint32_t)__popcll(__ballot(won));
+        }
+        wave_lds_order();
+      }
+#pragma unroll
+      for (int k = 0; k < R; ++k) T[k] += B[k];
+      empty -= tot;
+      idle = tot ? 0u : idle + 1u;
+      if (empty == 0 || idle >= F) return;
+    }
+  }
+}
+
+// The plain form (NIQKI_DENSIFY_WINDOW=0: the A/B figure in profiles/): every entry proposes in every pass.
 template <int R>
 __device__ __forceinline__ void densify_wave_entries(uint32_t *sk, const uint32_t *elist, uint32_t n_ent,
                                                      uint32_t F, uint32_t empty) {
@@ -955,7 +1041,14 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
         densify_wave_cells(sk, d, empty0);
       } else {
         const uint32_t rounds = (n_ent + 63u) >> 6;   // wave uniform
-        if (rounds <= 1) densify_wave_entries<1>(sk, elist, n_ent, F, empty0);
+        if (a.window) {
+          if (rounds <= 1) densify_wave_entries_window<1, 8>(sk, elist, n_ent, F, empty0);
+          else if (rounds <= 2) densify_wave_entries_window<2, 8>(sk, elist, n_ent, F, empty0);
+          else if (rounds <= 3) densify_wave_entries_window<3, 4>(sk, elist, n_ent, F, empty0);
+          else if (rounds <= 4) densify_wave_entries_window<4, 4>(sk, elist, n_ent, F, empty0);
+          else densify_wave_entries_window<6, 4>(sk, elist, n_ent, F, empty0);
+        }
+        else if (rounds <= 1) densify_wave_entries<1>(sk, elist, n_ent, F, empty0);
         else if (rounds <= 2) densify_wave_entries<2>(sk, elist, n_ent, F, empty0);
         else if (rounds <= 3) densify_wave_entries<3>(sk, elist, n_ent, F, empty0);
         else if (rounds <= 4) densify_wave_entries<4>(sk, elist, n_ent, F, empty0);
@@ -1045,6 +1138,8 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
     const char *wv = std::getenv("NIQKI_SKETCH_WAVE");
     const size_t wl = sketch_reads_lds_bytes(a.d);
     if (avg_len <= 4096 && a.splits == 1 && a.halves == 1 && wl <= 40 * 1024 && !(wv && std::atoi(wv) == 0)) {
+      const char *dw = std::getenv("NIQKI_DENSIFY_WINDOW");   // 0: every entry proposes in every pass (measurement)
+      a.window = (dw && std::atoi(dw) == 0) ? 0u : 1u;
       hipError_t e = hipFuncSetAttribute((const void *)sketch_reads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(sketch_reads_kernel, dim3(n_entry), dim3(64), wl, stream, a);
