@@ -269,3 +269,19 @@ def test_s16_case_vs_reference(po, native):
     assert int(vec["D5_hit_counts"].max()) == 1 << 16
     raw = ix.dump_bytes() + "".join("g%d\n" % i for i in range(len(genomes))).encode()
     assert len(raw) == m["dump_len"] and hashlib.md5(raw).hexdigest() == m["dump_md5"]
+
+
+def test_index_build_over_slot_ranges_gives_the_single_thread_arrays(po):
+    """nqo_index_build_mt (what the bench and the full-size tests build their large oracle indexes with): the same
+    offsets and ids as the plain build, whatever the thread count."""
+    import numpy as np
+    p = po.make_params(31, 9, 8, 4, 0.1)
+    rng = np.random.default_rng(17)
+    sk = rng.integers(-1, 1 << 8, (300, 1 << 9)).astype(np.int32)
+    sk[7] = -1                                   # an empty sketch
+    sk[:, 100] = 5                               # one bucket with every genome
+    one = po.Index(p, sk, threads=1)
+    for th in (2, 3, 8, 600):
+        many = po.Index(p, sk, threads=th)
+        assert np.array_equal(one.offsets(), many.offsets()) and np.array_equal(one.gids(), many.gids()), th
+        assert np.array_equal(one.counts(sk[3]), many.counts(sk[3]))
