@@ -960,11 +960,16 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
   const uint32_t K = d.K, Km1 = d.K - 1u;
 
   for (uint32_t i = lane; i < 256; i += 64) lut[i] = code_entry(i);
+  // (the kernel's time is its LDS instructions: the passes over all cells move 16 bytes per lane; F is a multiple
+  // of 256 on this path -- S >= 8 -- or the loops below fall back to single cells)
+  const bool quads = (F & 255u) == 0u && ((uintptr_t)a.sketches & 15u) == 0u;   // (the caller's rows: 16-byte aligned as a rule)
   if (a.accumulate) {
     const uint32_t *src = (const uint32_t *)a.sketches + (uint64_t)entry * F;
-    for (uint32_t i = lane; i < F; i += 64) sk[i] = src[i];
+    if (quads) for (uint32_t i = 4 * lane; i < F; i += 256) *(uint4 *)(sk + i) = *(const uint4 *)(src + i);
+    else for (uint32_t i = lane; i < F; i += 64) sk[i] = src[i];
   } else {
-    for (uint32_t i = lane; i < F; i += 64) sk[i] = kEmpty32;
+    if (quads) for (uint32_t i = 4 * lane; i < F; i += 256) *(uint4 *)(sk + i) = make_uint4(kEmpty32, kEmpty32, kEmpty32, kEmpty32);
+    else for (uint32_t i = lane; i < F; i += 64) sk[i] = kEmpty32;
   }
   __syncthreads();
 
@@ -1023,16 +1028,32 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
 
   uint32_t *out = (uint32_t *)a.sketches + (uint64_t)entry * F;
   if (a.densify) {
-    // ---- entries: occupied cells in ascending order, dealt round-robin to the lanes ----
+    // ---- entries: the occupied cells, dealt to the lanes (any order: an entry only knows its own cell and value) ----
     uint32_t n_ent = 0;
-    for (uint32_t c0 = 0; c0 < F; c0 += 64) {
-      const uint32_t c = c0 + lane;
-      const uint32_t v = c < F ? sk[c] : kEmpty32;
-      const uint64_t bal = __ballot(v != kEmpty32);
-      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-      const uint32_t at = n_ent + rank;
-      if (v != kEmpty32 && at < kReadMaxEntries) { elist[2 * at] = c; elist[2 * at + 1] = v; }
-      n_ent += (uint32_t)__popcll(bal);
+    if (quads) {
+      for (uint32_t c0 = 0; c0 < F; c0 += 256) {
+        const uint4 q4 = *(const uint4 *)(sk + c0 + 4 * lane);
+        const uint32_t w[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint64_t bal = __ballot(w[i] != kEmpty32);
+          if (bal) {   // (wave uniform: a read's sketch is nearly empty here)
+            const uint32_t at = n_ent + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (w[i] != kEmpty32 && at < kReadMaxEntries) { elist[2 * at] = c0 + 4 * lane + (uint32_t)i; elist[2 * at + 1] = w[i]; }
+            n_ent += (uint32_t)__popcll(bal);
+          }
+        }
+      }
+    } else {
+      for (uint32_t c0 = 0; c0 < F; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const uint32_t v = c < F ? sk[c] : kEmpty32;
+        const uint64_t bal = __ballot(v != kEmpty32);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        const uint32_t at = n_ent + rank;
+        if (v != kEmpty32 && at < kReadMaxEntries) { elist[2 * at] = c; elist[2 * at + 1] = v; }
+        n_ent += (uint32_t)__popcll(bal);
+      }
     }
     __syncthreads();
     const uint32_t empty0 = F - n_ent;
@@ -1058,7 +1079,8 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
     }
     __syncthreads();
   }
-  for (uint32_t i = lane; i < F; i += 64) out[i] = sk[i];
+  if (quads) for (uint32_t i = 4 * lane; i < F; i += 256) *(uint4 *)(out + i) = *(const uint4 *)(sk + i);
+  else for (uint32_t i = lane; i < F; i += 64) out[i] = sk[i];
 }
 
 static size_t sketch_lds_bytes(const Derived &d, bool distinct, uint32_t ring_waves, uint32_t halves = 1) {
