@@ -32,7 +32,7 @@ and the matrix path, each with its own in-run parity check.
                                       (slots [0, F/8), the full query batch): the
                                       compute half of the 1 -> 8 scaling curve
 
-The whole default run keeps to a wall-clock budget (--budget-s, default 150 s from the start of the process): the
+The whole default run keeps to a wall-clock budget (--budget-s, default 140 s from the start of the process): the
 headline, `roofline` and `cpu_baseline` always run, every other leg starts only while its time is left, child processes
 get min(their own limit, what is left), and `budget.dropped` names what did not run.
 """
@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not run the next batch's sketch kernel beside the gather and hit kernels (N = 1) / the exchange "
                          "(N > 1) of the current one")
-    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("NIQKI_BENCH_BUDGET_S", "150")),
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("NIQKI_BENCH_BUDGET_S", "140")),
                     help="wall-clock budget of the whole run in seconds, from the start of the process (see the module docstring)")
     ap.add_argument("--verify", action="store_true", help=argparse.SUPPRESS)        # (the default for N > 1 since round 6)
     ap.add_argument("--no-verify", action="store_true",
