@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1 << 20)
     ap.add_argument("--genomes", type=int, default=10_000)
     ap.add_argument("--min-score", type=int, default=2)
+    ap.add_argument("--gather-variants", default="", help="also the hit-list form under these gather_variant launch shapes (3: 512, 4: 256, 5: 128 threads)")
     args = ap.parse_args()
     import torch
     import bench
@@ -59,9 +60,11 @@ def main():
     rhc = torch.zeros(rcap, dtype=torch.int32, device=dev)
     rhg = torch.zeros(rcap, dtype=torch.int32, device=dev)
     ref = None
-    for name, opts in (("counter rows", {"hit_lists": 0}), ("hit lists, cap 256", {"hit_lists": 1, "hit_list_cap": 256}),
-                       ("hit lists, cap 64", {"hit_list_cap": 64}), ("hit lists, cap 512", {"hit_list_cap": 512}),
-                       ("hit lists, cap 1024", {"hit_list_cap": 1024})):
+    forms = [("counter rows", {"hit_lists": 0}), ("hit lists, cap 256", {"hit_lists": 1, "hit_list_cap": 256}),
+             ("hit lists, cap 64", {"hit_list_cap": 64}), ("hit lists, cap 512", {"hit_list_cap": 512}),
+             ("hit lists, cap 1024", {"hit_list_cap": 1024})]
+    forms += [("hit lists, cap 256, gather_variant %s" % v, {"hit_list_cap": 256, "gather_variant": int(v)}) for v in args.gather_variants.split(",") if v]
+    for name, opts in forms:
         for k, v in opts.items():
             e.set_option(k, v)
 
