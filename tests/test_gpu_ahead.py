@@ -132,3 +132,41 @@ def test_reads_ahead(native, po):
             lo, hi = int(got_off[i]), int(got_off[i + 1])
             assert np.array_equal(hc[lo:hi], ec) and np.array_equal(hg[lo:hi], eg), i
     e.close()
+
+
+@pytest.mark.parametrize("how", ["paged", "s16", "two_tiles_and_delta"])
+def test_ahead_on_the_other_index_forms(native, po, how):
+    """niqki_query_ahead is niqki_query behind a sketch made ahead: a paged index (counters added page by page), S = 16
+    (two counter planes, counts up to 2^16) and a two-tile index with a delta segment answer through it as they do
+    through niqki_query_sequences."""
+    import torch
+    Sx, Wx, Hx = (16, 10, 4) if how == "s16" else (9, 10, 3)
+    kw = dict(K=31, S=Sx, W=Wx, H=Hx, J=0.05)
+    if how == "paged":
+        kw["resident_mib"] = 1
+    if how == "two_tiles_and_delta":
+        kw["tile_genomes"] = 4160
+    e = native.Engine(**kw)
+    e.set_stream(torch.cuda.current_stream().cuda_stream)
+    n_gen, Lg = (40, 90_000) if how == "s16" else ((9000, 3_000) if how == "two_tiles_and_delta" else (300, 20_000))
+    fam, mem, rate = family_spec(max(1, n_gen // 10), 10)
+    fam, mem, rate = fam[:n_gen], mem[:n_gen], rate[:n_gen]
+    genomes = [native.synth_genome_host(23, int(f), int(m), int(r), Lg) for f, m, r in zip(fam, mem, rate)]
+    first = n_gen - (600 if how == "two_tiles_and_delta" else 0)
+    e.insert(e.sketch(genomes[:first]))
+    if how == "two_tiles_and_delta":
+        e.build()
+        e.insert(e.sketch(genomes[first:]))      # genomes after a build: the delta segment
+    nq = 12
+    qs = [native.synth_genome_host(23, i % 7, 2000 + i, 90, Lg - 11 * i) for i in range(nq)]
+    off = np.zeros(nq + 1, np.int64)
+    off[1:] = np.cumsum([len(s) for s in qs])
+    d_seq = torch.from_numpy(np.concatenate(qs + [np.zeros(native.SEQ_PAD, np.uint8)])).cuda()
+    d_off = torch.from_numpy(off).cuda()
+    want = e.query_sequences(qs)
+    for rep in range(2):
+        e.sketch_ahead_dev(d_seq, d_off, nq)
+        got = e.query_ahead(nq)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (how, rep)
+    assert int(want[0][-1]) > 0
+    e.close()
