@@ -297,7 +297,7 @@ int niqki_query_sequences(niqki_index *ix, const uint8_t *seqs,
  *     niqki_sketch_ahead(batch 0);
  *     for i: niqki_sketch_ahead(batch i + 1); niqki_query_ahead(hits of batch i);
  * -- has batch i + 1's sketch kernel (bound by vector instruction issue) running beside batch i's gather and hit
- * kernels (bound by HBM): 164 k against 156 k query genomes/s at the 100 000-genome shape.  At most two
+ * kernels (bound by HBM): 164 k against 158 k query genomes/s at the 100 000-genome shape.  At most two
  * batches are ahead at a time (NIQKI_E_STATE beyond).  Device memory only, and the one call whose device inputs are NOT
  * taken in the order of the handle's stream: `seqs`, `rec_off` and `entry_rec` are read on the sketch lane, so they must
  * be complete when niqki_sketch_ahead is called and stay untouched until the niqki_query_ahead that takes the batch
