@@ -54,9 +54,11 @@ constexpr uint32_t kQueue = 256;  // items per wave-private LDS work queue
 // loads of round r+1 are issued before the LDS atomics of round r; unconditional
 // loads, lanes past a chunk's end read what follows it and are masked).
 // The form of indexes that are not padded (and of the measurement modes); padded ones take PairWalk below.
-template <int UNROLL, int MODE>
+// n (wave uniform, PARTIAL only): how many of the 64 lanes hold a chunk -- the last batch of a tile's walk; a short
+// read's whole walk is such a batch of ~10 chunks per wave, and walking all 64 places cost it half of its instructions.
+template <int UNROLL, int MODE, bool PARTIAL = false>
 __device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t pos, uint32_t len,
-                                       uint32_t lane, uint32_t *cnt, uint32_t &sink) {
+                                       uint32_t lane, uint32_t *cnt, uint32_t &sink, uint32_t n = 64) {
   uint32_t ga[UNROLL], gb[UNROLL];
   auto fetch = [&](uint32_t j0, uint32_t (&g)[UNROLL]) {
 #pragma unroll
@@ -74,6 +76,20 @@ __device__ __forceinline__ void walk64(const uint16_t *gl, uint32_t a, uint32_t 
     }
   };
   fetch(0, ga);
+  if constexpr (PARTIAL) {
+#pragma unroll
+    for (uint32_t j0 = 0; j0 < 64; j0 += 2 * UNROLL) {
+      const bool more1 = j0 + UNROLL < n;   // (wave uniform)
+      if (more1) fetch(j0 + UNROLL, gb);
+      apply(j0, ga);
+      if (!more1) break;
+      const bool more2 = j0 + 2 * UNROLL < 64 && j0 + 2 * UNROLL < n;
+      if (more2) fetch(j0 + 2 * UNROLL, ga);
+      apply(j0 + UNROLL, gb);
+      if (!more2) break;
+    }
+    return;
+  }
 #pragma unroll
   for (uint32_t j0 = 0; j0 < 64; j0 += 2 * UNROLL) {
     fetch(j0 + UNROLL, gb);
@@ -441,7 +457,7 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
       } else {
         Item x = wq[(q_head + lane) & (kQueue - 1)];
         if (lane >= q_count) x = Item{PAD ? my_units[v.f_local] : 0u, 0u};
-        walk64<UNROLL, MODE>(gl, a, x.pos, x.len, lane, cnt, sink);
+        walk64<(UNROLL > 8 ? 8 : UNROLL), MODE, true>(gl, a, x.pos, x.len, lane, cnt, sink, q_count);
       }
     }
     return;
@@ -504,7 +520,7 @@ __device__ __forceinline__ void walk_tile(const IndexView &v, const int32_t *sk,
     } else {
       Item x = wq[(q_head + lane) & (kQueue - 1)];
       if (lane >= q_count) x = Item{PAD ? my_units[v.f_local] : 0u, 0u};
-      walk64<UNROLL, MODE>(gl, a, x.pos, x.len, lane, cnt, sink);
+      walk64<(UNROLL > 8 ? 8 : UNROLL), MODE, true>(gl, a, x.pos, x.len, lane, cnt, sink, q_count);
     }
   }
 }
