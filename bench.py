@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--priority-streams", action="store_true",
                     help="N = 1: the handle's stream at the top of the device's stream priority range, its sketch lane at the "
                          "bottom (option stream_priority of the C ABI)")
+    ap.add_argument("--gather-cus", type=int, default=0, help=argparse.SUPPRESS)     # experiment: the device split in two
     ap.add_argument("--no-overlap", action="store_true",
                     help="do not run the next batch's sketch kernel beside the gather and hit kernels (N = 1) / the exchange "
                          "(N > 1) of the current one")
@@ -327,6 +328,23 @@ def main():
     # beside batch i+1's sketch kernel: a second handle sketches on a side stream, niqki_group_query_begin
     # returns without waiting, niqki_group_query_end is the step's one host wait.
     ahead = not use_dist and not emu and not args.no_overlap
+    if args.gather_cus and not use_dist and not emu:
+        # experiment (profiles/r06_cu_split.txt): the handle's stream limited to the low --gather-cus compute units of
+        # the device's numbering (one in eight per XCD), the sketch lane to the others
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        words = (ctypes.c_uint32 * ((cus + 31) // 32))()
+        for c in range(min(args.gather_cus, cus)):
+            words[c // 32] |= 1 << (c % 32)
+        masked = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(masked), len(words), words)
+        assert rc == 0 and masked.value, rc
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.ExternalStream(masked.value, device=dev))
+        eng.set_stream(masked.value)
+        if ahead and args.gather_cus < cus:
+            eng.set_option("sketch_lane_cus", cus - args.gather_cus)
     overlap = use_dist and not args.no_overlap
     if overlap:
         sk_eng = niqki_amd.Engine(K=K, S=S, W=W, H=H, J=J, device=local_dev)

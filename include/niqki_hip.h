@@ -175,6 +175,9 @@ int niqki_synchronize(niqki_index *ix);
  * the device's stream priority range -- also after niqki_set_stream, whose stream stays the caller's --, so
  * that e.g. a query handle's short kernels are dispatched ahead of another handle's long sketch kernel;
  * niqki_get_stream returns it),
+ * "sketch_lane_cus" (0 = default: all; n: the lane of niqki_sketch_ahead is made anew on the TOP n compute units of the
+ * device's numbering (hipExtStreamCreateWithCUMask) -- for a caller that fences the two lanes, with its own stream
+ * limited to the other units; on one MI355X the split is no faster than the hardware's own dispatch),
  * "hit_lists" (1 = default: on an index of ONE counter tile of at most 12 288 genomes -- the short-read shape of
  * src/niqki_index.cpp:412-430 -- niqki_query* / niqki_staged_query take a query's thresholded hits out of the gather
  * kernel while its counters are in LDS, already ordered, instead of writing a 2N-byte counter row per query and reading

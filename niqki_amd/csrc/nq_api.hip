@@ -513,6 +513,21 @@ int niqki_set_option(niqki_index *ix, const char *key, int64_t value) {
     ix->stream_prio_set = true;
     return NIQKI_OK;
   }
+  if (!std::strcmp(key, "sketch_lane_cus")) {
+    // the lane of niqki_sketch_ahead limited to the TOP `value` compute units of the device's numbering (0 = all); a
+    // caller that queries on a stream limited to the others (hipExtStreamCreateWithCUMask) splits the device in two
+    NQ_HIP(ix, hipSetDevice(ix->device));
+    int cus = 0;
+    NQ_HIP(ix, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device));
+    if (value < 0 || value > cus) return fail(ix, NIQKI_E_INVALID, "sketch_lane_cus must be 0 (all) .. the device's compute units");
+    if (ix->sk_stream) {
+      NQ_HIP(ix, hipStreamSynchronize(ix->sk_stream));
+      (void)hipStreamDestroy(ix->sk_stream);
+      ix->sk_stream = nullptr;
+    }
+    ix->sk_lane_cus = (uint32_t)value;
+    return NIQKI_OK;
+  }
   if (!std::strcmp(key, "min_score")) { ix->p.min_score = ix->d.min_score = (uint32_t)value; return NIQKI_OK; }
   return fail(ix, NIQKI_E_INVALID, std::string("unknown option ") + key);
 }

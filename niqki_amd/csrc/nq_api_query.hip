@@ -520,7 +520,13 @@ int niqki_sketch_ahead(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec
   NQ_HIP(ix, hipSetDevice(ix->device));
   if (!ix->sk_stream) {
     // the sketch lane never outranks the handle's stream: what a query is waiting for runs there
-    if (ix->stream_prio_set) {
+    int cus = 0;
+    NQ_HIP(ix, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ix->device));
+    if (ix->sk_lane_cus && (int)ix->sk_lane_cus < cus) {
+      std::vector<uint32_t> mask(((size_t)cus + 31) / 32, 0u);
+      for (int c = cus - (int)ix->sk_lane_cus; c < cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+      NQ_HIP(ix, hipExtStreamCreateWithCUMask(&ix->sk_stream, (uint32_t)mask.size(), mask.data()));
+    } else if (ix->stream_prio_set) {
       int least = 0, greatest = 0;
       NQ_HIP(ix, hipDeviceGetStreamPriorityRange(&least, &greatest));
       NQ_HIP(ix, hipStreamCreateWithPriority(&ix->sk_stream, hipStreamNonBlocking, least));

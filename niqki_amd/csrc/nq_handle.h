@@ -134,6 +134,7 @@ struct niqki_index {
   // niqki_sketch_ahead / niqki_query_ahead: the sketches of up to two coming query batches, made on the sketch lane (a
   // side stream of the handle) beside whatever the handle's stream runs -- the gather and hit kernels of the batch before
   hipStream_t sk_stream = nullptr;
+  uint32_t sk_lane_cus = 0;      // option "sketch_lane_cus": the sketch lane's compute units (0 = all)
   struct Ahead {
     nqi::Buf sk;                 // n_entry x F cells
     uint32_t n_entry = 0;

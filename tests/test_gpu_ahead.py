@@ -170,3 +170,21 @@ def test_ahead_on_the_other_index_forms(native, po, how):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2]), (how, rep)
     assert int(want[0][-1]) > 0
     e.close()
+
+
+def test_sketch_lane_on_a_part_of_the_device(native, po):
+    """option "sketch_lane_cus": the sketch lane made anew on a compute-unit mask; same sketches, same hits"""
+    import torch
+    e, p, ix = make_index(native, po, torch)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    with pytest.raises(native.NiqkiError):
+        e.set_option("sketch_lane_cus", cus + 1)
+    seqs, d_seq, d_off = batch(native, torch, 3, 16)
+    esk, eoff, ec, eg = expected(po, p, ix, seqs)
+    for lane in (0, cus // 4, cus - 8, 0):        # (set between batches: the lane is drained and made anew)
+        e.set_option("sketch_lane_cus", lane)
+        e.sketch_ahead_dev(d_seq, d_off, 16)
+        off, hc, hg, sk = e.query_ahead(16, want_sketches=True)
+        assert np.array_equal(sk, esk) and np.array_equal(off, eoff), lane
+        assert np.array_equal(hc, ec) and np.array_equal(hg, eg), lane
+    e.close()
