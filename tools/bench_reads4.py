@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1 << 20)
     ap.add_argument("--genomes", type=int, default=10_000)
     ap.add_argument("--min-score", type=int, default=2)
+    ap.add_argument("--ahead", action="store_true", help="also: without the per-class timers, serial and with the two-halves calls")
     ap.add_argument("--gather-variants", default="", help="also the hit-list form under these gather_variant launch shapes (3: 512, 4: 256, 5: 128 threads)")
     args = ap.parse_args()
     import torch
@@ -64,17 +65,29 @@ def main():
              ("hit lists, cap 64", {"hit_list_cap": 64}), ("hit lists, cap 512", {"hit_list_cap": 512}),
              ("hit lists, cap 1024", {"hit_list_cap": 1024})]
     forms += [("hit lists, cap 256, gather_variant %s" % v, {"hit_list_cap": 256, "gather_variant": int(v)}) for v in args.gather_variants.split(",") if v]
+    if args.ahead:   # the last batch's hits are those of the serial forms: the same bytes are expected
+        forms += [("hit lists, cap 256, no profile", {"hit_list_cap": 256, "_profile": 0}),
+                  ("hit lists, cap 256, batch i + 1 sketched beside batch i's query (niqki_sketch_ahead / niqki_query_ahead)",
+                   {"hit_list_cap": 256, "_ahead": 1, "_profile": 0})]
     for name, opts in forms:
         for k, v in opts.items():
-            e.set_option(k, v)
+            if not k.startswith("_"):
+                e.set_option(k, v)
 
         def run():
+            if opts.get("_ahead"):
+                e.sketch_ahead_dev(reads, rro, RB)
+                for a in range(0, NR, RB):
+                    if a + RB < NR:
+                        e.sketch_ahead_dev(reads[(a + RB) * RL:], rro, RB)
+                    e.query_ahead_dev(rho, rhc, rhg, rcap)
+                return
             for a in range(0, NR, RB):
                 e.sketch_dev(reads[a * RL:], rro, RB, rsk)
                 e.query_dev(rsk, RB, rho, rhc, rhg, rcap)
         run()
         e.synchronize()
-        e.profile(True)
+        e.profile(bool(opts.get("_profile", 1)))
         e.profile_reset()
         t0 = time.perf_counter()
         run()
