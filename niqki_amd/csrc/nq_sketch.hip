@@ -812,6 +812,18 @@ __device__ __forceinline__ void wave_lds_order() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Sum of a per-lane count over the wave (the usual DPP ladder: shifts inside the rows of 16 lanes, then the rows' last
+// lanes broadcast onward; lane 63 ends up with the total).  No LDS instruction, unlike a __shfl reduction.
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    // row_shr:1
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, true);    // row_shr:4, lanes 4..15 of a row
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, true);    // row_shr:8, lanes 8..15 of a row
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // The passes over R register entries per lane (entry e = k*64 + lane of elist), targets read a window ahead.
 //
 // A pass of the reference's loop (src/niqki_index.cpp:313-331) changes a cell only where an entry's target is EMPTY,
@@ -830,6 +842,9 @@ __device__ __forceinline__ void densify_wave_entries_window(uint32_t *sk, const 
                                                             uint32_t F, uint32_t empty) {
   const uint32_t lane = threadIdx.x, Fm = F - 1u;
   uint32_t T[R], B[R], mk[R], V[R];
+  // A lane without an entry in round k watches a cell that is occupied from the start (entry 0's own) and never
+  // moves on (B = 0): its window reads never show "empty", so it never proposes and the passes need no validity test.
+  const uint32_t cell0 = elist[0];
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     const uint32_t e = (uint32_t)k * 64u + lane;
@@ -837,8 +852,8 @@ __device__ __forceinline__ void densify_wave_entries_window(uint32_t *sk, const 
     const uint32_t v = valid ? elist[2 * e + 1] : 0u;
     V[k] = v;
     mk[k] = valid ? (0x80000000u | elist[2 * e]) : kEmpty32;
-    T[k] = (uint32_t)unrev64(v);
-    B[k] = (uint32_t)rev64(v);
+    T[k] = valid ? (uint32_t)unrev64(v) : cell0;
+    B[k] = valid ? (uint32_t)rev64(v) : 0u;
   }
   uint32_t idle = 0;
   for (;;) {
@@ -856,25 +871,30 @@ __device__ __forceinline__ void densify_wave_entries_window(uint32_t *sk, const 
         }
     }
     wave_lds_order();
+    // The exit tests run once per window: a pass behind the one that filled the last cell finds no empty target
+    // (or a stale "empty", whose proposal changes nothing), and fruitless passes beyond the F that prove a fixpoint
+    // change nothing either -- the cells are those of the loop that stops at the pass itself.
+    uint32_t wins = 0;   // per lane; summed over the wave once per window
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       bool prop[R], any = false;
 #pragma unroll
       for (int k = 0; k < R; ++k) {
-        prop[k] = pre[u][k] == kEmpty32 && mk[k] != kEmpty32;   // (lanes without an entry never propose)
+        prop[k] = pre[u][k] == kEmpty32;
         any |= prop[k];
       }
-      uint32_t tot = 0;
       if (__any(any)) {   // wave uniform
 #pragma unroll
         for (int k = 0; k < R; ++k)
           if (prop[k]) atomicMin(&sk[T[k] & Fm], mk[k]);
         wave_lds_order();
         // all proposals of the wave are issued before any read-back: a read sees the surviving proposal of its cell
-        // (which names exactly one entry), or a value -- another pass's or, behind its winner's write, this pass's
+        // (which names exactly one entry: the markers of two entries never agree), or a value -- another pass's or,
+        // behind its winner's write, this pass's.  (Read by all lanes: the LDS is paid per instruction, and a mask
+        // around it costs two scalar instructions.)
         uint32_t back[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) back[k] = prop[k] ? sk[T[k] & Fm] : 0u;
+        for (int k = 0; k < R; ++k) back[k] = sk[T[k] & Fm];
         wave_lds_order();
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -884,17 +904,18 @@ __device__ __forceinline__ void densify_wave_entries_window(uint32_t *sk, const 
             sk[t] = V[k];
             const uint32_t m = 0x80000000u | t;
             mk[k] = m < mk[k] ? m : mk[k];
+            ++wins;
           }
-          tot += (uint32_t)__popcll(__ballot(won));
         }
         wave_lds_order();
       }
 #pragma unroll
       for (int k = 0; k < R; ++k) T[k] += B[k];
-      empty -= tot;
-      idle = tot ? 0u : idle + 1u;
-      if (empty == 0 || idle >= F) return;
     }
+    const uint32_t tot_w = wave_sum_u32(wins);
+    empty -= tot_w;
+    idle = tot_w ? 0u : idle + (uint32_t)U;
+    if (empty == 0 || idle >= F) return;
   }
 }
 

@@ -26,6 +26,9 @@ def main():
     import torch
     import bench
     import niqki_amd
+    if os.environ.get("NIQKI_EXP_LIB"):      # A/B against another build of the library (tools/bin/, never the product's path)
+        from niqki_amd import capi
+        capi._LIB = os.path.abspath(os.environ["NIQKI_EXP_LIB"])
     K, S, W, H = 31, 12, 10, 4
     F, N, L, RL, RB, NR = 1 << S, args.genomes, 5_000_000, 150, 65536, args.reads
     dev = torch.device("cuda", 0)
