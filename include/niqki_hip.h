@@ -46,6 +46,7 @@
  *                           strength (default: chosen per sketch).  Test switches of nq_sketch.hip's launch shapes.
  *   NIQKI_DENSIFY_WINDOW=0  the one-wavefront kernel's densification passes propose from every entry in every pass
  *                           instead of reading their targets a window ahead (the A/B figure in profiles/)
+ *   NIQKI_DENSIFY_TAIL=0    ... and run to the end instead of filling their last 16 empty cells in closed form
  * The `niqki` host program reads NIQKI_HOST_THREADS (reader threads; default: the CPUs the process may use),
  * NIQKI_HOST_TIMING (phase times on stderr), NIQKI_HOST_NO_PACK (plain FASTA files travel as their bytes),
  * NIQKI_HOST_NO_GPU_INFLATE (gzip files are always inflated by the reader threads), NIQKI_HOST_GPU_INFLATE_MIN (how many

@@ -824,6 +824,135 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// Minimum of a per-lane word over the wave (the same DPP ladder as wave_sum_u32; lanes the ladder leaves out bring
+// the identity 2^32 - 1).
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#define NQ_DPP_MIN(CTRL, ROWS, BANKS)                                                                      \
+  {                                                                                                        \
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROWS, BANKS, false);        \
+    v = o < v ? o : v;                                                                                     \
+  }
+  NQ_DPP_MIN(0x111, 0xf, 0xf)   // row_shr:1
+  NQ_DPP_MIN(0x112, 0xf, 0xf)   // row_shr:2
+  NQ_DPP_MIN(0x114, 0xf, 0xe)   // row_shr:4, lanes 4..15 of a row
+  NQ_DPP_MIN(0x118, 0xf, 0xc)   // row_shr:8, lanes 8..15 of a row
+  NQ_DPP_MIN(0x142, 0xa, 0xf)   // row_bcast:15 into rows 1 and 3
+  NQ_DPP_MIN(0x143, 0xc, 0xf)   // row_bcast:31 into rows 2 and 3
+#undef NQ_DPP_MIN
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// ---- the last cells of a short record's densification in closed form --------------------------------------------
+// Going from E empty cells to E - 1 takes F / (n E) passes (coupon collector; more where only few orbits reach a cell),
+// so more than half of a 150-base read's ~420 passes fill its last 16 cells, and a pass costs its LDS instructions
+// whatever it fills.  Once at most kTailCells cells are empty the passes stop.  An entry's target is affine in the
+// pass (src/niqki_index.cpp:308-310): T_k + s B_k = c (mod F) with B_k = 2^j odd has the solution
+//     s_k(c) = ((c - T_k) >> j) odd^-1  mod (F >> j)      if 2^j divides c - T_k, none otherwise
+// (odd^-1 by Newton steps, once per entry).  Cell c is filled in pass s* = min_k s_k(c) by the entry that reaches it
+// then -- among several, by the one whose value sits at the smallest cell index at the start of that pass (:313-331:
+// the first writer of the ascending loop).  The lanes keep their entries; the cells are taken one after another:
+// every lane solves for its own entries, one wave-wide minimum of (s << 15 | index at the start of the tail) names
+// pass and winner.  An index can still drop during the tail (an entry wins a cell below its own), which matters only
+// to a cell that several entries reach in its pass s*, and only if one of the LOSING ones has won some cell in an
+// earlier pass of the tail: that case (a few reads in a hundred) is detected and handed back to the passes, which
+// are exact for anything -- nothing is written before the check.  Cells no orbit reaches stay empty, as after the F
+// fruitless passes that end the loop (the oracle's rule).  Pinned by the goldens, tests/test_gpu_fuzz.py,
+// tests/test_gpu_reads_config.py.
+constexpr uint32_t kTailCells = 16;   // (8 .. 24 measure the same; 48: 3 % slower)
+
+// T: every entry's target of the NEXT pass, B its stride, mk = 2^31 | the smallest index that holds its value, V its
+// value (lanes without an entry: an occupied cell as T, B = 0 -- they reach no empty cell).  scratch: 2 x 64 words.
+// true: every reachable empty cell is filled; false: nothing was touched, the passes go on.
+template <int R>
+__device__ __forceinline__ bool densify_tail(uint32_t *sk, uint32_t *scratch, uint32_t F, const uint32_t (&T)[R],
+                                             const uint32_t (&B)[R], const uint32_t (&mk)[R], const uint32_t (&V)[R]) {
+  const uint32_t lane = threadIdx.x, Fm = F - 1u;
+  uint32_t *list = scratch, *vals = scratch + 64;
+  // ---- the empty cells (F is a multiple of 256 on this path) ----
+  uint32_t n_e = 0;
+  vals[lane] = kEmpty32;
+  for (uint32_t c0 = 0; c0 < F; c0 += 256) {
+    const uint4 v = *(const uint4 *)(sk + c0 + 4 * lane);
+    const uint32_t m01 = v.x > v.y ? v.x : v.y, m23 = v.z > v.w ? v.z : v.w;
+    if (__any((m01 > m23 ? m01 : m23) == kEmpty32)) {   // (wave uniform, rare: the sketch is nearly full)
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool e = w[i] == kEmpty32;
+        const uint64_t bal = __builtin_amdgcn_ballot_w64(e);
+        const uint32_t at = n_e + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (e && at < 64u) list[at] = c0 + 4 * lane + (uint32_t)i;
+        n_e += (uint32_t)__builtin_popcountll(bal);
+      }
+    }
+  }
+  wave_lds_sync();
+  if (n_e > 64u) return false;   // (cannot happen: the caller counted)
+  const uint32_t cells = lane < n_e ? list[lane] : 0u;
+  // ---- the entries' orbits: stride = 2^j odd; B = 0 (mod F): the orbit is the one cell T (j = log2 F, s = 0) ----
+  uint32_t low[R], jsh[R], inv[R], win_min[R], lose_max[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const uint32_t j = (uint32_t)__builtin_ctz((B[k] & Fm) | F);
+    const uint32_t odd = (B[k] >> j) | 1u;
+    uint32_t x = odd;                       // correct to 3 bits; every step doubles them
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x *= 2u - odd * x;
+    low[k] = (1u << j) - 1u;
+    jsh[k] = j;
+    inv[k] = x;
+    win_min[k] = 0xFFFFFFFFu;
+    lose_max[k] = 0u;
+  }
+  // one cell: its keys per entry (s << 15 | index; all ones: the orbit never reaches it) and the lane's smallest
+  auto solve = [&](uint32_t c, uint32_t (&key)[R]) -> uint32_t {
+    uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const uint32_t x = c - T[k];
+      const uint32_t s = ((x * inv[k]) & Fm) >> jsh[k];   // valid when 2^j divides x
+      key[k] = (x & low[k]) == 0u ? ((s << 15) | (mk[k] & 0x7FFFu)) : 0xFFFFFFFFu;
+      best = key[k] < best ? key[k] : best;
+    }
+    return best;
+  };
+  // ... and what follows from the wave's smallest key: the winner's value, the passes of wins and of lost ties
+  auto settle = [&](uint32_t ci, uint32_t wkey, const uint32_t (&key)[R]) {
+    if (wkey == 0xFFFFFFFFu) return;        // no orbit reaches the cell: it stays empty
+    const uint32_t s_star = wkey >> 15, top = wkey | 0x7FFFu;
+    uint32_t n_tied = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      n_tied += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[k] <= top));
+      if (key[k] == wkey) {
+        vals[ci] = V[k];
+        win_min[k] = s_star < win_min[k] ? s_star : win_min[k];
+      }
+    }
+    if (n_tied > 1u) {   // (wave uniform, rare) the entries that reach the cell in its pass and lose it
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+        if (key[k] <= top && key[k] != wkey) lose_max[k] = s_star > lose_max[k] ? s_star : lose_max[k];
+    }
+  };
+  for (uint32_t ci = 0; ci < n_e; ++ci) {   // (wave uniform; two cells per round are no faster)
+    uint32_t key[R];
+    const uint32_t best = solve((uint32_t)__builtin_amdgcn_readlane((int)cells, (int)ci), key);
+    settle(ci, wave_min_u32(best), key);
+  }
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < R; ++k) bad |= win_min[k] < lose_max[k];
+  if (__any(bad)) return false;
+  wave_lds_sync();
+  if (lane < n_e) {
+    const uint32_t v = vals[lane];
+    if (v != kEmpty32) sk[cells] = v;
+  }
+  wave_lds_sync();
+  return true;
+}
+
 // The passes over R register entries per lane (entry e = k*64 + lane of elist), targets read a window ahead.
 //
 // A pass of the reference's loop (src/niqki_index.cpp:313-331) changes a cell only where an entry's target is EMPTY,
@@ -839,7 +968,7 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 // where no lane proposes).
 template <int R, int U>
 __device__ __forceinline__ void densify_wave_entries_window(uint32_t *sk, const uint32_t *elist, uint32_t n_ent,
-                                                            uint32_t F, uint32_t empty) {
+                                                            uint32_t F, uint32_t empty, uint32_t *scratch, bool tail) {
   const uint32_t lane = threadIdx.x, Fm = F - 1u;
   uint32_t T[R], B[R], mk[R], V[R];
   // A lane without an entry in round k watches a cell that is occupied from the start (entry 0's own) and never
@@ -916,6 +1045,10 @@ __device__ __forceinline__ void densify_wave_entries_window(uint32_t *sk, const 
     empty -= tot_w;
     idle = tot_w ? 0u : idle + (uint32_t)U;
     if (empty == 0 || idle >= F) return;
+    if (tail && empty <= kTailCells) {   // (wave uniform) the last cells in closed form; once
+      if (densify_tail<R>(sk, scratch, F, T, B, mk, V)) return;
+      tail = false;
+    }
   }
 }
 
@@ -1084,11 +1217,15 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
       } else {
         const uint32_t rounds = (n_ent + 63u) >> 6;   // wave uniform
         if (a.window) {
-          if (rounds <= 1) densify_wave_entries_window<1, 8>(sk, elist, n_ent, F, empty0);
-          else if (rounds <= 2) densify_wave_entries_window<2, 8>(sk, elist, n_ent, F, empty0);
-          else if (rounds <= 3) densify_wave_entries_window<3, 4>(sk, elist, n_ent, F, empty0);
-          else if (rounds <= 4) densify_wave_entries_window<4, 4>(sk, elist, n_ent, F, empty0);
-          else densify_wave_entries_window<6, 4>(sk, elist, n_ent, F, empty0);
+          // (the position codes are done with: their space holds the tail's two lists)
+          uint32_t *scratch = (uint32_t *)codes;
+          static_assert(kReadTile >= 2 * 64 * 4, "the tail's lists live in the position codes' space");
+          const bool tail = a.window >= 2 && quads;
+          if (rounds <= 1) densify_wave_entries_window<1, 8>(sk, elist, n_ent, F, empty0, scratch, tail);
+          else if (rounds <= 2) densify_wave_entries_window<2, 8>(sk, elist, n_ent, F, empty0, scratch, tail);
+          else if (rounds <= 3) densify_wave_entries_window<3, 4>(sk, elist, n_ent, F, empty0, scratch, tail);
+          else if (rounds <= 4) densify_wave_entries_window<4, 4>(sk, elist, n_ent, F, empty0, scratch, tail);
+          else densify_wave_entries_window<6, 4>(sk, elist, n_ent, F, empty0, scratch, tail);
         }
         else if (rounds <= 1) densify_wave_entries<1>(sk, elist, n_ent, F, empty0);
         else if (rounds <= 2) densify_wave_entries<2>(sk, elist, n_ent, F, empty0);
@@ -1182,7 +1319,8 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
     const size_t wl = sketch_reads_lds_bytes(a.d);
     if (avg_len <= 4096 && a.splits == 1 && a.halves == 1 && wl <= 40 * 1024 && !(wv && std::atoi(wv) == 0)) {
       const char *dw = std::getenv("NIQKI_DENSIFY_WINDOW");   // 0: every entry proposes in every pass (measurement)
-      a.window = (dw && std::atoi(dw) == 0) ? 0u : 1u;
+      const char *dt = std::getenv("NIQKI_DENSIFY_TAIL");     // 0: passes to the end, no closed-form tail (measurement)
+      a.window = (dw && std::atoi(dw) == 0) ? 0u : (dt && std::atoi(dt) == 0) ? 1u : 2u;
       hipError_t e = hipFuncSetAttribute((const void *)sketch_reads_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL(sketch_reads_kernel, dim3(n_entry), dim3(64), wl, stream, a);

@@ -122,3 +122,33 @@ def test_long_records_random_parameters(native, po, seed):
         po.sketch_accumulate(p, part, acc)
     assert np.array_equal(sk2[0], po.densify(p, acc)[0]), (K, S, W, H)
     e.close()
+
+
+@pytest.mark.parametrize("seed", range(8 * SCALE))
+def test_short_reads_random_parameters(native, po, seed):
+    """The one-wavefront short-record kernel (entries in registers, targets read a window ahead, the last cells in
+    closed form with ties handed back to the passes) over random K, S, W, H: a few hundred reads of 40..400 bases, some
+    of them with foreign bytes or lower case, some repeated (duplicate fingerprints tie in every pass) -- every
+    sketch against the oracle's serial loop (src/niqki_index.cpp:313-331)."""
+    rng = np.random.default_rng(9000 + seed)
+    K = int(rng.integers(15, 32)) if seed % 3 else 31
+    S = int(rng.integers(8, 13))
+    W = int(rng.integers(4, 15))
+    H = int(rng.integers(0, min(W, 6) + 1))
+    p = po.make_params(K, S, W, H, 0.0)
+    e = native.Engine(K=K, S=S, W=W, H=H)
+    reads = []
+    for i in range(320):
+        L = int(rng.integers(40, 401))
+        r = random_record(rng, L, dirty=(i % 7 == 0))
+        if i % 11 == 0:                       # a short period: few distinct k-mers, many cells to fill from few values
+            unit = r[:int(rng.integers(3, 40))]
+            r = np.tile(unit, L // unit.size + 1)[:L].copy()
+        reads.append(r)
+    sk = e.sketch(reads)
+    off = np.zeros(len(reads) + 1, np.uint64)
+    off[1:] = np.cumsum([r.size for r in reads])
+    exp = po.sketch_batch(p, np.concatenate(reads), off)
+    bad = [i for i in range(len(reads)) if not np.array_equal(sk[i], exp[i])]
+    assert not bad, (K, S, W, H, bad[:8], [reads[i].size for i in bad[:8]])
+    e.close()

@@ -8,6 +8,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -104,7 +105,7 @@ def main():
         same = all(np.array_equal(x, y) for x, y in zip(ref, got))
         per = np.diff(got[0])
         print(json.dumps({"variant": name, "reads_per_s": NR / dt, "ms_per_batch": {k: round(v / (NR // RB), 3) for k, v in prof.items()},
-                          "hits_form": e.stat("last_hits_form"), "same_bytes_as_counter_rows": bool(same),
+                          "hits_form": e.stat("last_hits_form"), "hits_crc32": zlib.crc32(got[2].tobytes(), zlib.crc32(got[1].tobytes(), zlib.crc32(got[0].tobytes()))), "same_bytes_as_counter_rows": bool(same),
                           "hits_per_read_last_batch": float(per.mean()), "max": int(per.max()),
                           "frac_reads_over": {c: float((per > c).mean()) for c in (64, 256, 512, 1024)}}))
     e.close()
