@@ -1329,7 +1329,9 @@ def extra_workloads(niqki_amd, torch, dev, args, budget, out, guarded, reference
                        "note": "peak = niqki_measure_alu(5): the pass loop of the short-read kernel (8 one-wave workgroups per CU, two "
                                "proposals + two read-backs per lane and pass) with nothing but its LDS traffic and exit test, measured "
                                "in this run; achieved = reads/s of the sketch kernel x the passes the oracle's serial loop takes for "
-                               "64 of these reads (k-mer hashing and the entry list are inside the kernel's time, outside the peak)"},
+                               "64 of these reads (k-mer hashing and the entry list are inside the kernel's time, outside the peak; "
+                               "the kernel's own passes read their targets a window ahead and its last 16 cells are filled in closed "
+                               "form, so it issues fewer LDS instructions than the probe's passes: the fraction can pass 1)"},
             "gather": {"bound": "hbm", "algorithmic_bytes_per_read": g_bytes / NR, "gathered_ids_per_read": T4,
                        "achieved": g_bytes / g_s / 1e9 if g_s else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": g_bytes / g_s / 1e9 / HBM_PEAK_GBS if g_s else None,

@@ -19,6 +19,7 @@ struct SketchArgs {
   uint32_t densify;           // run densification before the store (splits == 1 only)
   uint32_t distinct;          // set by launch_sketch: densify over distinct values (short-read path)
   uint32_t filter;            // set by launch_sketch: candidate filter for long inputs
+  uint32_t read_entries;      // set by launch_sketch: capacity of the short-read kernel's entry list (192 or 384)
   uint32_t window;            // set by launch_sketch: the short-read kernel's passes read their targets a window ahead
 };
 // avg_len: average input bytes per sketch (picks the launch shape)

@@ -759,9 +759,15 @@ constexpr uint32_t kReadEntries = 6;                  // entries per lane (384: 
 constexpr uint32_t kReadMaxEntries = 64 * kReadEntries;
 constexpr uint32_t kReadTile = 512;                   // positions coded per tile
 
-static size_t sketch_reads_lds_bytes(const Derived &d) {
-  // sketch cells + entry list (cell, value) + position codes + code table
-  return (size_t)d.F * 4 + (size_t)kReadMaxEntries * 8 + kReadTile + 256 + 64;
+// entry list capacity by the records' average length: a 150-base read fills ~120 cells, and with 192 entries a
+// sketch of 2^12 cells leaves room for nine wavefronts per CU instead of eight (a record with more occupied cells
+// than the list holds takes the plain pass over all cells)
+static uint32_t sketch_reads_entries(uint64_t avg_len) { return avg_len <= 200 ? 192u : kReadMaxEntries; }
+static size_t sketch_reads_lds_bytes(const Derived &d, uint32_t entries = kReadMaxEntries) {
+  // sketch cells + one region that holds the position codes and the code table while the k-mers are hashed, the
+  // entry list (cell, value) afterwards, the closed-form tail's two lists at the end
+  const size_t region = std::max<size_t>((size_t)entries * 8, kReadTile + 256 + 64);
+  return (size_t)d.F * 4 + region;
 }
 
 // plain pass over all cells (more occupied cells than register entries: long records,
@@ -1107,9 +1113,11 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
   const Derived &d = a.d;
   const uint32_t F = d.F, lane = threadIdx.x;
   uint32_t *sk = smem;                                       // F cells
-  uint32_t *elist = smem + F;                                // kReadMaxEntries x {cell, value}
-  uint8_t *codes = (uint8_t *)(elist + 2 * kReadMaxEntries); // kReadTile position codes
+  // one region behind the cells: position codes + code table while the k-mers are hashed, then the entry list
+  uint32_t *elist = smem + F;                                // a.read_entries x {cell, value}
+  uint8_t *codes = (uint8_t *)elist;                         // kReadTile position codes
   uint8_t *lut = codes + kReadTile;                          // 256-byte code table
+  const uint32_t cap = a.read_entries;
   const uint32_t entry = blockIdx.x;
   const uint32_t K = d.K, Km1 = d.K - 1u;
 
@@ -1193,7 +1201,7 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
           const uint64_t bal = __ballot(w[i] != kEmpty32);
           if (bal) {   // (wave uniform: a read's sketch is nearly empty here)
             const uint32_t at = n_ent + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            if (w[i] != kEmpty32 && at < kReadMaxEntries) { elist[2 * at] = c0 + 4 * lane + (uint32_t)i; elist[2 * at + 1] = w[i]; }
+            if (w[i] != kEmpty32 && at < cap) { elist[2 * at] = c0 + 4 * lane + (uint32_t)i; elist[2 * at + 1] = w[i]; }
             n_ent += (uint32_t)__popcll(bal);
           }
         }
@@ -1205,21 +1213,21 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
         const uint64_t bal = __ballot(v != kEmpty32);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         const uint32_t at = n_ent + rank;
-        if (v != kEmpty32 && at < kReadMaxEntries) { elist[2 * at] = c; elist[2 * at + 1] = v; }
+        if (v != kEmpty32 && at < cap) { elist[2 * at] = c; elist[2 * at + 1] = v; }
         n_ent += (uint32_t)__popcll(bal);
       }
     }
     __syncthreads();
     const uint32_t empty0 = F - n_ent;
     if (empty0 != 0 && n_ent != 0) {
-      if (n_ent > kReadMaxEntries) {
+      if (n_ent > cap) {
         densify_wave_cells(sk, d, empty0);
       } else {
         const uint32_t rounds = (n_ent + 63u) >> 6;   // wave uniform
         if (a.window) {
-          // (the position codes are done with: their space holds the tail's two lists)
-          uint32_t *scratch = (uint32_t *)codes;
-          static_assert(kReadTile >= 2 * 64 * 4, "the tail's lists live in the position codes' space");
+          // (the entries are in registers by then: their list's space holds the tail's two lists)
+          uint32_t *scratch = elist;
+          static_assert(192 * 8 >= 2 * 64 * 4, "the tail's lists live in the entry list's space");
           const bool tail = a.window >= 2 && quads;
           if (rounds <= 1) densify_wave_entries_window<1, 8>(sk, elist, n_ent, F, empty0, scratch, tail);
           else if (rounds <= 2) densify_wave_entries_window<2, 8>(sk, elist, n_ent, F, empty0, scratch, tail);
@@ -1316,7 +1324,8 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   // several waves per CU (NIQKI_SKETCH_WAVE=0 switches this shape off)
   {
     const char *wv = std::getenv("NIQKI_SKETCH_WAVE");
-    const size_t wl = sketch_reads_lds_bytes(a.d);
+    a.read_entries = sketch_reads_entries(avg_len);
+    const size_t wl = sketch_reads_lds_bytes(a.d, a.read_entries);
     if (avg_len <= 4096 && a.splits == 1 && a.halves == 1 && wl <= 40 * 1024 && !(wv && std::atoi(wv) == 0)) {
       const char *dw = std::getenv("NIQKI_DENSIFY_WINDOW");   // 0: every entry proposes in every pass (measurement)
       const char *dt = std::getenv("NIQKI_DENSIFY_TAIL");     // 0: passes to the end, no closed-form tail (measurement)
@@ -1477,8 +1486,8 @@ __global__ __launch_bounds__(64) void lds_pass_probe_kernel(uint32_t iters, uint
 
 hipError_t launch_alu_probe(int what, uint32_t iters, uint32_t *sink, uint64_t *units, hipStream_t stream) {
   if (what == 5) {
-    const uint32_t blocks = 256 * 8 * 4;   // four rounds of 8 one-wave workgroups per CU
-    const size_t lds = 4096 * 4 + 2 * kReadMaxEntries * 4 + kReadTile + 256;   // sketch_reads_lds_bytes at S = 12
+    const uint32_t blocks = 256 * 9 * 4;   // four rounds of 9 one-wave workgroups per CU
+    const size_t lds = 4096 * 4 + 192 * 8;   // sketch_reads_lds_bytes at S = 12 for 150-base reads
     hipLaunchKernelGGL(lds_pass_probe_kernel, dim3(blocks), dim3(64), lds, stream, iters * 16, sink);
     *units = (uint64_t)blocks * iters * 16;
     return hipGetLastError();
