@@ -238,7 +238,9 @@ inline void tagged_inflate(const uint8_t *p, size_t total, std::vector<uint8_t> 
 class ParallelGzWriter {
  public:
   static constexpr size_t kPiece = size_t(8) << 20;
-  ParallelGzWriter(const std::string &path, unsigned threads) : threads_(threads ? threads : 1) {
+  // flush_pieces: how many pieces pile up before they are compressed and written (0: four per thread)
+  ParallelGzWriter(const std::string &path, unsigned threads, size_t flush_pieces = 0)
+      : threads_(threads ? threads : 1), flush_pieces_(flush_pieces ? flush_pieces : 4 * (size_t)(threads ? threads : 1)) {
     fd_ = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
     if (fd_ < 0) throw std::runtime_error("cannot open '" + path + "' for writing");
   }
@@ -259,16 +261,29 @@ class ParallelGzWriter {
     if (!block.n) return;
     pieces_ += (block.size() + kPiece - 1) / kPiece;
     pending_.push_back(std::move(block));
-    if (pieces_ >= 4 * (size_t)threads_) flush();
+    if (pieces_ >= flush_pieces_) flush();
   }
   void add(const std::vector<uint8_t> &bytes) {
     Block b(bytes.size());
     if (!bytes.empty()) std::memcpy(b.data(), bytes.data(), bytes.size());
     add(std::move(b));
   }
-  void finish() {
+  // empty_member: a file that was given nothing still holds one (empty) gzip member, as zlib's writer leaves it
+  void finish(bool empty_member = false) {
     flush();
     if (busy_.valid()) busy_.get();
+    if (empty_member && offset_ == 0 && fd_ >= 0) {
+      std::vector<uint8_t> m;
+      const uint8_t none = 0;
+      tagged_member(&none, 0, m);
+      size_t done = 0;
+      while (done < m.size()) {
+        const ssize_t w = pwrite(fd_, m.data() + done, m.size() - done, (off_t)done);
+        if (w <= 0) throw std::runtime_error("write failed");
+        done += (size_t)w;
+      }
+      offset_ = m.size();
+    }
     if (fd_ >= 0) {
       const int rc = ::close(fd_);
       fd_ = -1;
@@ -329,8 +344,54 @@ class ParallelGzWriter {
   std::future<void> busy_;
   int fd_ = -1;
   unsigned threads_;
+  size_t flush_pieces_;
   size_t pieces_ = 0;
   std::vector<Block> pending_;
+};
+
+// Text output (hit lines, matrix rows) with GzWriter's interface on top of ParallelGzWriter: the text is collected in
+// blocks of 8 MB, which become gzip members compressed side by side while the caller formats the next ones (one zlib
+// stream at level 1 takes a quarter of a second per 100 MB of hit lines: in lines mode the writer thread was what the
+// GPU waited for).  A concatenation of members is one gzip file to every reader.
+class ParallelTextWriter {
+ public:
+  ParallelTextWriter(const std::string &path, unsigned threads) : out_(path, threads, threads ? threads : 1) {}
+  ~ParallelTextWriter() {
+    try { close(); } catch (...) {}
+  }
+  ParallelTextWriter(const ParallelTextWriter &) = delete;
+  ParallelTextWriter &operator=(const ParallelTextWriter &) = delete;
+  void write(const void *p, size_t n) {
+    const uint8_t *c = (const uint8_t *)p;
+    while (n) {
+      if (!cur_.p) { cur_ = ParallelGzWriter::Block(ParallelGzWriter::kPiece); fill_ = 0; }
+      const size_t take = std::min(n, ParallelGzWriter::kPiece - fill_);
+      std::memcpy(cur_.data() + fill_, c, take);
+      fill_ += take;
+      c += take;
+      n -= take;
+      if (fill_ == ParallelGzWriter::kPiece) hand_over();
+    }
+  }
+  void write(const std::string &s) { write(s.data(), s.size()); }
+  void close() {
+    if (closed_) return;
+    closed_ = true;
+    if (fill_) hand_over();
+    out_.finish(true);
+  }
+
+ private:
+  void hand_over() {
+    cur_.n = fill_;
+    out_.add(std::move(cur_));
+    cur_ = ParallelGzWriter::Block();
+    fill_ = 0;
+  }
+  ParallelGzWriter out_;
+  ParallelGzWriter::Block cur_;
+  size_t fill_ = 0;
+  bool closed_ = false;
 };
 
 // Reader of such a file: the members are found by their tags and inflated by a pool of threads, a window ahead of

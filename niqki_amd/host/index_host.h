@@ -36,7 +36,7 @@ class Index {
   uint32_t K = 0, W = 0, H = 0, lF = 0, F = 0, min_score = 0;
   bool pretty_printing = true;
   std::vector<std::string> filenames;
-  std::unique_ptr<GzWriter> outfile;
+  std::unique_ptr<ParallelTextWriter> outfile;
 
   size_t getNbGenomes() const { return filenames.size(); }  // src/niqki_index.h:138-140
 
@@ -77,6 +77,7 @@ class Index {
   };
   void query_staged(size_t n, Hits &h);
   void write_hits(const Hits &h);
+  std::string out_text_;                // write_hits' lines before they go to the writer
   void stream_lines(const std::string &filestr, bool insert);
   void check(int rc, const char *what) const;
   void check_group(int rc, const char *what) const;
