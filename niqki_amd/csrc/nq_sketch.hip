@@ -862,7 +862,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 // to a cell that several entries reach in its pass s*, and only if one of the LOSING ones has won some cell in an
 // earlier pass of the tail: that case (a few reads in a hundred) is detected and handed back to the passes, which
 // are exact for anything -- nothing is written before the check.  Cells no orbit reaches stay empty, as after the F
-// fruitless passes that end the loop (the oracle's rule).  Pinned by the goldens, tests/test_gpu_fuzz.py,
+// fruitless passes that end the loop (documented divergences).  Pinned by the goldens, tests/test_gpu_fuzz.py,
 // tests/test_gpu_reads_config.py.
 constexpr uint32_t kTailCells = 16;   // (8 .. 24 measure the same; 48: 3 % slower)
 
