@@ -346,7 +346,7 @@ typedef struct niqki_raw_batch {
                                 than K (lines mode, n_files must be 1) */
   uint32_t final;            /* lines mode: raw reaches the end of the file; otherwise the last
                                 (possibly incomplete) record is left for the next call */
-  uint32_t max_entries;      /* lines mode: stop after this many sketches (1 .. 65536) */
+  uint32_t max_entries;      /* lines mode: stop after this many sketches */
   uint8_t *file_status;      /* optional HOST array, n_files, written when the call returns NIQKI_E_GZIP: 0, or why the
                                 device would not inflate gzip file f (1..13, nq_kernels.h InflateJob) */
 } niqki_raw_batch;

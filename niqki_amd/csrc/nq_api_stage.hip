@@ -121,9 +121,6 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   if (b->n_files && (!b->file_off || !b->file_type)) return NIQKI_E_INVALID;
   if (b->lines && b->n_files > 1) return fail(ix, NIQKI_E_INVALID, "lines mode frames one file per call");
   if (b->lines && b->max_entries == 0) return fail(ix, NIQKI_E_INVALID, "max_entries must be > 0");
-  // (the tested envelope: the host program asks for 65 536; with 131 072 and 24 MB pieces its 8-shard lines mode
-  // ended in a GPU memory fault that was not tracked down -- profiles/r06_cli_lines_mode_writer.txt)
-  if (b->lines && b->max_entries > 65536) return fail(ix, NIQKI_E_INVALID, "max_entries must be <= 65536");
   NQ_HIP(ix, hipSetDevice(ix->device));
   ix->staged.valid = false;
   ix->staged.sketched = false;
