@@ -1326,7 +1326,7 @@ def extra_workloads(niqki_amd, torch, dev, args, budget, out, guarded, reference
             "sketch": {"bound": "lds round trips of the densification passes", "passes_per_read": passes_per_read,
                        "achieved_passes_per_s": sk_pass_rate, "peak_passes_per_s": pass_rate,
                        "frac": sk_pass_rate / pass_rate if pass_rate else None,
-                       "note": "peak = niqki_measure_alu(5): the pass loop of the short-read kernel (8 one-wave workgroups per CU, two "
+                       "note": "peak = niqki_measure_alu(5): the pass loop of the short-read kernel (9 one-wave workgroups per CU, two "
                                "proposals + two read-backs per lane and pass) with nothing but its LDS traffic and exit test, measured "
                                "in this run; achieved = reads/s of the sketch kernel x the passes the oracle's serial loop takes for "
                                "64 of these reads (k-mer hashing and the entry list are inside the kernel's time, outside the peak; "

@@ -144,7 +144,7 @@ int niqki_synth_reads(niqki_index *ix, uint64_t seed, const uint32_t *family, co
  * every gfx950 vector opcode except add / sub / and / or / xor / mov / shift-right), 4 = a streaming
  * copy of 1 GiB (bytes read + written per second: the HBM rate a plain kernel reaches), 5 = the
  * densification passes of the short-read sketch kernel with nothing but their LDS traffic and exit
- * test (one wavefront per sketch, 8 per CU, two proposals + two read-backs per lane and pass: the
+ * test (one wavefront per sketch, 9 per CU, two proposals + two read-backs per lane and pass: the
  * LDS round-trip ceiling of src/niqki_index.cpp:313-331 on this device).
  * *rate = adds / multiplies / k-mers / instructions / bytes / passes per second over ~ms milliseconds. */
 int niqki_measure_alu(niqki_index *ix, int what, double ms, double *rate);

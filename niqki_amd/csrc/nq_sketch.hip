@@ -744,8 +744,8 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
 // ---- short records: one wavefront per sketch -----------------------------------------
 // A 150-base read holds ~120 k-mers but its densification takes ~350 passes
 // (SURVEY.md 8a a8), so the short-record kernel is built around the passes: one wave
-// owns one sketch, nothing is synchronised across waves, and a pass costs two LDS round
-// trips.  Each occupied cell of the sketch becomes an ENTRY held in registers
+// owns one sketch, nothing is synchronised across waves, and a pass costs one LDS round
+// trip.  Each occupied cell of the sketch becomes an ENTRY held in registers
 // (up to kReadEntries per lane): T = running low word of hash_family(v, step) (the target
 // is T mod F and T += B per pass, B = low word of revhash64(v), src/niqki_index.cpp:308-310),
 // mi = smallest cell index known to hold v.  A pass: every entry proposes
