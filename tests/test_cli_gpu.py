@@ -430,3 +430,31 @@ def test_the_reference_program_on_its_own_example_data(tmp_path, gold):
             h.update(blk)
             n += len(blk)
     assert n == exp["dump_len"] and h.hexdigest() == exp["dump_md5"]
+
+
+def test_lines_mode_many_reads_sharded_equals_one_gpu(tmp_path, native, monkeypatch):
+    """Lines mode at a size where the pipeline really runs (several 8 MB pieces, tens of thousands of entries per call,
+    the hit lines written as several gzip members): 300 000 reads of 150 bases against 24 genomes -- `niqki --gpus 8`
+    (8 slot shards on the one GPU of the box, every shard framing and sketching its run of each piece) writes the
+    bytes `niqki` writes on one GPU, one line per read in the file's order."""
+    monkeypatch.setenv("NIQKI_SHARDS_ON_ONE_DEVICE", "1")
+    names = []
+    for g in range(24):
+        seq = native.synth_genome_host(11, g // 4, g % 4, 0 if g % 4 == 0 else 30 * (g % 4), 400_000)
+        (tmp_path / ("g%02d.fa" % g)).write_bytes(b">g%02d\n" % g + bytes(seq) + b"\n")
+        names.append("g%02d.fa" % g)
+    (tmp_path / "fof.txt").write_text("\n".join(names) + "\n")
+    rng = np.random.default_rng(5)
+    src = native.synth_genome_host(11, 0, 0, 0, 400_000)
+    n_reads = 300_000
+    st = rng.integers(0, 400_000 - 150, n_reads)
+    with open(tmp_path / "reads.fa", "wb") as f:
+        for i in range(0, n_reads, 65536):
+            f.write(b"".join(b">r%d\n" % (i + j) + bytes(src[s:s + 150]) + b"\n" for j, s in enumerate(st[i:i + 65536])))
+    outs = {}
+    for gpus in (1, 8):
+        run(tmp_path, ["--gpus", str(gpus), "-I", "fof.txt", "-l", "reads.fa", "-S", "12", "-W", "10", "-J", "0.01", "-O", "o%d.gz" % gpus])
+        outs[gpus] = gunzip(tmp_path / ("o%d.gz" % gpus))
+    assert outs[1] == outs[8]
+    lines = outs[1].decode().split("\n")
+    assert len(lines) == n_reads + 1 and lines[0].startswith(">r0 ") and lines[n_reads - 1].startswith(">r%d " % (n_reads - 1))
