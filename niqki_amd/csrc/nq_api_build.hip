@@ -67,6 +67,8 @@ int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, ui
   a.accumulate = 0;
   a.densify = 1;
   a.splits = 1;
+  a.redo = nullptr;
+  a.redo_pass = 0;
   const uint64_t avg = total_bytes / n_entry;
   if (avg >= 16384 && !entry_rec && n_entry < 128 && avg >= (1u << 20))
     a.splits = std::min<uint32_t>(32, 512 / n_entry);
@@ -85,6 +87,20 @@ int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, ui
     b.accumulate = 1;
     b.densify = 1;
     NQ_HIP(ix, nq::launch_sketch(b, n_entry, (uint64_t)1 << 22, ix->stream));
+  } else if (nq::sketch_takes_small_read_list(ix->d, avg)) {
+    // short records: the one-wavefront kernel with its 192-entry list (nine sketches per CU); a record with more
+    // occupied cells than that -- far longer than the batch's average -- is flagged and sketched by a second launch
+    // with the 384-entry list, whose other workgroups leave at once (no record pays the plain pass over all cells)
+    nqi::Buf &flags = ix->ws_redo[ix->sk_stream && ix->stream == ix->sk_stream ? 1 : 0];
+    int rc = ensure(ix, flags, (size_t)n_entry * 4);
+    if (rc) return rc;
+    NQ_HIP(ix, hipMemsetAsync(flags.p, 0, (size_t)n_entry * 4, ix->stream));
+    Span sp(ix, NIQKI_KC_SKETCH);
+    a.redo = (uint32_t *)flags.p;
+    a.redo_pass = 1;
+    NQ_HIP(ix, nq::launch_sketch(a, n_entry, avg, ix->stream));
+    a.redo_pass = 2;
+    NQ_HIP(ix, nq::launch_sketch(a, n_entry, 1024, ix->stream));   // (an average that takes the long list)
   } else {
     Span sp(ix, NIQKI_KC_SKETCH);
     NQ_HIP(ix, nq::launch_sketch(a, n_entry, avg, ix->stream));
@@ -336,9 +352,12 @@ int niqki_densify(niqki_index *ix, int32_t *sketches, uint32_t n, int mem) {
   a.splits = 1;
   a.accumulate = 1;
   a.densify = 1;
+  a.redo = nullptr;
+  a.redo_pass = 0;
   {
     Span sp(ix, NIQKI_KC_DENSIFY);
-    NQ_HIP(ix, nq::launch_sketch(a, n, ix->d.F <= 4096 ? 150 : ((uint64_t)1 << 22), ix->stream));
+    // (an average that picks the one-wavefront kernel with its long entry list)
+    NQ_HIP(ix, nq::launch_sketch(a, n, ix->d.F <= 4096 ? 256 : ((uint64_t)1 << 22), ix->stream));
   }
   if (mem == NIQKI_MEM_HOST) {
     NQ_HIP(ix, hipMemcpyAsync(sketches, d_sk, bytes, hipMemcpyDeviceToHost, ix->stream));

@@ -122,6 +122,7 @@ struct niqki_index {
   // slots, taken in turn: the bytes of batch i + 1 may cross while batch i -- whose own (prefetched) bytes are still
   // being inflated / unpacked out of the other slot -- is staged.
   nqi::Buf ws_wire[2];
+  nqi::Buf ws_redo[2];   // sketch_dev: flags of short-record sketches left to the second launch ([1]: calls on the sketch lane)
   hipStream_t copy_stream = nullptr;
   struct {
     bool valid = false;

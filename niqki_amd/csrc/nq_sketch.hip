@@ -763,6 +763,7 @@ constexpr uint32_t kReadTile = 512;                   // positions coded per til
 // sketch of 2^12 cells leaves room for nine wavefronts per CU instead of eight (a record with more occupied cells
 // than the list holds takes the plain pass over all cells)
 static uint32_t sketch_reads_entries(uint64_t avg_len) { return avg_len <= 200 ? 192u : kReadMaxEntries; }
+static bool sketch_reads_shape(const Derived &d, uint64_t avg_len, uint32_t splits, uint32_t halves);
 static size_t sketch_reads_lds_bytes(const Derived &d, uint32_t entries = kReadMaxEntries) {
   // sketch cells + one region that holds the position codes and the code table while the k-mers are hashed, the
   // entry list (cell, value) afterwards, the closed-form tail's two lists at the end
@@ -1120,6 +1121,7 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
   const uint32_t cap = a.read_entries;
   const uint32_t entry = blockIdx.x;
   const uint32_t K = d.K, Km1 = d.K - 1u;
+  if (a.redo_pass == 2 && a.redo[entry] == 0u) return;   // (one wave: uniform) the first launch finished this sketch
 
   for (uint32_t i = lane; i < 256; i += 64) lut[i] = code_entry(i);
   // (the kernel's time is its LDS instructions: the passes over all cells move 16 bytes per lane; F is a multiple
@@ -1220,6 +1222,13 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
     __syncthreads();
     const uint32_t empty0 = F - n_ent;
     if (empty0 != 0 && n_ent != 0) {
+      if (n_ent > cap && a.redo_pass == 1) {
+        // more occupied cells than the short list holds (a record far longer than the batch's average): the second
+        // launch, with the long list, sketches it again -- the plain pass over all cells would take fifty times
+        // a read's time.  Nothing of this sketch is stored here.
+        if (lane == 0) a.redo[entry] = 1u;
+        return;
+      }
       if (n_ent > cap) {
         densify_wave_cells(sk, d, empty0);
       } else {
@@ -1305,6 +1314,17 @@ __global__ __launch_bounds__(1024) void densify_global_kernel(SketchArgs a) {
   }
 }
 
+// reads: one wavefront per sketch when the sketch and its entry list leave room for several waves per CU
+// (NIQKI_SKETCH_WAVE=0 switches this shape off)
+static bool sketch_reads_shape(const Derived &d, uint64_t avg_len, uint32_t splits, uint32_t halves) {
+  const char *wv = std::getenv("NIQKI_SKETCH_WAVE");
+  return avg_len <= 4096 && splits == 1 && halves == 1 && sketch_reads_lds_bytes(d, sketch_reads_entries(avg_len)) <= 40 * 1024 &&
+         !(wv && std::atoi(wv) == 0);
+}
+bool sketch_takes_small_read_list(const Derived &d, uint64_t avg_len) {
+  return sketch_reads_entries(avg_len) < kReadMaxEntries && sketch_reads_shape(d, avg_len, 1, sketch_needs_merge(d) ? 2u : 1u);
+}
+
 hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_len,
                          hipStream_t stream) {
   if (n_entry == 0) return hipSuccess;
@@ -1323,10 +1343,9 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   // reads: one wavefront per sketch when the sketch and its entry list leave room for
   // several waves per CU (NIQKI_SKETCH_WAVE=0 switches this shape off)
   {
-    const char *wv = std::getenv("NIQKI_SKETCH_WAVE");
     a.read_entries = sketch_reads_entries(avg_len);
     const size_t wl = sketch_reads_lds_bytes(a.d, a.read_entries);
-    if (avg_len <= 4096 && a.splits == 1 && a.halves == 1 && wl <= 40 * 1024 && !(wv && std::atoi(wv) == 0)) {
+    if (sketch_reads_shape(a.d, avg_len, a.splits, a.halves)) {
       const char *dw = std::getenv("NIQKI_DENSIFY_WINDOW");   // 0: every entry proposes in every pass (measurement)
       const char *dt = std::getenv("NIQKI_DENSIFY_TAIL");     // 0: passes to the end, no closed-form tail (measurement)
       a.window = (dw && std::atoi(dw) == 0) ? 0u : (dt && std::atoi(dt) == 0) ? 1u : 2u;

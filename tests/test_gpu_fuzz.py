@@ -152,3 +152,39 @@ def test_short_reads_random_parameters(native, po, seed):
     bad = [i for i in range(len(reads)) if not np.array_equal(sk[i], exp[i])]
     assert not bad, (K, S, W, H, bad[:8], [reads[i].size for i in bad[:8]])
     e.close()
+
+
+@pytest.mark.parametrize("seed", range(4 * SCALE))
+def test_short_batches_with_long_outliers(native, po, seed):
+    """A batch whose average record is short (the one-wavefront kernel takes its 192-entry list, nine sketches per CU)
+    but which holds records far longer than that: more occupied cells than the list holds.  Those are flagged by the
+    first launch and sketched by the second, with the 384-entry list; records beyond that one too (the plain pass over
+    all cells).  Every sketch against the oracle."""
+    rng = np.random.default_rng(9500 + seed)
+    K, S, W, H = (31, 12, 10, 4) if seed % 2 == 0 else (int(rng.integers(15, 32)), int(rng.integers(9, 13)), int(rng.integers(6, 13)), 3)
+    p = po.make_params(K, S, W, H, 0.0)
+    e = native.Engine(K=K, S=S, W=W, H=H)
+    reads = []
+    for i in range(400):
+        L = int(rng.integers(60, 160))
+        if i % 9 == 0:
+            L = int(rng.integers(230, 420))        # between the two lists' capacities
+        if i % 67 == 0:
+            L = int(rng.integers(500, 900))        # beyond both
+        reads.append(random_record(rng, L, dirty=(i % 13 == 0)))
+    assert sum(r.size for r in reads) / len(reads) <= 200
+    sk = e.sketch(reads)
+    off = np.zeros(len(reads) + 1, np.uint64)
+    off[1:] = np.cumsum([r.size for r in reads])
+    exp = po.sketch_batch(p, np.concatenate(reads), off)
+    bad = [i for i in range(len(reads)) if not np.array_equal(sk[i], exp[i])]
+    assert not bad, (K, S, W, H, bad[:8], [reads[i].size for i in bad[:8]])
+    # the same records one sketch per FILE of several records (entry_rec: cells accumulate over an entry's records)
+    er = np.arange(0, len(reads) + 1, 4, dtype=np.uint32)
+    sk2 = e.sketch(reads, entry_rec=er)
+    for j in range(len(er) - 1):
+        acc = np.full(1 << S, -1, np.int32)
+        for r in reads[er[j]:er[j + 1]]:
+            po.sketch_accumulate(p, r, acc)
+        assert np.array_equal(sk2[j], po.densify(p, acc)[0]), (K, S, W, H, j)
+    e.close()
