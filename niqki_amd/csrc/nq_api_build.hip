@@ -68,7 +68,7 @@ int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, ui
   a.densify = 1;
   a.splits = 1;
   a.redo = nullptr;
-  a.redo_pass = 0;
+  a.redo_only = a.redo_mark = 0;
   const uint64_t avg = total_bytes / n_entry;
   if (avg >= 16384 && !entry_rec && n_entry < 128 && avg >= (1u << 20))
     a.splits = std::min<uint32_t>(32, 512 / n_entry);
@@ -87,20 +87,28 @@ int sketch_dev(niqki_index *ix, const uint8_t *seqs, const uint64_t *rec_off, ui
     b.accumulate = 1;
     b.densify = 1;
     NQ_HIP(ix, nq::launch_sketch(b, n_entry, (uint64_t)1 << 22, ix->stream));
-  } else if (nq::sketch_takes_small_read_list(ix->d, avg)) {
-    // short records: the one-wavefront kernel with its 192-entry list (nine sketches per CU); a record with more
-    // occupied cells than that -- far longer than the batch's average -- is flagged and sketched by a second launch
-    // with the 384-entry list, whose other workgroups leave at once (no record pays the plain pass over all cells)
+  } else if (const uint32_t list = nq::sketch_read_list(ix->d, avg)) {
+    // Short records: the one-wavefront kernel, with its 192-entry list (nine sketches per CU) where the average record
+    // has at most 200 bases.  A record with more occupied cells than the list holds -- far longer than the batch's
+    // average -- is flagged instead of taking the plain pass over all cells (fifty reads' time) and sketched by the
+    // next launch: the 384-entry list, then the workgroup kernel; a launch's other workgroups leave at once.
     nqi::Buf &flags = ix->ws_redo[ix->sk_stream && ix->stream == ix->sk_stream ? 1 : 0];
     int rc = ensure(ix, flags, (size_t)n_entry * 4);
     if (rc) return rc;
     NQ_HIP(ix, hipMemsetAsync(flags.p, 0, (size_t)n_entry * 4, ix->stream));
     Span sp(ix, NIQKI_KC_SKETCH);
     a.redo = (uint32_t *)flags.p;
-    a.redo_pass = 1;
-    NQ_HIP(ix, nq::launch_sketch(a, n_entry, avg, ix->stream));
-    a.redo_pass = 2;
-    NQ_HIP(ix, nq::launch_sketch(a, n_entry, 1024, ix->stream));   // (an average that takes the long list)
+    if (list < 384) {
+      a.redo_only = 0; a.redo_mark = 1;
+      NQ_HIP(ix, nq::launch_sketch(a, n_entry, avg, ix->stream));
+      a.redo_only = 1; a.redo_mark = 2;
+      NQ_HIP(ix, nq::launch_sketch(a, n_entry, 400, ix->stream));   // (an average that takes the long list)
+    } else {
+      a.redo_only = 0; a.redo_mark = 2;
+      NQ_HIP(ix, nq::launch_sketch(a, n_entry, avg, ix->stream));
+    }
+    a.redo_only = 2; a.redo_mark = 0;
+    NQ_HIP(ix, nq::launch_sketch(a, n_entry, nq::kSketchWorkgroupLen, ix->stream));
   } else {
     Span sp(ix, NIQKI_KC_SKETCH);
     NQ_HIP(ix, nq::launch_sketch(a, n_entry, avg, ix->stream));
@@ -353,7 +361,7 @@ int niqki_densify(niqki_index *ix, int32_t *sketches, uint32_t n, int mem) {
   a.accumulate = 1;
   a.densify = 1;
   a.redo = nullptr;
-  a.redo_pass = 0;
+  a.redo_only = a.redo_mark = 0;
   {
     Span sp(ix, NIQKI_KC_DENSIFY);
     // (an average that picks the one-wavefront kernel with its long entry list)

@@ -20,17 +20,21 @@ struct SketchArgs {
   uint32_t distinct;          // set by launch_sketch: densify over distinct values (short-read path)
   uint32_t filter;            // set by launch_sketch: candidate filter for long inputs
   uint32_t read_entries;      // set by launch_sketch: capacity of the short-read kernel's entry list (192 or 384)
-  uint32_t *redo;             // short records with the 192-entry list: flags of the sketches whose occupied cells exceed it
-  uint32_t redo_pass;         // 0: no flags (such a sketch takes the plain pass over all cells); 1: flag it and leave it to
-                              // the second launch; 2: the second launch (384 entries) -- only flagged sketches are worked on
+  uint32_t *redo;             // short records: one flag per sketch, or nullptr (then a sketch with more occupied cells than the
+                              // one-wavefront kernel's entry list takes the plain pass over all cells)
+  uint32_t redo_only;         // != 0: this launch works only on the sketches whose flag has this value
+  uint32_t redo_mark;         // != 0 (one-wavefront kernel): a sketch that exceeds the entry list gets this flag and is left
+                              // to a later launch -- nothing of it is stored
   uint32_t window;            // set by launch_sketch: the short-read kernel's passes read their targets a window ahead
 };
 // avg_len: average input bytes per sketch (picks the launch shape)
 hipError_t launch_sketch(const SketchArgs &a, uint32_t n_entry, uint64_t avg_len,
                          hipStream_t stream);
 hipError_t launch_fill_u32(uint32_t *p, uint64_t n, uint32_t v, hipStream_t stream);
-// true: launch_sketch would take the one-wavefront short-record kernel with its 192-entry list for this average length
-bool sketch_takes_small_read_list(const Derived &d, uint64_t avg_len);
+// 0: launch_sketch would not take the one-wavefront short-record kernel for this average length; else the capacity of
+// the entry list it would take (192 or 384)
+uint32_t sketch_read_list(const Derived &d, uint64_t avg_len);
+constexpr uint64_t kSketchWorkgroupLen = 4097;   // an average length that makes launch_sketch take the workgroup kernel
 // true: launch_sketch cannot densify inside the kernel for these parameters -- the caller fills the
 // output with "empty" first, launches with densify = 0, then a densify-only launch (seqs = nullptr)
 bool sketch_needs_merge(const Derived &d);

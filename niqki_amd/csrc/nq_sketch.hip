@@ -652,6 +652,7 @@ __global__ __launch_bounds__(BLOCK) void sketch_kernel(SketchArgs a) {
   const uint32_t half = (blockIdx.x / a.splits) % a.halves;
   const uint32_t entry = blockIdx.x / (a.splits * a.halves);
   const uint32_t hsel = a.halves > 1 ? half + 1u : 0u;
+  if (a.redo_only && a.redo[entry] != a.redo_only) return;   // (uniform) not this launch's sketch
 
   for (uint32_t i = tid; i < 256; i += BLOCK) {
     const uint32_t e = code_entry(i);
@@ -1121,7 +1122,7 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
   const uint32_t cap = a.read_entries;
   const uint32_t entry = blockIdx.x;
   const uint32_t K = d.K, Km1 = d.K - 1u;
-  if (a.redo_pass == 2 && a.redo[entry] == 0u) return;   // (one wave: uniform) the first launch finished this sketch
+  if (a.redo_only && a.redo[entry] != a.redo_only) return;   // (one wave: uniform) not this launch's sketch
 
   for (uint32_t i = lane; i < 256; i += 64) lut[i] = code_entry(i);
   // (the kernel's time is its LDS instructions: the passes over all cells move 16 bytes per lane; F is a multiple
@@ -1222,11 +1223,11 @@ __global__ __launch_bounds__(64) void sketch_reads_kernel(SketchArgs a) {
     __syncthreads();
     const uint32_t empty0 = F - n_ent;
     if (empty0 != 0 && n_ent != 0) {
-      if (n_ent > cap && a.redo_pass == 1) {
-        // more occupied cells than the short list holds (a record far longer than the batch's average): the second
-        // launch, with the long list, sketches it again -- the plain pass over all cells would take fifty times
-        // a read's time.  Nothing of this sketch is stored here.
-        if (lane == 0) a.redo[entry] = 1u;
+      if (n_ent > cap && a.redo_mark) {
+        // more occupied cells than the entry list holds (a record far longer than the batch's average): a later
+        // launch -- the long list, then the workgroup kernel -- sketches it again; the plain pass over all cells
+        // would take fifty times a read's time.  Nothing of this sketch is stored here.
+        if (lane == 0) a.redo[entry] = a.redo_mark;
         return;
       }
       if (n_ent > cap) {
@@ -1318,11 +1319,13 @@ __global__ __launch_bounds__(1024) void densify_global_kernel(SketchArgs a) {
 // (NIQKI_SKETCH_WAVE=0 switches this shape off)
 static bool sketch_reads_shape(const Derived &d, uint64_t avg_len, uint32_t splits, uint32_t halves) {
   const char *wv = std::getenv("NIQKI_SKETCH_WAVE");
-  return avg_len <= 4096 && splits == 1 && halves == 1 && sketch_reads_lds_bytes(d, sketch_reads_entries(avg_len)) <= 40 * 1024 &&
+  // (records of up to 384 + K bases: their occupied cells fit the 384-entry list.  Longer ones would all take the plain
+  // pass over all cells -- 21 ms instead of the workgroup kernel's 4.9 per 16 384 records of 500 bases)
+  return avg_len <= 415 && splits == 1 && halves == 1 && sketch_reads_lds_bytes(d, sketch_reads_entries(avg_len)) <= 40 * 1024 &&
          !(wv && std::atoi(wv) == 0);
 }
-bool sketch_takes_small_read_list(const Derived &d, uint64_t avg_len) {
-  return sketch_reads_entries(avg_len) < kReadMaxEntries && sketch_reads_shape(d, avg_len, 1, sketch_needs_merge(d) ? 2u : 1u);
+uint32_t sketch_read_list(const Derived &d, uint64_t avg_len) {
+  return sketch_reads_shape(d, avg_len, 1, sketch_needs_merge(d) ? 2u : 1u) ? sketch_reads_entries(avg_len) : 0u;
 }
 
 hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_len,
