@@ -22,7 +22,7 @@ int staged_sketch_ws(niqki_index *ix) {
   int rc = ensure(ix, ix->ws_stsk, std::max<size_t>((size_t)n * ix->d.F * 4, 4));
   if (rc) return rc;
   rc = sketch_dev(ix, (const uint8_t *)ix->ws_seq.p, (const uint64_t *)ix->ws_recoff.p, ix->staged.n_rec,
-                  ix->staged.entry_rec, n, (int32_t *)ix->ws_stsk.p, ix->staged.seq_bytes);
+                  ix->staged.entry_rec, n, (int32_t *)ix->ws_stsk.p, ix->staged.entry_bytes);
   if (rc) return rc;
   ix->staged.sketched = true;
   return NIQKI_OK;
@@ -359,7 +359,7 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   NQ_HIP(ix, hipMemcpyAsync(a.rec_off + n_rec, a.totals + 1, 8, hipMemcpyDeviceToDevice, ix->stream));
   NQ_HIP(ix, hipMemsetAsync(a.seqs + kept, 0, NIQKI_SEQ_PAD, ix->stream));
   uint32_t n_entry = nf;
-  uint64_t consumed = T_raw;
+  uint64_t consumed = T_raw, entry_bytes = kept;
   const uint32_t *d_entry = a.file_nrec;  // whole mode: entry f = the records of file f
   if (b->lines) {
     const uint32_t n_use = b->final ? n_rec : (n_rec ? n_rec - 1 : 0);
@@ -372,8 +372,12 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
     NQ_HIP(ix, hipMemcpyAsync(res, d_res, 8, hipMemcpyDeviceToHost, ix->stream));
     NQ_HIP(ix, hipStreamSynchronize(ix->stream));
     n_entry = res[0];
-    if (res[1] < n_rec)
+    if (res[1] < n_rec) {
       NQ_HIP(ix, hipMemcpyAsync(&consumed, a.hdr_pos + res[1], 8, hipMemcpyDeviceToHost, ix->stream));
+      // (the launch shape of the sketch kernel goes by the entries' average length: the records behind the last entry
+      // are not theirs -- a piece of 50 000 reads staged 16 384 entries at a time looked like records of 457 bases)
+      NQ_HIP(ix, hipMemcpyAsync(&entry_bytes, a.rec_off + res[1], 8, hipMemcpyDeviceToHost, ix->stream));
+    }
     if (entry_hdr && n_entry)
       NQ_HIP(ix, hipMemcpyAsync(entry_hdr, ix->ws_ehdr.p, (size_t)n_entry * 8, hipMemcpyDeviceToHost, ix->stream));
     NQ_HIP(ix, hipStreamSynchronize(ix->stream));
@@ -383,6 +387,7 @@ int niqki_stage_raw(niqki_index *ix, const niqki_raw_batch *b, int mem, niqki_st
   ix->staged.n_entry = n_entry;
   ix->staged.n_rec = n_rec;
   ix->staged.seq_bytes = kept;
+  ix->staged.entry_bytes = entry_bytes;
   ix->staged.entry_rec = d_entry;
   info->n_entry = n_entry;
   info->n_rec = n_rec;

@@ -116,6 +116,7 @@ struct niqki_index {
     bool valid = false, sketched = false;
     uint32_t n_entry = 0, n_rec = 0;
     uint64_t seq_bytes = 0;
+    uint64_t entry_bytes = 0;   // sequence bytes of the records the entries cover (lines mode may stop before the last framed record)
     const uint32_t *entry_rec = nullptr;  // device, n_entry+1
   } staged;
   // niqki_stage_raw_prefetch: file bytes of coming batches on their way into ws_wire[slot] on copy_stream.  Two

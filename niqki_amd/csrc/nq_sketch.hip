@@ -1321,7 +1321,7 @@ static bool sketch_reads_shape(const Derived &d, uint64_t avg_len, uint32_t spli
   const char *wv = std::getenv("NIQKI_SKETCH_WAVE");
   // (records of up to 384 + K bases: their occupied cells fit the 384-entry list.  Longer ones would all take the plain
   // pass over all cells -- 21 ms instead of the workgroup kernel's 4.9 per 16 384 records of 500 bases)
-  return avg_len <= 415 && splits == 1 && halves == 1 && sketch_reads_lds_bytes(d, sketch_reads_entries(avg_len)) <= 40 * 1024 &&
+  return avg_len <= 415 && splits == 1 && halves == 1 && sketch_reads_lds_bytes(d, sketch_reads_entries(avg_len)) <= 160 * 1024 &&
          !(wv && std::atoi(wv) == 0);
 }
 uint32_t sketch_read_list(const Derived &d, uint64_t avg_len) {
