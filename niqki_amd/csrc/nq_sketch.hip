@@ -1359,14 +1359,18 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
     }
   }
   const bool short_records = avg_len < 16384;
-  // distinct-value densification where its tables leave room for >= 2 workgroups per CU
+  // distinct-value densification
   // after niqki_select_best_H the fingerprint parts may overlap and leave [0, 2^W): the
   // value-indexed tables and the filter's ordering argument need the regular form
   const bool regular = a.d.mask_m == (1u << a.d.M) - 1u && a.d.max_rem == (1u << a.d.H) - 1u;
   // ... and cells this launch produced itself: a caller's sketch (niqki_densify, accumulate) may hold
   // any value, the value-indexed tables only values below 2^W
   const bool own_cells = a.seqs != nullptr && !a.accumulate;
-  a.distinct = (regular && own_cells && short_records && a.halves == 1 && sketch_lds_bytes(a.d, true, 0) <= 64 * 1024) ? 1u : 0u;
+  // ... and where the values are few against the cells (a pass walks 2^W values instead of 2^S cells, but pays three table
+  // words per value: at 2^W = 2^S the plain passes are 1.6 x faster, at 2^S = 4 x 2^W the distinct ones 1.5 x, at 32 x
+  // seventeen times -- profiles/r06_densify_lean_and_tail.txt 7) and the tables fit the CU's LDS beside the cells
+  a.distinct = (regular && own_cells && short_records && a.halves == 1 && 4u * a.d.R <= a.d.F &&
+                sketch_lds_bytes(a.d, true, 0) <= 150 * 1024) ? 1u : 0u;
   // candidate filter: long records only (the kernel picks its strength per sketch);
   // NIQKI_SKETCH_FILTER=0 switches it off
   // NIQKI_SKETCH_FILTER: 0 = off, unset/1 = automatic, n >= 2 = force n-1 leading zeros (tests)
