@@ -1267,6 +1267,83 @@ constexpr size_t kLdsLimit = 160 * 1024;
 bool sketch_needs_merge(const Derived &d) { return sketch_lds_bytes(d, false, 16) > kLdsLimit; }
 
 // Densification of sketches whose F cells do not fit LDS (S = 16): the same pass-parallel algorithm as
+// Distinct-value densification as a launch of its own, for sketches whose cells leave no room for the three tables
+// of densify_lds_distinct beside them (the reference's defaults, S = 15 W = 12: 128 KB of cells, 48 KB of tables): a
+// thread's values are always the same ones (v = tid + k 1024, k < 4: 2^W <= 4096), so their two hash words live in its
+// registers and the LDS holds the cells and mi[v] alone.  The sketch kernel stores the cells as they are (densify = 0),
+// this kernel takes them from there.  Records of 0.6 .. 15 kbp at S = 15 W = 12: see profiles/r06_densify_lean_and_tail.txt.
+constexpr int kLateValues = 4;
+__global__ __launch_bounds__(1024) void densify_distinct_kernel(SketchArgs a) {
+  extern __shared__ __align__(16) uint32_t smem[];
+  const Derived &d = a.d;
+  const uint32_t F = d.F, R = d.R, W = d.W, tid = threadIdx.x;
+  const uint32_t entry = blockIdx.x;
+  if (a.redo_only && a.redo[entry] != a.redo_only) return;   // (uniform) not this launch's sketch
+  uint32_t *sk = smem, *mi = smem + F, *s_flag = mi + R;
+  uint32_t *row = (uint32_t *)a.sketches + (uint64_t)entry * F;
+  uint32_t local = 0;
+  for (uint32_t i = tid; i < F; i += 1024) {
+    const uint32_t v = row[i];
+    sk[i] = v;
+    local += (v == kEmpty32);
+  }
+  for (uint32_t v = tid; v < R; v += 1024) mi[v] = kEmpty32;
+  if (tid == 0) { s_flag[0] = 0; s_flag[1] = 0; }
+  __syncthreads();
+  if (local) atomicAdd(&s_flag[0], local);
+  for (uint32_t i = tid; i < F; i += 1024) {
+    const uint32_t v = sk[i];
+    if (v != kEmpty32) atomicMin(&mi[v], i);
+  }
+  __syncthreads();
+  uint32_t empty = s_flag[0];
+  if (empty == 0 || empty == F) return;   // (nothing to fill, or nothing to fill from: the row stays as it is)
+  uint32_t ra[kLateValues], rb[kLateValues];
+#pragma unroll
+  for (int k = 0; k < kLateValues; ++k) {
+    const uint32_t v = tid + (uint32_t)k * 1024u;
+    ra[k] = (uint32_t)unrev64(v);
+    rb[k] = (uint32_t)rev64(v);
+  }
+  uint32_t step = 0, idle = 0;
+  while (true) {
+    uint32_t mk[kLateValues], filled = 0;   // this pass's proposals (all ones: none)
+#pragma unroll
+    for (int k = 0; k < kLateValues; ++k) {
+      const uint32_t v = tid + (uint32_t)k * 1024u;
+      const uint32_t m = v < R ? mi[v] : kEmpty32;
+      const uint32_t t = (ra[k] + step * rb[k]) & (F - 1u);  // hash_family(v, step) % F, src/niqki_index.cpp:308-310,:319
+      const bool prop = m != kEmpty32 && sk[t] >= 0x80000000u;
+      mk[k] = prop ? (0x80000000u | (m << W) | v) : kEmpty32;
+      if (prop) atomicMin(&sk[t], mk[k]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kLateValues; ++k) {
+      const uint32_t v = tid + (uint32_t)k * 1024u;
+      const uint32_t t = (ra[k] + step * rb[k]) & (F - 1u);
+      const bool won = mk[k] != kEmpty32 && sk[t] == mk[k];
+      if (won) {
+        sk[t] = v;
+        if (t < ((mk[k] & 0x7FFFFFFFu) >> W)) mi[v] = t;
+      }
+      filled += won ? 1u : 0u;
+    }
+    if (filled) atomicAdd(&s_flag[1], filled);
+    __syncthreads();
+    const uint32_t tot = s_flag[1];  // every proposed-to cell now holds its winner's value
+    __syncthreads();
+    if (tid == 0) s_flag[1] = 0;
+    empty -= tot;
+    ++step;
+    idle = tot ? 0u : idle + 1u;
+    if (empty == 0 || idle >= F) break;
+    __syncthreads();
+  }
+  __syncthreads();
+  for (uint32_t i = tid; i < F; i += 1024) row[i] = sk[i];
+}
+
 // densify_lds on the cells in global memory.  One workgroup per sketch; the cells are read and
 // written with agent-scope atomics only (a plain load could see a stale L1 line behind another
 // wave's atomicMin).  Rare path: a 5 Mbp genome has no empty cell at S = 16 and leaves after the count.
@@ -1369,7 +1446,9 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   // ... and where the values are few against the cells (a pass walks 2^W values instead of 2^S cells, but pays three table
   // words per value: at 2^W = 2^S the plain passes are 1.6 x faster, at 2^S = 4 x 2^W the distinct ones 1.5 x, at 32 x
   // seventeen times -- profiles/r06_densify_lean_and_tail.txt 7) and the tables fit the CU's LDS beside the cells
-  a.distinct = (regular && own_cells && short_records && a.halves == 1 && 4u * a.d.R <= a.d.F &&
+  // -- inside the kernel for sketches of up to 2^13 cells; larger ones take the launch of its own below, which is faster
+  // there even where the tables would fit (S=14 W=12: 28 -> 9 ms per 4096 records of 600 bases)
+  a.distinct = (regular && own_cells && short_records && a.halves == 1 && 4u * a.d.R <= a.d.F && a.d.S <= 13 &&
                 sketch_lds_bytes(a.d, true, 0) <= 150 * 1024) ? 1u : 0u;
   // candidate filter: long records only (the kernel picks its strength per sketch);
   // NIQKI_SKETCH_FILTER=0 switches it off
@@ -1377,6 +1456,12 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   const char *fv = std::getenv("NIQKI_SKETCH_FILTER");
   const uint32_t fmode = fv ? (uint32_t)std::atoi(fv) : 1u;
   a.filter = (regular && !short_records && a.seqs != nullptr) ? fmode : 0u;
+  // ... or afterwards, as a launch of its own with a thread's hash words in registers, where the three tables do not fit
+  // beside the cells (densify_distinct_kernel)
+  const size_t late_lds = (size_t)a.d.F * 4 + (size_t)a.d.R * 4 + 64;
+  const bool late_distinct = a.densify && !a.distinct && regular && own_cells && short_records && a.halves == 1 && a.splits == 1 &&
+                             4u * a.d.R <= a.d.F && a.d.R <= (uint32_t)kLateValues * 1024u && late_lds <= kLdsLimit;
+  if (late_distinct) a.densify = 0;
   const size_t lds = sketch_lds_bytes(a.d, a.distinct != 0, a.filter ? (short_records ? 4 : 16) : 0, a.halves);
   dim3 grid(n_entry * a.splits * a.halves);
 #define NQ_LAUNCH_SKETCH(B, G, KF)                                                               \
@@ -1396,6 +1481,11 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
     if (a.d.K == 31) NQ_LAUNCH_SKETCH(1024, 32, 31); else NQ_LAUNCH_SKETCH(1024, 32, 0);
   }
 #undef NQ_LAUNCH_SKETCH
+  if (late_distinct) {
+    hipError_t e = hipFuncSetAttribute((const void *)densify_distinct_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)late_lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(densify_distinct_kernel, dim3(n_entry), dim3(1024), late_lds, stream, a);
+  }
   return hipGetLastError();
 }
 

@@ -188,3 +188,31 @@ def test_short_batches_with_long_outliers(native, po, seed):
             po.sketch_accumulate(p, r, acc)
         assert np.array_equal(sk2[j], po.densify(p, acc)[0]), (K, S, W, H, j)
     e.close()
+
+
+@pytest.mark.parametrize("seed", range(3 * SCALE))
+def test_mid_length_records_at_the_default_sketch_size(native, po, seed):
+    """Records of 0.5 .. 12 kbp at S = 15 with W = 11 / 12 (the reference's defaults): the workgroup kernel stores their
+    cells as they are and the distinct-value densification runs as a launch of its own, a thread's hash words in its
+    registers (the three tables do not fit beside 128 KB of cells).  Every sketch against the oracle, also with foreign
+    bytes and as several records per sketch."""
+    rng = np.random.default_rng(9800 + seed)
+    K, S, W, H = (31, 15, 12, 4) if seed % 3 == 0 else (int(rng.integers(17, 32)), 15, int(rng.integers(11, 13)), int(rng.integers(2, 6)))
+    p = po.make_params(K, S, W, H, 0.0)
+    e = native.Engine(K=K, S=S, W=W, H=H)
+    recs = [random_record(rng, int(rng.integers(500, 12000)), dirty=(i % 5 == 0)) for i in range(24)]
+    recs += [random_record(rng, int(rng.integers(0, 40)), False), random_record(rng, 450, False)]
+    sk = e.sketch(recs)
+    off = np.zeros(len(recs) + 1, np.uint64)
+    off[1:] = np.cumsum([r.size for r in recs])
+    exp = po.sketch_batch(p, np.concatenate(recs), off)
+    bad = [i for i in range(len(recs)) if not np.array_equal(sk[i], exp[i])]
+    assert not bad, (K, S, W, H, bad[:8], [recs[i].size for i in bad[:8]])
+    er = np.arange(0, len(recs) + 1, 2, dtype=np.uint32)
+    sk2 = e.sketch(recs, entry_rec=er)
+    for j in range(len(er) - 1):
+        acc = np.full(1 << S, -1, np.int32)
+        for r in recs[er[j]:er[j + 1]]:
+            po.sketch_accumulate(p, r, acc)
+        assert np.array_equal(sk2[j], po.densify(p, acc)[0]), (K, S, W, H, j)
+    e.close()
