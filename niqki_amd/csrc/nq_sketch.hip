@@ -1459,7 +1459,9 @@ hipError_t launch_sketch(const SketchArgs &a_in, uint32_t n_entry, uint64_t avg_
   // ... or afterwards, as a launch of its own with a thread's hash words in registers, where the three tables do not fit
   // beside the cells (densify_distinct_kernel)
   const size_t late_lds = (size_t)a.d.F * 4 + (size_t)a.d.R * 4 + 64;
-  const bool late_distinct = a.densify && !a.distinct && regular && own_cells && short_records && a.halves == 1 && a.splits == 1 &&
+  // (records of up to 2^19 bases: longer ones leave no cell empty at these sketch sizes, and a 5 Mbp genome's sketch must not
+  // pay a launch that finds nothing to do)
+  const bool late_distinct = a.densify && !a.distinct && regular && own_cells && avg_len < (1u << 19) && a.halves == 1 && a.splits == 1 &&
                              4u * a.d.R <= a.d.F && a.d.R <= (uint32_t)kLateValues * 1024u && late_lds <= kLdsLimit;
   if (late_distinct) a.densify = 0;
   const size_t lds = sketch_lds_bytes(a.d, a.distinct != 0, a.filter ? (short_records ? 4 : 16) : 0, a.halves);
