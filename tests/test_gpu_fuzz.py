@@ -203,6 +203,11 @@ def test_mid_length_records_at_the_default_sketch_size(native, po, seed):
     recs = [random_record(rng, int(rng.integers(500, 12000)), dirty=(i % 5 == 0)) for i in range(24)]
     recs += [random_record(rng, int(rng.integers(0, 40)), False), random_record(rng, 450, False)]
     sk = e.sketch(recs)
+    # ... and virus- / plasmid-sized records (the 1024-thread shapes in front of the same launch), a batch of their own
+    big = [random_record(rng, L, dirty=(L == 60_000)) for L in (20_000, 60_000, 150_000, 300_000)]
+    skb = e.sketch(big)
+    for i, r in enumerate(big):
+        assert np.array_equal(skb[i], po.compute_sketch(p, r)), (K, S, W, H, r.size)
     off = np.zeros(len(recs) + 1, np.uint64)
     off[1:] = np.cumsum([r.size for r in recs])
     exp = po.sketch_batch(p, np.concatenate(recs), off)
