@@ -221,3 +221,21 @@ def test_mid_length_records_at_the_default_sketch_size(native, po, seed):
             po.sketch_accumulate(p, r, acc)
         assert np.array_equal(sk2[j], po.densify(p, acc)[0]), (K, S, W, H, j)
     e.close()
+
+
+@pytest.mark.parametrize("S,W", [(12, 10), (15, 12), (14, 12)])
+def test_launch_shape_boundaries(native, po, S, W):
+    """Batches of ONE record length on either side of every length at which launch_sketch changes the kernel shape, the
+    entry list or the densification (200 / 201: the entry list of the one-wavefront kernel; 415 / 416: one-wavefront or
+    workgroup kernel; 16 383 / 16 384: 256 or 1024 threads; 2^18, 2^19 - 1 / 2^19: the distinct-value launch of its own;
+    2^21: the chunk length) -- every sketch against the oracle."""
+    rng = np.random.default_rng(77 + S)
+    p = po.make_params(31, S, W, 4, 0.0)
+    e = native.Engine(K=31, S=S, W=W, H=4)
+    for L in (199, 200, 201, 222, 223, 414, 415, 416, 450, 16383, 16384, 16385, (1 << 18) - 1, 1 << 18, (1 << 19) - 1, 1 << 19,
+              (1 << 21) - 1, (1 << 21) + 1):
+        recs = [random_record(rng, L, dirty=(j == 2)) for j in range(3 if L < 100000 else 2)]
+        sk = e.sketch(recs)
+        for r, got in zip(recs, sk):
+            assert np.array_equal(got, po.compute_sketch(p, r)), (S, W, L)
+    e.close()
