@@ -424,19 +424,19 @@ void Index::flush_query(Batch &b) {
       rank_share(n, per, r, lo, hi);
       n_entry[r] = (uint32_t)(hi - lo);
     }
-    Hits h;
-    h.names = b.names;
-    group_query_staged((uint32_t)per, n_entry, h);
+    auto h = std::make_unique<Hits>();
+    h->names = b.names;
+    group_query_staged((uint32_t)per, n_entry, *h);
     lap.to(t_dev_);
-    write_hits(h);
+    if (hits_sink_) hits_sink_(std::move(h)); else write_hits(*h);
     lap.to(t_out_);
     return;
   }
-  Hits h;
-  h.names = b.names;
-  query_staged(b.names.size(), h);
+  auto h = std::make_unique<Hits>();
+  h->names = b.names;
+  query_staged(b.names.size(), *h);
   lap.to(t_dev_);
-  write_hits(h);
+  if (hits_sink_) hits_sink_(std::move(h)); else write_hits(*h);
   lap.to(t_out_);
 }
 
@@ -492,6 +492,63 @@ void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*
   // BEFORE batch i is staged, so the copy runs under batch i's inflate kernel.  Other lists (64 files a batch, readers
   // about as fast as the device): batch i is staged first, so that the readers' buffers are not all spoken for while it
   // runs -- waiting for batch i + 1 up front cost a third of the rate there.
+  // Queries: a batch's hit lines are put together and written by a thread of their own while the next batch is on the
+  // GPU (at most four batches wait there; output order is batch order).  With thousands of hits per query the text
+  // took as long as the GPU calls: 4000 virus-sized genomes against themselves, 0.20 of 0.43 s.
+  struct HitsWriter {
+    Index *ix;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::unique_ptr<Hits>> q;
+    bool closed = false;
+    std::string err;
+    std::thread th;
+    explicit HitsWriter(Index *i) : ix(i), th([this] { run(); }) {}
+    void run() {
+      for (;;) {
+        std::unique_ptr<Hits> h;
+        {
+          std::unique_lock<std::mutex> g(mu);
+          cv.wait(g, [&] { return closed || !q.empty(); });
+          if (q.empty()) return;
+          h = std::move(q.front());
+          q.pop_front();
+        }
+        cv.notify_all();
+        try {
+          if (err.empty()) ix->write_hits(*h);
+        } catch (const std::exception &e) {
+          std::lock_guard<std::mutex> g(mu);
+          err = e.what();
+        }
+      }
+    }
+    void push(std::unique_ptr<Hits> h) {
+      std::unique_lock<std::mutex> g(mu);
+      cv.wait(g, [&] { return q.size() < 4; });
+      q.push_back(std::move(h));
+      g.unlock();
+      cv.notify_all();
+    }
+    void finish() {   // everything handed over is written (or the first error kept) when this returns
+      {
+        std::lock_guard<std::mutex> g(mu);
+        closed = true;
+      }
+      cv.notify_all();
+      if (th.joinable()) th.join();
+    }
+    ~HitsWriter() { finish(); }
+  };
+  std::unique_ptr<HitsWriter> writer;
+  if (flush == &Index::flush_query) {
+    writer.reset(new HitsWriter(this));
+    hits_sink_ = [&writer](std::unique_ptr<Hits> h) { writer->push(std::move(h)); };
+  }
+  struct SinkReset {   // (also when a GPU call throws: nothing may hand hits to a writer that is gone)
+    std::function<void(std::unique_ptr<Hits>)> &f;
+    ~SinkReset() { f = nullptr; }
+  } sink_reset{hits_sink_};
   Batch cur, nxt;
   assemble(cur);
   if (!cur.files.empty()) stage_batch(cur, true);
@@ -515,6 +572,12 @@ void Index::for_each_batch(const std::vector<std::string> &paths, void (Index::*
     for (auto *f : cur.files) rd.release(f);
     cur = std::move(nxt);
     nxt = Batch();
+  }
+  if (writer) {
+    Lap lap;
+    writer->finish();
+    lap.to(t_out_);
+    if (!writer->err.empty()) throw std::runtime_error(writer->err);
   }
   if (timing)
     std::cerr << "[niqki timing] " << paths.size() << " files: total "

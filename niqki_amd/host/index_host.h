@@ -4,6 +4,7 @@
 // query_sketch) batched through the C ABI of libniqki_hip.so.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <utility>
@@ -88,6 +89,9 @@ class Index {
   niqki_index *h_ = nullptr;            // shard 0 (the only one with one GPU)
   std::vector<niqki_index *> sh_;       // all shards, rank order
   niqki_group *grp_ = nullptr;          // null with one GPU
+  // whole-file queries: where flush_query hands a batch's hits (for_each_batch: a writer thread formats and writes them
+  // while the next batch is on the GPU); empty: written on the spot
+  std::function<void(std::unique_ptr<Hits>)> hits_sink_;
   double t_stage_ = 0, t_dev_ = 0, t_out_ = 0;  // NIQKI_HOST_TIMING: copy + frame / sketch + insert or query / output text
 };
 
